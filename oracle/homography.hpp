@@ -1,0 +1,183 @@
+// ORACLE — test infrastructure only (see cvx_core.hpp header).  PARITY UNPINNED.
+//
+// Stand-in for cv::findHomography(src, dst, noArray(), cv::RHO) (reference DynaDetect.cc:1235).
+// OpenCV's RHO estimator (calib3d/src/rho.cpp, ~2.6 kLoC: PROSAC sampling + SPRT + its own LM) is not
+// vendored under /root/reference and cannot be restated bit for bit from memory; SURVEY.md App. B
+// allows "a documented seeded substitute".  This is that substitute, keeping what the caller relies on:
+//   * correspondences are assumed sorted by decreasing quality (PROSAC ordering, Chum & Matas 2005);
+//   * reprojection threshold 3 px, confidence 0.995, at most 2000 hypotheses;
+//   * deterministic RNG (cv::RNG recurrence, fixed seed);
+//   * final refinement on the inlier set (normalised least squares + Gauss-Newton on the transfer error);
+//   * result scaled so H(2,2) = 1, returned as 9 doubles row-major; all-zero if estimation fails.
+// The product carries its own implementation of the same specification (sindslam_amd/csrc/host/).
+#pragma once
+#include "cvx_core.hpp"
+
+namespace cvx {
+
+struct Pt2f { float x, y; };
+
+namespace hdetail {
+// Gaussian elimination with partial pivoting, n<=8.  Returns false if singular.
+inline bool solve_linear(int n, double* A /*n x n row-major*/, double* b, double* x) {
+    for (int c = 0; c < n; c++) {
+        int piv = c; double best = std::fabs(A[c * n + c]);
+        for (int r = c + 1; r < n; r++) { double v = std::fabs(A[r * n + c]); if (v > best) { best = v; piv = r; } }
+        if (best < 1e-12) return false;
+        if (piv != c) { for (int k = 0; k < n; k++) std::swap(A[c * n + k], A[piv * n + k]); std::swap(b[c], b[piv]); }
+        for (int r = c + 1; r < n; r++) {
+            double f = A[r * n + c] / A[c * n + c];
+            if (f == 0) continue;
+            for (int k = c; k < n; k++) A[r * n + k] -= f * A[c * n + k];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = n - 1; r >= 0; r--) {
+        double s = b[r];
+        for (int k = r + 1; k < n; k++) s -= A[r * n + k] * x[k];
+        x[r] = s / A[r * n + r];
+    }
+    return true;
+}
+// H (h33 = 1) from 4 correspondences: 8x8 linear system.
+inline bool h_from_4(const Pt2f* s, const Pt2f* d, const int idx[4], double H[9]) {
+    double A[64], b[8], x[8];
+    for (int i = 0; i < 4; i++) {
+        double X = s[idx[i]].x, Y = s[idx[i]].y, u = d[idx[i]].x, v = d[idx[i]].y;
+        double* r0 = &A[(2 * i) * 8]; double* r1 = &A[(2 * i + 1) * 8];
+        r0[0] = X; r0[1] = Y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -u * X; r0[7] = -u * Y; b[2 * i] = u;
+        r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = X; r1[4] = Y; r1[5] = 1; r1[6] = -v * X; r1[7] = -v * Y; b[2 * i + 1] = v;
+    }
+    if (!solve_linear(8, A, b, x)) return false;
+    for (int i = 0; i < 8; i++) H[i] = x[i];
+    H[8] = 1.0;
+    return true;
+}
+inline double reproj_err2(const double H[9], const Pt2f& s, const Pt2f& d) {
+    double w = H[6] * s.x + H[7] * s.y + H[8];
+    if (std::fabs(w) < 1e-12) return 1e30;
+    double px = (H[0] * s.x + H[1] * s.y + H[2]) / w, py = (H[3] * s.x + H[4] * s.y + H[5]) / w;
+    double ex = px - d.x, ey = py - d.y;
+    return ex * ex + ey * ey;
+}
+// three of the four sample points (nearly) collinear in either image -> degenerate
+inline bool degenerate4(const Pt2f* p, const int idx[4]) {
+    for (int a = 0; a < 4; a++) for (int b = a + 1; b < 4; b++) for (int c = b + 1; c < 4; c++) {
+        double x1 = p[idx[b]].x - p[idx[a]].x, y1 = p[idx[b]].y - p[idx[a]].y;
+        double x2 = p[idx[c]].x - p[idx[a]].x, y2 = p[idx[c]].y - p[idx[a]].y;
+        if (std::fabs(x1 * y2 - x2 * y1) < 1e-3 * (std::fabs(x1 * x2 + y1 * y2) + 1.0)) return true;
+    }
+    return false;
+}
+// least-squares H (h33=1) over a subset, Hartley-normalised normal equations, then Gauss-Newton.
+inline bool refine_h(const Pt2f* s, const Pt2f* d, const std::vector<int>& in, double H[9]) {
+    const int n = (int)in.size();
+    if (n < 4) return false;
+    double cs[2] = {0, 0}, cd[2] = {0, 0};
+    for (int i : in) { cs[0] += s[i].x; cs[1] += s[i].y; cd[0] += d[i].x; cd[1] += d[i].y; }
+    cs[0] /= n; cs[1] /= n; cd[0] /= n; cd[1] /= n;
+    double ms = 0, md = 0;
+    for (int i : in) {
+        ms += std::sqrt((s[i].x - cs[0]) * (s[i].x - cs[0]) + (s[i].y - cs[1]) * (s[i].y - cs[1]));
+        md += std::sqrt((d[i].x - cd[0]) * (d[i].x - cd[0]) + (d[i].y - cd[1]) * (d[i].y - cd[1]));
+    }
+    if (ms < 1e-9 || md < 1e-9) return false;
+    const double ss = std::sqrt(2.0) * n / ms, sd = std::sqrt(2.0) * n / md;
+    double AtA[64], Atb[8], x[8];
+    std::fill(AtA, AtA + 64, 0.0); std::fill(Atb, Atb + 8, 0.0);
+    for (int i : in) {
+        double X = (s[i].x - cs[0]) * ss, Y = (s[i].y - cs[1]) * ss, u = (d[i].x - cd[0]) * sd, v = (d[i].y - cd[1]) * sd;
+        double r0[8] = {X, Y, 1, 0, 0, 0, -u * X, -u * Y}, r1[8] = {0, 0, 0, X, Y, 1, -v * X, -v * Y};
+        for (int a = 0; a < 8; a++) {
+            for (int b = 0; b < 8; b++) AtA[a * 8 + b] += r0[a] * r0[b] + r1[a] * r1[b];
+            Atb[a] += r0[a] * u + r1[a] * v;
+        }
+    }
+    if (!solve_linear(8, AtA, Atb, x)) return false;
+    // de-normalise: H = Td^-1 * Hn * Ts
+    double Hn[9] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], 1.0};
+    double Ts[9] = {ss, 0, -ss * cs[0], 0, ss, -ss * cs[1], 0, 0, 1};
+    double Tdi[9] = {1 / sd, 0, cd[0], 0, 1 / sd, cd[1], 0, 0, 1};
+    double M[9], R[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += Hn[r * 3 + k] * Ts[k * 3 + c]; M[r * 3 + c] = a; }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += Tdi[r * 3 + k] * M[k * 3 + c]; R[r * 3 + c] = a; }
+    if (std::fabs(R[8]) < 1e-12) return false;
+    for (int i = 0; i < 9; i++) H[i] = R[i] / R[8];
+    // Gauss-Newton on the forward transfer error, 8 parameters, 10 iterations
+    for (int it = 0; it < 10; it++) {
+        double JtJ[64], Jtr[8], dx[8];
+        std::fill(JtJ, JtJ + 64, 0.0); std::fill(Jtr, Jtr + 8, 0.0);
+        for (int i : in) {
+            double X = s[i].x, Y = s[i].y;
+            double w = H[6] * X + H[7] * Y + 1.0; if (std::fabs(w) < 1e-12) continue;
+            double iw = 1.0 / w, px = (H[0] * X + H[1] * Y + H[2]) * iw, py = (H[3] * X + H[4] * Y + H[5]) * iw;
+            double rx = d[i].x - px, ry = d[i].y - py;
+            double jx[8] = {X * iw, Y * iw, iw, 0, 0, 0, -X * px * iw, -Y * px * iw};
+            double jy[8] = {0, 0, 0, X * iw, Y * iw, iw, -X * py * iw, -Y * py * iw};
+            for (int a = 0; a < 8; a++) {
+                for (int b = 0; b < 8; b++) JtJ[a * 8 + b] += jx[a] * jx[b] + jy[a] * jy[b];
+                Jtr[a] += jx[a] * rx + jy[a] * ry;
+            }
+        }
+        if (!solve_linear(8, JtJ, Jtr, dx)) break;
+        double step = 0;
+        for (int a = 0; a < 8; a++) { H[a] += dx[a]; step += dx[a] * dx[a]; }
+        if (step < 1e-20) break;
+    }
+    return true;
+}
+}  // namespace hdetail
+
+// src -> dst homography; points sorted by decreasing quality.  Returns false (H = 0) on failure.
+inline bool find_homography_prosac(const std::vector<Pt2f>& src, const std::vector<Pt2f>& dst, double H[9],
+                                   double thresh = 3.0, double confidence = 0.995, int maxIters = 2000) {
+    using namespace hdetail;
+    const int N = (int)src.size();
+    std::fill(H, H + 9, 0.0);
+    if (N < 4) return false;
+    const double t2 = thresh * thresh;
+    RNG rng(0x9E3779B97F4A7C15ull);
+    // PROSAC growth function
+    double Tn = maxIters;
+    for (int i = 0; i < 4; i++) Tn *= (double)(4 - i) / (double)(N - i);
+    int n = 4, Tn_prime = 1, best_cnt = 0, iters_needed = maxIters;
+    double bestH[9];
+    for (int t = 1; t <= iters_needed && t <= maxIters; t++) {
+        if (t == Tn_prime && n < N) {
+            double Tn1 = Tn * (double)(n + 1) / (double)(n + 1 - 4);
+            Tn_prime += (int)std::ceil(Tn1 - Tn);
+            Tn = Tn1; n++;
+        }
+        int idx[4];
+        if (Tn_prime < t) {            // plain RANSAC draw from the first n
+            for (int k = 0; k < 4; k++) { bool dup; do { idx[k] = (int)(rng.next() % (uint32_t)n); dup = false; for (int q = 0; q < k; q++) dup |= idx[q] == idx[k]; } while (dup); }
+        } else {                       // n-th point plus 3 from the first n-1
+            idx[3] = n - 1;
+            for (int k = 0; k < 3; k++) { bool dup; do { idx[k] = (int)(rng.next() % (uint32_t)(n - 1)); dup = false; for (int q = 0; q < k; q++) dup |= idx[q] == idx[k]; } while (dup); }
+        }
+        if (degenerate4(src.data(), idx) || degenerate4(dst.data(), idx)) continue;
+        double Hc[9];
+        if (!h_from_4(src.data(), dst.data(), idx, Hc)) continue;
+        int cnt = 0;
+        for (int i = 0; i < N; i++) cnt += reproj_err2(Hc, src[i], dst[i]) <= t2;
+        if (cnt > best_cnt) {
+            best_cnt = cnt; std::copy(Hc, Hc + 9, bestH);
+            double eps = (double)cnt / N, p4 = eps * eps * eps * eps;
+            if (p4 > 1.0 - 1e-12) iters_needed = t;
+            else { double k = std::log(1.0 - confidence) / std::log(1.0 - p4); iters_needed = (int)std::min<double>(maxIters, std::ceil(k)); }
+        }
+    }
+    if (best_cnt < 4) return false;
+    std::vector<int> inl;
+    for (int i = 0; i < N; i++) if (reproj_err2(bestH, src[i], dst[i]) <= t2) inl.push_back(i);
+    double Hr[9]; std::copy(bestH, bestH + 9, Hr);
+    if (refine_h(src.data(), dst.data(), inl, Hr)) {
+        // keep the refinement only if it does not lose support
+        int cnt = 0; for (int i = 0; i < N; i++) cnt += reproj_err2(Hr, src[i], dst[i]) <= t2;
+        if (cnt >= best_cnt) std::copy(Hr, Hr + 9, bestH);
+    }
+    std::copy(bestH, bestH + 9, H);
+    return true;
+}
+
+}  // namespace cvx

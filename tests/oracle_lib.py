@@ -1,0 +1,217 @@
+"""ctypes access to oracle/liboracle.so — TEST INFRASTRUCTURE ONLY (never imported by sindslam_amd/)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(_ORACLE_DIR, "liboracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    try:
+        return _lib
+    except NameError:
+        pass
+    if not os.path.exists(_SO):
+        build()
+    _lib = C.CDLL(_SO)
+    _lib.orc_otsu.restype = C.c_double
+    _lib.orc_triangle.restype = C.c_double
+    _lib.orc_fast_atan2.restype = C.c_float
+    _lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    _lib.orc_dyna_create.restype = C.c_void_p
+    _lib.orc_orb_create.restype = C.c_void_p
+    _lib.orc_baseline_run.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class KP(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int), ("class_id", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
+                     ("octave", "i4"), ("class_id", "i4")])
+
+
+def bgr2gray(bgr, swap_rb=False):
+    h, w, _ = bgr.shape; out = np.empty((h, w), np.uint8)
+    lib().orc_bgr2gray(_p(np.ascontiguousarray(bgr)), w, h, int(swap_rb), _p(out)); return out
+
+
+def resize_u8(src, dw, dh):
+    h, w = src.shape; out = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_u8(_p(np.ascontiguousarray(src)), w, h, dw, dh, _p(out)); return out
+
+
+def resize_f32(src, dw, dh):
+    src = np.ascontiguousarray(src, np.float32)
+    h, w = src.shape[:2]; cn = 1 if src.ndim == 2 else src.shape[2]
+    out = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.float32)
+    lib().orc_resize_f32(_p(src), w, h, cn, dw, dh, _p(out)); return out
+
+
+def gaussian_blur_u8(src, ksize=7, sigma=2.0):
+    h, w = src.shape; out = np.empty_like(src)
+    lib().orc_gaussian_blur_u8(_p(np.ascontiguousarray(src)), w, h, ksize, C.c_double(sigma), _p(out)); return out
+
+
+def gaussian_blur3_f32(src, sigma=0.6):
+    src = np.ascontiguousarray(src, np.float32); h, w = src.shape; out = np.empty_like(src)
+    lib().orc_gaussian_blur3_f32(_p(src), w, h, C.c_double(sigma), _p(out)); return out
+
+
+def otsu(hist):
+    hist = np.ascontiguousarray(hist, np.int32); return lib().orc_otsu(_p(hist), int(hist.sum()))
+
+
+def triangle(hist):
+    hist = np.ascontiguousarray(hist, np.int32); return lib().orc_triangle(_p(hist))
+
+
+def rng_gaussian(seed, sigma, n):
+    out = np.empty(n, np.float32); lib().orc_rng_gaussian(C.c_uint64(seed), C.c_double(sigma), n, _p(out)); return out
+
+
+def deepflow_levels(w, h):
+    ws = np.zeros(256, np.int32); hs = np.zeros(256, np.int32)
+    n = lib().orc_deepflow_levels(w, h, _p(ws), _p(hs), 256); return list(zip(ws[:n].tolist(), hs[:n].tolist()))
+
+
+VARREF_INTER = ["warped", "Ix", "Iy", "Iz", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz", "A11", "A12", "A22", "b1", "b2", "wgt", "dWu", "dWv"]
+
+
+def varref(i0, i1, wu, wv, fp_iters=5, sor_iters=5, alpha=20.0, delta=5.0, gamma=10.0, omega=1.6, want_inter=False):
+    i0 = np.ascontiguousarray(i0, np.float32); i1 = np.ascontiguousarray(i1, np.float32)
+    wu = np.array(wu, np.float32, copy=True); wv = np.array(wv, np.float32, copy=True)
+    h, w = i0.shape
+    inter = {k: np.empty((h, w), np.float32) for k in VARREF_INTER} if want_inter else None
+    arr = (C.c_void_p * 17)(*[inter[k].ctypes.data for k in VARREF_INTER]) if want_inter else None
+    lib().orc_varref(_p(i0), _p(i1), w, h, _p(wu), _p(wv), fp_iters, sor_iters, C.c_float(alpha), C.c_float(delta),
+                     C.c_float(gamma), C.c_float(omega), arr)
+    return (wu, wv, inter) if want_inter else (wu, wv)
+
+
+def deepflow(i0, i1):
+    h, w = i0.shape; out = np.empty((h, w, 2), np.float32)
+    lib().orc_deepflow(_p(np.ascontiguousarray(i0)), _p(np.ascontiguousarray(i1)), w, h, _p(out)); return out
+
+
+def find_homography(src, dst):
+    src = np.ascontiguousarray(src, np.float32); dst = np.ascontiguousarray(dst, np.float32); H = np.zeros(9, np.float64)
+    ok = lib().orc_find_homography(_p(src), _p(dst), len(src), _p(H)); return ok, H.reshape(3, 3)
+
+
+def morph(src, n, op):
+    h, w = src.shape; out = np.empty_like(src)
+    lib().orc_morph(_p(np.ascontiguousarray(src)), w, h, n, {"dilate": 0, "erode": 1, "open": 2, "close": 3}[op], _p(out)); return out
+
+
+def find_contours(src, external_only=True):
+    h, w = src.shape; pts = np.zeros((w * h * 4, 2), np.int32); lens = np.zeros(w * h, np.int32)
+    n = lib().orc_find_contours(_p(np.ascontiguousarray(src)), w, h, int(external_only), _p(pts), len(pts), _p(lens), len(lens))
+    out = []; o = 0
+    for i in range(n):
+        out.append(pts[o:o + lens[i]].copy()); o += lens[i]
+    return out
+
+
+def median5_f32(src):
+    src = np.ascontiguousarray(src, np.float32); h, w = src.shape; out = np.empty_like(src)
+    lib().orc_median5_f32(_p(src), w, h, _p(out)); return out
+
+
+def dilate15(src):
+    h, w = src.shape; out = np.empty_like(src); lib().orc_dilate15(_p(np.ascontiguousarray(src)), w, h, _p(out)); return out
+
+
+class DynaDetect:
+    def __init__(self, bgr_last, bgr_lastlast, fx, fy, cx, cy, depth_scale):
+        self.h, self.w, _ = bgr_last.shape
+        self.p = C.c_void_p(lib().orc_dyna_create(_p(np.ascontiguousarray(bgr_last)), _p(np.ascontiguousarray(bgr_lastlast)), self.w, self.h,
+                                                  C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_float(depth_scale)))
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            lib().orc_dyna_destroy(self.p); self.p = None
+
+    def detect(self, bgr, depth):
+        dyna = np.empty((self.h, self.w), np.uint8); label = np.empty((self.h, self.w), np.uint8)
+        lib().orc_dyna_detect(self.p, _p(np.ascontiguousarray(bgr)), _p(np.ascontiguousarray(depth)), _p(dyna), _p(label)); return dyna, label
+
+    def flow_only(self, bgr):
+        fw, fh = int(np.float32(0.6) * self.w), int(np.float32(0.6) * self.h)
+        full = np.empty((self.h, self.w, 2), np.float32); deep = np.empty((fh, fw, 2), np.float32); ref = np.empty((fh, fw, 2), np.float32)
+        lm = C.c_int(0)
+        lib().orc_dyna_flow_only(self.p, _p(np.ascontiguousarray(bgr)), _p(full), _p(deep), _p(ref), C.byref(lm))
+        return full, deep, ref, bool(lm.value)
+
+    def detect_with_flow(self, bgr, depth, flow_full):
+        dyna = np.empty((self.h, self.w), np.uint8); label = np.empty((self.h, self.w), np.uint8)
+        lib().orc_dyna_detect_with_flow(self.p, _p(np.ascontiguousarray(bgr)), _p(np.ascontiguousarray(depth)),
+                                        _p(np.ascontiguousarray(flow_full, np.float32)), _p(dyna), _p(label)); return dyna, label
+
+    def debug(self):
+        h, w = self.h, self.w
+        d = dict(flow_full=np.empty((h, w, 2), np.float32), H=np.zeros(9), thr=np.zeros(5, np.float32), hist=np.zeros(256, np.int32),
+                 mask_low=np.empty((h, w), np.uint8), mask_high=np.empty((h, w), np.uint8), kmeans_label=np.empty((h, w), np.uint8),
+                 centers=np.zeros((12, 3), np.float32), occ1=np.empty((h, w), np.uint8), occ2=np.empty((h, w), np.uint8),
+                 total_area=np.empty((h, w), np.uint8), mag_u8=np.empty((h, w), np.uint8), info=np.zeros(3, np.int32))
+        lib().orc_dyna_debug(self.p, *[_p(d[k]) for k in ["flow_full", "H", "thr", "hist", "mask_low", "mask_high", "kmeans_label", "centers",
+                                                          "occ1", "occ2", "total_area", "mag_u8", "info"]])
+        d["H"] = d["H"].reshape(3, 3); return d
+
+
+class ORBextractor:
+    def __init__(self, nfeatures=1500, scale=1.2, nlevels=8, ini_th=15, min_th=5):
+        self.nlevels = nlevels
+        self.p = C.c_void_p(lib().orc_orb_create(nfeatures, C.c_float(scale), nlevels, ini_th, min_th))
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            lib().orc_orb_destroy(self.p); self.p = None
+
+    def extract(self, gray, mask=None, cap=20000):
+        h, w = gray.shape; kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        n = lib().orc_orb_extract(self.p, _p(np.ascontiguousarray(gray)), w, h, _p(None if mask is None else np.ascontiguousarray(mask)), _p(kps), cap, _p(desc))
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level_size(self, level):
+        w = C.c_int(); h = C.c_int(); lib().orc_orb_level_size(self.p, level, C.byref(w), C.byref(h)); return w.value, h.value
+
+    def level_padded(self, level):
+        w, h = self.level_size(level); out = np.empty((h + 38, w + 38), np.uint8); lib().orc_orb_level_padded(self.p, level, _p(out)); return out
+
+    def fast_keypoints(self, level, cap=100000):
+        kps = np.zeros(cap, KP_DTYPE); n = lib().orc_orb_fast_keypoints(self.p, level, _p(kps), cap); return kps[:n].copy()
+
+    def selected(self, level, cap=20000):
+        kps = np.zeros(cap, KP_DTYPE); n = lib().orc_orb_selected(self.p, level, _p(kps), cap); return kps[:n].copy()
+
+    def tables(self):
+        n = self.nlevels
+        t = dict(scale=np.zeros(n, np.float32), inv_scale=np.zeros(n, np.float32), sigma2=np.zeros(n, np.float32), inv_sigma2=np.zeros(n, np.float32),
+                 per_level=np.zeros(n, np.int32), umax=np.zeros(16, np.int32))
+        lib().orc_orb_tables(self.p, *[_p(t[k]) for k in ["scale", "inv_scale", "sigma2", "inv_sigma2", "per_level", "umax"]]); return t
+
+
+def baseline_run(bgr, depth, intr, nfeatures=1500, scale=1.2, nlevels=8):
+    n, h, w, _ = bgr.shape; st = np.zeros(3)
+    t = lib().orc_baseline_run(_p(np.ascontiguousarray(bgr)), _p(np.ascontiguousarray(depth)), n, w, h, C.c_float(intr["fx"]), C.c_float(intr["fy"]),
+                               C.c_float(intr["cx"]), C.c_float(intr["cy"]), C.c_float(intr["depth_factor"]), nfeatures, C.c_float(scale), nlevels,
+                               intr["ini_th"], intr["min_th"], _p(st))
+    return t, st

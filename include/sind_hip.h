@@ -1,0 +1,57 @@
+/* libsind_hip — C ABI of the MI355X-native DynaDetect + ORBextractor hot path.
+ *
+ * The reference (qimao7213/SInDSLAM) has no FFI layer: its boundary is two C++ classes,
+ *   ORB_SLAM2::DynaDetect    (ORB_SLAM2/include/DynaDetect.h:95-131, src/DynaDetect.cc:1377-1666)
+ *   ORB_SLAM2::ORBextractor  (ORB_SLAM2/include/ORBextractor.h:54-88, src/ORBextractor.cc:1043-1164)
+ * called from Examples/RGB-D/rgbd_tum_noros.cc:106-107,135,138 and src/Frame.cc:308.  Each entry point below names
+ * the reference member it replaces.  include/DynaDetect.h and include/ORBextractor.h are header-only C++ shims with
+ * the reference's class names and signatures on top of this ABI.
+ *
+ * Conventions: plain pointers and sizes, caller-owned memory, row strides in BYTES, return 0 on success or a negative
+ * SIND_E_* code (sind_last_error() gives the text), no exceptions cross the ABI.  A handle is bound to one GPU and
+ * one HIP stream and is not thread-safe; use one handle per thread.  "_dev" entry points take DEVICE pointers
+ * (inputs already resident in HBM) and are asynchronous on the handle's stream until sind_*_sync().
+ */
+#ifndef SIND_HIP_H
+#define SIND_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIND_OK 0
+#define SIND_E_ARG (-1)
+#define SIND_E_HIP (-2)
+#define SIND_E_ALLOC (-3)
+#define SIND_E_STATE (-4)
+#define SIND_E_CAPACITY (-5)
+
+const char* sind_last_error(void);
+int sind_device_count(int* count);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Dense flow stage (state free).  Replaces, for B frame pairs at once on the 0.6-scaled grid:
+ *   cv::optflow::createOptFlow_DeepFlow()->calc(I_n, I_prev, flow)      DynaDetect.cc:1031,1075,1127
+ *   cv::VariationalRefinement::create()->calc(I_n, I_prev, flow)        DynaDetect.cc:1133-1143
+ * Images: u8 [B][fh][fw] dense.  Flow: two planes u, v, f32 [B][fh][fw] (the reference's CV_32FC2 de-interleaved).
+ */
+typedef struct sind_flow sind_flow;
+int sind_flow_create(int fw, int fh, int max_batch, int device, sind_flow** out);
+int sind_flow_destroy(sind_flow* f);
+int sind_flow_levels(sind_flow* f, int* widths, int* heights, int cap);          /* returns the level count */
+int sind_flow_deepflow(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v);       /* host pointers */
+int sind_flow_refine(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v);         /* host, u/v in-out */
+int sind_flow_varref_f32(sind_flow* f, const float* i0, const float* i1, int w, int h, int B, float* u, float* v,
+                         int fixed_point_iters, int sor_iters, float alpha, float delta, float gamma, float omega); /* host, one level */
+int sind_flow_deepflow_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v);   /* device pointers, async */
+int sind_flow_refine_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v);
+int sind_flow_sync(sind_flow* f);
+/* HIP-event timing of everything enqueued on the handle's stream between begin and end (bench.py roofline leg) */
+int sind_flow_timer_begin(sind_flow* f);
+int sind_flow_timer_end(sind_flow* f, float* milliseconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

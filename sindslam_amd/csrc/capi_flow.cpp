@@ -1,0 +1,104 @@
+// C ABI: dense flow stage (include/sind_hip.h).
+#include "../../include/sind_hip.h"
+#include "flow.hpp"
+
+struct sind_flow {
+    int device = 0; hipStream_t stream = nullptr; sind::FlowEngine eng;
+    DevBuf<uint8_t> g0, g1; DevBuf<float> u, v, f0, f1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+int sind_device_count(int* count) { if (!count) return SIND_E_ARG; HIP_TRY(hipGetDeviceCount(count)); return SIND_OK; }
+
+int sind_flow_create(int fw, int fh, int max_batch, int device, sind_flow** out) {
+    if (!out || fw < 32 || fh < 32 || max_batch < 1) { sind_set_error("sind_flow_create: bad arguments"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    sind_flow* f = new sind_flow(); f->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&f->ev0)); HIP_TRY(hipEventCreate(&f->ev1));
+    int r = f->eng.init(fw, fh, max_batch, f->stream);
+    if (r != SIND_OK) { delete f; return r; }
+    *out = f; return SIND_OK;
+}
+int sind_flow_destroy(sind_flow* f) {
+    if (!f) return SIND_OK;
+    (void)hipSetDevice(f->device);
+    if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
+    if (f->ev0) (void)hipEventDestroy(f->ev0);
+    if (f->ev1) (void)hipEventDestroy(f->ev1);
+    delete f; return SIND_OK;
+}
+int sind_flow_levels(sind_flow* f, int* ws, int* hs, int cap) {
+    if (!f) return SIND_E_ARG;
+    for (int i = 0; i < (int)f->eng.levels.size() && i < cap; i++) { ws[i] = f->eng.levels[i].first; hs[i] = f->eng.levels[i].second; }
+    return (int)f->eng.levels.size();
+}
+static int stage_in(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B) {
+    const size_t n = (size_t)f->eng.fw * f->eng.fh * B;
+    SIND_TRY(f->g0.alloc(n)); SIND_TRY(f->g1.alloc(n)); SIND_TRY(f->u.alloc(n)); SIND_TRY(f->v.alloc(n));
+    HIP_TRY(hipMemcpyAsync(f->g0.p, i0, n, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(f->g1.p, i1, n, hipMemcpyHostToDevice, f->stream));
+    return SIND_OK;
+}
+int sind_flow_deepflow(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v) {
+    if (!f || !i0 || !i1 || !u || !v || B < 1 || B > f->eng.maxB) { sind_set_error("sind_flow_deepflow: bad arguments"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(f->device));
+    SIND_TRY(stage_in(f, i0, i1, B));
+    SIND_TRY(f->eng.deepflow(f->g0.p, f->g1.p, B, f->u.p, f->v.p));
+    const size_t n = (size_t)f->eng.fw * f->eng.fh * B;
+    HIP_TRY(hipMemcpyAsync(u, f->u.p, n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIP_TRY(hipMemcpyAsync(v, f->v.p, n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    return SIND_OK;
+}
+int sind_flow_refine(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v) {
+    if (!f || !i0 || !i1 || !u || !v || B < 1 || B > f->eng.maxB) { sind_set_error("sind_flow_refine: bad arguments"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(f->device));
+    SIND_TRY(stage_in(f, i0, i1, B));
+    const size_t n = (size_t)f->eng.fw * f->eng.fh * B;
+    HIP_TRY(hipMemcpyAsync(f->u.p, u, n * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(f->v.p, v, n * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    SIND_TRY(f->eng.refine(f->g0.p, f->g1.p, B, f->u.p, f->v.p));
+    HIP_TRY(hipMemcpyAsync(u, f->u.p, n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIP_TRY(hipMemcpyAsync(v, f->v.p, n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    return SIND_OK;
+}
+int sind_flow_varref_f32(sind_flow* f, const float* i0, const float* i1, int w, int h, int B, float* u, float* v,
+                         int fp, int sor, float alpha, float delta, float gamma, float omega) {
+    if (!f || !i0 || !i1 || !u || !v || B < 1 || B > f->eng.maxB || w < 2 || h < 2 || (size_t)w * h > (size_t)f->eng.fw * f->eng.fh) { sind_set_error("sind_flow_varref_f32: bad arguments"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(f->device));
+    const size_t n = (size_t)w * h * B;
+    SIND_TRY(f->f0.alloc(n)); SIND_TRY(f->f1.alloc(n)); SIND_TRY(f->u.alloc(n)); SIND_TRY(f->v.alloc(n));
+    HIP_TRY(hipMemcpyAsync(f->f0.p, i0, n * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(f->f1.p, i1, n * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(f->u.p, u, n * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(f->v.p, v, n * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    sind::VarParams V; V.fixedPointIterations = fp; V.sorIterations = sor; V.alpha = alpha; V.delta = delta; V.gamma = gamma; V.omega = omega;
+    SIND_TRY(f->eng.varref_f32(f->f0.p, f->f1.p, w, h, B, f->u.p, f->v.p, V));
+    HIP_TRY(hipMemcpyAsync(u, f->u.p, n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIP_TRY(hipMemcpyAsync(v, f->v.p, n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    return SIND_OK;
+}
+int sind_flow_deepflow_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v) {
+    if (!f || !i0 || !i1 || !u || !v) { sind_set_error("sind_flow_deepflow_dev: null argument"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(f->device));
+    return f->eng.deepflow(i0, i1, B, u, v);
+}
+int sind_flow_refine_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v) {
+    if (!f || !i0 || !i1 || !u || !v) { sind_set_error("sind_flow_refine_dev: null argument"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(f->device));
+    return f->eng.refine(i0, i1, B, u, v);
+}
+int sind_flow_sync(sind_flow* f) { if (!f) return SIND_E_ARG; HIP_TRY(hipStreamSynchronize(f->stream)); return SIND_OK; }
+int sind_flow_timer_begin(sind_flow* f) { if (!f) return SIND_E_ARG; HIP_TRY(hipEventRecord(f->ev0, f->stream)); return SIND_OK; }
+int sind_flow_timer_end(sind_flow* f, float* ms) {
+    if (!f || !ms) return SIND_E_ARG;
+    HIP_TRY(hipEventRecord(f->ev1, f->stream)); HIP_TRY(hipEventSynchronize(f->ev1)); HIP_TRY(hipEventElapsedTime(ms, f->ev0, f->ev1));
+    return SIND_OK;
+}
+
+}  // extern "C"

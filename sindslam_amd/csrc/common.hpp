@@ -1,0 +1,61 @@
+// Shared host/device helpers for libsind_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+// error codes returned across the C ABI (include/sind_hip.h)
+#define SIND_OK 0
+#define SIND_E_ARG (-1)
+#define SIND_E_HIP (-2)
+#define SIND_E_ALLOC (-3)
+#define SIND_E_STATE (-4)
+#define SIND_E_CAPACITY (-5)
+
+extern "C" const char* sind_last_error();
+void sind_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            sind_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return SIND_E_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+#define SIND_TRY(expr)            \
+    do {                          \
+        int _r = (expr);          \
+        if (_r != SIND_OK) return _r; \
+    } while (0)
+
+static inline int divup(int a, int b) { return (a + b - 1) / b; }
+
+// simple owning device buffer
+template <class T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    int alloc(size_t count) {
+        if (count <= n && p) return SIND_OK;
+        release();
+        if (hipMalloc((void**)&p, count * sizeof(T)) != hipSuccess) { p = nullptr; n = 0; sind_set_error("hipMalloc(%zu bytes) failed", count * sizeof(T)); return SIND_E_ALLOC; }
+        n = count; return SIND_OK;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    ~DevBuf() { release(); }
+    DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+};
+
+#ifdef __HIPCC__
+// OpenCV-compatible scalar helpers (device)
+__device__ __forceinline__ int d_cvRound(float v) { return __float2int_rn(v); }          // round half to even
+__device__ __forceinline__ int d_cvFloorf(float v) { return (int)floorf(v); }
+__device__ __forceinline__ int d_clip(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+__device__ __forceinline__ int d_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+#endif

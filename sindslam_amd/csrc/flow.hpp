@@ -1,0 +1,52 @@
+// Flow engine interface (host side of flow_kernels.hip).
+#pragma once
+#include "common.hpp"
+
+namespace sind {
+
+struct VarParams {      // cv::VariationalRefinement parameters (variational_refinement.cpp defaults)
+    int fixedPointIterations = 5, sorIterations = 5;
+    float alpha = 20.0f, delta = 5.0f, gamma = 10.0f, omega = 1.6f, zeta = 0.1f, epsilon = 0.001f;
+};
+struct HMat { double h[9]; };
+
+// per-level working planes, each [B][h][w] float, allocated once for the finest level
+struct FlowPlanes {
+    float *avg, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz;   // warped-average image and its derivatives
+    float *A11, *A12, *A22, *b1, *b2, *wgt;                   // linear system + smoothness weights
+    float *Wu, *Wv, *dWu, *dWv, *tWu, *tWv;                    // level flow, increment, W + dW
+};
+
+int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w, int h, int B, float k0, float k1, bool blur);
+int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
+int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img);
+int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb);
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V);
+int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, unsigned* maxbits, int* hist, uint8_t* out_u8, int n, int B);
+int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h);
+int launch_threshold_masks(hipStream_t s, const uint8_t* magu8, float lo, float hi, uint8_t* low, uint8_t* high, int n);
+int launch_gather_grid(hipStream_t s, const float* u, const float* v, float* out, int w, int h, int step);
+int launch_scale2(hipStream_t s, float* a, float* b, float sc, size_t n);
+
+// Batched DeepFlow + VariationalRefinement for B frame pairs at the flow grid (fw x fh).
+class FlowEngine {
+public:
+    int fw = 0, fh = 0, maxB = 0;
+    hipStream_t stream = nullptr;
+    std::vector<std::pair<int, int>> levels;     // OpticalFlowDeepFlow::buildPyramid sizes
+    std::vector<size_t> level_off;               // offset (in pixels per image) of each level inside a pyramid
+    size_t pyr_pixels = 0;
+    int init(int fw, int fh, int maxB, hipStream_t s);
+    // g0/g1: device u8 [B][fh][fw].  u/v: device f32 [B][fh*fw], raw DeepFlow output (not negated).
+    int deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, float* v);
+    // cv::VariationalRefinement::create()->calc(g0, g1, flow) with defaults; u/v in-out.
+    int refine(const uint8_t* g0, const uint8_t* g1, int B, float* u, float* v);
+    // expose one-level refinement on float images for stage-level parity tests
+    int varref_f32(const float* I0, const float* I1, int w, int h, int B, float* u, float* v, const VarParams& V);
+    FlowPlanes planes{};
+private:
+    DevBuf<float> plane_store, pyr0, pyr1;
+    float* level_ptr(DevBuf<float>& pyr, int l, int B) { return pyr.p + level_off[l] * (size_t)B; }
+};
+
+}  // namespace sind

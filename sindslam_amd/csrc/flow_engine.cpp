@@ -1,0 +1,94 @@
+// Host orchestration of the batched dense-flow path (OpticalFlowDeepFlow::calc and VariationalRefinement::calc
+// call structure, opencv_contrib 4.2.0 deepflow.cpp / opencv 4.2.0 variational_refinement.cpp; call sites in the
+// reference: DynaDetect.cc:1031, 1075, 1127, 1133-1143).  All work is enqueued on one HIP stream; nothing here syncs.
+#include <cmath>
+#include <cstdarg>
+#include "flow.hpp"
+
+namespace sind {
+
+static std::vector<std::pair<int, int>> deepflow_sizes(int w, int h) {
+    const float downscale = 0.95f; const int minSize = 25, maxLayers = 200;
+    std::vector<std::pair<int, int>> s; s.push_back({w, h});
+    for (int i = 0; i < maxLayers; i++) {
+        int nw = (int)(s.back().first * downscale + 0.5f), nh = (int)(s.back().second * downscale + 0.5f);
+        if (nh <= minSize || nw <= minSize) break;
+        s.push_back({nw, nh});
+    }
+    return s;
+}
+
+int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
+    fw = fw_; fh = fh_; maxB = maxB_; stream = s;
+    levels = deepflow_sizes(fw, fh);
+    level_off.clear(); pyr_pixels = 0;
+    for (auto& l : levels) { level_off.push_back(pyr_pixels); pyr_pixels += (size_t)l.first * l.second; }
+    const size_t n0 = (size_t)fw * fh * maxB;
+    SIND_TRY(plane_store.alloc(n0 * 21));
+    float** f = reinterpret_cast<float**>(&planes);
+    for (int i = 0; i < 21; i++) f[i] = plane_store.p + n0 * i;
+    SIND_TRY(pyr0.alloc(pyr_pixels * maxB));
+    SIND_TRY(pyr1.alloc(pyr_pixels * maxB));
+    return SIND_OK;
+}
+
+int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, float* v) {
+    if (B < 1 || B > maxB) { sind_set_error("deepflow: batch %d outside [1,%d]", B, maxB); return SIND_E_ARG; }
+    // getGaussianKernel(3, 0.6): exp(-x^2/(2 sigma^2)) normalised, cast to float
+    const double sigma = 0.6f; const double e = std::exp(-0.5 * 1.0 * 1.0 / (sigma * sigma)), sum = (e + 1.0) + e;
+    const float k0 = (float)(1.0 / sum), k1 = (float)(e / sum);
+    const int L = (int)levels.size();
+    SIND_TRY(launch_u8_to_f32_blur3(stream, g0, level_ptr(pyr0, 0, B), fw, fh, B, k0, k1, true));
+    SIND_TRY(launch_u8_to_f32_blur3(stream, g1, level_ptr(pyr1, 0, B), fw, fh, B, k0, k1, true));
+    for (int l = 1; l < L; l++) {
+        SIND_TRY(launch_resize_f32(stream, level_ptr(pyr0, l - 1, B), level_ptr(pyr0, l, B), levels[l - 1].first, levels[l - 1].second, levels[l].first, levels[l].second, B, 1.f, false));
+        SIND_TRY(launch_resize_f32(stream, level_ptr(pyr1, l - 1, B), level_ptr(pyr1, l, B), levels[l - 1].first, levels[l - 1].second, levels[l].first, levels[l].second, B, 1.f, false));
+    }
+    VarParams V;   // OpticalFlowDeepFlow defaults: alpha 1, delta 0.5, gamma 5 -> 4*alpha, delta/3, gamma/3; 5 x 25, omega 1.6
+    V.alpha = 4 * 1.0f; V.delta = 0.5f / 3; V.gamma = 5.0f / 3; V.fixedPointIterations = 5; V.sorIterations = 25; V.omega = 1.6f;
+    const float inv_scale = 1.0f / 0.95f;
+    FlowPlanes& P = planes;
+    const size_t nc = (size_t)levels[L - 1].first * levels[L - 1].second * B;
+    HIP_TRY(hipMemsetAsync(P.Wu, 0, nc * sizeof(float), stream));
+    HIP_TRY(hipMemsetAsync(P.Wv, 0, nc * sizeof(float), stream));
+    for (int l = L - 1; l >= 0; --l) {
+        const int w = levels[l].first, h = levels[l].second;
+        SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V));
+        if (l > 0) {
+            const int nw = levels[l - 1].first, nh = levels[l - 1].second;
+            SIND_TRY(launch_resize_f32(stream, P.Wu, P.tWu, w, h, nw, nh, B, inv_scale, true));
+            SIND_TRY(launch_resize_f32(stream, P.Wv, P.tWv, w, h, nw, nh, B, inv_scale, true));
+            std::swap(P.Wu, P.tWu); std::swap(P.Wv, P.tWv);
+        }
+    }
+    const size_t n = (size_t)fw * fh * B;
+    HIP_TRY(hipMemcpyAsync(u, P.Wu, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(v, P.Wv, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return SIND_OK;
+}
+
+int FlowEngine::refine(const uint8_t* g0, const uint8_t* g1, int B, float* u, float* v) {
+    if (B < 1 || B > maxB) { sind_set_error("refine: batch %d outside [1,%d]", B, maxB); return SIND_E_ARG; }
+    float* I0 = level_ptr(pyr0, 0, B); float* I1 = level_ptr(pyr1, 0, B);
+    SIND_TRY(launch_u8_to_f32_blur3(stream, g0, I0, fw, fh, B, 1.f, 0.f, false));
+    SIND_TRY(launch_u8_to_f32_blur3(stream, g1, I1, fw, fh, B, 1.f, 0.f, false));
+    return varref_f32(I0, I1, fw, fh, B, u, v, VarParams());
+}
+
+int FlowEngine::varref_f32(const float* I0, const float* I1, int w, int h, int B, float* u, float* v, const VarParams& V) {
+    if (B < 1 || B > maxB || (size_t)w * h > (size_t)fw * fh) { sind_set_error("varref_f32: bad shape"); return SIND_E_ARG; }
+    const size_t n = (size_t)w * h * B;
+    HIP_TRY(hipMemcpyAsync(planes.Wu, u, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(planes.Wv, v, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    SIND_TRY(varref_level(stream, planes, I0, I1, w, h, B, V));
+    HIP_TRY(hipMemcpyAsync(u, planes.Wu, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(v, planes.Wv, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return SIND_OK;
+}
+
+}  // namespace sind
+
+// ---------------------------------------------------------------- error string (shared by the whole library)
+static thread_local char g_err[512] = "";
+void sind_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
+extern "C" const char* sind_last_error() { return g_err; }

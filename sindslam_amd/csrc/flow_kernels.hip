@@ -1,0 +1,385 @@
+// Dense variational optical flow for DynaDetect on gfx950 (CDNA4): batched DeepFlow (variational part) and
+// VariationalRefinement, i.e. the path reference DynaDetect.cc:1031-1147 spends ~99 % of its bytes in
+// (SURVEY.md §8 a-3..a-7).  Every kernel is batched over B frame pairs: planes are laid out [B][h][w] in HBM,
+// blockIdx.z (or .y for 1-D kernels) is the pair index, consecutive lanes walk consecutive x (coalesced rows).
+//
+// Arithmetic contract: built with -ffp-contract=off and IEEE divide/sqrt so that every FP32 expression below is
+// evaluated exactly like OpenCV's scalar code paths (variational_refinement.cpp, deepflow.cpp, resize.cpp,
+// imgwarp.cpp remap); the parity tests compare these kernels with the CPU oracle bit for bit.
+//
+// Roofline: all kernels here are HBM/L2-bound stencil passes (no MFMA: nothing is a contraction).
+#include "common.hpp"
+#include "flow.hpp"
+
+namespace sind {
+
+// ---------------------------------------------------------------------------------------------------------
+// u8 -> f32 (+ optional 3x3 Gaussian, BORDER_REFLECT_101): deepflow.cpp pre-smoothing with sigma = 0.6.
+// Separable form kept (row pass value T, then column pass over T) so rounding matches sepFilter2D.
+__global__ void k_u8_to_f32_blur3(const uint8_t* __restrict__ src, float* __restrict__ dst, int w, int h, float k0, float k1, int do_blur) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t* S = src + (size_t)b * w * h;
+    float* D = dst + (size_t)b * w * h;
+    if (!do_blur) { D[y * w + x] = (float)S[y * w + x]; return; }
+    const int xl = d_reflect101(x - 1, w), xr = d_reflect101(x + 1, w);
+    const int yu = d_reflect101(y - 1, h), yd = d_reflect101(y + 1, h);
+    auto rowv = [&](int yy) { const uint8_t* r = S + yy * w; return (float)r[x] * k0 + ((float)r[xl] + (float)r[xr]) * k1; };
+    const float U = rowv(yu), C = rowv(y), L = rowv(yd);
+    D[y * w + x] = C * k0 + (U + L) * k1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cv::resize(INTER_LINEAR) on CV_32F (resize.cpp): used for the 0.95 pyramid, the flow up-sampling between
+// levels (post = 1/0.95) and the final 384x288 -> 640x480 up-scale (post = 1/0.6).  scale_* are doubles computed
+// on the host exactly as OpenCV does (1 / ((double)dsize/ssize)).
+__global__ void k_resize_f32(const float* __restrict__ src, float* __restrict__ dst, int sw, int sh, int dw, int dh,
+                             double scale_x, double scale_y, float post, int has_post) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, b = blockIdx.z;
+    if (dx >= dw) return;
+    const float* S = src + (size_t)b * sw * sh;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = d_cvFloorf(fx); fx -= sx;
+    const bool two = sx + 1 < sw;            // dx < xmax in OpenCV's HResizeLinear
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = d_cvFloorf(fy); fy -= sy;
+    const int y0 = d_clip(sy, 0, sh), y1 = d_clip(sy + 1, 0, sh);
+    const float a1 = fx, a0 = 1.f - a1, b1 = fy, b0 = 1.f - b1;
+    const float* R0 = S + (size_t)y0 * sw; const float* R1 = S + (size_t)y1 * sw;
+    float r0, r1;
+    if (two) { r0 = R0[sx] * a0 + R0[sx + 1] * a1; r1 = R1[sx] * a0 + R1[sx + 1] * a1; }
+    else     { r0 = R0[sx] * 1.f;                  r1 = R1[sx] * 1.f; }
+    float v = r0 * b0 + r1 * b1;
+    if (has_post) v = v * post;
+    dst[(size_t)b * dw * dh + (size_t)dy * dw + dx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// VariationalRefinementImpl::prepareBuffers, part 1: warp I1 by the level's initial flow (cv::remap, INTER_LINEAR,
+// BORDER_REPLICATE, coordinates quantised to 1/32 px), averaged image and temporal difference.
+__global__ void k_warp_avg_iz(const float* __restrict__ I0, const float* __restrict__ I1, const float* __restrict__ Wu,
+                              const float* __restrict__ Wv, float* __restrict__ avg, float* __restrict__ Iz, int w, int h) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= w) return;
+    const size_t base = (size_t)b * w * h; const int i = y * w + x;
+    const float* S = I1 + base;
+    const float mx = x + Wu[base + i], my = y + Wv[base + i];
+    int sx = d_cvRound(mx * 32.f), sy = d_cvRound(my * 32.f);
+    const int fxq = sx & 31, fyq = sy & 31;
+    sx >>= 5; sy >>= 5;
+    sx = max(-32768, min(32767, sx)); sy = max(-32768, min(32767, sy));
+    const float tx1 = fxq * (1.f / 32), tx0 = 1.f - tx1, ty1 = fyq * (1.f / 32), ty0 = 1.f - ty1;
+    const float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
+    const int x0 = d_clip(sx, 0, w), x1 = d_clip(sx + 1, 0, w), y0 = d_clip(sy, 0, h), y1 = d_clip(sy + 1, 0, h);
+    const float v0 = S[y0 * w + x0], v1 = S[y0 * w + x1], v2 = S[y1 * w + x0], v3 = S[y1 * w + x1];
+    const float wv = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+    const float i0 = I0[base + i];
+    avg[base + i] = i0 * 0.5f + wv * 0.5f;
+    Iz[base + i] = wv - i0;
+}
+
+// prepareBuffers, part 2: the seven Sobel(ksize=1, BORDER_REPLICATE) derivative images.  Second derivatives are
+// differences of first-derivative values at replicated positions, recomputed here from avg with clamped indices
+// (same float operations as differencing the stored Ix / Iy images).
+__global__ void k_derivs(const float* __restrict__ avg, const float* __restrict__ Iz, float* __restrict__ Ix, float* __restrict__ Iy,
+                         float* __restrict__ Ixx, float* __restrict__ Ixy, float* __restrict__ Iyy, float* __restrict__ Ixz,
+                         float* __restrict__ Iyz, int w, int h) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= w) return;
+    const size_t base = (size_t)b * w * h; const int i = y * w + x;
+    const float* A = avg + base; const float* Z = Iz + base;
+    auto cx = [&](int v) { return min(max(v, 0), w - 1); };
+    auto cy = [&](int v) { return min(max(v, 0), h - 1); };
+    auto dX = [&](const float* P, int yy, int xx) { return P[yy * w + cx(xx + 1)] - P[yy * w + cx(xx - 1)]; };
+    auto dY = [&](const float* P, int yy, int xx) { return P[cy(yy + 1) * w + xx] - P[cy(yy - 1) * w + xx]; };
+    Ix[base + i] = dX(A, y, x);
+    Iy[base + i] = dY(A, y, x);
+    Ixz[base + i] = dX(Z, y, x);
+    Iyz[base + i] = dY(Z, y, x);
+    Ixx[base + i] = dX(A, y, cx(x + 1)) - dX(A, y, cx(x - 1));
+    Ixy[base + i] = dX(A, cy(y + 1), x) - dX(A, cy(y - 1), x);
+    Iyy[base + i] = dY(A, cy(y + 1), x) - dY(A, cy(y - 1), x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One fixed-point iteration set-up: ComputeDataTerm + ComputeSmoothnessTerm{Hor,Vert}Pass gathered per pixel.
+// The four smoothness contributions are added in the order OpenCV's red/black passes produce for the pixel's colour.
+__global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gIx, const float* __restrict__ gIy, const float* __restrict__ gIz,
+                       const float* __restrict__ gIxx, const float* __restrict__ gIxy, const float* __restrict__ gIyy,
+                       const float* __restrict__ gIxz, const float* __restrict__ gIyz, const float* __restrict__ gWu,
+                       const float* __restrict__ gWv, const float* __restrict__ gtWu, const float* __restrict__ gtWv,
+                       const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
+                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= w) return;
+    const size_t base = (size_t)b * w * h; const int i = y * w + x;
+    const float zeta2 = P.zeta * P.zeta, eps2 = P.epsilon * P.epsilon, gamma2 = P.gamma / 2, delta2 = P.delta / 2, alpha2 = P.alpha / 2;
+    const float Ix = gIx[base + i], Iy = gIy[base + i], Iz = gIz[base + i], Ixx = gIxx[base + i], Ixy = gIxy[base + i],
+                Iyy = gIyy[base + i], Ixz = gIxz[base + i], Iyz = gIyz[base + i], dU = gdWu[base + i], dV = gdWv[base + i];
+    float derivNorm = Ix * Ix + Iy * Iy + zeta2;
+    const float Ik1z = Iz + Ix * dU + Iy * dV;
+    float weight = (delta2 / sqrtf(Ik1z * Ik1z / derivNorm + eps2)) / derivNorm;
+    float a11 = weight * (Ix * Ix) + zeta2;
+    float a12 = weight * (Ix * Iy);
+    float a22 = weight * (Iy * Iy) + zeta2;
+    float b1 = -weight * (Iz * Ix);
+    float b2 = -weight * (Iz * Iy);
+    derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
+    const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
+    const float Ik1zx = Ixz + Ixx * dU + Ixy * dV;
+    const float Ik1zy = Iyz + Ixy * dU + Iyy * dV;
+    weight = gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
+    a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
+    a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
+    a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
+    b1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
+    b2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+
+    const float* tU = gtWu + base; const float* tV = gtWv + base; const float* WU = gWu + base; const float* WV = gWv + base;
+    auto wgt_at = [&](int yy, int xx) {
+        const int xn = min(xx + 1, w - 1), yn = min(yy + 1, h - 1);
+        const float c_u = tU[yy * w + xx], c_v = tV[yy * w + xx];
+        const float ux = tU[yy * w + xn] - c_u, vx = tV[yy * w + xn] - c_v;
+        const float uy = tU[yn * w + xx] - c_u, vy = tV[yn * w + xx] - c_v;
+        return alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
+    };
+    const float wp = wgt_at(y, x);
+    const float wu_c = WU[i], wv_c = WV[i];
+    const bool red = ((x + y) & 1) == 0;
+    // the four link updates (no-ops at the image border)
+    #define OWN_H() if (x < w - 1) { b1 += wp * (WU[i + 1] - wu_c); a11 += wp; b2 += wp * (WV[i + 1] - wv_c); a22 += wp; }
+    #define LEFT_H() if (x > 0) { const float wl = wgt_at(y, x - 1); b1 -= wl * (wu_c - WU[i - 1]); a11 += wl; b2 -= wl * (wv_c - WV[i - 1]); a22 += wl; }
+    #define OWN_V() if (y < h - 1) { b1 += wp * (WU[i + w] - wu_c); a11 += wp; b2 += wp * (WV[i + w] - wv_c); a22 += wp; }
+    #define UP_V() if (y > 0) { const float wq = wgt_at(y - 1, x); b1 -= wq * (wu_c - WU[i - w]); a11 += wq; b2 -= wq * (wv_c - WV[i - w]); a22 += wq; }
+    if (red) { OWN_H() LEFT_H() OWN_V() UP_V() }
+    else     { LEFT_H() OWN_H() UP_V() OWN_V() }
+    #undef OWN_H
+    #undef LEFT_H
+    #undef OWN_V
+    #undef UP_V
+    A11[base + i] = a11; A12[base + i] = a12; A22[base + i] = a22; B1[base + i] = b1; B2[base + i] = b2; Wgt[base + i] = wp;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RedBlackSOR_ParBody: one colour of one SOR iteration (plain version: one thread per pixel of the colour).
+// Out-of-image neighbours contribute exactly 0 (zero weight / zero increment in OpenCV's buffer borders).
+__global__ void k_sor_color(int w, int h, float omega, int color, const float* __restrict__ A11, const float* __restrict__ A12,
+                            const float* __restrict__ A22, const float* __restrict__ B1, const float* __restrict__ B2,
+                            const float* __restrict__ Wgt, float* __restrict__ dWu, float* __restrict__ dWv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int x = 2 * k + ((y + color) & 1);
+    if (x >= w) return;
+    const size_t base = (size_t)b * w * h; const int i = y * w + x;
+    const float* Wg = Wgt + base; float* U = dWu + base; float* V = dWv + base;
+    const float wp = Wg[i];
+    const float wl = x > 0 ? Wg[i - 1] : 0.f, wu = y > 0 ? Wg[i - w] : 0.f;
+    const float ul = x > 0 ? U[i - 1] : 0.f, vl = x > 0 ? V[i - 1] : 0.f;
+    const float ur = x < w - 1 ? U[i + 1] : 0.f, vr = x < w - 1 ? V[i + 1] : 0.f;
+    const float uu = y > 0 ? U[i - w] : 0.f, vu = y > 0 ? V[i - w] : 0.f;
+    const float ud = y < h - 1 ? U[i + w] : 0.f, vd = y < h - 1 ? V[i + w] : 0.f;
+    const float sigmaU = wl * ul + wp * ur + wu * uu + wp * ud;
+    const float sigmaV = wl * vl + wp * vr + wu * vu + wp * vd;
+    float du = U[i], dv = V[i];
+    const float a12 = A12[base + i];
+    du += omega * ((sigmaU + B1[base + i] - dv * a12) / A11[base + i] - du);
+    dv += omega * ((sigmaV + B2[base + i] - du * a12) / A22[base + i] - dv);
+    U[i] = du; V[i] = dv;
+}
+
+// tempW = W + dW (end of a fixed-point iteration); with commit != 0 also W = tempW (end of the level)
+__global__ void k_add_flow(const float* __restrict__ Wu, const float* __restrict__ Wv, const float* __restrict__ dWu,
+                           const float* __restrict__ dWv, float* __restrict__ tWu, float* __restrict__ tWv, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    tWu[i] = Wu[i] + dWu[i]; tWv[i] = Wv[i] + dWv[i];
+}
+
+__global__ void k_scale(float* __restrict__ a, float* __restrict__ b, float s, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    a[i] = a[i] * s; b[i] = b[i] * s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Large-motion test, reference DynaDetect.cc:1081-1114: magnitude, max, u8 normalisation, 256-bin histogram.
+// Pass 1: per-image max of |flow| (non-negative floats order like their bit patterns -> integer atomicMax).
+__global__ void k_mag_max(const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ mag, unsigned* __restrict__ maxbits, int n) {
+    const int b = blockIdx.y;
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float x = u[(size_t)b * n + i], y = v[(size_t)b * n + i];
+        const float g = sqrtf(x * x + y * y);
+        if (mag) mag[(size_t)b * n + i] = g;
+        m = fmaxf(m, g);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&maxbits[b], __float_as_uint(m));
+}
+// Pass 2: histogram of saturate_cast<uchar>(mag * (float)(255.0/max)); LDS histogram per workgroup, one global
+// atomic per bin per workgroup.  Optionally stores the u8 image (residual stage).
+__global__ void k_mag_hist(const float* __restrict__ mag, const unsigned* __restrict__ maxbits, int* __restrict__ hist,
+                           uint8_t* __restrict__ out_u8, int n) {
+    __shared__ int lh[256];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const float a = (float)(255.0 / (double)__uint_as_float(maxbits[b]));
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int q = d_cvRound(mag[(size_t)b * n + i] * a);
+        q = min(max(q, 0), 255);
+        if (out_u8) out_u8[(size_t)b * n + i] = (uint8_t)q;
+        atomicAdd(&lh[q], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) if (lh[i]) atomicAdd(&hist[b * 256 + i], lh[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Residual stage, reference DynaDetect.cc:1252-1271: flow - (p - H p), homography part in FP64 then cast to FP32.
+__global__ void k_residual_mag(const float* __restrict__ u, const float* __restrict__ v, HMat Hm, float* __restrict__ mag,
+                               unsigned* __restrict__ maxbits, int w, int h) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    float m = 0.f;
+    if (col < w) {
+        const double* H = Hm.h;
+        const double den = H[6] * col + H[7] * row + H[8];
+        const double fx2 = (col - (H[0] * col + H[1] * row + H[2]) / den);
+        const double fy2 = (row - (H[3] * col + H[4] * row + H[5]) / den);
+        const float dx = u[row * w + col] - (float)fx2, dy = v[row * w + col] - (float)fy2;
+        m = sqrtf(dx * dx + dy * dy);
+        mag[row * w + col] = m;
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxbits, __float_as_uint(m));
+}
+// masks from the u8 residual: low -> 128, high -> 255 (stImgMasks), thresholds decided on the host from the histogram
+__global__ void k_threshold_masks(const uint8_t* __restrict__ magu8, float thr_low, float thr_high, uint8_t* __restrict__ low,
+                                  uint8_t* __restrict__ high, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double q = (double)magu8[i];
+    low[i] = q > (double)thr_low ? 128 : 0;
+    high[i] = q > (double)thr_high ? 255 : 0;
+}
+// gather flow at the 63x47 sample grid (DD:1182-1204) so the host can build the PROSAC-ordered pairs
+__global__ void k_gather_grid(const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ out, int w, int h, int step) {
+    const int gx = (w - 1) / step, gy = (h - 1) / step;   // points at step, 2*step, ... < w
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= gx * gy) return;
+    const int r = (i / gx + 1) * step, c = (i % gx + 1) * step;
+    out[2 * i] = u[r * w + c]; out[2 * i + 1] = v[r * w + c];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cvtColor(BGR2GRAY) 8U fixed point and cv::resize(INTER_LINEAR) 8U (11-bit coefficients), reference DD:1390-1392, 1037-1039
+__global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, size_t n, int cb, int cr) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = bgr + i * 3;
+    gray[i] = (uint8_t)((p[0] * cb + p[1] * 9617 + p[2] * cr + 8192) >> 14);
+}
+__global__ void k_resize_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int sw, int sh, int dw, int dh,
+                            double scale_x, double scale_y, int s_stride, int d_stride, size_t s_img, size_t d_img) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, b = blockIdx.z;
+    if (dx >= dw) return;
+    const uint8_t* S = src + (size_t)b * s_img;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = d_cvFloorf(fx); fx -= sx;
+    const bool two = sx + 1 < sw;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = d_cvFloorf(fy); fy -= sy;
+    const int y0 = d_clip(sy, 0, sh), y1 = d_clip(sy + 1, 0, sh);
+    const int ax0 = (short)d_cvRound((1.f - fx) * 2048), ax1 = (short)d_cvRound(fx * 2048);
+    const int b0 = (short)d_cvRound((1.f - fy) * 2048), b1 = (short)d_cvRound(fy * 2048);
+    const uint8_t* R0 = S + (size_t)y0 * s_stride; const uint8_t* R1 = S + (size_t)y1 * s_stride;
+    int r0, r1;
+    if (two) { r0 = R0[sx] * ax0 + R0[sx + 1] * ax1; r1 = R1[sx] * ax0 + R1[sx + 1] * ax1; }
+    else     { r0 = R0[sx] * 2048;                   r1 = R1[sx] * 2048; }
+    dst[(size_t)b * d_img + (size_t)dy * d_stride + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side launchers
+static inline dim3 grid2d(int w, int h, int B, int bx = 128) { return dim3(divup(w, bx), h, B); }
+
+int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w, int h, int B, float k0, float k1, bool blur) {
+    hipLaunchKernelGGL(k_u8_to_f32_blur3, grid2d(w, h, B), dim3(128), 0, s, src, dst, w, h, k0, k1, blur ? 1 : 0);
+    return SIND_OK;
+}
+int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post) {
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    hipLaunchKernelGGL(k_resize_f32, grid2d(dw, dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, scale_x, scale_y, post, has_post ? 1 : 0);
+    return SIND_OK;
+}
+int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img) {
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    hipLaunchKernelGGL(k_resize_u8, grid2d(dw, dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, scale_x, scale_y, s_stride, d_stride, s_img, d_img);
+    return SIND_OK;
+}
+int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb) {
+    hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, bgr, gray, npix, swap_rb ? 4899 : 1868, swap_rb ? 1868 : 4899);
+    return SIND_OK;
+}
+
+// VariationalRefinement::calcUV on one pyramid level for B pairs.  Wu/Wv: initial flow in, refined flow out.
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V) {
+    const size_t n = (size_t)w * h * B;
+    const dim3 g = grid2d(w, h, B), blk(128);
+    hipLaunchKernelGGL(k_warp_avg_iz, g, blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, w, h);
+    hipLaunchKernelGGL(k_derivs, g, blk, 0, s, P.avg, P.Iz, P.Ix, P.Iy, P.Ixx, P.Ixy, P.Iyy, P.Ixz, P.Iyz, w, h);
+    HIP_TRY(hipMemsetAsync(P.dWu, 0, n * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(P.dWv, 0, n * sizeof(float), s));
+    HIP_TRY(hipMemcpyAsync(P.tWu, P.Wu, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(P.tWv, P.Wv, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const dim3 gs(divup(divup(w, 2), 64), h, B), bs(64);
+    for (int it = 0; it < V.fixedPointIterations; it++) {
+        hipLaunchKernelGGL(k_coef, g, blk, 0, s, V, w, h, P.Ix, P.Iy, P.Iz, P.Ixx, P.Ixy, P.Iyy, P.Ixz, P.Iyz, P.Wu, P.Wv, P.tWu, P.tWv,
+                           P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt);
+        for (int k = 0; k < V.sorIterations; k++) {
+            hipLaunchKernelGGL(k_sor_color, gs, bs, 0, s, w, h, V.omega, 0, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
+            hipLaunchKernelGGL(k_sor_color, gs, bs, 0, s, w, h, V.omega, 1, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
+        }
+        hipLaunchKernelGGL(k_add_flow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.tWu, P.tWv, n);
+    }
+    HIP_TRY(hipMemcpyAsync(P.Wu, P.tWu, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(P.Wv, P.tWv, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipGetLastError());
+    return SIND_OK;
+}
+
+int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, unsigned* maxbits, int* hist, uint8_t* out_u8, int n, int B) {
+    HIP_TRY(hipMemsetAsync(maxbits, 0, B * sizeof(unsigned), s));
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)B * 256 * sizeof(int), s));
+    const int gx = std::min(divup(n, 256), 64);
+    hipLaunchKernelGGL(k_mag_max, dim3(gx, B), dim3(256), 0, s, u, v, mag, maxbits, n);
+    hipLaunchKernelGGL(k_mag_hist, dim3(gx, B), dim3(256), 0, s, mag, maxbits, hist, out_u8, n);
+    return SIND_OK;
+}
+int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h) {
+    HMat Hm; for (int i = 0; i < 9; i++) Hm.h[i] = H[i];
+    HIP_TRY(hipMemsetAsync(maxbits, 0, sizeof(unsigned), s));
+    HIP_TRY(hipMemsetAsync(hist, 0, 256 * sizeof(int), s));
+    hipLaunchKernelGGL(k_residual_mag, dim3(divup(w, 128), h), dim3(128), 0, s, u, v, Hm, mag, maxbits, w, h);
+    const int n = w * h, gx = std::min(divup(n, 256), 64);
+    hipLaunchKernelGGL(k_mag_hist, dim3(gx, 1), dim3(256), 0, s, mag, maxbits, hist, magu8, n);
+    return SIND_OK;
+}
+int launch_threshold_masks(hipStream_t s, const uint8_t* magu8, float lo, float hi, uint8_t* low, uint8_t* high, int n) {
+    hipLaunchKernelGGL(k_threshold_masks, dim3(divup(n, 256)), dim3(256), 0, s, magu8, lo, hi, low, high, n);
+    return SIND_OK;
+}
+int launch_gather_grid(hipStream_t s, const float* u, const float* v, float* out, int w, int h, int step) {
+    const int cnt = ((w - 1) / step) * ((h - 1) / step);
+    hipLaunchKernelGGL(k_gather_grid, dim3(divup(cnt, 256)), dim3(256), 0, s, u, v, out, w, h, step);
+    return SIND_OK;
+}
+int launch_scale2(hipStream_t s, float* a, float* b, float sc, size_t n) {
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, sc, n);
+    return SIND_OK;
+}
+
+}  // namespace sind

@@ -1,0 +1,60 @@
+"""Dense-flow stage handle (sind_flow_* in include/sind_hip.h): batched DeepFlow + VariationalRefinement on the GPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib, ptr
+
+
+class FlowStage:
+    def __init__(self, fw: int = 384, fh: int = 288, max_batch: int = 8, device: int = 0):
+        self.fw, self.fh, self.max_batch = fw, fh, max_batch
+        h = C.c_void_p()
+        check(lib().sind_flow_create(fw, fh, max_batch, device, C.byref(h)), "sind_flow_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sind_flow_destroy(self._h); self._h = None
+
+    __del__ = close
+
+    def levels(self):
+        ws = np.zeros(256, np.int32); hs = np.zeros(256, np.int32)
+        n = check(lib().sind_flow_levels(self._h, ptr(ws), ptr(hs), 256)); return list(zip(ws[:n].tolist(), hs[:n].tolist()))
+
+    def deepflow(self, i0: np.ndarray, i1: np.ndarray):
+        """i0, i1: u8 [B, fh, fw] -> (u, v) f32 [B, fh, fw] (raw DeepFlow output, not negated)."""
+        i0 = np.ascontiguousarray(i0, np.uint8); i1 = np.ascontiguousarray(i1, np.uint8)
+        B = i0.shape[0]; u = np.empty(i0.shape, np.float32); v = np.empty(i0.shape, np.float32)
+        check(lib().sind_flow_deepflow(self._h, ptr(i0), ptr(i1), B, ptr(u), ptr(v)), "sind_flow_deepflow"); return u, v
+
+    def refine(self, i0, i1, u, v):
+        i0 = np.ascontiguousarray(i0, np.uint8); i1 = np.ascontiguousarray(i1, np.uint8)
+        u = np.array(u, np.float32, copy=True, order="C"); v = np.array(v, np.float32, copy=True, order="C")
+        check(lib().sind_flow_refine(self._h, ptr(i0), ptr(i1), i0.shape[0], ptr(u), ptr(v)), "sind_flow_refine"); return u, v
+
+    def varref_f32(self, i0, i1, u, v, fp_iters=5, sor_iters=5, alpha=20.0, delta=5.0, gamma=10.0, omega=1.6):
+        i0 = np.ascontiguousarray(i0, np.float32); i1 = np.ascontiguousarray(i1, np.float32)
+        u = np.array(u, np.float32, copy=True, order="C"); v = np.array(v, np.float32, copy=True, order="C")
+        B, h, w = i0.shape
+        check(lib().sind_flow_varref_f32(self._h, ptr(i0), ptr(i1), w, h, B, ptr(u), ptr(v), fp_iters, sor_iters, C.c_float(alpha),
+                                         C.c_float(delta), C.c_float(gamma), C.c_float(omega)), "sind_flow_varref_f32"); return u, v
+
+    # device-pointer, asynchronous variants (bench / pipeline)
+    def deepflow_dev(self, i0_ptr: int, i1_ptr: int, B: int, u_ptr: int, v_ptr: int):
+        check(lib().sind_flow_deepflow_dev(self._h, ptr(i0_ptr), ptr(i1_ptr), B, ptr(u_ptr), ptr(v_ptr)), "sind_flow_deepflow_dev")
+
+    def refine_dev(self, i0_ptr, i1_ptr, B, u_ptr, v_ptr):
+        check(lib().sind_flow_refine_dev(self._h, ptr(i0_ptr), ptr(i1_ptr), B, ptr(u_ptr), ptr(v_ptr)), "sind_flow_refine_dev")
+
+    def sync(self):
+        check(lib().sind_flow_sync(self._h), "sind_flow_sync")
+
+    def timer_begin(self):
+        check(lib().sind_flow_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float(); check(lib().sind_flow_timer_end(self._h, C.byref(ms))); return ms.value

@@ -1,0 +1,70 @@
+"""GPU parity: dense-flow stage (libsind_hip via the C ABI) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fs():
+    from sindslam_amd.flow import FlowStage
+    f = FlowStage(384, 288, max_batch=4)
+    yield f
+    f.close()
+
+
+def _small_pair(frames, w, h):
+    bgr, _ = frames
+    g0 = O.resize_u8(O.bgr2gray(bgr[2]), w, h); g1 = O.resize_u8(O.bgr2gray(bgr[0]), w, h)
+    return g0, g1
+
+
+def test_levels_match_oracle(fs):
+    assert fs.levels() == O.deepflow_levels(384, 288)
+    assert len(fs.levels()) == 49 and fs.levels()[-1] == (33, 26)
+
+
+@pytest.mark.parametrize("w,h", [(33, 26), (64, 48), (97, 61), (128, 96)])
+def test_varref_one_level_bitexact(fs, frames, w, h):
+    g0, g1 = _small_pair(frames, w, h)
+    rng = np.random.default_rng(w * 1000 + h)
+    u0 = rng.normal(0, 1.0, (h, w)).astype(np.float32); v0 = rng.normal(0, 1.0, (h, w)).astype(np.float32)
+    i0 = g0.astype(np.float32); i1 = g1.astype(np.float32)
+    # DeepFlow-level parameters (4*alpha, delta/3, gamma/3, 5 x 25) -- float32 arithmetic as in deepflow.cpp
+    a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
+    ou, ov = O.varref(i0, i1, u0, v0, 5, 25, a, d, g, 1.6)
+    gu, gv = fs.varref_f32(np.stack([i0, i0]), np.stack([i1, i1]), np.stack([u0, u0]), np.stack([v0, v0]), 5, 25, a, d, g, 1.6)
+    for b in range(2):     # both batch entries identical and equal to the oracle
+        assert np.array_equal(gu[b].view(np.uint32), ou.view(np.uint32)), np.abs(gu[b] - ou).max()
+        assert np.array_equal(gv[b].view(np.uint32), ov.view(np.uint32)), np.abs(gv[b] - ov).max()
+
+
+def test_deepflow_small_bitexact(frames):
+    from sindslam_amd.flow import FlowStage
+    w, h = 96, 72
+    g0, g1 = _small_pair(frames, w, h)
+    f = FlowStage(w, h, max_batch=2)
+    assert f.levels() == O.deepflow_levels(w, h)
+    u, v = f.deepflow(np.stack([g0, g1]), np.stack([g1, g0]))
+    of = O.deepflow(g0, g1); ob = O.deepflow(g1, g0)
+    assert np.array_equal(u[0].view(np.uint32), of[..., 0].view(np.uint32)), np.abs(u[0] - of[..., 0]).max()
+    assert np.array_equal(v[0].view(np.uint32), of[..., 1].view(np.uint32))
+    assert np.array_equal(u[1].view(np.uint32), ob[..., 0].view(np.uint32))
+    assert np.array_equal(v[1].view(np.uint32), ob[..., 1].view(np.uint32))
+    f.close()
+
+
+def test_deepflow_full_size(fs, frames):
+    """384x288 (the reference's flow grid): tolerance stated by SURVEY §8c is 1e-3 px; we expect bit equality."""
+    g0, g1 = _small_pair(frames, 384, 288)
+    u, v = fs.deepflow(g0[None], g1[None])
+    o = O.deepflow(g0, g1)
+    err = max(np.abs(u[0] - o[..., 0]).max(), np.abs(v[0] - o[..., 1]).max())
+    assert err <= 1e-3, err
+    assert np.array_equal(u[0].view(np.uint32), o[..., 0].view(np.uint32)) and np.array_equal(v[0].view(np.uint32), o[..., 1].view(np.uint32))
+    # refinement on top of the negated flow (reference DynaDetect.cc:1080, 1133-1143)
+    ru, rv = fs.refine(g0[None], g1[None], -u, -v)
+    ou, ov = O.varref(g0.astype(np.float32), g1.astype(np.float32), -o[..., 0], -o[..., 1])
+    assert np.array_equal(ru[0].view(np.uint32), ou.view(np.uint32)) and np.array_equal(rv[0].view(np.uint32), ov.view(np.uint32))

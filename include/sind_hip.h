@@ -51,6 +51,33 @@ int sind_flow_sync(sind_flow* f);
 int sind_flow_timer_begin(sind_flow* f);
 int sind_flow_timer_end(sind_flow* f, float* milliseconds);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * ORBextractor.  Replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:54-88):
+ *   ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)     src/ORBextractor.cc:410-470  -> sind_orb_create
+ *   operator()(image, mask, keypoints, descriptors)                         src/ORBextractor.cc:1043-1164 -> sind_orb_extract
+ *   GetLevels / GetScaleFactor(s) / GetInverseScaleFactors / Get(Inverse)ScaleSigmaSquares -> sind_orb_tables
+ *   public member mvImagePyramid (read by Frame::ComputeStereoMatches)                     -> sind_orb_pyramid
+ * sind_keypoint mirrors cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id).
+ * mask: the dilated imgDyna (255 = dynamic) or NULL; "empty image -> silent return" maps to n = 0 with SIND_OK.
+ */
+typedef struct sind_orb sind_orb;
+typedef struct sind_keypoint { float x, y, size, angle, response; int octave, class_id; } sind_keypoint;
+int sind_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device, sind_orb** out);
+int sind_orb_destroy(sind_orb* o);
+int sind_orb_reserve(sind_orb* o, int width, int height, int max_batch);   /* optional: pre-size the workspaces */
+int sind_orb_extract(sind_orb* o, const uint8_t* gray, int width, int height, int stride, const uint8_t* mask_or_null, int mask_stride,
+                     sind_keypoint* kps, int cap, int* n, uint8_t* desc /* cap x 32 */);
+/* B images [B][height][width] dense (host); masks [B][height][width] or NULL; outputs [B][cap], n[B], desc [B][cap][32] */
+int sind_orb_extract_batch(sind_orb* o, const uint8_t* gray, int width, int height, int B, const uint8_t* masks_or_null,
+                           sind_keypoint* kps, int cap, int* n, uint8_t* desc);
+int sind_orb_tables(sind_orb* o, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int* features_per_level, int* umax16);
+/* padded pyramid level of frame `frame` of the last call (19-px REFLECT_101 border): copies (w+38)*(h+38) bytes */
+int sind_orb_pyramid(sind_orb* o, int frame, int level, uint8_t* out, int* w, int* h);
+/* parity-test access to the stage outputs of the last call: cell-wise FAST keypoints of one level (x, y, response triplets,
+ * coordinates relative to the 16-px min border) and the octree survivors with their orientation before mask erasure */
+int sind_orb_debug_fast(sind_orb* o, int frame, int level, float* xyr, int cap);
+int sind_orb_debug_selected(sind_orb* o, int frame, sind_keypoint* kps, int cap, uint8_t* desc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,29 @@ int sind_orb_pyramid(sind_orb* o, int frame, int level, uint8_t* out, int* w, in
 int sind_orb_debug_fast(sind_orb* o, int frame, int level, float* xyr, int cap);
 int sind_orb_debug_selected(sind_orb* o, int frame, sind_keypoint* kps, int cap, uint8_t* desc);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * DynaDetect.  Replaces ORB_SLAM2::DynaDetect (include/DynaDetect.h:95-131):
+ *   DynaDetect(imgLast, imgLastLast, fx, fy, cx, cy, depthScale)   DynaDetect.h:98-126         -> sind_dyna_create + sind_dyna_prime
+ *   DetectDynaArea(img, imgDepth, imgDyna, imgLabel, nImg)         DynaDetect.cc:1377-1666     -> sind_dyna_detect
+ * img: CV_8UC3 BGR, imgDepth: CV_16UC1 (raw units = metres * depthScale), imgDyna: CV_8UC1 0 invalid / 125 static /
+ * 255 dynamic, imgLabel: CV_8UC1 0 invalid, 1..n.  The reference's imshow / waitKey / stdout side effects are dropped.
+ * Like the reference class the handle carries inter-frame state and is not re-entrant.
+ */
+typedef struct sind_dyna sind_dyna;
+int sind_dyna_create(int width, int height, float fx, float fy, float cx, float cy, float depth_scale, int device, sind_dyna** out);
+int sind_dyna_destroy(sind_dyna* d);
+int sind_dyna_prime(sind_dyna* d, const uint8_t* bgr_last, const uint8_t* bgr_lastlast, int stride);
+int sind_dyna_detect(sind_dyna* d, const uint8_t* bgr, int bgr_stride, const uint16_t* depth, int depth_stride,
+                     uint8_t* dyna_out, uint8_t* label_out, int n_img);
+/* caller-side 15x15 elliptical dilation of imgDyna before tracking (Examples/RGB-D/rgbd_tum_noros.cc:108,138), in place */
+int sind_dyna_dilate15(sind_dyna* d, uint8_t* dyna_inout);
+/* parity-test access to the stage outputs of the last sind_dyna_detect call; any pointer may be NULL.
+ * flow_*: f32 planes (u then v), deep/refined at the 0.6 grid, full at width x height.  thr = {maxError, otsu, triangle, low, high}.
+ * info = {largeMotion, nPairs, nPieces}. */
+int sind_dyna_debug(sind_dyna* d, float* flow_deep, float* flow_refined, float* flow_full, double* H9, float* thr5, int* hist256,
+                    uint8_t* mask_low, uint8_t* mask_high, uint8_t* kmeans_label, float* centers36, uint8_t* occ1, uint8_t* occ2,
+                    uint8_t* total_area, uint8_t* grad_edge, uint8_t* plane_contours, int* info3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,10 @@ void orc_dyna_debug(void* p, float* flow_full, double* H, float* thr /*maxError,
     if (info) { info[0] = g.largeMotion; info[1] = g.nPairs; info[2] = g.nClusters; }
 }
 
+void orc_dyna_debug2(void* p, uint8_t* grad_edge, uint8_t* plane_contours, uint8_t* label_for_seg_edge) {
+    DynaDetect* d = (DynaDetect*)p; put(d->dbg.gradEdge, grad_edge); put(d->dbg.planeContours, plane_contours); put(d->dbg.labelForSegEdge, label_for_seg_edge);
+}
+
 // ---------------------------------------------------------------- ORBextractor
 struct OrcKp { float x, y, size, angle, response; int octave, class_id; };
 void* orc_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh) { return new ORBextractor(nfeatures, scaleFactor, nlevels, iniTh, minTh); }

@@ -1,0 +1,108 @@
+// C ABI: DynaDetect, single stream, one frame per call (include/sind_hip.h).
+#include <cstring>
+#include "../../include/sind_hip.h"
+#include "dyna.hpp"
+
+struct sind_dyna {
+    sind::DynaConfig cfg; hipStream_t stream = nullptr; sind::DynaFront front; sind::DynaTail tail;
+    DevBuf<uint8_t> bgr, gray, pool, dil_a, dil_b; DevBuf<uint16_t> depth; DevBuf<float> U, V;
+    int t = 0; bool primed = false; int largeMotion = 0;
+    std::vector<float> deep, refined;
+};
+
+extern "C" {
+
+int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float ds, int device, sind_dyna** out) {
+    if (!out || w < 64 || h < 64 || ds <= 0) { sind_set_error("sind_dyna_create: bad arguments"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    sind_dyna* d = new sind_dyna();
+    d->cfg.W = w; d->cfg.H = h; d->cfg.fx = fx; d->cfg.fy = fy; d->cfg.cx = cx; d->cfg.cy = cy; d->cfg.depthScale = ds; d->cfg.device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    int r = d->front.init(d->cfg, 1, d->stream);
+    if (r == SIND_OK) r = d->tail.init(d->cfg, d->stream);
+    const size_t np = (size_t)w * h;
+    if (r == SIND_OK) r = d->bgr.alloc(np * 3);
+    if (r == SIND_OK) r = d->gray.alloc(np);
+    if (r == SIND_OK) r = d->pool.alloc((size_t)d->front.fw * d->front.fh * 3);
+    if (r == SIND_OK) r = d->depth.alloc(np);
+    if (r == SIND_OK) r = d->U.alloc(np);
+    if (r == SIND_OK) r = d->V.alloc(np);
+    if (r == SIND_OK) r = d->dil_a.alloc(np);
+    if (r == SIND_OK) r = d->dil_b.alloc(np);
+    if (r != SIND_OK) { delete d; return r; }
+    d->tail.keep_debug = true;
+    *out = d; return SIND_OK;
+}
+int sind_dyna_destroy(sind_dyna* d) {
+    if (!d) return SIND_OK;
+    (void)hipSetDevice(d->cfg.device);
+    hipStream_t s = d->stream; if (s) (void)hipStreamSynchronize(s);
+    delete d; if (s) (void)hipStreamDestroy(s);
+    return SIND_OK;
+}
+static int upload_bgr(sind_dyna* d, const uint8_t* bgr, int stride, int slot) {
+    const int w = d->cfg.W, h = d->cfg.H;
+    HIP_TRY(hipMemcpy2DAsync(d->bgr.p, (size_t)w * 3, bgr, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, d->stream));
+    return d->front.gray_and_min(d->bgr.p, 1, d->gray.p, d->pool.p + (size_t)d->front.fw * d->front.fh * slot);
+}
+int sind_dyna_prime(sind_dyna* d, const uint8_t* last, const uint8_t* lastlast, int stride) {
+    if (!d || !last || !lastlast) { sind_set_error("sind_dyna_prime: null argument"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    if (stride <= 0) stride = d->cfg.W * 3;
+    SIND_TRY(upload_bgr(d, lastlast, stride, 0));       // frame n-2
+    SIND_TRY(upload_bgr(d, last, stride, 1));           // frame n-1
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->t = 2; d->primed = true; d->tail.reset();
+    return SIND_OK;
+}
+int sind_dyna_detect(sind_dyna* d, const uint8_t* bgr, int bstride, const uint16_t* depth, int dstride, uint8_t* dyna_out, uint8_t* label_out, int) {
+    if (!d || !bgr || !depth || !dyna_out || !label_out) { sind_set_error("sind_dyna_detect: null argument"); return SIND_E_ARG; }
+    if (!d->primed) { sind_set_error("sind_dyna_detect: call sind_dyna_prime first (the reference constructor takes the two previous frames)"); return SIND_E_STATE; }
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    const int w = d->cfg.W, h = d->cfg.H;
+    if (bstride <= 0) bstride = w * 3;
+    if (dstride <= 0) dstride = w * 2;
+    const int cur = d->t % 3, p1 = (d->t + 2) % 3, p2 = (d->t + 1) % 3;
+    SIND_TRY(upload_bgr(d, bgr, bstride, cur));
+    std::vector<uint16_t> dh((size_t)w * h);
+    for (int y = 0; y < h; y++) std::memcpy(&dh[(size_t)y * w], (const uint8_t*)depth + (size_t)y * dstride, (size_t)w * 2);
+    HIP_TRY(hipMemcpyAsync(d->depth.p, dh.data(), dh.size() * 2, hipMemcpyHostToDevice, d->stream));
+    const size_t nf = (size_t)d->front.fw * d->front.fh;
+    d->deep.resize(nf * 2); d->refined.resize(nf * 2);
+    SIND_TRY(d->front.dense_flow(d->pool.p, &cur, &p1, &p2, 1, d->U.p, d->V.p, &d->largeMotion, d->deep.data(), d->deep.data() + nf, d->refined.data(), d->refined.data() + nf));
+    SIND_TRY(d->tail.process(dh.data(), d->depth.p, d->U.p, d->V.p, dyna_out, label_out));
+    d->t++;
+    return SIND_OK;
+}
+int sind_dyna_dilate15(sind_dyna* d, uint8_t* io) {
+    if (!d || !io) return SIND_E_ARG;
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    const size_t np = (size_t)d->cfg.W * d->cfg.H;
+    HIP_TRY(hipMemcpyAsync(d->dil_a.p, io, np, hipMemcpyHostToDevice, d->stream));
+    SIND_TRY(sind::launch_morph(d->stream, d->dil_a.p, d->dil_b.p, d->cfg.W, d->cfg.H, 15, true));
+    HIP_TRY(hipMemcpyAsync(io, d->dil_b.p, np, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SIND_OK;
+}
+int sind_dyna_debug(sind_dyna* d, float* flow_deep, float* flow_refined, float* flow_full, double* H9, float* thr5, int* hist256, uint8_t* mask_low,
+                    uint8_t* mask_high, uint8_t* kmeans_label, float* centers36, uint8_t* occ1, uint8_t* occ2, uint8_t* total_area, uint8_t* grad_edge,
+                    uint8_t* plane_contours, int* info3) {
+    if (!d) return SIND_E_ARG;
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    const size_t np = (size_t)d->cfg.W * d->cfg.H;
+    const sind::DynaDebug& g = d->tail.dbg;
+    if (flow_deep && !d->deep.empty()) std::memcpy(flow_deep, d->deep.data(), d->deep.size() * 4);
+    if (flow_refined && !d->refined.empty()) std::memcpy(flow_refined, d->refined.data(), d->refined.size() * 4);
+    if (flow_full) { HIP_TRY(hipMemcpy(flow_full, d->U.p, np * 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(flow_full + np, d->V.p, np * 4, hipMemcpyDeviceToHost)); }
+    if (H9) std::memcpy(H9, g.H, sizeof(g.H));
+    if (thr5) { thr5[0] = g.maxError; thr5[1] = g.otsu; thr5[2] = g.triangle; thr5[3] = g.thr_low; thr5[4] = g.thr_high; }
+    if (hist256) std::memcpy(hist256, g.hist, sizeof(g.hist));
+    auto put = [&](uint8_t* dst, const std::vector<uint8_t>& src) { if (dst && src.size() == np) std::memcpy(dst, src.data(), np); };
+    put(mask_low, g.maskLow); put(mask_high, g.maskHigh); put(kmeans_label, g.kmeansLabel); put(occ1, g.occ1); put(occ2, g.occ2);
+    put(total_area, g.totalArea); put(grad_edge, g.gradEdge); put(plane_contours, g.planeContours);
+    if (centers36) std::memcpy(centers36, g.centers, sizeof(g.centers));
+    if (info3) { info3[0] = d->largeMotion; info3[1] = g.nPairs; info3[2] = g.nClusters; }
+    return SIND_OK;
+}
+
+}  // extern "C"

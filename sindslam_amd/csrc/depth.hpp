@@ -1,0 +1,35 @@
+// Depth-side device stage interface (host side of depth_kernels.hip).
+#pragma once
+#include <cmath>
+#include "common.hpp"
+
+namespace sind {
+
+#define KM_K 12               /* numCluster = 3 x 4, reference DynaDetect.cc:46-47 */
+#define KM_MAX_BLOCKS 240
+#define MORPH_MAX 16
+
+struct KmCenters { float c[KM_K][3]; };
+struct MorphElem { int n, ax, ay; int j1[MORPH_MAX], j2[MORPH_MAX]; };
+struct PeacBlockStats { double sx, sy, sz, sxx, syy, szz, sxy, syz, sxz; int N, valid; };
+
+MorphElem make_ellipse(int n);
+int launch_depth_half(hipStream_t s, const uint16_t* src, uint16_t* dst, int dw, int dh);
+int launch_points(hipStream_t s, const uint16_t* depth, float* px, float* py, float* pz, int w, int h, float scale, float fx, float fy, float cx, float cy, float depthScale);
+int launch_labels_grid(hipStream_t s, int* labels, int w, int h);
+int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw, int sh, int dw, int dh);
+int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh);
+int launch_kmeans_sums(hipStream_t s, const float* px, const float* py, const float* pz, const int* labels, int n, double* partial, double* sums);
+int launch_kmeans_assign(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, const KmCenters& C);
+int launch_kmeans_farthest(hipStream_t s, const float* px, const float* py, const float* pz, const int* labels, int n, int which, const float c[3], unsigned long long* best);
+int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n);
+int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h);
+int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out);
+int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, uint8_t* edge, uint8_t* total_area, int w, int h, float depthScale);
+int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, int n, bool dilate);
+int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out);
+int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n);
+int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int w, int h, int wpr, const uint8_t* occ2, const uint8_t* depthN,
+                     int* overlap, int* overlapPlane, int* ljOverlap, int* ljArea, int* hist);
+
+}  // namespace sind

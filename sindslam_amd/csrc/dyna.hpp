@@ -1,0 +1,63 @@
+// DynaDetect engine interface: state-free GPU front (gray, 0.6 resize, dense flow, up-scale) and the stateful
+// per-stream tail (k-means, depth edges, PEAC, split/merge re-clustering, residual thresholds, mask fusion).
+#pragma once
+#include <memory>
+#include <vector>
+#include "common.hpp"
+#include "depth.hpp"
+#include "flow.hpp"
+#include "host/host.hpp"
+
+namespace sind {
+
+struct DynaConfig { int W = 640, H = 480; float fx = 0, fy = 0, cx = 0, cy = 0, depthScale = 5000.f; int device = 0; };
+
+// ---- state-free front for B frames at once (reference DynaDetect.cc:1386-1392 gray, :1033-1147 flow) ------------------
+class DynaFront {
+public:
+    DynaConfig cfg; int fw = 0, fh = 0, maxB = 0; hipStream_t stream = nullptr;
+    FlowEngine flow;
+    int init(const DynaConfig& c, int maxB, hipStream_t s);
+    // bgr: device u8 [n][H][W][3] -> gray [n][H][W] and grayMin [n][fh][fw] (both device, caller-owned)
+    int gray_and_min(const uint8_t* bgr, int n, uint8_t* gray, uint8_t* grayMin);
+    // Dense flow for B pairs.  pool: device u8 frames [*][fh][fw]; cur/prev1/prev2: HOST index arrays into the pool
+    // (frame n, n-1, n-2 of each pair).  U/V: device f32 [B][H*W] full-resolution flow (negated, refined, *1/0.6).
+    // large_motion (host, optional): per-pair flag of the reference's second DeepFlow pass.
+    int dense_flow(const uint8_t* pool, const int* cur, const int* prev1, const int* prev2, int B, float* U, float* V, int* large_motion,
+                   float* dbg_deep_u = nullptr, float* dbg_deep_v = nullptr, float* dbg_ref_u = nullptr, float* dbg_ref_v = nullptr);
+private:
+    DevBuf<uint8_t> g0, g1; DevBuf<float> u, v, mag, u2, v2; DevBuf<unsigned> maxbits; DevBuf<int> hist, idx_dev;
+    int gather(const uint8_t* pool, const int* idx_host, int B, uint8_t* out);
+};
+
+struct DynaDebug {           // stage outputs of the last tail call (parity tests)
+    double H[9] = {0}; int nPairs = 0, hist[256] = {0}; float maxError = 0, otsu = 0, triangle = 0, thr_low = 0, thr_high = 0;
+    std::vector<uint8_t> maskLow, maskHigh, kmeansLabel, occ1, occ2, totalArea, gradEdge, planeContours;
+    float centers[KM_K][3] = {{0}}; int nClusters = 0;
+};
+
+// ---- stateful tail of one stream (reference DynaDetect.cc:1377-1666 minus the dense flow) ---------------------------------
+class DynaTail {
+public:
+    DynaConfig cfg; hipStream_t stream = nullptr; DynaDebug dbg; bool keep_debug = false;
+    int init(const DynaConfig& c, hipStream_t s);
+    // depth_host: H x W u16 (host); depth_dev: same on the device; U/V: device full-resolution flow of this frame.
+    // dyna_out / label_out: host H x W u8 (0 invalid / 125 static / 255 dynamic ; 0 invalid, 1..n clusters).
+    int process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out);
+    void reset();
+private:
+    int W = 0, H = 0, N = 0;
+    std::vector<uint8_t> dynaLast, labelLast, highLast;       // host state images (DynaDetect.h:172-178)
+    bool labelLastAny = false;
+    // device workspaces
+    DevBuf<uint16_t> dpyr[4], filt; DevBuf<float> px, py, pz; DevBuf<int> lab[4]; DevBuf<uint8_t> lab8, labPrev8, edge, edgeTmp, total, depthN, occ2_d, magu8, low_d, high_d;
+    DevBuf<double> kpart, ksums; DevBuf<unsigned long long> far_d, planes_d; DevBuf<unsigned> umax_d, maxbits; DevBuf<int> hist_d, rag_d; DevBuf<float> mag, grid_d;
+    DevBuf<PeacBlockStats> blocks_d;
+    int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high);
+    int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
+    int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2);
+    int seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,
+                      const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew);
+};
+
+}  // namespace sind

@@ -1,0 +1,508 @@
+// DynaDetect engine: orchestration of the HIP stages and the serial host stages.
+// Reference walk: ORB_SLAM2/src/DynaDetect.cc DetectDynaArea :1377-1666, DetectDynaByDenseOpticalFLow :1023-1374,
+// SegByKmeans :315-420, CalOccluded :429-642, SegAndMergeV2 :653-1018, cal_hist :1685-1739.
+// Per-pixel work runs in flow_kernels.hip / depth_kernels.hip; contour / graph / flood-fill logic is serial, tiny and
+// order-defined and runs on bit-packed masks on the host (DESIGN.md "host stages").  No CPU fallback exists for any
+// device stage: every launch error is returned to the caller.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include "dyna.hpp"
+#include "host/rng.hpp"
+
+namespace sind {
+
+// ======================================================================================================= front
+int DynaFront::init(const DynaConfig& c, int maxB_, hipStream_t s) {
+    cfg = c; maxB = maxB_; stream = s;
+    const float scale_element = 0.6f;                                   // DD:1033
+    fw = (int)(scale_element * c.W); fh = (int)(scale_element * c.H);
+    SIND_TRY(flow.init(fw, fh, maxB, s));
+    const size_t nf = (size_t)fw * fh * maxB;
+    SIND_TRY(g0.alloc(nf)); SIND_TRY(g1.alloc(nf)); SIND_TRY(u.alloc(nf)); SIND_TRY(v.alloc(nf)); SIND_TRY(u2.alloc(nf)); SIND_TRY(v2.alloc(nf)); SIND_TRY(mag.alloc(nf));
+    SIND_TRY(maxbits.alloc(maxB)); SIND_TRY(hist.alloc((size_t)maxB * 256)); SIND_TRY(idx_dev.alloc(maxB));
+    return SIND_OK;
+}
+
+int DynaFront::gray_and_min(const uint8_t* bgr, int n, uint8_t* gray, uint8_t* grayMin) {
+    const size_t np = (size_t)cfg.W * cfg.H;
+    SIND_TRY(launch_bgr2gray(stream, bgr, gray, np * n, false));
+    SIND_TRY(launch_resize_u8(stream, gray, grayMin, cfg.W, cfg.H, fw, fh, n, cfg.W, fw, np, (size_t)fw * fh));
+    return SIND_OK;
+}
+
+int DynaFront::gather(const uint8_t* pool, const int* idx, int B, uint8_t* out) {
+    const size_t fb = (size_t)fw * fh;
+    for (int b = 0; b < B; b++) HIP_TRY(hipMemcpyAsync(out + fb * b, pool + fb * idx[b], fb, hipMemcpyDeviceToDevice, stream));
+    return SIND_OK;
+}
+
+int DynaFront::dense_flow(const uint8_t* pool, const int* cur, const int* prev1, const int* prev2, int B, float* U, float* V, int* large_motion,
+                          float* dbg_du, float* dbg_dv, float* dbg_ru, float* dbg_rv) {
+    if (B < 1 || B > maxB) { sind_set_error("dense_flow: batch %d outside [1,%d]", B, maxB); return SIND_E_ARG; }
+    const int nf = fw * fh; const size_t nfB = (size_t)nf * B;
+    // pass 1: flow(n, n-2) for every pair (DD:1075)
+    SIND_TRY(gather(pool, cur, B, g0.p)); SIND_TRY(gather(pool, prev2, B, g1.p));
+    SIND_TRY(flow.deepflow(g0.p, g1.p, B, u.p, v.p));
+    // large-motion test on |flow| (DD:1081-1114): max, u8 normalisation, histogram on the GPU, percentile test here
+    SIND_TRY(launch_mag_stats(stream, u.p, v.p, mag.p, maxbits.p, hist.p, nullptr, nf, B));
+    std::vector<unsigned> h_max(B); std::vector<int> h_hist((size_t)B * 256);
+    HIP_TRY(hipMemcpyAsync(h_max.data(), maxbits.p, B * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_hist.data(), hist.p, (size_t)B * 256 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<int> flagged; std::vector<int> lm(B, 0);
+    const float scale_element = 0.6f;
+    for (int b = 0; b < B; b++) {
+        float maxFlowf; std::memcpy(&maxFlowf, &h_max[b], 4);
+        const double maxFlow = maxFlowf;
+        const int endFlow = (int)(10.0f * scale_element * 255.0f / maxFlow);
+        int endFlow2 = 0; float ratio = 0.0f;
+        const float totalpixel = cfg.W * cfg.H * scale_element * scale_element;
+        for (int i = 0; i < 255; ++i) { ratio += (float)h_hist[(size_t)b * 256 + i]; if (ratio > 0.3f * totalpixel) { endFlow2 = i; break; } }
+        if (endFlow2 > endFlow) { lm[b] = 1; flagged.push_back(b); }
+    }
+    if (large_motion) std::copy(lm.begin(), lm.end(), large_motion);
+    // pass 2: flow(n, n-1) for the flagged pairs only (DD:1121-1131)
+    if (!flagged.empty()) {
+        const int B2 = (int)flagged.size();
+        std::vector<int> c2(B2), p2(B2);
+        for (int k = 0; k < B2; k++) { c2[k] = cur[flagged[k]]; p2[k] = prev1[flagged[k]]; }
+        SIND_TRY(gather(pool, c2.data(), B2, g0.p)); SIND_TRY(gather(pool, p2.data(), B2, g1.p));
+        SIND_TRY(flow.deepflow(g0.p, g1.p, B2, u2.p, v2.p));
+        for (int k = 0; k < B2; k++) {
+            HIP_TRY(hipMemcpyAsync(u.p + (size_t)nf * flagged[k], u2.p + (size_t)nf * k, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(v.p + (size_t)nf * flagged[k], v2.p + (size_t)nf * k, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    SIND_TRY(launch_scale2(stream, u.p, v.p, -1.0f, nfB));                                   // imgDenseFlow *= -1 (DD:1080, 1129)
+    if (dbg_du) { HIP_TRY(hipMemcpyAsync(dbg_du, u.p, nfB * 4, hipMemcpyDeviceToHost, stream)); HIP_TRY(hipMemcpyAsync(dbg_dv, v.p, nfB * 4, hipMemcpyDeviceToHost, stream)); }
+    // refinement against the frame actually used (DD:1133-1143)
+    std::vector<int> sel(B); for (int b = 0; b < B; b++) sel[b] = lm[b] ? prev1[b] : prev2[b];
+    SIND_TRY(gather(pool, cur, B, g0.p)); SIND_TRY(gather(pool, sel.data(), B, g1.p));
+    SIND_TRY(flow.refine(g0.p, g1.p, B, u.p, v.p));
+    if (dbg_ru) { HIP_TRY(hipMemcpyAsync(dbg_ru, u.p, nfB * 4, hipMemcpyDeviceToHost, stream)); HIP_TRY(hipMemcpyAsync(dbg_rv, v.p, nfB * 4, hipMemcpyDeviceToHost, stream)); }
+    // resize to the full frame and undo the 0.6 scale (DD:1144-1147)
+    const float inv = 1.0f / scale_element;
+    SIND_TRY(launch_resize_f32(stream, u.p, U, fw, fh, cfg.W, cfg.H, B, inv, true));
+    SIND_TRY(launch_resize_f32(stream, v.p, V, fw, fh, cfg.W, cfg.H, B, inv, true));
+    HIP_TRY(hipGetLastError());
+    return SIND_OK;
+}
+
+// ======================================================================================================= tail
+int DynaTail::init(const DynaConfig& c, hipStream_t s) {
+    cfg = c; stream = s; W = c.W; H = c.H; N = W * H;
+    if (W % 64 != 0 || W % 8 != 0 || H % 8 != 0) { sind_set_error("DynaTail: width must be a multiple of 64 and height of 8 (got %dx%d)", W, H); return SIND_E_ARG; }
+    reset();
+    for (int l = 1; l < 4; l++) SIND_TRY(dpyr[l].alloc((size_t)N >> (2 * l)));
+    for (int l = 0; l < 4; l++) SIND_TRY(lab[l].alloc((size_t)N >> (2 * l)));
+    SIND_TRY(filt.alloc(N)); SIND_TRY(px.alloc(N)); SIND_TRY(py.alloc(N)); SIND_TRY(pz.alloc(N)); SIND_TRY(lab8.alloc(N)); SIND_TRY(labPrev8.alloc(N));
+    SIND_TRY(edge.alloc(N)); SIND_TRY(edgeTmp.alloc(N)); SIND_TRY(total.alloc(N)); SIND_TRY(depthN.alloc(N)); SIND_TRY(occ2_d.alloc(N));
+    SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc(N)); SIND_TRY(high_d.alloc(N)); SIND_TRY(mag.alloc(N));
+    SIND_TRY(kpart.alloc((size_t)KM_MAX_BLOCKS * KM_K * 4)); SIND_TRY(ksums.alloc(KM_K * 4)); SIND_TRY(far_d.alloc(1)); SIND_TRY(umax_d.alloc(2)); SIND_TRY(maxbits.alloc(1));
+    SIND_TRY(hist_d.alloc(256)); SIND_TRY(grid_d.alloc(2 * 64 * 48)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
+    return SIND_OK;
+}
+void DynaTail::reset() { dynaLast.assign(N, 0); labelLast.assign(N, 0); highLast.assign(N, 0); labelLastAny = false; }
+
+// ---- DD:1163-1367: sample weights -> PROSAC pairs -> homography -> residual -> Otsu / Triangle thresholds -> masks
+int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& high) {
+    const int numCluster = KM_K;
+    SIND_TRY(launch_gather_grid(stream, U, V, grid_d.p, W, H, 10));
+    const int gx = (W - 1) / 10, gy = (H - 1) / 10;
+    std::vector<float> gridFlow((size_t)2 * gx * gy);
+    HIP_TRY(hipMemcpyAsync(gridFlow.data(), grid_d.p, gridFlow.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    // previous-frame dynamic ratio per cluster (DD:1169-1177)
+    std::vector<float> clusterWeight(numCluster, 0.0f);
+    { int nC[256] = {0}, nD[256] = {0};
+      for (int k = 0; k < N; k++) { const int l = labelLast[k]; nC[l]++; nD[l] += dynaLast[k] == 255; }
+      for (int i = 1; i < numCluster; i++) clusterWeight[i] = (float)nD[i] / (float)(nC[i] + 1.0f); }
+    struct PW { int x, y; float weight; };
+    std::vector<PW> pts; pts.reserve((size_t)gx * gy);
+    CvRng rng(12345);
+    for (int row = 10; row < H; row += 10) for (int col = 10; col < W; col += 10) {
+        const float randomd = (float)rng.gaussian(0.5);
+        const uint8_t dl = dynaLast[(size_t)row * W + col];
+        if (dl < 20) pts.push_back({col, row, randomd + 1.0f});
+        else if ((unsigned)(dl - 20) <= 230 - 20) { const int label = labelLast[(size_t)row * W + col]; pts.push_back({col, row, randomd + 1.2f * (1.0f - clusterWeight[label])}); }
+        else pts.push_back({col, row, randomd + 0.4f});
+    }
+    std::sort(pts.begin(), pts.end(), [](const PW& a, const PW& b) { return a.weight > b.weight; });
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<Pt2f> in, inLast;
+    for (const PW& p : pts) {
+        const int gi = (p.y / 10 - 1) * gx + (p.x / 10 - 1);
+        const float ptCol = (float)p.x, ptRow = (float)p.y, fxv = gridFlow[2 * gi], fyv = gridFlow[2 * gi + 1];
+        const int r = (int)(ptRow - fyv), c = (int)(ptCol - fxv);
+        if ((unsigned)r <= (unsigned)H && (unsigned)c <= (unsigned)W) { in.push_back({ptCol, ptRow}); inLast.push_back({ptCol - fxv, ptRow - fyv}); }
+    }
+    double Hm[9];
+    find_homography_prosac(in, inLast, Hm);
+    SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, maxbits.p, hist_d.p, magu8.p, W, H));
+    unsigned mb; int hist[256];
+    HIP_TRY(hipMemcpyAsync(&mb, maxbits.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(hist, hist_d.p, sizeof(hist), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float maxErrorf; std::memcpy(&maxErrorf, &mb, 4);
+    // cv::threshold(THRESH_OTSU / THRESH_TRIANGLE) return values from the 256-bin histogram (imgproc/thresh.cpp)
+    auto otsu = [&]() {
+        double mu = 0; const double scale = 1. / N;
+        for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
+        mu *= scale;
+        double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+        for (int i = 0; i < 256; i++) {
+            const double p_i = hist[i] * scale; mu1 *= q1; q1 += p_i; const double q2 = 1. - q1;
+            if (std::min(q1, q2) < FLT_EPSILON || std::max(q1, q2) > 1. - FLT_EPSILON) continue;
+            mu1 = (mu1 + i * p_i) / q1; const double mu2 = (mu - q1 * mu1) / q2, sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+            if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+        }
+        return max_val;
+    };
+    auto triangle = [&]() {
+        int h[256]; std::memcpy(h, hist, sizeof(h));
+        int left = 0, right = 0, max_ind = 0, mx = 0; bool flipped = false;
+        for (int i = 0; i < 256; i++) if (h[i] > 0) { left = i; break; }
+        if (left > 0) left--;
+        for (int i = 255; i > 0; i--) if (h[i] > 0) { right = i; break; }
+        if (right < 255) right++;
+        for (int i = 0; i < 256; i++) if (h[i] > mx) { mx = h[i]; max_ind = i; }
+        if (max_ind - left < right - max_ind) { flipped = true; std::reverse(h, h + 256); left = 255 - right; max_ind = 255 - max_ind; }
+        double thresh = left, a = mx, b = left - max_ind, dist = 0;
+        for (int i = left + 1; i <= max_ind; i++) { const double t = a * i + b * h[i]; if (t > dist) { dist = t; thresh = i; } }
+        thresh--;
+        if (flipped) thresh = 255 - thresh;
+        return thresh;
+    };
+    float thred1 = (float)otsu(), thred2 = (float)triangle();
+    dbg.maxError = maxErrorf; dbg.otsu = thred1; dbg.triangle = thred2; dbg.nPairs = (int)in.size(); std::copy(Hm, Hm + 9, dbg.H); std::copy(hist, hist + 256, dbg.hist);
+    auto count_gt = [&](float t) { int n = 0; for (int v = 0; v < 256; v++) if ((double)v > (double)t) n += hist[v]; return n; };
+    float lo, hi;
+    if (thred1 < thred2) {                                    // DD:1309-1336
+        if (thred1 < 1.7f * 255.0f / maxErrorf) thred1 = 1.7f * 255.0f / maxErrorf;
+        else if (thred1 > 3.0f * 255.0f / maxErrorf) thred1 = 3.0f * 255.0f / maxErrorf;
+        if (count_gt(thred1) > 0.5 * W * H) thred1 = thred1 + 0.2f * 255.0f / maxErrorf;
+        if (thred2 < std::max(3.0f * 255.0f / maxErrorf, thred1 * 1.2f)) thred2 = std::max(3.0f * 255.0f / maxErrorf, thred1 * 1.2f);
+        else if (thred2 > 10.0f * 255.0f / maxErrorf) thred2 = 10.0f * 255.0f / maxErrorf;
+        lo = thred1; hi = thred2;
+    } else {                                                  // DD:1337-1367 (the relaxation test there is dead code)
+        if (thred2 < 1.7f * 255.0f / maxErrorf) thred2 = 1.7f * 255.0f / maxErrorf;
+        else if (thred2 > 3.0f * 255.0f / maxErrorf) thred2 = 3.0f * 255.0f / maxErrorf;
+        if (thred1 < std::max(3.0f * 255.0f / maxErrorf, thred2 * 1.2f)) thred1 = std::max(3.0f * 255.0f / maxErrorf, thred2 * 1.2f);
+        else if (thred1 > 10.0f * 255.0f / maxErrorf) thred1 = 10.0f * 255.0f / maxErrorf;
+        lo = thred2; hi = thred1;
+    }
+    dbg.thr_low = lo; dbg.thr_high = hi;
+    SIND_TRY(launch_threshold_masks(stream, magu8.p, lo, hi, low_d.p, high_d.p, N));
+    std::vector<uint8_t> l8(N), h8(N);
+    HIP_TRY(hipMemcpyAsync(l8.data(), low_d.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h8.data(), high_d.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    low = BitImg::from_u8(l8.data(), W, H, W); high = BitImg::from_u8(h8.data(), W, H, W);
+    if (keep_debug) { dbg.maskLow = l8; dbg.maskHigh = h8; }
+    return SIND_OK;
+}
+
+// ---- DD:315-420: 4-level k-means, K = 12, criteria (EPS+COUNT, 4, 0.07), KMEANS_USE_INITIAL_LABELS
+int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
+    const float scales[4] = {1.0f, 0.5f, 0.25f, 0.125f};
+    const uint16_t* dl[4] = {depth_dev, dpyr[1].p, dpyr[2].p, dpyr[3].p};
+    for (int l = 1; l < 4; l++) SIND_TRY(launch_depth_half(stream, dl[l - 1], dpyr[l].p, W >> l, H >> l));
+    const double eps2 = 0.07 * 0.07; const int maxCount = 4;
+    for (int level = 3; level >= 0; level--) {
+        const int hp = (int)(H * scales[level]), wp = (int)(W * scales[level]), n = hp * wp;
+        SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale));
+        if (level == 3) {
+            if (!labelLastAny) SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp));
+            else { HIP_TRY(hipMemcpyAsync(labPrev8.p, labelLast.data(), N, hipMemcpyHostToDevice, stream)); SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp)); }
+        } else SIND_TRY(launch_labels_resize_i32(stream, lab[level + 1].p, lab[level].p, wp / 2, hp / 2, wp, hp));
+        float ctr[KM_K][3] = {{0}}, old[KM_K][3] = {{0}}; int cnt[KM_K] = {0};
+        for (int iter = 0;;) {
+            double max_center_shift = iter == 0 ? DBL_MAX : 0.0;
+            std::memcpy(old, ctr, sizeof(ctr));
+            SIND_TRY(launch_kmeans_sums(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, ksums.p));
+            double sums[KM_K * 4];
+            HIP_TRY(hipMemcpyAsync(sums, ksums.p, sizeof(sums), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (int k = 0; k < KM_K; k++) { for (int j = 0; j < 3; j++) ctr[k][j] = (float)sums[k * 4 + j]; cnt[k] = (int)sums[k * 4 + 3]; }
+            for (int k = 0; k < KM_K; k++) {                  // empty cluster: split the farthest point off the biggest one
+                if (cnt[k] != 0) continue;
+                int max_k = 0; for (int k1 = 1; k1 < KM_K; k1++) if (cnt[max_k] < cnt[k1]) max_k = k1;
+                const float sc = 1.f / cnt[max_k]; float base[3]; for (int j = 0; j < 3; j++) base[j] = ctr[max_k][j] * sc;
+                SIND_TRY(launch_kmeans_farthest(stream, px.p, py.p, pz.p, lab[level].p, n, max_k, base, far_d.p));
+                unsigned long long key; HIP_TRY(hipMemcpyAsync(&key, far_d.p, 8, hipMemcpyDeviceToHost, stream)); HIP_TRY(hipStreamSynchronize(stream));
+                const int fi = (int)(key & 0xffffffffu); float smp[3];
+                HIP_TRY(hipMemcpy(&smp[0], px.p + fi, 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(&smp[1], py.p + fi, 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(&smp[2], pz.p + fi, 4, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(lab[level].p + fi, &k, 4, hipMemcpyHostToDevice));
+                cnt[max_k]--; cnt[k]++;
+                for (int j = 0; j < 3; j++) { ctr[max_k][j] -= smp[j]; ctr[k][j] += smp[j]; }
+            }
+            for (int k = 0; k < KM_K; k++) {
+                const float sc = 1.f / cnt[k];
+                for (int j = 0; j < 3; j++) ctr[k][j] *= sc;
+                if (iter > 0) { double dist = 0; for (int j = 0; j < 3; j++) { const double t = ctr[k][j] - old[k][j]; dist += t * t; } max_center_shift = std::max(max_center_shift, dist); }
+            }
+            const bool isLast = (++iter == std::max(maxCount, 2) || max_center_shift <= eps2);
+            if (isLast) break;
+            KmCenters C; std::memcpy(C.c, ctr, sizeof(ctr));
+            SIND_TRY(launch_kmeans_assign(stream, px.p, py.p, pz.p, lab[level].p, n, C));
+        }
+        if (level == 0) { std::memcpy(centers, ctr, sizeof(ctr)); std::memcpy(counts, cnt, sizeof(cnt)); }
+    }
+    SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N));
+    label8.resize(N);
+    HIP_TRY(hipMemcpyAsync(label8.data(), lab8.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return SIND_OK;
+}
+
+// ---- DD:429-642: depth-gradient edges (GPU), end points, PEAC plane contours, plane-edge filtering (host)
+int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2) {
+    SIND_TRY(launch_median5(stream, depth_dev, filt.p, W, H));
+    SIND_TRY(launch_max_u16(stream, filt.p, N, umax_d.p));
+    SIND_TRY(launch_grad_edge(stream, filt.p, umax_d.p, edge.p, total.p, W, H, cfg.depthScale));
+    SIND_TRY(launch_morph(stream, edge.p, edgeTmp.p, W, H, 4, false));      // MORPH_OPEN, element4 = erode then dilate
+    SIND_TRY(launch_morph(stream, edgeTmp.p, edge.p, W, H, 4, true));
+    SIND_TRY(launch_peac_block_stats(stream, depth_dev, W, H, 16, 16, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale, blocks_d.p));
+    std::vector<uint8_t> e8(N), t8(N); std::vector<PeacBlockStats> blocks((size_t)(W / 16) * (H / 16));
+    HIP_TRY(hipMemcpyAsync(e8.data(), edge.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(t8.data(), total.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(blocks.data(), blocks_d.p, blocks.size() * sizeof(PeacBlockStats), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const BitImg occ = BitImg::from_u8(e8.data(), W, H, W);
+    totalArea = BitImg::from_u8(t8.data(), W, H, W);
+    // end points: edge pixels with at most 4 of the 12 radius-2 ring pixels set (DD:498-532), greedy NMS radius 6 in scan order
+    static const int ring[12][2] = {{0,-2},{1,-2},{2,-1},{2,0},{2,1},{1,2},{0,2},{-1,2},{-2,1},{-2,0},{-2,-1},{-1,-2}};
+    std::vector<PtI> endPoints;
+    for (int row = 3; row < H - 3; ++row) for (int col = 3; col < W - 3; ++col) {
+        if (!occ.get(col, row)) continue;
+        int s = 0; for (int i = 0; i < 12; i++) s += occ.get(col + ring[i][0], row + ring[i][1]);
+        if (s <= 4) endPoints.push_back({col, row});
+    }
+    { std::vector<PtI> sel; for (const PtI& e : endPoints) { bool ov = false; for (const PtI& q : sel) { const int dx = e.x - q.x, dy = e.y - q.y; if ((float)dx * dx + dy * dy < 6.0f * 6.0f) { ov = true; break; } } if (!ov) sel.push_back(e); } endPoints.swap(sel); }
+    // PEAC plane contours (DD:558-593)
+    BitImg planeC; PeacInput pin{blocks.data(), depth_host, W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale};
+    peac_plane_contours(pin, planeC);
+    BitImg edgeByPlane = planeC; edgeByPlane.andnot(occ);                       // DD:599
+    std::vector<Contour> contours; find_contours(edgeByPlane, contours, true);
+    BitImg acc(W, H);
+    const EllipseElem e10(10), e7(7), e3(3);
+    for (const Contour& c : contours) {
+        if (c.size() < 25) continue;
+        BitImg one(W, H); draw_thick2(one, c);
+        const Rect bb = contour_bbox(c);
+        one = one.dilated(e10, bb.y0 - 1, bb.y1 + 1);
+        bool isEnd = false; for (const PtI& e : endPoints) if (one.get(e.x, e.y)) { isEnd = true; break; }
+        if (isEnd) acc |= one.eroded(e7);
+    }
+    occ2 = acc;
+    BitImg u = occ; u |= acc; occ1 = u.closed(e3);
+    if (keep_debug) { dbg.gradEdge = e8; dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
+    return SIND_OK;
+}
+
+// ---- DD:653-1018: split every depth cluster on edges into pieces, region-adjacency statistics on the GPU, greedy merge on the host
+int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,
+                            const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew) {
+    struct Piece { BitImg img, dil, lianjie; bool hasLianjie = false; float area = 0, score = -10, cz = 0; };
+    std::vector<Piece> all;
+    const EllipseElem e4(4), e7(7), e9(9), e10(10);
+    const BitImg occDil = occ1.dilated(e10);
+    const float depth_weight = 1.5f;
+    for (int i = 0; i + 1 < (int)allLabels.size(); i++) {
+        const BitImg& orig = allLabels[i];
+        BitImg each = orig; each.andnot(occ1); each = each.opened(e4);
+        std::vector<Contour> contours; find_contours(each, contours, true);
+        for (const Contour& c : contours) {
+            if (!(c.size() > 50 && contour_area(c) > 80)) continue;
+            const Rect bb = contour_bbox(c);
+            Piece p; BitImg temp(W, H); draw_filled(temp, c);
+            temp = temp.dilated(e9, bb.y0, bb.y1); temp &= orig;
+            p.img = temp; p.area = (float)temp.count();
+            p.dil = temp.dilated(e7, bb.y0 - 5, bb.y1 + 5);
+            BitImg t1(W, H); draw_thick2(t1, c); t1.andnot(occDil); t1 &= labelForSegEdge;
+            if (t1.count() > 20) {
+                std::vector<Contour> c2; const Rect r2{std::max(bb.x0 - 2, 0), std::max(bb.y0 - 2, 0), std::min(bb.x1 + 2, W - 1), std::min(bb.y1 + 2, H - 1)};
+                find_contours(t1, c2, true, &r2);
+                std::vector<const Contour*> kept; for (const Contour& q : c2) if (q.size() >= 30) kept.push_back(&q);
+                if (!kept.empty()) { p.lianjie.create(W, H); draw_filled(p.lianjie, kept); p.hasLianjie = true; }
+            }
+            // myCluster::calCenterPoint (DD:256-293): float sums in row-major order; only z is used afterwards
+            { float f3 = 0.f; const Rect ib = p.img.bbox();
+              for (int y = ib.y0; y <= ib.y1; y++) { const uint64_t* r = p.img.row(y);
+                for (int k = 0; k < p.img.wpr; k++) { uint64_t m = r[k]; while (m) { const int x = (k << 6) + __builtin_ctzll(m); m &= m - 1;
+                    const uint16_t d = depth_host[(size_t)y * W + x];
+                    float pzv = 0.f; if (!((float)d / cfg.depthScale >= (float)(uint16_t)6 || d == 0)) { const float depth2 = (float)d * (1.0f / cfg.depthScale); pzv = (float)(depth2 * depth_weight); }
+                    f3 += pzv; } } }
+              p.cz = f3 / p.area; }
+            all.push_back(std::move(p));
+        }
+    }
+    const int C = (int)all.size();
+    dbg.nClusters = C;
+    labelNew.assign(N, 0);
+    if (C == 0) return SIND_OK;
+    if (C > 254) { sind_set_error("seg_and_merge: %d pieces exceed the 8-bit label range of the reference", C); return SIND_E_CAPACITY; }
+    for (Piece& p : all) p.score = (float)(p.area * 0.0003f - p.cz);
+    std::sort(all.begin(), all.end(), [](const Piece& a, const Piece& b) { return a.score > b.score; });
+    std::vector<uint8_t> total(N, (uint8_t)(C + 1));
+    for (int i = 0; i < C; i++) all[i].img.paint_u8(total.data(), W, (uint8_t)i);
+    // ---- RAG statistics on the GPU: upload the 3*C bit planes, one pass over the frame
+    const int wpr = W / 64; const size_t pw = (size_t)H * wpr;
+    std::vector<unsigned long long> planes((size_t)3 * C * pw, 0);
+    for (int i = 0; i < C; i++) {
+        std::memcpy(&planes[((size_t)0 * C + i) * pw], all[i].img.d.data(), pw * 8);
+        std::memcpy(&planes[((size_t)1 * C + i) * pw], all[i].dil.d.data(), pw * 8);
+        if (all[i].hasLianjie) std::memcpy(&planes[((size_t)2 * C + i) * pw], all[i].lianjie.d.data(), pw * 8);
+    }
+    SIND_TRY(planes_d.alloc(planes.size())); SIND_TRY(rag_d.alloc((size_t)3 * C * C + C + (size_t)C * 256));
+    HIP_TRY(hipMemcpyAsync(planes_d.p, planes.data(), planes.size() * 8, hipMemcpyHostToDevice, stream));
+    std::vector<uint8_t> o2(N); occ2.to_u8(o2.data(), W, 255);
+    HIP_TRY(hipMemcpyAsync(occ2_d.p, o2.data(), N, hipMemcpyHostToDevice, stream));
+    SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1));
+    SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, depthN.p, N));
+    int* ov_d = rag_d.p; int* ovp_d = ov_d + C * C; int* lj_d = ovp_d + C * C; int* la_d = lj_d + C * C; int* hist_dd = la_d + C;
+    SIND_TRY(launch_rag_stats(stream, planes_d.p, C, W, H, wpr, occ2_d.p, depthN.p, ov_d, ovp_d, lj_d, la_d, hist_dd));
+    std::vector<int> rag((size_t)3 * C * C + C + (size_t)C * 256);
+    HIP_TRY(hipMemcpyAsync(rag.data(), rag_d.p, rag.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const int* ov = rag.data(); const int* ovp = ov + C * C; const int* ljo = ovp + C * C; const int* lja = ljo + C * C; const int* hst = lja + C;
+    // cal_hist (DD:1685-1739) from the two masked histograms
+    auto cal_hist = [&](int a, int b, double out[3]) {
+        float h1[256], h2[256]; double m1 = 0, m2 = 0, mn1 = DBL_MAX, mn2 = DBL_MAX;
+        for (int i = 0; i < 256; i++) { h1[i] = (float)hst[a * 256 + i]; h2[i] = (float)hst[b * 256 + i]; m1 = std::max<double>(m1, h1[i]); m2 = std::max<double>(m2, h2[i]); mn1 = std::min<double>(mn1, h1[i]); mn2 = std::min<double>(mn2, h2[i]); }
+        const int hist_h = 400;
+        auto norm_minmax = [&](float* h, double mn, double mx) { const double scale = (mx - mn) > DBL_EPSILON ? (double)hist_h / (mx - mn) : 0, shift = 0 - mn * scale; for (int i = 0; i < 256; i++) h[i] = h[i] * (float)scale + (float)shift; };
+        if (m1 > m2) { norm_minmax(h1, mn1, m1); const float s = (float)(1.0 / (m1 / hist_h)); for (int i = 0; i < 256; i++) h2[i] = h2[i] * s; }
+        else         { norm_minmax(h2, mn2, m2); const float s = (float)(1.0 / (m2 / hist_h)); for (int i = 0; i < 256; i++) h1[i] = h1[i] * s; }
+        double s1 = 0, s2 = 0, s11 = 0, s12 = 0, s22 = 0, bh = 0, inter = 0;
+        for (int j = 0; j < 256; j++) { const double x = h1[j], y = h2[j]; s12 += x * y; s1 += x; s11 += x * x; s2 += y; s22 += y * y; bh += std::sqrt(x * y); inter += std::min(h1[j], h2[j]); }
+        const double scale = 1. / 256, num = s12 - s1 * s2 * scale, denom2 = (s11 - s1 * s1 * scale) * (s22 - s2 * s2 * scale);
+        out[0] = std::fabs(denom2) > DBL_EPSILON ? num / std::sqrt(denom2) : 1.;
+        double ss = s1 * s2; ss = std::fabs(ss) > FLT_EPSILON ? 1. / std::sqrt(ss) : 1.;
+        out[1] = 1 - std::sqrt(std::max(1. - bh * ss, 0.));
+        out[2] = inter;
+    };
+    const int M = C + 1, numCluster = KM_K;
+    std::vector<float> mTotal((size_t)M * M, 0.f), m2((size_t)M * M, 0.f), m3((size_t)M * M, 0.f), wgt((size_t)M * M, 1.f), rej((size_t)M * M, 1.f);
+    const float thredshold = 0.9f; const int smallLabel = (int)std::min(0.7f * C, 15.0f);
+    for (int i = 0; i < C; i++) for (int j = i + 1; j < C; j++) {
+        float v2 = 0, v3 = 0, lessArea; int lessLabel;
+        if (all[i].area < all[j].area) { lessArea = all[i].area; lessLabel = i; } else { lessArea = all[j].area; lessLabel = j; }
+        if (lessLabel < 10) wgt[i * M + j] = wgt[j * M + i] = 0.7f;
+        else if (lessLabel > smallLabel) wgt[i * M + j] = wgt[j * M + i] = 2.0f;
+        const int overlap = ov[i * C + j], overlapPlane = ovp[i * C + j];
+        if (overlap > std::min(200.0f, lessArea * 0.4f)) {
+            double isMerge[3]; cal_hist(i, j, isMerge);
+            v3 = (float)(isMerge[0] + isMerge[1] + isMerge[2] * 0.0005);
+            if (overlapPlane > 100 && lessLabel < smallLabel) { rej[i * M + j] = rej[j * M + i] = 0.f; continue; }
+            else if (v3 < 0.19f && lessLabel < smallLabel) { rej[i * M + j] = rej[j * M + i] = 0.f; continue; }
+            if (all[i].hasLianjie && all[j].hasLianjie) {
+                const int o = ljo[i * C + j];
+                if (o > 0) { const int a1 = lja[i], a2 = lja[j];
+                    if (o > std::min(50, (int)(0.5 * std::min(a1, a2)))) { v2 = (float)o; if ((o > 0.62 * a1) || (o > 0.62 * a2)) v2 = (float)std::max(250, o); } }
+            }
+            m2[i * M + j] = m2[j * M + i] = v2; m3[i * M + j] = m3[j * M + i] = v3;
+        }
+    }
+    for (size_t k = 0; k < mTotal.size(); k++) mTotal[k] = ((m2[k] * 0.01f + m3[k]) * rej[k]) * wgt[k];
+    int countMerged = 0;
+    std::vector<std::vector<int>> merge(M); std::vector<int> mergeSit(M, 0);
+    auto fold = [&](int dst, int j) {
+        std::vector<float> col(M); for (int r = 0; r < M; r++) col[r] = mTotal[r * M + j];
+        for (int r = 0; r < M; r++) mTotal[r * M + dst] += col[r];
+        for (int c = 0; c < M; c++) mTotal[dst * M + c] += col[c];
+        for (int r = 0; r < M; r++) mTotal[r * M + j] = 0.f;
+        for (int c = 0; c < M; c++) mTotal[j * M + c] = 0.f;
+    };
+    for (int i = 0; i < std::min(numCluster - 1 + countMerged, C); i++)
+        for (int j = i + 1; j < std::min(numCluster - 1 + countMerged, C); j++) {
+            const float sorce = mTotal[j * M + i];
+            if (sorce > thredshold) {
+                int toMerge = i; const float toMergeValue = mTotal[j * M + i];
+                for (int k = 0; k < j; k++) if (mTotal[k * M + j] > toMergeValue) toMerge = k;
+                mergeSit[j] = 1; merge[toMerge].push_back(j); fold(toMerge, j); countMerged++;
+            }
+        }
+    for (int i = std::min(numCluster - 1 + countMerged, C); i < C; i++) {
+        int mergeCluster = C; float maxScore = 0.2f;
+        for (int j = 0; j < i; j++) { const float score = mTotal[j * M + i]; if (score > maxScore) { maxScore = score; mergeCluster = j; } }
+        mergeSit[i] = 1; merge[mergeCluster].push_back(i); fold(mergeCluster, i);
+    }
+    int labelindex = 1; std::vector<uint8_t> lut(256, 0);
+    for (int i = 0; i < C; i++) {
+        if (mergeSit[i]) continue;
+        std::vector<char> sel(M + 1, 0); sel[i] = 1;
+        for (int mj : merge[i]) { sel[mj] = 1; for (int mk : merge[mj]) sel[mk] = 1; }
+        // the reference paints labels in increasing order, a later group overwrites an earlier one on shared pieces
+        for (int q = 0; q <= M; q++) if (sel[q]) lut[q] = (uint8_t)labelindex;
+        labelindex++;
+    }
+    for (int k = 0; k < N; k++) labelNew[k] = lut[total[k]];
+    return SIND_OK;
+}
+
+// ---- DD:1377-1666
+int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out) {
+    HIP_TRY(hipSetDevice(cfg.device));
+    BitImg maskLow, maskHigh;
+    SIND_TRY(flow_masks(U, V, maskLow, maskHigh));
+    // k-means (DD:1410-1414)
+    std::vector<uint8_t> label8; float centers[KM_K][3]; int counts[KM_K];
+    SIND_TRY(kmeans(depth_dev, label8, centers, counts));
+    if (keep_debug) { dbg.kmeansLabel = label8; std::memcpy(dbg.centers, centers, sizeof(centers)); }
+    // nearest clusters first (DD:1428-1491)
+    float depth_vals[KM_K]; int order[KM_K];
+    for (int i = 0; i < KM_K; i++) { depth_vals[i] = centers[i][2]; if (depth_vals[i] < 0.2) depth_vals[i] += 20.0f; order[i] = i; }
+    std::stable_sort(order, order + KM_K, [&](int a, int b) { return depth_vals[a] < depth_vals[b]; });
+    std::vector<BitImg> labelMask(KM_K); for (auto& m : labelMask) m.create(W, H);
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const int l = label8[(size_t)y * W + x]; if (l < KM_K) labelMask[l].set(x, y); }
+    std::vector<BitImg> allLabels; BitImg labelForSegEdge(W, H);
+    float ratioArea = 0.0f; const float TotalArea = (float)(H * W); int count0 = 0;
+    for (int i = 0; i < KM_K; i++) {
+        const int idx = order[i]; const int cnt = labelMask[idx].count();
+        if (cnt < 60) continue;
+        allLabels.push_back(labelMask[idx]);
+        const float ratio = (float)cnt * (1.0f / TotalArea); ratioArea += ratio;
+        if (count0 <= 5 && ratioArea < 0.6f) { labelForSegEdge |= labelMask[idx]; ++count0; }
+    }
+    labelForSegEdge = labelForSegEdge.dilated(EllipseElem(7));
+    BitImg totalArea, occ1, occ2;
+    SIND_TRY(cal_occluded(depth_host, depth_dev, totalArea, occ1, occ2));
+    std::vector<uint8_t> label3(N, 0);
+    if (!allLabels.empty()) SIND_TRY(seg_and_merge(allLabels, occ1, occ2, labelForSegEdge, depth_host, depth_dev, label3));
+    int maxNum = 0; for (uint8_t v : label3) maxNum = std::max<int>(maxNum, v);
+    if (keep_debug) { dbg.occ1.resize(N); occ1.to_u8(dbg.occ1.data(), W, 255); dbg.occ2.resize(N); occ2.to_u8(dbg.occ2.data(), W, 255); dbg.totalArea.resize(N); totalArea.to_u8(dbg.totalArea.data(), W, 255); }
+    // fusion (DD:1553-1636)
+    BitImg low = BitImg::from_u8(highLast.data(), W, H, W); low |= maskLow; low &= totalArea;
+    low = low.dilated(EllipseElem(5));
+    const BitImg notLow = low.inverted();
+    BitImg dyna(W, H);
+    std::vector<BitImg> clusters(maxNum + 1); for (auto& m : clusters) m.create(W, H);
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const int l = label3[(size_t)y * W + x]; if (l) clusters[l].set(x, y); }
+    for (int n = 1; n <= maxNum; n++) {
+        const BitImg& one = clusters[n]; const int oneCnt = one.count();
+        BitImg blocked = one.inverted(), filled(W, H);
+        BitImg oneHigh = one; oneHigh &= maskHigh;
+        if (oneHigh.count() > 100) {
+            std::vector<Contour> cs; find_contours(oneHigh, cs, false);
+            for (const Contour& c : cs) {
+                const double area = contour_area(c), len = arc_length_closed(c), roundness = (4 * M_PI * area) / (len * len);
+                PtI seed{0, 0};
+                for (const PtI& p : c) if (low.get(p.x, p.y)) { seed = p; break; }
+                if ((area > 100.0 && roundness > 0.2) || area > 2000.0) flood_fill(low.get(seed.x, seed.y) ? low : notLow, blocked, filled, seed);
+            }
+        }
+        if (filled.count() > 0.5 * oneCnt) dyna |= one; else dyna |= filled;
+    }
+    dyna = dyna.dilated(EllipseElem(9));
+    std::vector<uint8_t> out(N, 0);
+    totalArea.paint_u8(out.data(), W, 125); dyna.paint_u8(out.data(), W, 255);
+    std::memcpy(dyna_out, out.data(), N); std::memcpy(label_out, label3.data(), N);
+    // roll the state (DD:1660-1664)
+    dynaLast = out; labelLast = label3; maskHigh.to_u8(highLast.data(), W, 255);
+    labelLastAny = false; for (uint8_t v : label3) if (v) { labelLastAny = true; break; }
+    return SIND_OK;
+}
+
+}  // namespace sind

@@ -1,0 +1,51 @@
+"""DynaDetect — Python mirror of ORB_SLAM2::DynaDetect (reference include/DynaDetect.h:95-131) over the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib, ptr
+
+
+class DynaDetect:
+    """DynaDetect(imgLast, imgLastLast, fx, fy, cx, cy, depthScale); DetectDynaArea(img, imgDepth, nImg) -> (imgDyna, imgLabel)."""
+
+    def __init__(self, imgLast: np.ndarray, imgLastLast: np.ndarray, fx: float, fy: float, cx: float, cy: float, depthScale: float,
+                 device: int = 0):
+        assert imgLast.dtype == np.uint8 and imgLast.ndim == 3 and imgLast.shape[2] == 3, "CV_8UC3 BGR expected"
+        self.h, self.w = imgLast.shape[:2]
+        h = C.c_void_p()
+        check(lib().sind_dyna_create(self.w, self.h, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_float(depthScale), device,
+                                     C.byref(h)), "sind_dyna_create")
+        self._h = h
+        check(lib().sind_dyna_prime(self._h, ptr(np.ascontiguousarray(imgLast)), ptr(np.ascontiguousarray(imgLastLast)), self.w * 3), "sind_dyna_prime")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sind_dyna_destroy(self._h); self._h = None
+
+    __del__ = close
+
+    def DetectDynaArea(self, img: np.ndarray, imgDepth: np.ndarray, nImg: int = 0):
+        img = np.ascontiguousarray(img, np.uint8); imgDepth = np.ascontiguousarray(imgDepth, np.uint16)
+        dyna = np.empty((self.h, self.w), np.uint8); label = np.empty((self.h, self.w), np.uint8)
+        check(lib().sind_dyna_detect(self._h, ptr(img), self.w * 3, ptr(imgDepth), self.w * 2, ptr(dyna), ptr(label), nImg), "sind_dyna_detect")
+        return dyna, label
+
+    def dilate15(self, dyna: np.ndarray) -> np.ndarray:
+        """the caller-side morphologyEx(imDynaMask, DILATE, ellipse 15x15) of rgbd_tum_noros.cc:138"""
+        out = np.array(dyna, np.uint8, copy=True, order="C")
+        check(lib().sind_dyna_dilate15(self._h, ptr(out)), "sind_dyna_dilate15"); return out
+
+    def debug(self):
+        h, w = self.h, self.w; fw, fh = int(np.float32(0.6) * w), int(np.float32(0.6) * h)
+        d = dict(flow_deep=np.zeros((2, fh, fw), np.float32), flow_refined=np.zeros((2, fh, fw), np.float32), flow_full=np.zeros((2, h, w), np.float32),
+                 H=np.zeros(9), thr=np.zeros(5, np.float32), hist=np.zeros(256, np.int32), mask_low=np.zeros((h, w), np.uint8),
+                 mask_high=np.zeros((h, w), np.uint8), kmeans_label=np.zeros((h, w), np.uint8), centers=np.zeros((12, 3), np.float32),
+                 occ1=np.zeros((h, w), np.uint8), occ2=np.zeros((h, w), np.uint8), total_area=np.zeros((h, w), np.uint8),
+                 grad_edge=np.zeros((h, w), np.uint8), plane_contours=np.zeros((h, w), np.uint8), info=np.zeros(3, np.int32))
+        keys = ["flow_deep", "flow_refined", "flow_full", "H", "thr", "hist", "mask_low", "mask_high", "kmeans_label", "centers", "occ1", "occ2",
+                "total_area", "grad_edge", "plane_contours", "info"]
+        check(lib().sind_dyna_debug(self._h, *[ptr(d[k]) for k in keys]), "sind_dyna_debug")
+        d["H"] = d["H"].reshape(3, 3); return d

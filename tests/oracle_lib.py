@@ -173,7 +173,11 @@ class DynaDetect:
                  total_area=np.empty((h, w), np.uint8), mag_u8=np.empty((h, w), np.uint8), info=np.zeros(3, np.int32))
         lib().orc_dyna_debug(self.p, *[_p(d[k]) for k in ["flow_full", "H", "thr", "hist", "mask_low", "mask_high", "kmeans_label", "centers",
                                                           "occ1", "occ2", "total_area", "mag_u8", "info"]])
-        d["H"] = d["H"].reshape(3, 3); return d
+        d["H"] = d["H"].reshape(3, 3)
+        for k in ("grad_edge", "plane_contours", "label_for_seg_edge"):
+            d[k] = np.empty((h, w), np.uint8)
+        lib().orc_dyna_debug2(self.p, _p(d["grad_edge"]), _p(d["plane_contours"]), _p(d["label_for_seg_edge"]))
+        return d
 
 
 class ORBextractor:

@@ -101,6 +101,36 @@ int sind_dyna_debug(sind_dyna* d, float* flow_deep, float* flow_refined, float* 
                     uint8_t* mask_low, uint8_t* mask_high, uint8_t* kmeans_label, float* centers36, uint8_t* occ1, uint8_t* occ2,
                     uint8_t* total_area, uint8_t* grad_edge, uint8_t* plane_contours, int* info3);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Batched multi-stream pipeline: S independent camera streams x T consecutive frames per step through
+ * DynaDetect + 15x15 dilation + ORBextractor, i.e. the body of the frame loop of Examples/RGB-D/rgbd_tum_noros.cc:110-170
+ * for S sequences at once.  The state-free stages (gray, resize, dense flow, ORB pyramid/FAST/orientation/BRIEF) are
+ * batched over all S*T frames; the stateful tail of each stream runs in frame order on its own host thread + HIP stream.
+ * A stream is exactly one reference DynaDetect instance: results equal S sequential single-stream runs.
+ * Layouts (dense): bgr [S][T][H][W][3] u8, depth [S][T][H][W] u16, dyna/label/mask [S][T][H][W] u8,
+ * kps [S][T][cap], nkp [S][T], desc [S][T][cap][32].  "_dev" takes DEVICE input pointers (frames already in HBM);
+ * outputs are always host pointers (they feed the host-side tracker).
+ */
+typedef struct sind_pipe sind_pipe;
+typedef struct sind_pipe_config {
+    int width, height; float fx, fy, cx, cy, depth_scale;
+    int nfeatures; float scale_factor; int nlevels, ini_th_fast, min_th_fast;
+    int orb_gray_rgb_order;      /* 1: ORB gray uses RGB2GRAY on the BGR buffer (Camera.RGB: 1, src/Tracking.cc:246-251), 0: BGR2GRAY */
+    int streams, frames_per_step, device;
+    int host_threads;            /* 0 = one per stream */
+} sind_pipe_config;
+int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out);
+int sind_pipe_destroy(sind_pipe* p);
+int sind_pipe_prime(sind_pipe* p, int stream, const uint8_t* bgr_last, const uint8_t* bgr_lastlast);          /* host pointers */
+int sind_pipe_process(sind_pipe* p, const uint8_t* bgr, const uint16_t* depth, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated,
+                      sind_keypoint* kps, int cap, int* nkp, uint8_t* desc);                                    /* host inputs */
+int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* depth_dev, uint8_t* dyna, uint8_t* label,
+                          uint8_t* mask_dilated, sind_keypoint* kps, int cap, int* nkp, uint8_t* desc);          /* device inputs */
+/* per-stage wall times of the last step in milliseconds: {front_gray, dense_flow, orb_front, depth_copy, tails, total},
+ * plus HIP-event statistics of the flow solver: sor_launches, sor_ms (sum of event-bracketed SOR launch groups),
+ * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */
+int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, double* sor_ms, double* sor_alg_bytes);
+
 #ifdef __cplusplus
 }
 #endif

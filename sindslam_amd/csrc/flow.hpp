@@ -17,11 +17,23 @@ struct FlowPlanes {
     float *Wu, *Wv, *dWu, *dWv, *tWu, *tWv;                    // level flow, increment, W + dW
 };
 
+// HIP-event brackets around the SOR launch groups of the flow solver (bench.py's roofline leg): events are recorded on the
+// stream the kernels run on; collect() sums the elapsed times after the stream has been synchronised.
+struct SorTimer {
+    std::vector<hipEvent_t> ev; size_t used = 0; bool enabled = false;
+    double alg_bytes = 0; long long launches = 0;
+    void begin(hipStream_t s) { if (!enabled) return; if (used + 2 > ev.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); ev.push_back(a); ev.push_back(b); } (void)hipEventRecord(ev[used], s); }
+    void end(hipStream_t s, long long n_launches, double bytes) { if (!enabled) return; (void)hipEventRecord(ev[used + 1], s); used += 2; launches += n_launches; alg_bytes += bytes; }
+    void reset() { used = 0; alg_bytes = 0; launches = 0; }
+    double collect_ms() { double t = 0; for (size_t i = 0; i + 1 < used; i += 2) { float ms = 0; if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) t += ms; } return t; }
+    ~SorTimer() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+};
+
 int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w, int h, int B, float k0, float k1, bool blur);
 int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img);
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb);
-int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V);
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr);
 int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, unsigned* maxbits, int* hist, uint8_t* out_u8, int n, int B);
 int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h);
 int launch_threshold_masks(hipStream_t s, const uint8_t* magu8, float lo, float hi, uint8_t* low, uint8_t* high, int n);
@@ -44,6 +56,7 @@ public:
     // expose one-level refinement on float images for stage-level parity tests
     int varref_f32(const float* I0, const float* I1, int w, int h, int B, float* u, float* v, const VarParams& V);
     FlowPlanes planes{};
+    SorTimer sor_timer;
 private:
     DevBuf<float> plane_store, pyr0, pyr1;
     float* level_ptr(DevBuf<float>& pyr, int l, int B) { return pyr.p + level_off[l] * (size_t)B; }

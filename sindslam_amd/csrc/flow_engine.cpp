@@ -53,7 +53,7 @@ int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, 
     HIP_TRY(hipMemsetAsync(P.Wv, 0, nc * sizeof(float), stream));
     for (int l = L - 1; l >= 0; --l) {
         const int w = levels[l].first, h = levels[l].second;
-        SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V));
+        SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V, &sor_timer));
         if (l > 0) {
             const int nw = levels[l - 1].first, nh = levels[l - 1].second;
             SIND_TRY(launch_resize_f32(stream, P.Wu, P.tWu, w, h, nw, nh, B, inv_scale, true));
@@ -80,7 +80,7 @@ int FlowEngine::varref_f32(const float* I0, const float* I1, int w, int h, int B
     const size_t n = (size_t)w * h * B;
     HIP_TRY(hipMemcpyAsync(planes.Wu, u, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(planes.Wv, v, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    SIND_TRY(varref_level(stream, planes, I0, I1, w, h, B, V));
+    SIND_TRY(varref_level(stream, planes, I0, I1, w, h, B, V, &sor_timer));
     HIP_TRY(hipMemcpyAsync(u, planes.Wu, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(v, planes.Wv, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return SIND_OK;

@@ -326,7 +326,7 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 }
 
 // VariationalRefinement::calcUV on one pyramid level for B pairs.  Wu/Wv: initial flow in, refined flow out.
-int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V) {
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer) {
     const size_t n = (size_t)w * h * B;
     const dim3 g = grid2d(w, h, B), blk(128);
     hipLaunchKernelGGL(k_warp_avg_iz, g, blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, w, h);
@@ -339,10 +339,13 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     for (int it = 0; it < V.fixedPointIterations; it++) {
         hipLaunchKernelGGL(k_coef, g, blk, 0, s, V, w, h, P.Ix, P.Iy, P.Iz, P.Ixx, P.Ixy, P.Iyy, P.Ixz, P.Iyz, P.Wu, P.Wv, P.tWu, P.tWv,
                            P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt);
+        if (timer) timer->begin(s);
         for (int k = 0; k < V.sorIterations; k++) {
             hipLaunchKernelGGL(k_sor_color, gs, bs, 0, s, w, h, V.omega, 0, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
             hipLaunchKernelGGL(k_sor_color, gs, bs, 0, s, w, h, V.omega, 1, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
         }
+        // algorithmic bytes: 44 B per pixel per red+black iteration (9 reads + 2 writes of f32), SURVEY.md §8d
+        if (timer) timer->end(s, 2LL * V.sorIterations, 44.0 * (double)w * h * B * V.sorIterations);
         hipLaunchKernelGGL(k_add_flow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.tWu, P.tWv, n);
     }
     HIP_TRY(hipMemcpyAsync(P.Wu, P.tWu, n * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -1,0 +1,62 @@
+"""Batched multi-stream pipeline (sind_pipe_* in include/sind_hip.h): S streams x T frames per step through
+DynaDetect + 15x15 dilation + ORBextractor, the frame-loop body of the reference's rgbd_tum_noros.cc."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib, ptr
+from .orb import KP_DTYPE
+
+
+class PipeConfig(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("depth_scale", C.c_float), ("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("orb_gray_rgb_order", C.c_int), ("streams", C.c_int),
+                ("frames_per_step", C.c_int), ("device", C.c_int), ("host_threads", C.c_int)]
+
+
+class Pipeline:
+    def __init__(self, streams: int, frames_per_step: int, width=640, height=480, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_scale=5000.0,
+                 nfeatures=1500, scale_factor=1.2, nlevels=8, ini_th=15, min_th=5, orb_gray_rgb_order=0, device=0, host_threads=0):
+        self.S, self.T, self.w, self.h = streams, frames_per_step, width, height
+        self.cap = 2 * nfeatures + 256
+        cfg = PipeConfig(width, height, fx, fy, cx, cy, depth_scale, nfeatures, scale_factor, nlevels, ini_th, min_th, orb_gray_rgb_order,
+                         streams, frames_per_step, device, host_threads)
+        h = C.c_void_p()
+        check(lib().sind_pipe_create(C.byref(cfg), C.byref(h)), "sind_pipe_create")
+        self._h = h
+        B = streams * frames_per_step
+        self.dyna = np.zeros((streams, frames_per_step, height, width), np.uint8)
+        self.label = np.zeros_like(self.dyna); self.mask = np.zeros_like(self.dyna)
+        self.kps = np.zeros((B, self.cap), KP_DTYPE); self.nkp = np.zeros(B, np.int32); self.desc = np.zeros((B, self.cap, 32), np.uint8)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sind_pipe_destroy(self._h); self._h = None
+
+    __del__ = close
+
+    def prime(self, stream: int, bgr_last: np.ndarray, bgr_lastlast: np.ndarray):
+        check(lib().sind_pipe_prime(self._h, stream, ptr(np.ascontiguousarray(bgr_last)), ptr(np.ascontiguousarray(bgr_lastlast))), "sind_pipe_prime")
+
+    def process(self, bgr: np.ndarray, depth: np.ndarray):
+        """bgr u8 [S, T, H, W, 3], depth u16 [S, T, H, W] (host) -> results in self.dyna / label / mask / kps / nkp / desc"""
+        bgr = np.ascontiguousarray(bgr, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        assert bgr.shape == (self.S, self.T, self.h, self.w, 3) and depth.shape == (self.S, self.T, self.h, self.w)
+        check(lib().sind_pipe_process(self._h, ptr(bgr), ptr(depth), ptr(self.dyna), ptr(self.label), ptr(self.mask), ptr(self.kps), self.cap,
+                                      ptr(self.nkp), ptr(self.desc)), "sind_pipe_process")
+
+    def process_dev(self, bgr_dev_ptr: int, depth_dev_ptr: int):
+        """inputs already resident in HBM (e.g. torch tensors' data_ptr()); same layouts"""
+        check(lib().sind_pipe_process_dev(self._h, ptr(bgr_dev_ptr), ptr(depth_dev_ptr), ptr(self.dyna), ptr(self.label), ptr(self.mask),
+                                          ptr(self.kps), self.cap, ptr(self.nkp), ptr(self.desc)), "sind_pipe_process_dev")
+
+    def keypoints(self, s: int, t: int):
+        k = s * self.T + t; n = self.nkp[k]; return self.kps[k, :n], self.desc[k, :n]
+
+    def stats(self):
+        st = np.zeros(6); nl = C.c_longlong(); ms = C.c_double(); by = C.c_double()
+        check(lib().sind_pipe_stats(self._h, ptr(st), C.byref(nl), C.byref(ms), C.byref(by)))
+        return dict(front_ms=st[0], flow_ms=st[1], orb_ms=st[2], tails_ms=st[4], total_ms=st[5], sor_launches=nl.value, sor_ms=ms.value, sor_alg_bytes=by.value)

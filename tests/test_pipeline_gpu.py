@@ -1,0 +1,40 @@
+"""GPU parity: the batched multi-stream pipeline equals independent single-stream oracle runs."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from sindslam_amd.synth import TUM3
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipeline_two_streams(frames):
+    from sindslam_amd.pipeline import Pipeline
+    bgr, depth = frames                       # 6 frames
+    S, T = 2, 2
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    # stream 0 = the sequence, stream 1 = its horizontal mirror
+    sb = np.stack([bgr, bgr[:, :, ::-1]]); sd = np.stack([depth, depth[:, :, ::-1]])
+    pipe = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5, orb_gray_rgb_order=1)
+    refs = [O.DynaDetect(np.ascontiguousarray(sb[s, 1]), np.ascontiguousarray(sb[s, 0]), *K) for s in range(S)]
+    orb_ref = O.ORBextractor(1500, 1.2, 8, 15, 5)
+    for s in range(S):
+        pipe.prime(s, sb[s, 1], sb[s, 0])
+    for step in range(2):                     # two steps exercise the history roll
+        lo = 2 + step * T
+        pipe.process(sb[:, lo:lo + T], sd[:, lo:lo + T])
+        for s in range(S):
+            for t in range(T):
+                rd, rl = refs[s].detect(np.ascontiguousarray(sb[s, lo + t]), np.ascontiguousarray(sd[s, lo + t]))
+                gd = pipe.dyna[s, t]
+                u = np.logical_or(gd == 255, rd == 255).sum()
+                iou = 1.0 if u == 0 else np.logical_and(gd == 255, rd == 255).sum() / u
+                assert iou >= 0.99, (step, s, t, iou)
+                assert np.array_equal(pipe.mask[s, t], O.dilate15(gd))
+                gray = O.bgr2gray(np.ascontiguousarray(sb[s, lo + t]), swap_rb=True)      # Camera.RGB: 1 quirk
+                rk, rdesc = orb_ref.extract(gray, pipe.mask[s, t])
+                k, d = pipe.keypoints(s, t)
+                assert k.tobytes() == rk.tobytes() and np.array_equal(d, rdesc), (step, s, t)
+    st = pipe.stats()
+    assert st["sor_launches"] > 0 and st["sor_ms"] > 0
+    pipe.close()

@@ -20,13 +20,15 @@ static std::vector<std::pair<int, int>> deepflow_sizes(int w, int h) {
 
 int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     fw = fw_; fh = fh_; maxB = maxB_; stream = s;
+    if (const char* e = getenv("SIND_SOR_MODE")) g_sor_mode = atoi(e);       // 0: per-colour launches, 1: fused (default)
+    if (const char* e = getenv("SIND_SOR_FUSE")) g_sor_fuse = std::max(1, std::min(atoi(e), 12));
     levels = deepflow_sizes(fw, fh);
     level_off.clear(); pyr_pixels = 0;
     for (auto& l : levels) { level_off.push_back(pyr_pixels); pyr_pixels += (size_t)l.first * l.second; }
     const size_t n0 = (size_t)fw * fh * maxB;
-    SIND_TRY(plane_store.alloc(n0 * 21));
+    SIND_TRY(plane_store.alloc(n0 * 23));
     float** f = reinterpret_cast<float**>(&planes);
-    for (int i = 0; i < 21; i++) f[i] = plane_store.p + n0 * i;
+    for (int i = 0; i < 23; i++) f[i] = plane_store.p + n0 * i;
     SIND_TRY(pyr0.alloc(pyr_pixels * maxB));
     SIND_TRY(pyr1.alloc(pyr_pixels * maxB));
     return SIND_OK;

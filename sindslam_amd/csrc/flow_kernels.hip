@@ -188,6 +188,135 @@ __global__ void k_sor_color(int w, int h, float omega, int color, const float* _
     U[i] = du; V[i] = dv;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused red-black SOR: `iters` full iterations per launch with the linear system held in REGISTERS.
+//   * a workgroup owns an extended tile E (EW x EH pixels); every thread owns a 1x8 pixel strip of one row and keeps
+//     its 8 x (A11, A12, A22, b1, b2, w, w_up) + w_left in VGPRs for the whole launch (the CU's 512 KB register file is
+//     the largest on-chip store; LDS only carries the flow increments);
+//   * the increments (du, dv) live in LDS in a checkerboard-split layout (plane[parity][component][row][x/2]) so that the
+//     four up / down neighbours of a thread's four same-colour pixels are ONE ds_read_b128 per plane; horizontal
+//     neighbours are the thread's own other-colour registers plus one LDS word at the strip edge;
+//   * waves are row-parity uniform (first half of the block = even rows, second half = odd rows), so the choice of which
+//     four strip pixels carry the active colour is wave-uniform: no divergence;
+//   * tiles overlap by a halo of 2*iters pixels: stale values creep inwards one pixel per half-sweep from the tile edge, so
+//     the interior (written back) is exact; at image borders E is clipped and the boundary condition is exact.
+// Arithmetic per pixel is identical to k_sor_color / OpenCV RedBlackSOR_ParBody, so results stay bit-exact.
+#define SOR_PX 8
+#define SOR_NT 512
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };     // 4-byte aligned 16-byte load (gfx950 allows unaligned dwordx4)
+__device__ __forceinline__ void ld8(const float* __restrict__ p, float (&d)[SOR_PX]) {
+    const F4u a = *reinterpret_cast<const F4u*>(p), c = *reinterpret_cast<const F4u*>(p + 4);
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = c.x; d[5] = c.y; d[6] = c.z; d[7] = c.w;
+}
+__global__ void __launch_bounds__(SOR_NT, 4) k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo, int ntx, int iters, float omega,
+                                                      const float* __restrict__ gA11, const float* __restrict__ gA12, const float* __restrict__ gA22,
+                                                      const float* __restrict__ gB1, const float* __restrict__ gB2, const float* __restrict__ gW,
+                                                      const float* __restrict__ gUin, const float* __restrict__ gVin, float* __restrict__ gUout,
+                                                      float* __restrict__ gVout) {
+    extern __shared__ float4 lds4[];             // float4-indexed so that every strip access is one ds_read/write_b128
+    float* lds = reinterpret_cast<float*>(lds4);
+    const int SW = EW / SOR_PX;                  // strips per row
+    const int RS4 = EW / 8 + 2;                  // LDS row stride in float4 (one guard float4 on each side)
+    const int half = blockDim.x >> 1;
+    const int NR = 2 * (half / SW);              // rows covered by the thread block (>= EH; surplus rows stay zero)
+    const int PL4 = (NR + 2) * RS4;              // one plane (guard row above and below)
+    const int tid = threadIdx.x;
+    const int idx = tid < half ? tid : tid - half;
+    const int j = idx % SW, ly = 2 * (idx / SW) + (tid < half ? 0 : 1);
+    const int tile = blockIdx.x, tx = tile % ntx, ty = tile / ntx, b = blockIdx.y;
+    const int ex0 = tx * IW - halo, ey0 = ty * IH - halo;           // E origin in image coordinates (may be negative)
+    const int gy = ey0 + ly, gx0 = ex0 + SOR_PX * j;
+    const size_t base = (size_t)b * w * h;
+    const int off = (ex0 + ey0) & 1;             // local parity of the globally "red" pixels
+
+    for (int i = tid; i < 4 * PL4; i += blockDim.x) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);      // also zeroes the guard ring
+    float a11[SOR_PX], a12[SOR_PX], a22[SOR_PX], b1[SOR_PX], b2[SOR_PX], wp[SOR_PX], wu[SOR_PX], du[SOR_PX], dv[SOR_PX];
+    float wl0 = 0.f;
+    unsigned valid = 0;
+    const bool row_ok = ly < EH && gy >= 0 && gy < h;
+    #pragma unroll
+    for (int i = 0; i < SOR_PX; i++) { a11[i] = 1.f; a12[i] = 0.f; a22[i] = 1.f; b1[i] = 0.f; b2[i] = 0.f; wp[i] = 0.f; wu[i] = 0.f; du[i] = 0.f; dv[i] = 0.f; }
+    if (row_ok && gx0 >= 0 && gx0 + SOR_PX <= w) {        // whole strip inside the image: 16-byte loads
+        const size_t g = base + (size_t)gy * w + gx0;
+        valid = 0xffu;
+        ld8(gA11 + g, a11); ld8(gA12 + g, a12); ld8(gA22 + g, a22); ld8(gB1 + g, b1); ld8(gB2 + g, b2); ld8(gW + g, wp); ld8(gUin + g, du); ld8(gVin + g, dv);
+        if (gy > 0) ld8(gW + g - w, wu);
+    } else if (row_ok) {
+        #pragma unroll
+        for (int i = 0; i < SOR_PX; i++) {
+            const int gx = gx0 + i;
+            if (gx >= 0 && gx < w) {
+                const size_t g = base + (size_t)gy * w + gx;
+                valid |= 1u << i;
+                a11[i] = gA11[g]; a12[i] = gA12[g]; a22[i] = gA22[g]; b1[i] = gB1[g]; b2[i] = gB2[g]; wp[i] = gW[g];
+                wu[i] = gy > 0 ? gW[g - w] : 0.f;
+                du[i] = gUin[g]; dv[i] = gVin[g];
+            }
+        }
+    }
+    if (row_ok && gx0 - 1 >= 0 && gx0 - 1 < w) wl0 = gW[base + (size_t)gy * w + gx0 - 1];
+    __syncthreads();
+    // LDS addressing (float4 units): plane(parity q, component c) at (q*2 + c)*PL4; strip j of row ly at (ly+1)*RS4 + 1 + j
+    const int ro4 = (ly + 1) * RS4 + 1 + j;
+    const int s0 = ly & 1;                       // strip pixels i with ((i + ly) & 1) == q have local parity q
+    {   // initial state of both parities: strip pixels s0, s0+2, ... are local-even, the others local-odd
+        const float4 au = make_float4(du[0], du[2], du[4], du[6]), bu = make_float4(du[1], du[3], du[5], du[7]);
+        const float4 av = make_float4(dv[0], dv[2], dv[4], dv[6]), bv = make_float4(dv[1], dv[3], dv[5], dv[7]);
+        const int pe = s0 == 0 ? 0 : 2, po = s0 == 0 ? 2 : 0;      // plane pair receiving the i-even / i-odd pixels
+        lds4[(pe + 0) * PL4 + ro4] = au; lds4[(pe + 1) * PL4 + ro4] = av;
+        lds4[(po + 0) * PL4 + ro4] = bu; lds4[(po + 1) * PL4 + ro4] = bv;
+    }
+    __syncthreads();
+
+    // one half-sweep over the strip pixels START, START+2, START+4, START+6 (compile-time START keeps register indices static);
+    // Q = local parity being updated.  Invalid pixels (outside the image / surplus rows) keep du = dv = 0.
+    #define SOR_HALF(START, Q)                                                                                                    \
+        {                                                                                                                         \
+            const int oq = (Q) ^ 1;                                                                                               \
+            const float4 t0 = lds4[(oq * 2 + 0) * PL4 + ro4 - RS4], t1 = lds4[(oq * 2 + 1) * PL4 + ro4 - RS4];                    \
+            const float4 t2 = lds4[(oq * 2 + 0) * PL4 + ro4 + RS4], t3 = lds4[(oq * 2 + 1) * PL4 + ro4 + RS4];                    \
+            const float uu[4] = {t0.x, t0.y, t0.z, t0.w}, vu[4] = {t1.x, t1.y, t1.z, t1.w};                                       \
+            const float ud[4] = {t2.x, t2.y, t2.z, t2.w}, vd[4] = {t3.x, t3.y, t3.z, t3.w};                                       \
+            /* strip-edge horizontal neighbour: left of pixel 0 (START == 0) or right of pixel 7 (START == 1) */                   \
+            const float eu = lds[4 * ((oq * 2 + 0) * PL4 + ro4) + ((START) == 0 ? -1 : 4)];                                       \
+            const float ev = lds[4 * ((oq * 2 + 1) * PL4 + ro4) + ((START) == 0 ? -1 : 4)];                                       \
+            _Pragma("unroll")                                                                                                     \
+            for (int k = 0; k < 4; k++) {                                                                                         \
+                const int i = (START) + 2 * k;                                                                                    \
+                const float wl = i == 0 ? wl0 : wp[i == 0 ? 0 : i - 1];                                                           \
+                const float ul = i == 0 ? eu : du[i == 0 ? 0 : i - 1], vl = i == 0 ? ev : dv[i == 0 ? 0 : i - 1];                \
+                const float ur = i == 7 ? eu : du[i == 7 ? 7 : i + 1], vr = i == 7 ? ev : dv[i == 7 ? 7 : i + 1];                \
+                const float sigmaU = wl * ul + wp[i] * ur + wu[i] * uu[k] + wp[i] * ud[k];                                        \
+                const float sigmaV = wl * vl + wp[i] * vr + wu[i] * vu[k] + wp[i] * vd[k];                                        \
+                float nu = du[i], nv = dv[i];                                                                                     \
+                nu += omega * ((sigmaU + b1[i] - nv * a12[i]) / a11[i] - nu);                                                     \
+                nv += omega * ((sigmaV + b2[i] - nu * a12[i]) / a22[i] - nv);                                                     \
+                const bool ok = (valid >> i) & 1u;                                                                                \
+                du[i] = ok ? nu : 0.f; dv[i] = ok ? nv : 0.f;                                                                     \
+            }                                                                                                                     \
+            lds4[((Q) * 2 + 0) * PL4 + ro4] = make_float4(du[START], du[(START) + 2], du[(START) + 4], du[(START) + 6]);         \
+            lds4[((Q) * 2 + 1) * PL4 + ro4] = make_float4(dv[START], dv[(START) + 2], dv[(START) + 4], dv[(START) + 6]);         \
+        }
+
+    // globally red pixels have local parity `off`; in this thread's row they are the strip pixels i == c (mod 2), c wave-uniform
+    if ((off ^ s0) == 0) {
+        for (int it = 0; it < iters; it++) { SOR_HALF(0, off) __syncthreads(); SOR_HALF(1, off ^ 1) __syncthreads(); }
+    } else {
+        for (int it = 0; it < iters; it++) { SOR_HALF(1, off) __syncthreads(); SOR_HALF(0, off ^ 1) __syncthreads(); }
+    }
+    #undef SOR_HALF
+    if (row_ok) {
+        const int ix0 = tx * IW, iy0 = ty * IH;
+        if (gy >= iy0 && gy < iy0 + IH) {
+            #pragma unroll
+            for (int i = 0; i < SOR_PX; i++) {
+                const int gx = gx0 + i;
+                if (((valid >> i) & 1u) && gx >= ix0 && gx < ix0 + IW) { const size_t g = base + (size_t)gy * w + gx; gUout[g] = du[i]; gVout[g] = dv[i]; }
+            }
+        }
+    }
+}
+
 // tempW = W + dW (end of a fixed-point iteration); with commit != 0 also W = tempW (end of the level)
 __global__ void k_add_flow(const float* __restrict__ Wu, const float* __restrict__ Wv, const float* __restrict__ dWu,
                            const float* __restrict__ dWv, float* __restrict__ tWu, float* __restrict__ tWv, size_t n) {
@@ -325,6 +454,45 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
     return SIND_OK;
 }
 
+// `total` red-black SOR iterations on the level's system.  Small levels: the whole image is one tile and all iterations run
+// in one launch; larger levels: 64 x 64 tiles, SOR_FUSE iterations per launch with a 2*SOR_FUSE halo, ping-pong between the
+// two increment buffers (a tile reads its halo from neighbours that another workgroup of the same launch rewrites).
+int g_sor_mode = 1;          // 1 = fused kernel (default), 0 = one launch per colour (kept for A/B timing and as a cross-check)
+int g_sor_fuse = 5;
+int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch) {
+    if (g_sor_mode == 0) {
+        const dim3 gs(divup(divup(w, 2), 64), h, B), bs(64);
+        for (int k = 0; k < total; k++) {
+            hipLaunchKernelGGL(k_sor_color, gs, bs, 0, s, w, h, omega, 0, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
+            hipLaunchKernelGGL(k_sor_color, gs, bs, 0, s, w, h, omega, 1, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
+        }
+        *nlaunch += 2LL * total; return SIND_OK;
+    }
+    static bool attr = false;
+    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_sor_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
+    auto sor_lds_bytes = [](int EW, int nt) { const int NR = 2 * ((nt / 2) / (EW / SOR_PX)); return (size_t)4 * (NR + 2) * (EW / 8 + 2) * sizeof(float4); };
+    auto threads_for = [](int EW, int EH) { const int halfn = (EW / SOR_PX) * ((EH + 1) / 2); return 2 * ((halfn + 63) / 64 * 64); };
+    const int EWw = (w + SOR_PX - 1) / SOR_PX * SOR_PX;
+    if (threads_for(EWw, h) <= SOR_NT) {               // whole image in one workgroup: every iteration in one launch, in place
+        const int EW = EWw, EH = h, nt = threads_for(EW, EH);
+        const size_t shm = sor_lds_bytes(EW, nt);
+        hipLaunchKernelGGL(k_sor_fused, dim3(1, B), dim3(nt), shm, s, w, h, EW, EH, EW, EH, 0, 1, total, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt,
+                           P.dWu, P.dWv, P.dWu, P.dWv);
+        *nlaunch += 1; return SIND_OK;
+    }
+    const int EW = 64, EH = 64, nt = threads_for(EW, EH);
+    const size_t shm = sor_lds_bytes(EW, nt);
+    for (int done = 0; done < total;) {
+        const int k = std::min(g_sor_fuse, total - done), halo = 2 * k, IW = EW - 2 * halo, IH = EH - 2 * halo;
+        const int ntx = divup(w, IW), nty = divup(h, IH);
+        hipLaunchKernelGGL(k_sor_fused, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo, ntx, k, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
+                           P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
+        std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);
+        done += k; *nlaunch += 1;
+    }
+    return SIND_OK;
+}
+
 // VariationalRefinement::calcUV on one pyramid level for B pairs.  Wu/Wv: initial flow in, refined flow out.
 int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer) {
     const size_t n = (size_t)w * h * B;
@@ -335,17 +503,14 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     HIP_TRY(hipMemsetAsync(P.dWv, 0, n * sizeof(float), s));
     HIP_TRY(hipMemcpyAsync(P.tWu, P.Wu, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(P.tWv, P.Wv, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    const dim3 gs(divup(divup(w, 2), 64), h, B), bs(64);
     for (int it = 0; it < V.fixedPointIterations; it++) {
         hipLaunchKernelGGL(k_coef, g, blk, 0, s, V, w, h, P.Ix, P.Iy, P.Iz, P.Ixx, P.Ixy, P.Iyy, P.Ixz, P.Iyz, P.Wu, P.Wv, P.tWu, P.tWv,
                            P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt);
         if (timer) timer->begin(s);
-        for (int k = 0; k < V.sorIterations; k++) {
-            hipLaunchKernelGGL(k_sor_color, gs, bs, 0, s, w, h, V.omega, 0, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
-            hipLaunchKernelGGL(k_sor_color, gs, bs, 0, s, w, h, V.omega, 1, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
-        }
+        long long nlaunch = 0;
+        SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch));
         // algorithmic bytes: 44 B per pixel per red+black iteration (9 reads + 2 writes of f32), SURVEY.md §8d
-        if (timer) timer->end(s, 2LL * V.sorIterations, 44.0 * (double)w * h * B * V.sorIterations);
+        if (timer) timer->end(s, nlaunch, 44.0 * (double)w * h * B * V.sorIterations);
         hipLaunchKernelGGL(k_add_flow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.tWu, P.tWv, n);
     }
     HIP_TRY(hipMemcpyAsync(P.Wu, P.tWu, n * sizeof(float), hipMemcpyDeviceToDevice, s));

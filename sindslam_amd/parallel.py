@@ -1,0 +1,39 @@
+"""Multi-GPU layer: streams shard across ranks (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI on
+ROCm, "gloo" on CPU for tests).  The hot path itself has no cross-rank dependency -- a stream is a self-contained sequence --
+so the only collective is the gather of the per-frame dynamic masks that the north star asks for."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_streams(total_streams: int, rank: int, world: int):
+    """Contiguous block of stream ids for `rank`; the first (total % world) ranks take one extra."""
+    base, extra = divmod(total_streams, world)
+    lo = rank * base + min(rank, extra)
+    return list(range(lo, lo + base + (1 if rank < extra else 0)))
+
+
+def gather_masks(local_masks, group=None):
+    """local_masks: torch u8 tensor [S_local, T, H, W] (equal shape on every rank) -> [world, S_local, T, H, W] on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(local_masks.shape), dtype=local_masks.dtype, device=local_masks.device)
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(local_masks) for _ in range(world)]
+        dist.all_gather(parts, local_masks.contiguous(), group=group)
+        for i, p in enumerate(parts):
+            out[i] = p
+    else:
+        dist.all_gather_into_tensor(out, local_masks.contiguous(), group=group)
+    return out
+
+
+def frame_pairs_per_second(local_pairs: int, local_seconds: float, group=None):
+    """whole-job throughput: all ranks' units over the slowest rank's time"""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([local_seconds], dtype=torch.float64, device=dev); n = torch.tensor([local_pairs], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group); dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+    return float(n.item() / t.item())

@@ -1,0 +1,99 @@
+"""CPU: the product's HOST stages (libsind_host.so = sindslam_amd/csrc/host/*, built with plain g++) against the oracle.
+These stages are serial by design (DESIGN.md "host stages") and are written independently of the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H():
+    so = os.path.join(ROOT, "sindslam_amd", "libsind_host.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "sindslam_amd", "csrc"), "../libsind_host.so"])
+    return C.CDLL(so)
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def blobs(seed, density=0.02):
+    rng = np.random.default_rng(seed)
+    m = (rng.random((480, 640)) < density).astype(np.uint8) * 255
+    for _ in range(12):
+        x, y, w, h = rng.integers(0, 600), rng.integers(0, 440), rng.integers(5, 120), rng.integers(5, 90)
+        m[y:y + h, x:x + w] = 255
+    m[0:5, 0:7] = 255; m[470:480, 630:640] = 255
+    return m
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 9, 10, 15])
+def test_bit_morphology_matches_oracle(H, n):
+    m = blobs(n)
+    for op, code in (("dilate", 0), ("erode", 1), ("open", 2), ("close", 3)):
+        a = np.zeros_like(m); H.sindh_morph(P(m), 640, 480, n, code, P(a))
+        assert np.array_equal(a, O.morph(m, n, op)), (n, op)
+
+
+@pytest.mark.parametrize("external", [1, 0])
+def test_contours_match_oracle(H, external):
+    m = O.morph(blobs(77, 0.002), 5, "close")
+    m[100:160, 100:200] = 255; m[120:140, 130:170] = 0; m[125:135, 140:160] = 255      # nested hole / island
+    pts = np.zeros((400000, 2), np.int32); lens = np.zeros(20000, np.int32)
+    n = H.sindh_find_contours(P(m), 640, 480, external, P(pts), len(pts), P(lens), len(lens))
+    ref = O.find_contours(m, bool(external))
+    assert n == len(ref) and lens[:n].tolist() == [len(c) for c in ref]
+    assert np.array_equal(pts[:lens[:n].sum()], np.concatenate(ref))
+
+
+def test_drawing_matches_oracle_pipeline(H):
+    m = O.morph(blobs(5, 0.0), 3, "open")
+    for filled in (1, 0):
+        a = np.zeros_like(m); H.sindh_draw(P(m), 640, 480, filled, P(a))
+        if filled:      # filled external contours = the blobs with their holes closed; every source pixel is covered
+            assert np.all(a[m > 0] == 255)
+        else:           # thickness 2 = border pixels dilated by the 3x3 cross
+            cs = O.find_contours(m, True); b = np.zeros_like(m)
+            for c in cs:
+                for dx, dy in ((0, 0), (1, 0), (-1, 0), (0, 1), (0, -1)):
+                    x = np.clip(c[:, 0] + dx, 0, 639); y = np.clip(c[:, 1] + dy, 0, 479); b[y, x] = 255
+            assert np.array_equal(a, b)
+
+
+def test_homography_identical_to_oracle(H):
+    rng = np.random.default_rng(3); Hm = np.array([[0.99, 0.01, 4.0], [-0.01, 1.0, 1.5], [2e-6, 1e-6, 1.0]])
+    src = rng.uniform(0, 640, (2500, 2)).astype(np.float32)
+    p = np.c_[src, np.ones(len(src))] @ Hm.T; dst = (p[:, :2] / p[:, 2:] + rng.normal(0, 0.3, (len(src), 2))).astype(np.float32)
+    dst[::7] += 25
+    out = np.zeros(9)
+    assert H.sindh_find_homography(P(src), P(dst), len(src), P(out)) == 1
+    ok, ref = O.find_homography(src, dst)
+    assert ok and np.array_equal(out.reshape(3, 3), ref)                         # same specification, same bits
+
+
+def test_peac_plane_contours_identical(H, frames):
+    from sindslam_amd.synth import TUM3
+    bgr, depth = frames
+    dd = O.DynaDetect(bgr[1], bgr[0], TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    dd.detect(bgr[2], depth[2])
+    out = np.zeros((480, 640), np.uint8); d = np.ascontiguousarray(depth[2])
+    H.sindh_peac(P(d), 640, 480, C.c_float(TUM3["fx"]), C.c_float(TUM3["fy"]), C.c_float(TUM3["cx"]), C.c_float(TUM3["cy"]), C.c_float(5000.0), P(out))
+    assert np.array_equal(out, dd.debug()["plane_contours"]) and out.any()
+
+
+def test_octree_identical(H, frames):
+    bgr, _ = frames; orb = O.ORBextractor(1500, 1.2, 8, 15, 5); orb.extract(O.bgr2gray(bgr[2]))
+    per = orb.tables()["per_level"]
+    for lv in range(8):
+        fk = orb.fast_keypoints(lv); sel = orb.selected(lv); w, h = orb.level_size(lv)
+        xyr = np.stack([fk["x"], fk["y"], fk["response"]], 1).astype(np.float32).copy(); out = np.zeros((4000, 3), np.float32)
+        n = H.sindh_octree(P(xyr), len(xyr), 16, w - 16, 16, h - 16, int(per[lv]), P(out), 4000)
+        assert n == len(sel)
+        assert np.array_equal(out[:n, 0] + 16, sel["x"]) and np.array_equal(out[:n, 1] + 16, sel["y"]) and np.array_equal(out[:n, 2], sel["response"])

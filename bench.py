@@ -53,11 +53,13 @@ def cpu_baseline(n_pairs=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=16)
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync", action="store_true", help="no software pipelining across steps")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
     args = ap.parse_args()
 
     import torch
@@ -65,10 +67,11 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    local = local % torch.cuda.device_count()          # rehearsal on a 1-GPU box: ranks share the card
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)     # backend "nccl" is RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)     # backend "nccl" is RCCL on ROCm
 
     from sindslam_amd.pipeline import Pipeline
     from sindslam_amd.synth import TUM3
@@ -82,33 +85,37 @@ def main():
     # inputs resident in HBM before the timed region, laid out [step][S][T]...
     dev_b = [torch.from_numpy(np.ascontiguousarray(bgr[:, 2 + i * T: 2 + (i + 1) * T])).cuda() for i in range(nsteps)]
     dev_d = [torch.from_numpy(np.ascontiguousarray(depth[:, 2 + i * T: 2 + (i + 1) * T]).view(np.int16)).cuda() for i in range(nsteps)]
-    gather_buf = torch.empty((world, S, T, 480, 640), dtype=torch.uint8, device="cuda") if world > 1 else None
     torch.cuda.synchronize()
+    from sindslam_amd.parallel import gather_masks
 
-    def step(i):
-        pipe.process_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr())
+    def gather():
         if world > 1:   # RCCL gather of the per-frame dynamic masks over xGMI
-            m = torch.from_numpy(pipe.dyna).cuda(non_blocking=False)
-            dist.all_gather_into_tensor(gather_buf, m)
+            m = torch.from_numpy(pipe.dyna)
+            gather_masks(m.cuda() if args.backend == "nccl" else m)
 
-    for i in range(Wm):
-        step(i)
+    for i in range(Wm):                     # warm-up: synchronous steps
+        pipe.process_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()); gather()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sor_ms = sor_bytes = 0.0; sor_launches = 0; stages = np.zeros(5)
-    for i in range(Wm, Wm + K):
-        step(i)
+    for i in range(Wm, Wm + K):             # timed: software-pipelined steps (phase A of step i overlaps the tails of step i-1)
+        if args.sync:
+            pipe.process_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()); gather()
+        elif pipe.submit_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()):
+            gather()
         st = pipe.stats()
         sor_ms += st["sor_ms"]; sor_bytes += st["sor_alg_bytes"]; sor_launches += st["sor_launches"]
         stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"]])
+    if not args.sync and pipe.flush():      # drain the last step inside the timed region
+        gather()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     pairs = S * T * K * world
     if rank == 0:
         achieved = sor_bytes / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0      # GB/s, algorithmic bytes / event-timed SOR time
@@ -117,9 +124,9 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "TUM fr3/walking_xyz-shaped synthetic RGB-D stream, 640x480, TUM3 intrinsics, FAST 15/5, 1500 features",
-                       "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world, "parallelism": f"stream-sharded x{world}"},
+                       "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world, "parallelism": f"stream-sharded x{world}", "pipelined": not args.sync},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "k_sor_color", "launches": sor_launches, "avg_launch_us": (sor_ms * 1e3 / sor_launches) if sor_launches else None,
+                         "kernel": "k_sor_fused", "launches": sor_launches, "avg_launch_us": (sor_ms * 1e3 / sor_launches) if sor_launches else None,
                          "alg_bytes_per_launch": (sor_bytes / sor_launches) if sor_launches else None},
             "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "total": stages[4] / K},
         }

@@ -126,6 +126,13 @@ int sind_pipe_process(sind_pipe* p, const uint8_t* bgr, const uint16_t* depth, u
                       sind_keypoint* kps, int cap, int* nkp, uint8_t* desc);                                    /* host inputs */
 int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* depth_dev, uint8_t* dyna, uint8_t* label,
                           uint8_t* mask_dilated, sind_keypoint* kps, int cap, int* nkp, uint8_t* desc);          /* device inputs */
+/* Software-pipelined form: phase A (GPU batch) of the submitted step overlaps with phase B (per-stream tails) of the previously
+ * submitted one.  The output pointers of call i receive the results of step i-1 (*have_output = 0 on the first call);
+ * sind_pipe_flush drains the last step.  Device inputs only need to stay valid until the call returns. */
+int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* depth_dev, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated,
+                         sind_keypoint* kps, int cap, int* nkp, uint8_t* desc, int* have_output);
+int sind_pipe_flush(sind_pipe* p, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated, sind_keypoint* kps, int cap, int* nkp, uint8_t* desc,
+                    int* have_output);
 /* per-stage wall times of the last step in milliseconds: {front_gray, dense_flow, orb_front, depth_copy, tails, total},
  * plus HIP-event statistics of the flow solver: sor_launches, sor_ms (sum of event-bracketed SOR launch groups),
  * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */

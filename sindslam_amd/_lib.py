@@ -22,6 +22,15 @@ def lib() -> C.CDLL:
     if _lib is None:
         if not os.path.exists(SO_PATH):
             raise SindError(f"{SO_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+        # PyTorch's ROCm wheel bundles its own libamdhip64 / libhsa-runtime64.  When this process also uses torch, let torch
+        # bring its HIP runtime up FIRST: initialising the system runtime (which libsind_hip links) before torch's copy has been
+        # seen to leave torch with "No HIP GPUs are available".  Plumbing only; the library itself never calls into torch.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         _lib = C.CDLL(SO_PATH)
         _lib.sind_last_error.restype = C.c_char_p
     return _lib

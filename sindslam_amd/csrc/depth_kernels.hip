@@ -121,6 +121,112 @@ __global__ void __launch_bounds__(256) k_kmeans_farthest(const float* __restrict
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(b, o); b = b > t ? b : t; }
     if ((threadIdx.x & 63) == 0) atomicMax(best, b);
 }
+// ---------------------------------------------------------------- device-resident k-means control (no host round trip per iteration)
+// One KmState per tail.  k_km_update runs the centre step of cv::kmeans (sums -> centres, empty-cluster repair, shift test,
+// last-iteration decision) in a single thread, exactly like the host loop it replaces (same FP32/FP64 operations).
+__device__ void km_try_finalize(KmState* st) {
+    // look for an empty cluster; if there is one, request a farthest-point search and return
+    for (int k = 0; k < KM_K; k++) {
+        if (st->cnt[k] != 0) continue;
+        int max_k = 0; for (int k1 = 1; k1 < KM_K; k1++) if (st->cnt[max_k] < st->cnt[k1]) max_k = k1;
+        const float sc = 1.f / st->cnt[max_k];
+        for (int j = 0; j < 3; j++) st->base[j] = st->ctr[max_k][j] * sc;
+        st->fix_k = k; st->max_k = max_k; st->far = 0ull;
+        return;
+    }
+    st->fix_k = -1;
+    double max_center_shift = st->iter == 0 ? 1.7976931348623157e308 : 0.0;
+    for (int k = 0; k < KM_K; k++) {
+        const float sc = 1.f / st->cnt[k];
+        for (int j = 0; j < 3; j++) st->ctr[k][j] *= sc;
+        if (st->iter > 0) { double dist = 0; for (int j = 0; j < 3; j++) { const double t = st->ctr[k][j] - st->old[k][j]; dist += t * t; } max_center_shift = max_center_shift > dist ? max_center_shift : dist; }
+    }
+    st->iter++;
+    st->phase = 1;                                        // centres of this iteration are final
+    if (st->iter == (st->maxCount > 2 ? st->maxCount : 2) || max_center_shift <= st->eps2) st->done = 1;
+}
+// mode 0: start of an iteration (reduce the per-block partial sums); mode 1: after a farthest-point search
+__global__ void k_km_update(const double* __restrict__ partial, int nblocks, KmState* __restrict__ st, int mode,
+                            const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int* __restrict__ labels) {
+    __shared__ double sums[KM_K * 4];
+    __shared__ double stage[KM_MAX_BLOCKS * KM_K * 4];
+    if (st->done) return;
+    if (mode == 0) {
+        const int t = threadIdx.x;
+        for (int i = t; i < nblocks * KM_K * 4; i += blockDim.x) stage[i] = partial[i];     // parallel fetch, then a fixed-order (deterministic) sum
+        __syncthreads();
+        if (t < KM_K * 4) { double v = 0; for (int b = 0; b < nblocks; b++) v += stage[b * KM_K * 4 + t]; sums[t] = v; }
+        __syncthreads();
+        if (t == 0) {
+            if (st->phase == 0 && st->fix_k >= 0) st->overflow = 1;      // the previous iteration ran out of repair rounds
+            st->phase = 0;
+            for (int k = 0; k < KM_K; k++) { for (int j = 0; j < 3; j++) { st->old[k][j] = st->ctr[k][j]; st->ctr[k][j] = (float)sums[k * 4 + j]; } st->cnt[k] = (int)sums[k * 4 + 3]; }
+            km_try_finalize(st);
+        }
+    } else if (threadIdx.x == 0 && st->phase == 0 && st->fix_k >= 0) {
+        const int fi = (int)(st->far & 0xffffffffull), k = st->fix_k, max_k = st->max_k;
+        const float smp[3] = {px[fi], py[fi], pz[fi]};
+        labels[fi] = k;
+        st->cnt[max_k]--; st->cnt[k]++;
+        for (int j = 0; j < 3; j++) { st->ctr[max_k][j] -= smp[j]; st->ctr[k][j] += smp[j]; }
+        km_try_finalize(st);
+    }
+}
+__global__ void __launch_bounds__(256) k_km_partial_dev(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                        const int* __restrict__ labels, int n, double* __restrict__ partial, const KmState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ double acc[KM_K][4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double s[KM_K][4];
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++) { s[k][0] = s[k][1] = s[k][2] = s[k][3] = 0.0; }
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        const int l = labels[i]; const double x = px[i], y = py[i], z = pz[i];
+        #pragma unroll
+        for (int k = 0; k < KM_K; k++) if (l == k) { s[k][0] += x; s[k][1] += y; s[k][2] += z; s[k][3] += 1.0; }
+    }
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++)
+        #pragma unroll
+        for (int c = 0; c < 4; c++) { double v = s[k][c]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); if (lane == 0) acc[k][c][wv] = v; }
+    __syncthreads();
+    if (tid < KM_K * 4) { const int k = tid >> 2, c = tid & 3; partial[((size_t)blockIdx.x * KM_K + k) * 4 + c] = ((acc[k][c][0] + acc[k][c][1]) + acc[k][c][2]) + acc[k][c][3]; }
+}
+__global__ void __launch_bounds__(256) k_km_farthest_dev(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                         const int* __restrict__ labels, int n, KmState* __restrict__ st) {
+    if (st->done || st->phase != 0 || st->fix_k < 0) return;
+    const int which = st->max_k; const float c0 = st->base[0], c1 = st->base[1], c2 = st->base[2];
+    unsigned long long b = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (labels[i] != which) continue;
+        float t = px[i] - c0; float d = 0.f; d += t * t; t = py[i] - c1; d += t * t; t = pz[i] - c2; d += t * t;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+        b = b > key ? b : key;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(b, o); b = b > t ? b : t; }
+    if ((threadIdx.x & 63) == 0) atomicMax(&st->far, b);
+}
+__global__ void k_km_assign_dev(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int* __restrict__ labels,
+                                int n, const KmState* __restrict__ st) {
+    if (st->done || st->phase != 1) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = px[i], y = py[i], z = pz[i];
+    int best = 0; float md = 3.402823466e+38f;
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++) {
+        float t = x - st->ctr[k][0]; float dist = 0.f; dist += t * t;
+        t = y - st->ctr[k][1]; dist += t * t;
+        t = z - st->ctr[k][2]; dist += t * t;
+        if (md > dist) { md = dist; best = k; }
+    }
+    labels[i] = best;
+}
+__global__ void k_km_reset(KmState* st, int maxCount, double eps2) {
+    if (threadIdx.x == 0) { st->iter = 0; st->done = 0; st->phase = 0; st->overflow = 0; st->fix_k = -1; st->max_k = 0; st->far = 0ull; st->maxCount = maxCount; st->eps2 = eps2;
+        for (int k = 0; k < KM_K; k++) { st->cnt[k] = 0; for (int j = 0; j < 3; j++) { st->ctr[k][j] = 0.f; st->old[k][j] = 0.f; } } }
+}
+
 __global__ void k_labels_to_u8(const int* __restrict__ labels, uint8_t* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const int v = labels[i]; out[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
@@ -310,6 +416,24 @@ int launch_kmeans_assign(hipStream_t s, const float* px, const float* py, const 
 int launch_kmeans_farthest(hipStream_t s, const float* px, const float* py, const float* pz, const int* labels, int n, int which, const float c[3], unsigned long long* best) {
     HIP_TRY(hipMemsetAsync(best, 0, sizeof(unsigned long long), s));
     hipLaunchKernelGGL(k_kmeans_farthest, dim3(std::min(divup(n, 256), 256)), dim3(256), 0, s, px, py, pz, labels, n, which, c[0], c[1], c[2], best); return SIND_OK; }
+// whole cv::kmeans(K=12, USE_INITIAL_LABELS) loop of one pyramid level, enqueued without any host synchronisation.
+// `fix_rounds` empty-cluster repairs are provisioned per iteration; KmState::phase == 0 with fix_k >= 0 after the last
+// iteration's repairs means more were needed (the caller then falls back to the host-stepped loop).
+int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, double* partial, KmState* st,
+                        int maxCount, double eps2, int fix_rounds) {
+    const int nb = std::min(divup(n, 256), KM_MAX_BLOCKS), iters = std::max(maxCount, 2);
+    hipLaunchKernelGGL(k_km_reset, dim3(1), dim3(64), 0, s, st, maxCount, eps2);
+    for (int it = 0; it < iters; it++) {
+        hipLaunchKernelGGL(k_km_partial_dev, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, partial, st);
+        hipLaunchKernelGGL(k_km_update, dim3(1), dim3(256), 0, s, partial, nb, st, 0, px, py, pz, labels);
+        for (int f = 0; f < fix_rounds; f++) {
+            hipLaunchKernelGGL(k_km_farthest_dev, dim3(std::min(divup(n, 256), 128)), dim3(256), 0, s, px, py, pz, labels, n, st);
+            hipLaunchKernelGGL(k_km_update, dim3(1), dim3(64), 0, s, partial, nb, st, 1, px, py, pz, labels);
+        }
+        if (it + 1 < iters) hipLaunchKernelGGL(k_km_assign_dev, dim3(divup(n, 256)), dim3(256), 0, s, px, py, pz, labels, n, st);
+    }
+    return SIND_OK;
+}
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n) { hipLaunchKernelGGL(k_labels_to_u8, dim3(divup(n, 256)), dim3(256), 0, s, labels, out, n); return SIND_OK; }
 int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h) { hipLaunchKernelGGL(k_median5_u16, dim3(divup(w, 64), h), dim3(64), 0, s, src, dst, w, h); return SIND_OK; }
 int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out) {

@@ -45,6 +45,8 @@ public:
     // dyna_out / label_out: host H x W u8 (0 invalid / 125 static / 255 dynamic ; 0 invalid, 1..n clusters).
     int process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out);
     void reset();
+    double t_stage[6] = {0, 0, 0, 0, 0, 0}; long n_frames = 0;
+    double t_fine[12] = {0};       // cal_occluded: gpu+d2h, pack, endpoints, peac, contour filter, close | seg_merge: pieces, planes+h2d, rag gpu, merge    // flow masks, k-means, label prep, CalOccluded, SegAndMerge, fusion (ms, SIND_TAIL_TIMING=1)
 private:
     int W = 0, H = 0, N = 0;
     std::vector<uint8_t> dynaLast, labelLast, highLast;       // host state images (DynaDetect.h:172-178)
@@ -55,6 +57,8 @@ private:
     DevBuf<PeacBlockStats> blocks_d;
     int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high);
     int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
+    int kmeans_stepped(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
+    DevBuf<KmState> kstate;
     int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2);
     int seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,
                       const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew);

@@ -9,9 +9,12 @@
 #include <cmath>
 #include <cstring>
 #include "dyna.hpp"
+#include <chrono>
 #include "host/rng.hpp"
 
 namespace sind {
+
+static inline double tick_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ======================================================================================================= front
 int DynaFront::init(const DynaConfig& c, int maxB_, hipStream_t s) {
@@ -204,7 +207,7 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
 }
 
 // ---- DD:315-420: 4-level k-means, K = 12, criteria (EPS+COUNT, 4, 0.07), KMEANS_USE_INITIAL_LABELS
-int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
+int DynaTail::kmeans_stepped(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
     const float scales[4] = {1.0f, 0.5f, 0.25f, 0.125f};
     const uint16_t* dl[4] = {depth_dev, dpyr[1].p, dpyr[2].p, dpyr[3].p};
     for (int l = 1; l < 4; l++) SIND_TRY(launch_depth_half(stream, dl[l - 1], dpyr[l].p, W >> l, H >> l));
@@ -256,8 +259,36 @@ int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, fl
     return SIND_OK;
 }
 
+// Fast path of the same computation: the whole 4-level k-means is enqueued without a single host round trip (the centre
+// step, empty-cluster repair and the stop test run in k_km_update on the device); one D2H of the four KmStates + labels at the
+// end.  If an iteration needed more empty-cluster repairs than were provisioned, the host-stepped loop above redoes the frame.
+int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
+    const float scales[4] = {1.0f, 0.5f, 0.25f, 0.125f};
+    const uint16_t* dl[4] = {depth_dev, dpyr[1].p, dpyr[2].p, dpyr[3].p};
+    SIND_TRY(kstate.alloc(4));
+    for (int l = 1; l < 4; l++) SIND_TRY(launch_depth_half(stream, dl[l - 1], dpyr[l].p, W >> l, H >> l));
+    if (labelLastAny) HIP_TRY(hipMemcpyAsync(labPrev8.p, labelLast.data(), N, hipMemcpyHostToDevice, stream));
+    for (int level = 3; level >= 0; level--) {
+        const int hp = (int)(H * scales[level]), wp = (int)(W * scales[level]), n = hp * wp;
+        SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale));
+        if (level == 3) { if (!labelLastAny) SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp)); else SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp)); }
+        else SIND_TRY(launch_labels_resize_i32(stream, lab[level + 1].p, lab[level].p, wp / 2, hp / 2, wp, hp));
+        SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, kstate.p + level, 4, 0.07 * 0.07, 2));
+    }
+    SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N));
+    KmState st[4]; label8.resize(N);
+    HIP_TRY(hipMemcpyAsync(st, kstate.p, sizeof(st), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(label8.data(), lab8.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int l = 0; l < 4; l++) if (st[l].overflow || (st[l].phase == 0 && st[l].fix_k >= 0)) return kmeans_stepped(depth_dev, label8, centers, counts);
+    std::memcpy(centers, st[0].ctr, sizeof(st[0].ctr)); std::memcpy(counts, st[0].cnt, sizeof(st[0].cnt));
+    return SIND_OK;
+}
+
 // ---- DD:429-642: depth-gradient edges (GPU), end points, PEAC plane contours, plane-edge filtering (host)
 int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2) {
+    double tf = tick_ms();
+    #define FLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tf; tf = t_; }
     SIND_TRY(launch_median5(stream, depth_dev, filt.p, W, H));
     SIND_TRY(launch_max_u16(stream, filt.p, N, umax_d.p));
     SIND_TRY(launch_grad_edge(stream, filt.p, umax_d.p, edge.p, total.p, W, H, cfg.depthScale));
@@ -269,8 +300,10 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     HIP_TRY(hipMemcpyAsync(t8.data(), total.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(blocks.data(), blocks_d.p, blocks.size() * sizeof(PeacBlockStats), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    FLAP(0)
     const BitImg occ = BitImg::from_u8(e8.data(), W, H, W);
     totalArea = BitImg::from_u8(t8.data(), W, H, W);
+    FLAP(1)
     // end points: edge pixels with at most 4 of the 12 radius-2 ring pixels set (DD:498-532), greedy NMS radius 6 in scan order
     static const int ring[12][2] = {{0,-2},{1,-2},{2,-1},{2,0},{2,1},{1,2},{0,2},{-1,2},{-2,1},{-2,0},{-2,-1},{-1,-2}};
     std::vector<PtI> endPoints;
@@ -280,9 +313,11 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
         if (s <= 4) endPoints.push_back({col, row});
     }
     { std::vector<PtI> sel; for (const PtI& e : endPoints) { bool ov = false; for (const PtI& q : sel) { const int dx = e.x - q.x, dy = e.y - q.y; if ((float)dx * dx + dy * dy < 6.0f * 6.0f) { ov = true; break; } } if (!ov) sel.push_back(e); } endPoints.swap(sel); }
+    FLAP(2)
     // PEAC plane contours (DD:558-593)
     BitImg planeC; PeacInput pin{blocks.data(), depth_host, W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale};
     peac_plane_contours(pin, planeC);
+    FLAP(3)
     BitImg edgeByPlane = planeC; edgeByPlane.andnot(occ);                       // DD:599
     std::vector<Contour> contours; find_contours(edgeByPlane, contours, true);
     BitImg acc(W, H);
@@ -293,10 +328,13 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
         const Rect bb = contour_bbox(c);
         one = one.dilated(e10, bb.y0 - 1, bb.y1 + 1);
         bool isEnd = false; for (const PtI& e : endPoints) if (one.get(e.x, e.y)) { isEnd = true; break; }
-        if (isEnd) acc |= one.eroded(e7);
+        if (isEnd) acc |= one.eroded_rows(e7, bb.y0 - 7, bb.y1 + 7);
     }
+    FLAP(4)
     occ2 = acc;
     BitImg u = occ; u |= acc; occ1 = u.closed(e3);
+    FLAP(5)
+    #undef FLAP
     if (keep_debug) { dbg.gradEdge = e8; dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
     return SIND_OK;
 }
@@ -306,6 +344,8 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
                             const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew) {
     struct Piece { BitImg img, dil, lianjie; bool hasLianjie = false; float area = 0, score = -10, cz = 0; };
     std::vector<Piece> all;
+    double tf = tick_ms();
+    #define FLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tf; tf = t_; }
     const EllipseElem e4(4), e7(7), e9(9), e10(10);
     const BitImg occDil = occ1.dilated(e10);
     const float depth_weight = 1.5f;
@@ -338,6 +378,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
             all.push_back(std::move(p));
         }
     }
+    FLAP(6)
     const int C = (int)all.size();
     dbg.nClusters = C;
     labelNew.assign(N, 0);
@@ -359,6 +400,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     HIP_TRY(hipMemcpyAsync(planes_d.p, planes.data(), planes.size() * 8, hipMemcpyHostToDevice, stream));
     std::vector<uint8_t> o2(N); occ2.to_u8(o2.data(), W, 255);
     HIP_TRY(hipMemcpyAsync(occ2_d.p, o2.data(), N, hipMemcpyHostToDevice, stream));
+    FLAP(7)
     SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1));
     SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, depthN.p, N));
     int* ov_d = rag_d.p; int* ovp_d = ov_d + C * C; int* lj_d = ovp_d + C * C; int* la_d = lj_d + C * C; int* hist_dd = la_d + C;
@@ -366,6 +408,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     std::vector<int> rag((size_t)3 * C * C + C + (size_t)C * 256);
     HIP_TRY(hipMemcpyAsync(rag.data(), rag_d.p, rag.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    FLAP(8)
     const int* ov = rag.data(); const int* ovp = ov + C * C; const int* ljo = ovp + C * C; const int* lja = ljo + C * C; const int* hst = lja + C;
     // cal_hist (DD:1685-1739) from the two masked histograms
     auto cal_hist = [&](int a, int b, double out[3]) {
@@ -439,6 +482,8 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
         labelindex++;
     }
     for (int k = 0; k < N; k++) labelNew[k] = lut[total[k]];
+    FLAP(9)
+    #undef FLAP
     return SIND_OK;
 }
 
@@ -446,11 +491,15 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
 int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out) {
     HIP_TRY(hipSetDevice(cfg.device));
     BitImg maskLow, maskHigh;
+    double tk = tick_ms(); n_frames++;
+    #define LAP(i) { const double t_ = tick_ms(); t_stage[i] += t_ - tk; tk = t_; }
     SIND_TRY(flow_masks(U, V, maskLow, maskHigh));
+    LAP(0)
     // k-means (DD:1410-1414)
     std::vector<uint8_t> label8; float centers[KM_K][3]; int counts[KM_K];
     SIND_TRY(kmeans(depth_dev, label8, centers, counts));
     if (keep_debug) { dbg.kmeansLabel = label8; std::memcpy(dbg.centers, centers, sizeof(centers)); }
+    LAP(1)
     // nearest clusters first (DD:1428-1491)
     float depth_vals[KM_K]; int order[KM_K];
     for (int i = 0; i < KM_K; i++) { depth_vals[i] = centers[i][2]; if (depth_vals[i] < 0.2) depth_vals[i] += 20.0f; order[i] = i; }
@@ -468,9 +517,12 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     }
     labelForSegEdge = labelForSegEdge.dilated(EllipseElem(7));
     BitImg totalArea, occ1, occ2;
+    LAP(2)
     SIND_TRY(cal_occluded(depth_host, depth_dev, totalArea, occ1, occ2));
+    LAP(3)
     std::vector<uint8_t> label3(N, 0);
     if (!allLabels.empty()) SIND_TRY(seg_and_merge(allLabels, occ1, occ2, labelForSegEdge, depth_host, depth_dev, label3));
+    LAP(4)
     int maxNum = 0; for (uint8_t v : label3) maxNum = std::max<int>(maxNum, v);
     if (keep_debug) { dbg.occ1.resize(N); occ1.to_u8(dbg.occ1.data(), W, 255); dbg.occ2.resize(N); occ2.to_u8(dbg.occ2.data(), W, 255); dbg.totalArea.resize(N); totalArea.to_u8(dbg.totalArea.data(), W, 255); }
     // fusion (DD:1553-1636)
@@ -502,6 +554,8 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     // roll the state (DD:1660-1664)
     dynaLast = out; labelLast = label3; maskHigh.to_u8(highLast.data(), W, 255);
     labelLastAny = false; for (uint8_t v : label3) if (v) { labelLastAny = true; break; }
+    LAP(5)
+    #undef LAP
     return SIND_OK;
 }
 

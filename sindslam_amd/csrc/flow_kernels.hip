@@ -202,13 +202,13 @@ __global__ void k_sor_color(int w, int h, float omega, int color, const float* _
 //     the interior (written back) is exact; at image borders E is clipped and the boundary condition is exact.
 // Arithmetic per pixel is identical to k_sor_color / OpenCV RedBlackSOR_ParBody, so results stay bit-exact.
 #define SOR_PX 8
-#define SOR_NT 512
+#define SOR_NT 1024
 struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };     // 4-byte aligned 16-byte load (gfx950 allows unaligned dwordx4)
 __device__ __forceinline__ void ld8(const float* __restrict__ p, float (&d)[SOR_PX]) {
     const F4u a = *reinterpret_cast<const F4u*>(p), c = *reinterpret_cast<const F4u*>(p + 4);
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = c.x; d[5] = c.y; d[6] = c.z; d[7] = c.w;
 }
-__global__ void __launch_bounds__(SOR_NT, 4) k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo, int ntx, int iters, float omega,
+__global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo, int ntx, int iters, float omega,
                                                       const float* __restrict__ gA11, const float* __restrict__ gA12, const float* __restrict__ gA22,
                                                       const float* __restrict__ gB1, const float* __restrict__ gB2, const float* __restrict__ gW,
                                                       const float* __restrict__ gUin, const float* __restrict__ gVin, float* __restrict__ gUout,
@@ -459,6 +459,7 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 // two increment buffers (a tile reads its halo from neighbours that another workgroup of the same launch rewrites).
 int g_sor_mode = 1;          // 1 = fused kernel (default), 0 = one launch per colour (kept for A/B timing and as a cross-check)
 int g_sor_fuse = 5;
+int g_sor_tile_w = 64;       // 128 x 64 tiles (1024 threads) or 64 x 64 (512 threads)
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch) {
     if (g_sor_mode == 0) {
         const dim3 gs(divup(divup(w, 2), 64), h, B), bs(64);
@@ -480,7 +481,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
                            P.dWu, P.dWv, P.dWu, P.dWv);
         *nlaunch += 1; return SIND_OK;
     }
-    const int EW = 64, EH = 64, nt = threads_for(EW, EH);
+    const int EW = g_sor_tile_w, EH = 64, nt = threads_for(EW, EH);
     const size_t shm = sor_lds_bytes(EW, nt);
     for (int done = 0; done < total;) {
         const int k = std::min(g_sor_fuse, total - done), halo = 2 * k, IW = EW - 2 * halo, IH = EH - 2 * halo;

@@ -124,6 +124,17 @@ public:
     }
     // erosion: positions outside the image are ignored, i.e. erode(X) = ~dilate(~X) inside the image
     BitImg eroded(const EllipseElem& e) const { return inverted().dilated(e).inverted(); }
+    // erosion of an image whose set pixels all lie in rows [y0, y1]: the result is a subset of the source, so only those rows
+    // are evaluated (complement rows further than the element height away cannot influence them)
+    BitImg eroded_rows(const EllipseElem& e, int y0, int y1) const {
+        y0 = std::max(y0, 0); y1 = std::min(y1, h - 1);
+        BitImg out(w, h);
+        if (y1 < y0) return out;
+        const BitImg d = inverted().dilated(e, y0 - e.n, y1 + e.n);
+        const uint64_t tm = tail_mask();
+        for (int y = y0; y <= y1; y++) { const uint64_t* p = d.row(y); uint64_t* o = out.row(y); for (int k = 0; k < wpr; k++) o[k] = ~p[k]; o[wpr - 1] &= tm; }
+        return out;
+    }
     BitImg opened(const EllipseElem& e) const { return eroded(e).dilated(e); }
     BitImg closed(const EllipseElem& e) const { return dilated(e).eroded(e); }
 };

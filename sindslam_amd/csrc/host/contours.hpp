@@ -21,7 +21,10 @@ inline void find_contours(const BitImg& src, std::vector<Contour>& out, bool ext
     bb.x0 = std::max(bb.x0, 0); bb.y0 = std::max(bb.y0, 0); bb.x1 = std::min(bb.x1, src.w - 1); bb.y1 = std::min(bb.y1, src.h - 1);
     const int bw = bb.x1 - bb.x0 + 1, bh = bb.y1 - bb.y0 + 1, w = bw + 2, h = bh + 2;
     std::vector<signed char> img((size_t)w * h, 0);
-    for (int y = 0; y < bh; y++) for (int x = 0; x < bw; x++) if (src.get(bb.x0 + x, bb.y0 + y)) img[(size_t)(y + 1) * w + x + 1] = 1;
+    for (int y = 0; y < bh; y++) {                                     // expand the set bits of the bounding box rows
+        const uint64_t* r = src.row(bb.y0 + y); signed char* o = &img[(size_t)(y + 1) * w + 1 - bb.x0];
+        for (int k = bb.x0 >> 6; k <= bb.x1 >> 6; k++) { uint64_t m = r[k]; while (m) { const int x = (k << 6) + __builtin_ctzll(m); m &= m - 1; if (x >= bb.x0 && x <= bb.x1) o[x] = 1; } }
+    }
     const int d8[8] = {1, -w + 1, -w, -w - 1, -1, w - 1, w, w + 1};
     int deltas[16]; for (int i = 0; i < 16; i++) deltas[i] = d8[i & 7];
     static const int cdx[8] = {1, 1, 0, -1, -1, -1, 0, 1}, cdy[8] = {0, -1, -1, -1, 0, 1, 1, 1};

@@ -77,11 +77,19 @@ struct Fitter {
     void unite(int x, int y) { int a = find(x), b = find(y); if (a == b) return; if (dsSize[a] < dsSize[b]) { dsParent[a] = b; dsSize[b] += dsSize[a]; } else { dsParent[b] = a; dsSize[a] += dsSize[b]; } }
     void link(int a, int b) { pool[a].nbs.insert(b); pool[b].nbs.insert(a); }
     void unlink_all(int a) { for (int nb : pool[a].nbs) pool[nb].nbs.erase(a); pool[a].nbs.clear(); }
+    std::vector<float> cloud;     // organised cloud (x, y, z) of the frame, z = NaN-equivalent flag -1 for missing depth
+    void build_cloud() {
+        cloud.resize((size_t)W * H * 3);
+        const float inv = 1.0f / in.depthScale;
+        for (int row = 0; row < H; row++) { const uint16_t* dr = in.depth + (size_t)row * W; float* c = &cloud[(size_t)row * W * 3];
+            for (int col = 0; col < W; col++) { const float d = (float)dr[col];
+                if (d < 1e-3f) { c[3 * col + 2] = -1.f; continue; }
+                const float z = d * inv; c[3 * col] = (col - in.cx) * z / in.fx; c[3 * col + 1] = (row - in.cy) * z / in.fy; c[3 * col + 2] = z; } }
+    }
     bool point(int row, int col, double p[3]) const {
-        const float d = (float)in.depth[(size_t)row * W + col];
-        if (d < 1e-3f) return false;
-        const float z = d * (1.0f / in.depthScale);
-        p[0] = (double)((col - in.cx) * z / in.fx); p[1] = (double)((row - in.cy) * z / in.fy); p[2] = (double)z;
+        const float* c = &cloud[((size_t)row * W + col) * 3];
+        if (c[2] < 0.f) return false;
+        p[0] = (double)c[0]; p[1] = (double)c[1]; p[2] = (double)c[2];
         return true;
     }
 
@@ -150,6 +158,7 @@ struct Fitter {
             else --i;
         }
         cluster(q);
+        build_cloud();
         // ---- refineDetails: block erosion, seeds, region grow, last merge
         std::vector<int> planes = extracted; extracted.clear();
         std::map<int, int> rid2pl; for (int k = 0; k < (int)planes.size(); k++) rid2pl.insert({pool[planes[k]].rid, k});
@@ -186,7 +195,9 @@ struct Fitter {
                 const int blk = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
                 if (blk >= 0 && blkMap[blk] >= 0) continue;
                 double pt[3]; float cdist = -1;
-                if (point(cy, cx, pt) && std::pow(cdist = (float)std::fabs(S.dist(pt)), 2) < 9 * S.mse + 1e-5) {
+                const bool has_pt = point(cy, cx, pt);
+                if (has_pt) cdist = (float)std::fabs(S.dist(pt));
+                if (has_pt && (double)cdist * (double)cdist < 9 * S.mse + 1e-5) {
                     if (trail >= 0) { Seg& O = pool[planes[trail]]; if (S.similarity(O) >= P.simRefine) link(planes[trail], planes[pl]); }
                     float& od = distMap[c];
                     if (cdist < od) { trail = pl; od = cdist; seeds.push_back({c, pl}); }

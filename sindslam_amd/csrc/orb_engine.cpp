@@ -3,6 +3,7 @@
 // and BRIEF on the GPU for the survivors; mask erasure / fallback / scaling (:1063-1163) in finish().
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include "orb.hpp"
 
 namespace sind {
@@ -120,7 +121,8 @@ int OrbEngine::extract_all(const uint8_t* gray, int B, std::vector<OrbFrameResul
     std::vector<OrbSelKp> h_sel((size_t)B * sel_cap); std::vector<int> h_nsel(B, 0);
     std::vector<std::vector<OctKp>> sel_resp(B);
     int max_sel = 0;
-    for (int b = 0; b < B; b++) {
+    std::vector<int> frame_rc(B, SIND_OK);
+    auto octree_frame = [&](int b) {
         const OrbRawKp* D = &h_dense[(size_t)b * std::max(max_total, 1)];
         int n = 0;
         for (int l = 0; l < nlevels; l++) {
@@ -134,13 +136,20 @@ int OrbEngine::extract_all(const uint8_t* gray, int B, std::vector<OrbFrameResul
             std::vector<OctKp> sel;
             if (!in.empty()) distribute_octree(in, minBX, maxBX, minBY, maxBY, mnFeaturesPerLevel[l], sel);
             for (const OctKp& k : sel) {
-                if (n >= sel_cap) { sind_set_error("OrbEngine: more than %d selected keypoints", sel_cap); return SIND_E_CAPACITY; }
+                if (n >= sel_cap) { frame_rc[b] = SIND_E_CAPACITY; return; }
                 h_sel[(size_t)b * sel_cap + n] = {k.x + minBX, k.y + minBY, l};
                 sel_resp[b].push_back(k); n++;
             }
         }
-        h_nsel[b] = n; max_sel = std::max(max_sel, n);
+        h_nsel[b] = n;
+    };
+    {   // the quadtree of a frame is serial, frames are independent: spread them over host threads
+        const int nth = std::max(1, std::min<int>(B, std::min<int>(12, (int)std::thread::hardware_concurrency())));
+        std::vector<std::thread> th;
+        for (int t = 0; t < nth; t++) th.emplace_back([&, t] { for (int b = t; b < B; b += nth) octree_frame(b); });
+        for (auto& t : th) t.join();
     }
+    for (int b = 0; b < B; b++) { if (frame_rc[b] != SIND_OK) { sind_set_error("OrbEngine: more than %d selected keypoints", sel_cap); return frame_rc[b]; } max_sel = std::max(max_sel, h_nsel[b]); }
     // ---- orientation + descriptors on the GPU
     HIP_TRY(hipMemcpyAsync(sel_dev.p, h_sel.data(), h_sel.size() * sizeof(OrbSelKp), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(nsel_dev.p, h_nsel.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));

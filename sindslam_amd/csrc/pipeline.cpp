@@ -18,8 +18,11 @@ struct sind_pipe {
     sind_pipe_config c{}; DynaConfig dc; int S = 0, T = 0, fw = 0, fh = 0;
     hipStream_t stream = nullptr; std::vector<hipStream_t> tail_streams;
     DynaFront front; OrbEngine orb; std::vector<std::unique_ptr<DynaTail>> tails;
-    DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d; DevBuf<float> U, V;
-    std::vector<uint16_t> depth_h; std::vector<char> primed;
+    DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
+    // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
+    struct StepBuf { DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; std::vector<uint16_t> depth_h; std::vector<OrbFrameResult> orb; bool pending = false; } sb[2];
+    int cur = 0;
+    std::vector<char> primed;
     double stage_ms[6] = {0}; double sor_ms = 0, sor_bytes = 0; long long sor_launches = 0;
 };
 
@@ -49,17 +52,24 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->stream));
     p->tail_streams.resize(p->S); p->tails.resize(p->S);
     for (int s = 0; s < p->S; s++) {
-        HIP_TRY(hipStreamCreateWithFlags(&p->tail_streams[s], hipStreamNonBlocking));
+        { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIP_TRY(hipStreamCreateWithPriority(&p->tail_streams[s], hipStreamNonBlocking, hi)); }   // tails' small kernels overtake the next step's flow
         p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->tail_streams[s]));
     }
     SIND_TRY(p->gray.alloc(np * B)); SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
     if (cfg->orb_gray_rgb_order) SIND_TRY(p->gray_orb.alloc(np * B));
-    SIND_TRY(p->U.alloc(np * B)); SIND_TRY(p->V.alloc(np * B));
-    p->depth_h.resize(np * B); p->primed.assign(p->S, 0);
+    for (int k = 0; k < 2; k++) { SIND_TRY(p->sb[k].U.alloc(np * B)); SIND_TRY(p->sb[k].V.alloc(np * B)); SIND_TRY(p->sb[k].depth_dev.alloc(np * B)); p->sb[k].depth_h.resize(np * B); }
+    p->primed.assign(p->S, 0);
     *out = p.release(); return SIND_OK;
 }
 int sind_pipe_destroy(sind_pipe* p) {
     if (!p) return SIND_OK;
+    if (getenv("SIND_TAIL_TIMING")) {
+        double t[6] = {0}; long n = 0;
+        for (auto& tl : p->tails) { for (int i = 0; i < 6; i++) t[i] += tl->t_stage[i]; n += tl->n_frames; }
+        double f[12] = {0}; for (auto& tl : p->tails) for (int i = 0; i < 12; i++) f[i] += tl->t_fine[i];
+        if (n) fprintf(stderr, "[sind] cal_occluded: gpu+d2h %.2f pack %.2f endpoints %.2f peac %.2f contour-filter %.2f close %.2f | seg_merge: pieces %.2f planes+h2d %.2f rag %.2f merge %.2f\n", f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5] / n, f[6] / n, f[7] / n, f[8] / n, f[9] / n);
+        if (n) fprintf(stderr, "[sind] tail ms/frame over %ld frames: flow_masks %.2f kmeans %.2f labels %.2f cal_occluded %.2f seg_merge %.2f fusion %.2f\n", n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n);
+    }
     (void)hipSetDevice(p->c.device);
     (void)hipDeviceSynchronize();
     std::vector<hipStream_t> ss = p->tail_streams; ss.push_back(p->stream);
@@ -80,71 +90,131 @@ int sind_pipe_prime(sind_pipe* p, int s, const uint8_t* last, const uint8_t* las
     return SIND_OK;
 }
 
-int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* depth_dev, uint8_t* dyna, uint8_t* label, uint8_t* mask_dil,
-                          sind_keypoint* kps, int cap, int* nkp, uint8_t* desc) {
-    if (!p || !bgr_dev || !depth_dev) { sind_set_error("sind_pipe_process: null input"); return SIND_E_ARG; }
-    for (int s = 0; s < p->S; s++) if (!p->primed[s]) { sind_set_error("sind_pipe_process: stream %d was not primed", s); return SIND_E_STATE; }
-    HIP_TRY(hipSetDevice(p->c.device));
+// ---- phase A of one step (state free, batched over S*T frames, shared HIP stream): fills a StepBuf
+static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev, const uint16_t* depth_dev, double t[4]) {
     const int S = p->S, T = p->T, B = S * T, W = p->c.width, H = p->c.height;
     const size_t np = (size_t)W * H, fb = (size_t)p->fw * p->fh;
-    const double t0 = now_ms();
-    // ---- phase A1: gray for all frames, 0.6-scaled gray into the per-stream pools behind the two history slots
+    t[0] = now_ms();
+    // gray for all frames, 0.6-scaled gray into the per-stream pools behind the two history slots
     SIND_TRY(launch_bgr2gray(p->stream, bgr_dev, p->gray.p, np * B, false));
     for (int s = 0; s < S; s++)
         SIND_TRY(launch_resize_u8(p->stream, p->gray.p + np * (size_t)s * T, p->pool.p + fb * ((size_t)s * (T + 2) + 2), W, H, p->fw, p->fh, T, W, p->fw, np, fb));
     const uint8_t* gray_for_orb = p->gray.p;
     if (p->c.orb_gray_rgb_order) { SIND_TRY(launch_bgr2gray(p->stream, bgr_dev, p->gray_orb.p, np * B, true)); gray_for_orb = p->gray_orb.p; }
-    // depth to the host (PEAC region grow and cluster centres read single pixels); overlaps with the flow below
-    HIP_TRY(hipMemcpyAsync(p->depth_h.data(), depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToHost, p->stream));
-    const double t1 = now_ms();
-    // ---- phase A2: dense flow for every (n, n-2) pair, second pass for large-motion pairs, refinement, up-scale
+    // private copies of the depth frames: device (tail kernels of this step run while the caller may reuse its buffer) and host
+    HIP_TRY(hipMemcpyAsync(sb.depth_dev.p, depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(sb.depth_h.data(), sb.depth_dev.p, np * B * sizeof(uint16_t), hipMemcpyDeviceToHost, p->stream));
+    t[1] = now_ms();
+    // dense flow for every (n, n-2) pair, second pass for large-motion pairs, refinement, up-scale
     std::vector<int> cur(B), p1(B), p2(B);
-    for (int s = 0; s < S; s++) for (int t = 0; t < T; t++) { const int k = s * T + t, base = s * (T + 2) + t; cur[k] = base + 2; p1[k] = base + 1; p2[k] = base; }
+    for (int s = 0; s < S; s++) for (int tt = 0; tt < T; tt++) { const int k = s * T + tt, base = s * (T + 2) + tt; cur[k] = base + 2; p1[k] = base + 1; p2[k] = base; }
     p->front.flow.sor_timer.enabled = true; p->front.flow.sor_timer.reset();
-    SIND_TRY(p->front.dense_flow(p->pool.p, cur.data(), p1.data(), p2.data(), B, p->U.p, p->V.p, nullptr));
+    SIND_TRY(p->front.dense_flow(p->pool.p, cur.data(), p1.data(), p2.data(), B, sb.U.p, sb.V.p, nullptr));
     HIP_TRY(hipStreamSynchronize(p->stream));
     p->sor_ms = p->front.flow.sor_timer.collect_ms(); p->sor_bytes = p->front.flow.sor_timer.alg_bytes; p->sor_launches = p->front.flow.sor_timer.launches;
-    const double t2 = now_ms();
-    // ---- phase A3: ORB front (pyramid, FAST, octree, orientation, blur, BRIEF) for all frames
-    std::vector<OrbFrameResult> orb_all;
-    SIND_TRY(p->orb.extract_all(gray_for_orb, B, orb_all));
+    t[2] = now_ms();
+    // ORB front (pyramid, FAST, octree, orientation, blur, BRIEF) for all frames
+    SIND_TRY(p->orb.extract_all(gray_for_orb, B, sb.orb));
     // roll the gray history: the last two frames of every stream become slots 0, 1
     for (int s = 0; s < S; s++) {
         uint8_t* base = p->pool.p + fb * (size_t)s * (T + 2);
-        if (T >= 2) HIP_TRY(hipMemcpyAsync(base, base + fb * T, fb * 2, hipMemcpyDeviceToDevice, p->stream));
+        if (T >= 2) { HIP_TRY(hipMemcpyAsync(base, base + fb * T, fb * 2, hipMemcpyDeviceToDevice, p->stream)); }
         else { HIP_TRY(hipMemcpyAsync(base, base + fb, fb, hipMemcpyDeviceToDevice, p->stream)); HIP_TRY(hipMemcpyAsync(base + fb, base + fb * 2, fb, hipMemcpyDeviceToDevice, p->stream)); }
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
-    const double t3 = now_ms();
-    // ---- phase B: stateful tails, one host thread per stream (or a bounded pool)
+    t[3] = now_ms();
+    sb.pending = true;
+    return SIND_OK;
+}
+
+// ---- phase B of one step (stateful tails, one host thread per stream or a bounded pool, each on its own HIP stream)
+struct PipeOut { uint8_t *dyna, *label, *mask; sind_keypoint* kps; int cap; int* nkp; uint8_t* desc; };
+static int phase_b(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
+    const int S = p->S, T = p->T, W = p->c.width, H = p->c.height; const size_t np = (size_t)W * H;
     std::vector<int> rc(S, SIND_OK); std::vector<std::string> err(S);
-    int nthreads = p->c.host_threads > 0 ? std::min(p->c.host_threads, S) : S;
+    const int nthreads = p->c.host_threads > 0 ? std::min(p->c.host_threads, S) : S;
     std::vector<std::thread> th;
     auto work = [&](int tid) {
         for (int s = tid; s < S; s += nthreads) {
             std::vector<uint8_t> dy(np), lb(np), dil(np);
             for (int t = 0; t < T && rc[s] == SIND_OK; t++) {
                 const int k = s * T + t;
-                int r = p->tails[s]->process(p->depth_h.data() + np * k, depth_dev + np * k, p->U.p + np * k, p->V.p + np * k, dy.data(), lb.data());
+                int r = p->tails[s]->process(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.U.p + np * k, sb.V.p + np * k, dy.data(), lb.data());
                 if (r != SIND_OK) { rc[s] = r; err[s] = sind_last_error(); break; }
                 dilate15_codes(dy.data(), W, H, dil.data());
-                if (dyna) std::memcpy(dyna + np * k, dy.data(), np);
-                if (label) std::memcpy(label + np * k, lb.data(), np);
-                if (mask_dil) std::memcpy(mask_dil + np * k, dil.data(), np);
+                if (o.dyna) std::memcpy(o.dyna + np * k, dy.data(), np);
+                if (o.label) std::memcpy(o.label + np * k, lb.data(), np);
+                if (o.mask) std::memcpy(o.mask + np * k, dil.data(), np);
                 std::vector<OrbKeyPoint> kk; std::vector<uint8_t> dd;
-                p->orb.finish(orb_all[k], dil.data(), W, kk, dd);
-                if ((int)kk.size() > cap && kps) { rc[s] = SIND_E_CAPACITY; err[s] = "keypoint capacity exceeded"; break; }
-                if (nkp) nkp[k] = (int)kk.size();
-                if (kps) std::memcpy(kps + (size_t)k * cap, kk.data(), kk.size() * sizeof(sind_keypoint));
-                if (desc) std::memcpy(desc + (size_t)k * cap * 32, dd.data(), dd.size());
+                p->orb.finish(sb.orb[k], dil.data(), W, kk, dd);
+                if ((int)kk.size() > o.cap && o.kps) { rc[s] = SIND_E_CAPACITY; err[s] = "keypoint capacity exceeded"; break; }
+                if (o.nkp) o.nkp[k] = (int)kk.size();
+                if (o.kps) std::memcpy(o.kps + (size_t)k * o.cap, kk.data(), kk.size() * sizeof(sind_keypoint));
+                if (o.desc) std::memcpy(o.desc + (size_t)k * o.cap * 32, dd.data(), dd.size());
             }
         }
     };
     for (int i = 0; i < nthreads; i++) th.emplace_back(work, i);
     for (auto& t : th) t.join();
-    const double t4 = now_ms();
+    sb.pending = false;
     for (int s = 0; s < S; s++) if (rc[s] != SIND_OK) { sind_set_error("stream %d: %s", s, err[s].c_str()); return rc[s]; }
-    p->stage_ms[0] = t1 - t0; p->stage_ms[1] = t2 - t1; p->stage_ms[2] = t3 - t2; p->stage_ms[3] = 0; p->stage_ms[4] = t4 - t3; p->stage_ms[5] = t4 - t0;
+    return SIND_OK;
+}
+
+static int check_inputs(sind_pipe* p, const void* a, const void* b) {
+    if (!p || !a || !b) { sind_set_error("sind_pipe: null input"); return SIND_E_ARG; }
+    for (int s = 0; s < p->S; s++) if (!p->primed[s]) { sind_set_error("sind_pipe: stream %d was not primed", s); return SIND_E_STATE; }
+    HIP_TRY(hipSetDevice(p->c.device));
+    return SIND_OK;
+}
+
+// synchronous step: phase A then phase B
+int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* depth_dev, uint8_t* dyna, uint8_t* label, uint8_t* mask_dil,
+                          sind_keypoint* kps, int cap, int* nkp, uint8_t* desc) {
+    SIND_TRY(check_inputs(p, bgr_dev, depth_dev));
+    if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_process: a submitted step is still pending, call sind_pipe_flush first"); return SIND_E_STATE; }
+    double t[4]; const double t0 = now_ms();
+    SIND_TRY(phase_a(p, p->sb[0], bgr_dev, depth_dev, t));
+    const PipeOut o{dyna, label, mask_dil, kps, cap, nkp, desc};
+    SIND_TRY(phase_b(p, p->sb[0], o));
+    const double t4 = now_ms();
+    p->stage_ms[0] = t[1] - t[0]; p->stage_ms[1] = t[2] - t[1]; p->stage_ms[2] = t[3] - t[2]; p->stage_ms[3] = 0; p->stage_ms[4] = t4 - t[3]; p->stage_ms[5] = t4 - t0;
+    return SIND_OK;
+}
+
+// pipelined step: phase A of THIS step runs while the tails of the PREVIOUS submitted step finish on the host threads.
+// Outputs receive the previous step's results; *have_output tells whether there was one.
+int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* depth_dev, uint8_t* dyna, uint8_t* label, uint8_t* mask_dil,
+                         sind_keypoint* kps, int cap, int* nkp, uint8_t* desc, int* have_output) {
+    SIND_TRY(check_inputs(p, bgr_dev, depth_dev));
+    const int prev = p->cur ^ 1;
+    const bool has_prev = p->sb[prev].pending;
+    if (have_output) *have_output = has_prev ? 1 : 0;
+    const PipeOut o{dyna, label, mask_dil, kps, cap, nkp, desc};
+    int rb = SIND_OK; std::string eb; double tb0 = now_ms(), tb1 = tb0;
+    std::thread bth;
+    if (has_prev) bth = std::thread([&] { (void)hipSetDevice(p->c.device); rb = phase_b(p, p->sb[prev], o); if (rb != SIND_OK) eb = sind_last_error(); tb1 = now_ms(); });
+    double t[4]; const double t0 = now_ms();
+    const int ra = phase_a(p, p->sb[p->cur], bgr_dev, depth_dev, t);
+    if (bth.joinable()) bth.join();
+    const double t4 = now_ms();
+    if (rb != SIND_OK) { sind_set_error("%s", eb.c_str()); return rb; }
+    SIND_TRY(ra);
+    p->stage_ms[0] = t[1] - t[0]; p->stage_ms[1] = t[2] - t[1]; p->stage_ms[2] = t[3] - t[2]; p->stage_ms[3] = 0; p->stage_ms[4] = tb1 - tb0; p->stage_ms[5] = t4 - t0;
+    p->cur ^= 1;
+    return SIND_OK;
+}
+// drain: finish the last submitted step
+int sind_pipe_flush(sind_pipe* p, uint8_t* dyna, uint8_t* label, uint8_t* mask_dil, sind_keypoint* kps, int cap, int* nkp, uint8_t* desc, int* have_output) {
+    if (!p) return SIND_E_ARG;
+    HIP_TRY(hipSetDevice(p->c.device));
+    const int prev = p->cur ^ 1;
+    if (have_output) *have_output = p->sb[prev].pending ? 1 : 0;
+    if (!p->sb[prev].pending) return SIND_OK;
+    const PipeOut o{dyna, label, mask_dil, kps, cap, nkp, desc};
+    const double t0 = now_ms();
+    SIND_TRY(phase_b(p, p->sb[prev], o));
+    p->stage_ms[4] = now_ms() - t0;
     return SIND_OK;
 }
 

@@ -53,6 +53,19 @@ class Pipeline:
         check(lib().sind_pipe_process_dev(self._h, ptr(bgr_dev_ptr), ptr(depth_dev_ptr), ptr(self.dyna), ptr(self.label), ptr(self.mask),
                                           ptr(self.kps), self.cap, ptr(self.nkp), ptr(self.desc)), "sind_pipe_process_dev")
 
+    def submit_dev(self, bgr_dev_ptr: int, depth_dev_ptr: int) -> bool:
+        """pipelined: enqueue a step; self.dyna/... receive the PREVIOUS step's results (returns False on the first call)"""
+        have = C.c_int(0)
+        check(lib().sind_pipe_submit_dev(self._h, ptr(bgr_dev_ptr), ptr(depth_dev_ptr), ptr(self.dyna), ptr(self.label), ptr(self.mask),
+                                         ptr(self.kps), self.cap, ptr(self.nkp), ptr(self.desc), C.byref(have)), "sind_pipe_submit_dev")
+        return bool(have.value)
+
+    def flush(self) -> bool:
+        have = C.c_int(0)
+        check(lib().sind_pipe_flush(self._h, ptr(self.dyna), ptr(self.label), ptr(self.mask), ptr(self.kps), self.cap, ptr(self.nkp), ptr(self.desc),
+                                    C.byref(have)), "sind_pipe_flush")
+        return bool(have.value)
+
     def keypoints(self, s: int, t: int):
         k = s * self.T + t; n = self.nkp[k]; return self.kps[k, :n], self.desc[k, :n]
 

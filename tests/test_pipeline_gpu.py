@@ -38,3 +38,35 @@ def test_pipeline_two_streams(frames):
     st = pipe.stats()
     assert st["sor_launches"] > 0 and st["sor_ms"] > 0
     pipe.close()
+
+
+def test_pipelined_submit_equals_sync(frames):
+    """submit/flush (phase A of step i overlapping the tails of step i-1) returns exactly the synchronous results, one call later"""
+    import torch
+    from sindslam_amd.pipeline import Pipeline
+    bgr, depth = frames
+    S, T = 2, 2
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    sb = np.stack([bgr, bgr[:, ::-1]]); sd = np.stack([depth, depth[:, ::-1]])
+    ref = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5); pip = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5)
+    for s in range(S):
+        ref.prime(s, sb[s, 1], sb[s, 0]); pip.prime(s, sb[s, 1], sb[s, 0])
+    expect = []
+    for step in range(2):
+        lo = 2 + step * T
+        ref.process(sb[:, lo:lo + T], sd[:, lo:lo + T])
+        expect.append((ref.dyna.copy(), ref.label.copy(), ref.mask.copy(), ref.nkp.copy(), ref.kps.copy(), ref.desc.copy()))
+    dev = [(torch.from_numpy(np.ascontiguousarray(sb[:, 2 + i * T: 4 + i * T])).cuda(), torch.from_numpy(np.ascontiguousarray(sd[:, 2 + i * T: 4 + i * T]).view(np.int16)).cuda()) for i in range(2)]
+    got = []
+    assert pip.submit_dev(dev[0][0].data_ptr(), dev[0][1].data_ptr()) is False
+    assert pip.submit_dev(dev[1][0].data_ptr(), dev[1][1].data_ptr()) is True
+    got.append((pip.dyna.copy(), pip.label.copy(), pip.mask.copy(), pip.nkp.copy(), pip.kps.copy(), pip.desc.copy()))
+    assert pip.flush() is True
+    got.append((pip.dyna.copy(), pip.label.copy(), pip.mask.copy(), pip.nkp.copy(), pip.kps.copy(), pip.desc.copy()))
+    assert pip.flush() is False
+    for e, g in zip(expect, got):
+        for a, b in zip(e[:4], g[:4]):
+            assert np.array_equal(a, b)
+        for k in range(S * T):
+            n = e[3][k]; assert e[4][k, :n].tobytes() == g[4][k, :n].tobytes() and np.array_equal(e[5][k, :n], g[5][k, :n])
+    ref.close(); pip.close()

@@ -50,15 +50,25 @@ def cpu_baseline(n_pairs=4):
             "sample": f"{n_pairs} frame pairs of the synthetic 640x480 stream, {t:.1f} s (flow {st[0]:.1f} s, tail {st[1]:.1f} s, orb {st[2]:.1f} s)"}
 
 
+def pmc_traffic(pairs_per_step):
+    """HBM bytes per k_sor_fused launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_k_sor_fused.json: separate
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction), scaled to this batch; None if absent."""
+    f = os.path.join(ROOT, "profiles", "r01", "pmc_k_sor_fused.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    return d["hbm_bytes_per_launch_per_pair"] * pairs_per_step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=16)
+    ap.add_argument("--streams", type=int, default=32)
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sync", action="store_true", help="no software pipelining across steps")
+    ap.add_argument("--pipelined", action="store_true", help="software-pipeline consecutive steps (submit/flush); off by default: measured slower on MI355X")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
     args = ap.parse_args()
 
@@ -101,14 +111,14 @@ def main():
     t0 = time.perf_counter()
     sor_ms = sor_bytes = 0.0; sor_launches = 0; stages = np.zeros(5)
     for i in range(Wm, Wm + K):             # timed: software-pipelined steps (phase A of step i overlaps the tails of step i-1)
-        if args.sync:
+        if not args.pipelined:
             pipe.process_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()); gather()
         elif pipe.submit_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()):
             gather()
         st = pipe.stats()
         sor_ms += st["sor_ms"]; sor_bytes += st["sor_alg_bytes"]; sor_launches += st["sor_launches"]
         stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"]])
-    if not args.sync and pipe.flush():      # drain the last step inside the timed region
+    if args.pipelined and pipe.flush():      # drain the last step inside the timed region
         gather()
     torch.cuda.synchronize()
     if world > 1:
@@ -124,8 +134,8 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "TUM fr3/walking_xyz-shaped synthetic RGB-D stream, 640x480, TUM3 intrinsics, FAST 15/5, 1500 features",
-                       "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world, "parallelism": f"stream-sharded x{world}", "pipelined": not args.sync},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                       "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world, "parallelism": f"stream-sharded x{world}", "pipelined": bool(args.pipelined)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": pmc_traffic(S * T),
                          "kernel": "k_sor_fused", "launches": sor_launches, "avg_launch_us": (sor_ms * 1e3 / sor_launches) if sor_launches else None,
                          "alg_bytes_per_launch": (sor_bytes / sor_launches) if sor_launches else None},
             "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "total": stages[4] / K},

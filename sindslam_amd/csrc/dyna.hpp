@@ -36,6 +36,8 @@ struct DynaDebug {           // stage outputs of the last tail call (parity test
     float centers[KM_K][3] = {{0}}; int nClusters = 0;
 };
 
+struct OccResult { BitImg totalArea, occ1, occ2; bool ready = false; };     // CalOccluded outputs of one frame (state free)
+
 // ---- stateful tail of one stream (reference DynaDetect.cc:1377-1666 minus the dense flow) ---------------------------------
 class DynaTail {
 public:
@@ -43,7 +45,11 @@ public:
     int init(const DynaConfig& c, hipStream_t s);
     // depth_host: H x W u16 (host); depth_dev: same on the device; U/V: device full-resolution flow of this frame.
     // dyna_out / label_out: host H x W u8 (0 invalid / 125 static / 255 dynamic ; 0 invalid, 1..n clusters).
-    int process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out);
+    int process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out,
+                const OccResult* precomputed = nullptr);
+    // CalOccluded (DD:429-642) depends on the depth frame only: the pipeline runs it on this tail's stream while the dense flow
+    // of the step is still on the GPU and the host cores are idle
+    int compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out);
     void reset();
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; long n_frames = 0;
     double t_fine[12] = {0};       // cal_occluded: gpu+d2h, pack, endpoints, peac, contour filter, close | seg_merge: pieces, planes+h2d, rag gpu, merge    // flow masks, k-means, label prep, CalOccluded, SegAndMerge, fusion (ms, SIND_TAIL_TIMING=1)

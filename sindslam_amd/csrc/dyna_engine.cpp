@@ -488,7 +488,14 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
 }
 
 // ---- DD:1377-1666
-int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out) {
+int DynaTail::compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out) {
+    HIP_TRY(hipSetDevice(cfg.device));
+    SIND_TRY(cal_occluded(depth_host, depth_dev, out.totalArea, out.occ1, out.occ2));
+    out.ready = true; return SIND_OK;
+}
+
+int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out,
+                      const OccResult* pre) {
     HIP_TRY(hipSetDevice(cfg.device));
     BitImg maskLow, maskHigh;
     double tk = tick_ms(); n_frames++;
@@ -518,7 +525,8 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     labelForSegEdge = labelForSegEdge.dilated(EllipseElem(7));
     BitImg totalArea, occ1, occ2;
     LAP(2)
-    SIND_TRY(cal_occluded(depth_host, depth_dev, totalArea, occ1, occ2));
+    if (pre && pre->ready) { totalArea = pre->totalArea; occ1 = pre->occ1; occ2 = pre->occ2; }
+    else SIND_TRY(cal_occluded(depth_host, depth_dev, totalArea, occ1, occ2));
     LAP(3)
     std::vector<uint8_t> label3(N, 0);
     if (!allLabels.empty()) SIND_TRY(seg_and_merge(allLabels, occ1, occ2, labelForSegEdge, depth_host, depth_dev, label3));

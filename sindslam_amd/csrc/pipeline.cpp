@@ -20,7 +20,7 @@ struct sind_pipe {
     DynaFront front; OrbEngine orb; std::vector<std::unique_ptr<DynaTail>> tails;
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
-    struct StepBuf { DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; std::vector<uint16_t> depth_h; std::vector<OrbFrameResult> orb; bool pending = false; } sb[2];
+    struct StepBuf { DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; std::vector<uint16_t> depth_h; std::vector<OrbFrameResult> orb; std::vector<OccResult> occ; bool pending = false; } sb[2];
     int cur = 0;
     std::vector<char> primed;
     double stage_ms[6] = {0}; double sor_ms = 0, sor_bytes = 0; long long sor_launches = 0;
@@ -104,6 +104,20 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     // private copies of the depth frames: device (tail kernels of this step run while the caller may reuse its buffer) and host
     HIP_TRY(hipMemcpyAsync(sb.depth_dev.p, depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(sb.depth_h.data(), sb.depth_dev.p, np * B * sizeof(uint16_t), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    // CalOccluded of every frame (state free: depth only) on the streams' own host threads / HIP streams, concurrent with the
+    // dense flow below (the host cores would otherwise idle while the GPU runs the flow solver)
+    sb.occ.assign(B, OccResult());
+    std::vector<int> occ_rc(S, SIND_OK); std::vector<std::string> occ_err(S);
+    const int occ_threads = p->c.host_threads > 0 ? std::min(p->c.host_threads, S) : std::min(S, 16);
+    std::vector<std::thread> occ_th;
+    for (int i = 0; i < occ_threads; i++) occ_th.emplace_back([&, i] {
+        for (int s = i; s < S; s += occ_threads) for (int tt = 0; tt < T; tt++) {
+            const int k = s * T + tt;
+            const int r = p->tails[s]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
+            if (r != SIND_OK) { occ_rc[s] = r; occ_err[s] = sind_last_error(); break; }
+        } });
+    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{occ_th};
     t[1] = now_ms();
     // dense flow for every (n, n-2) pair, second pass for large-motion pairs, refinement, up-scale
     std::vector<int> cur(B), p1(B), p2(B);
@@ -122,6 +136,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         else { HIP_TRY(hipMemcpyAsync(base, base + fb, fb, hipMemcpyDeviceToDevice, p->stream)); HIP_TRY(hipMemcpyAsync(base + fb, base + fb * 2, fb, hipMemcpyDeviceToDevice, p->stream)); }
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
+    for (auto& x : occ_th) x.join();
+    for (int s = 0; s < S; s++) if (occ_rc[s] != SIND_OK) { sind_set_error("stream %d (CalOccluded): %s", s, occ_err[s].c_str()); return occ_rc[s]; }
     t[3] = now_ms();
     sb.pending = true;
     return SIND_OK;
@@ -132,14 +148,14 @@ struct PipeOut { uint8_t *dyna, *label, *mask; sind_keypoint* kps; int cap; int*
 static int phase_b(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
     const int S = p->S, T = p->T, W = p->c.width, H = p->c.height; const size_t np = (size_t)W * H;
     std::vector<int> rc(S, SIND_OK); std::vector<std::string> err(S);
-    const int nthreads = p->c.host_threads > 0 ? std::min(p->c.host_threads, S) : S;
+    const int nthreads = p->c.host_threads > 0 ? std::min(p->c.host_threads, S) : std::min(S, 16);   // default: the box's CPU share per GPU
     std::vector<std::thread> th;
     auto work = [&](int tid) {
         for (int s = tid; s < S; s += nthreads) {
             std::vector<uint8_t> dy(np), lb(np), dil(np);
             for (int t = 0; t < T && rc[s] == SIND_OK; t++) {
                 const int k = s * T + t;
-                int r = p->tails[s]->process(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.U.p + np * k, sb.V.p + np * k, dy.data(), lb.data());
+                int r = p->tails[s]->process(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.U.p + np * k, sb.V.p + np * k, dy.data(), lb.data(), &sb.occ[k]);
                 if (r != SIND_OK) { rc[s] = r; err[s] = sind_last_error(); break; }
                 dilate15_codes(dy.data(), W, H, dil.data());
                 if (o.dyna) std::memcpy(o.dyna + np * k, dy.data(), np);

@@ -145,31 +145,53 @@ __device__ void km_try_finalize(KmState* st) {
     st->phase = 1;                                        // centres of this iteration are final
     if (st->iter == (st->maxCount > 2 ? st->maxCount : 2) || max_center_shift <= st->eps2) st->done = 1;
 }
-// mode 0: start of an iteration (reduce the per-block partial sums); mode 1: after a farthest-point search
-__global__ void k_km_update(const double* __restrict__ partial, int nblocks, KmState* __restrict__ st, int mode,
-                            const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int* __restrict__ labels) {
+// Centre step of one k-means iteration in ONE workgroup: reduce the per-block partial sums, repair every empty cluster
+// (block-wide farthest-point search over the biggest cluster, as cv::kmeans does, repeated until no cluster is empty), scale,
+// shift test, stop decision.  No host round trip and no provisioning limit.
+__global__ void __launch_bounds__(1024) k_km_update(const double* __restrict__ partial, int nblocks, KmState* __restrict__ st,
+                                                    const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                    int* __restrict__ labels, int n) {
     __shared__ double sums[KM_K * 4];
     __shared__ double stage[KM_MAX_BLOCKS * KM_K * 4];
+    __shared__ unsigned long long wbest[16];
+    __shared__ int s_fix;
     if (st->done) return;
-    if (mode == 0) {
-        const int t = threadIdx.x;
-        for (int i = t; i < nblocks * KM_K * 4; i += blockDim.x) stage[i] = partial[i];     // parallel fetch, then a fixed-order (deterministic) sum
-        __syncthreads();
-        if (t < KM_K * 4) { double v = 0; for (int b = 0; b < nblocks; b++) v += stage[b * KM_K * 4 + t]; sums[t] = v; }
+    const int t = threadIdx.x;
+    for (int i = t; i < nblocks * KM_K * 4; i += blockDim.x) stage[i] = partial[i];     // parallel fetch, then a fixed-order (deterministic) sum
+    __syncthreads();
+    if (t < KM_K * 4) { double v = 0; for (int b = 0; b < nblocks; b++) v += stage[b * KM_K * 4 + t]; sums[t] = v; }
+    __syncthreads();
+    if (t == 0) {
+        st->phase = 0;
+        for (int k = 0; k < KM_K; k++) { for (int j = 0; j < 3; j++) { st->old[k][j] = st->ctr[k][j]; st->ctr[k][j] = (float)sums[k * 4 + j]; } st->cnt[k] = (int)sums[k * 4 + 3]; }
+        km_try_finalize(st);
+        s_fix = st->fix_k;
+    }
+    __syncthreads();
+    while (s_fix >= 0) {                                   // uniform: s_fix is shared
+        const int which = st->max_k; const float c0 = st->base[0], c1 = st->base[1], c2 = st->base[2];
+        unsigned long long b = 0;
+        for (int i = t; i < n; i += blockDim.x) {
+            if (labels[i] != which) continue;
+            float d0 = px[i] - c0; float d = 0.f; d += d0 * d0; d0 = py[i] - c1; d += d0 * d0; d0 = pz[i] - c2; d += d0 * d0;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;      // ties -> largest index ("max_dist <= dist")
+            b = b > key ? b : key;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(b, o); b = b > v ? b : v; }
+        if ((t & 63) == 0) wbest[t >> 6] = b;
         __syncthreads();
         if (t == 0) {
-            if (st->phase == 0 && st->fix_k >= 0) st->overflow = 1;      // the previous iteration ran out of repair rounds
-            st->phase = 0;
-            for (int k = 0; k < KM_K; k++) { for (int j = 0; j < 3; j++) { st->old[k][j] = st->ctr[k][j]; st->ctr[k][j] = (float)sums[k * 4 + j]; } st->cnt[k] = (int)sums[k * 4 + 3]; }
+            unsigned long long m = 0; for (int q = 0; q < (int)(blockDim.x >> 6); q++) m = m > wbest[q] ? m : wbest[q];
+            const int fi = (int)(m & 0xffffffffull), k = st->fix_k, max_k = st->max_k;
+            const float smp[3] = {px[fi], py[fi], pz[fi]};
+            labels[fi] = k;
+            st->cnt[max_k]--; st->cnt[k]++;
+            for (int j = 0; j < 3; j++) { st->ctr[max_k][j] -= smp[j]; st->ctr[k][j] += smp[j]; }
             km_try_finalize(st);
+            s_fix = st->fix_k;
         }
-    } else if (threadIdx.x == 0 && st->phase == 0 && st->fix_k >= 0) {
-        const int fi = (int)(st->far & 0xffffffffull), k = st->fix_k, max_k = st->max_k;
-        const float smp[3] = {px[fi], py[fi], pz[fi]};
-        labels[fi] = k;
-        st->cnt[max_k]--; st->cnt[k]++;
-        for (int j = 0; j < 3; j++) { st->ctr[max_k][j] -= smp[j]; st->ctr[k][j] += smp[j]; }
-        km_try_finalize(st);
+        __threadfence_block();
+        __syncthreads();
     }
 }
 __global__ void __launch_bounds__(256) k_km_partial_dev(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
@@ -191,20 +213,6 @@ __global__ void __launch_bounds__(256) k_km_partial_dev(const float* __restrict_
         for (int c = 0; c < 4; c++) { double v = s[k][c]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); if (lane == 0) acc[k][c][wv] = v; }
     __syncthreads();
     if (tid < KM_K * 4) { const int k = tid >> 2, c = tid & 3; partial[((size_t)blockIdx.x * KM_K + k) * 4 + c] = ((acc[k][c][0] + acc[k][c][1]) + acc[k][c][2]) + acc[k][c][3]; }
-}
-__global__ void __launch_bounds__(256) k_km_farthest_dev(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                         const int* __restrict__ labels, int n, KmState* __restrict__ st) {
-    if (st->done || st->phase != 0 || st->fix_k < 0) return;
-    const int which = st->max_k; const float c0 = st->base[0], c1 = st->base[1], c2 = st->base[2];
-    unsigned long long b = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (labels[i] != which) continue;
-        float t = px[i] - c0; float d = 0.f; d += t * t; t = py[i] - c1; d += t * t; t = pz[i] - c2; d += t * t;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
-        b = b > key ? b : key;
-    }
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(b, o); b = b > t ? b : t; }
-    if ((threadIdx.x & 63) == 0) atomicMax(&st->far, b);
 }
 __global__ void k_km_assign_dev(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int* __restrict__ labels,
                                 int n, const KmState* __restrict__ st) {
@@ -425,13 +433,10 @@ int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const f
     hipLaunchKernelGGL(k_km_reset, dim3(1), dim3(64), 0, s, st, maxCount, eps2);
     for (int it = 0; it < iters; it++) {
         hipLaunchKernelGGL(k_km_partial_dev, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, partial, st);
-        hipLaunchKernelGGL(k_km_update, dim3(1), dim3(256), 0, s, partial, nb, st, 0, px, py, pz, labels);
-        for (int f = 0; f < fix_rounds; f++) {
-            hipLaunchKernelGGL(k_km_farthest_dev, dim3(std::min(divup(n, 256), 128)), dim3(256), 0, s, px, py, pz, labels, n, st);
-            hipLaunchKernelGGL(k_km_update, dim3(1), dim3(64), 0, s, partial, nb, st, 1, px, py, pz, labels);
-        }
+        hipLaunchKernelGGL(k_km_update, dim3(1), dim3(1024), 0, s, partial, nb, st, px, py, pz, labels, n);
         if (it + 1 < iters) hipLaunchKernelGGL(k_km_assign_dev, dim3(divup(n, 256)), dim3(256), 0, s, px, py, pz, labels, n, st);
     }
+    (void)fix_rounds;
     return SIND_OK;
 }
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n) { hipLaunchKernelGGL(k_labels_to_u8, dim3(divup(n, 256)), dim3(256), 0, s, labels, out, n); return SIND_OK; }

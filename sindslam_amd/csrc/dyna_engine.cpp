@@ -104,7 +104,7 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     SIND_TRY(edge.alloc(N)); SIND_TRY(edgeTmp.alloc(N)); SIND_TRY(total.alloc(N)); SIND_TRY(depthN.alloc(N)); SIND_TRY(occ2_d.alloc(N));
     SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc(N)); SIND_TRY(high_d.alloc(N)); SIND_TRY(mag.alloc(N));
     SIND_TRY(kpart.alloc((size_t)KM_MAX_BLOCKS * KM_K * 4)); SIND_TRY(ksums.alloc(KM_K * 4)); SIND_TRY(far_d.alloc(1)); SIND_TRY(umax_d.alloc(2)); SIND_TRY(maxbits.alloc(1));
-    SIND_TRY(hist_d.alloc(256)); SIND_TRY(grid_d.alloc(2 * 64 * 48)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
+    SIND_TRY(hist_d.alloc(256)); SIND_TRY(grid_d.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
     return SIND_OK;
 }
 void DynaTail::reset() { dynaLast.assign(N, 0); labelLast.assign(N, 0); highLast.assign(N, 0); labelLastAny = false; }

@@ -68,8 +68,9 @@ int OrbEngine::init(int W_, int H_, int nf, float sf, int nl, int ini, int mn, i
         }
     }
     level_cell_begin.push_back((int)cells.size());
-    dense_cap = 32768; sel_cap = nfeatures * 2 + 256;
     const int nc = (int)cells.size();
+    dense_cap = nc * ORB_CELL_CAP;          // tight upper bound (every cell full): the dense list can never overflow
+    sel_cap = nfeatures * 2 + 256;
     SIND_TRY(slab.alloc(slab_bytes * maxB)); SIND_TRY(blurred.alloc(blur_bytes * maxB)); SIND_TRY(blur_tmp.alloc(blur_bytes * maxB));
     SIND_TRY(cells_dev.alloc(nc)); SIND_TRY(levels_dev.alloc(nl));
     HIP_TRY(hipMemcpy(cells_dev.p, cells.data(), nc * sizeof(OrbCell), hipMemcpyHostToDevice));

@@ -1,0 +1,60 @@
+"""GPU: edge cases (SURVEY §8c asks for empty / degenerate inputs) and the 1280x720 configuration of BASELINE.json."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from sindslam_amd.synth import D455, TUM3, SyntheticStream
+
+pytestmark = pytest.mark.gpu
+K3 = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+
+
+def test_no_valid_depth_and_static_scene(frames):
+    """all-zero depth (everything invalid) and three identical frames (zero flow): no crash, legal output codes"""
+    from sindslam_amd.dyna import DynaDetect
+    bgr, depth = frames
+    dd = DynaDetect(bgr[1], bgr[0], *K3)
+    dy, lb = dd.DetectDynaArea(bgr[2], np.zeros_like(depth[2]), 2)
+    assert not dy.any() and not lb.any()                      # no valid depth -> nothing static, nothing dynamic
+    ref = O.DynaDetect(bgr[1], bgr[0], *K3); rd, rl = ref.detect(bgr[2], np.zeros_like(depth[2]))
+    assert np.array_equal(dy, rd) and np.array_equal(lb, rl)
+    dy, lb = dd.DetectDynaArea(bgr[3], depth[3], 3)           # recovers on the next good frame
+    assert set(np.unique(dy)) <= {0, 125, 255} and (dy == 125).sum() > 10000
+    st = DynaDetect(bgr[0], bgr[0], *K3)
+    dy, lb = st.DetectDynaArea(bgr[0], depth[0], 2)           # identical frames: flow == 0 everywhere
+    assert set(np.unique(dy)) <= {0, 125, 255}
+    dd.close(); st.close()
+
+
+def test_orb_textureless_and_tiny_feature_budget(frames):
+    from sindslam_amd.orb import ORBextractor
+    bgr, _ = frames; g = O.bgr2gray(bgr[2])
+    o = ORBextractor(100, 1.2, 4, 20, 7); r = O.ORBextractor(100, 1.2, 4, 20, 7)
+    k, d = o(g); rk, rd = r.extract(g)
+    assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd) and 0 < len(k) <= 140
+    noise = np.random.default_rng(0).integers(0, 256, (480, 640), dtype=np.uint8)      # maximum corner density
+    k, d = o(noise); rk, rd = r.extract(noise)
+    assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+    o.close()
+
+
+@pytest.mark.timeout(900)
+def test_1280x720_d455():
+    """BASELINE.json configs[4]: 1280x720, D455 intrinsics x2, depth factor 1000, FAST 20/7 (flow grid 768x432, 57 levels)"""
+    from sindslam_amd.dyna import DynaDetect
+    from sindslam_amd.orb import ORBextractor
+    s = SyntheticStream(width=1280, height=720, intr=D455)
+    bgr, depth = s.frames(0, 3)
+    Kd = (s.fx, s.fy, s.cx, s.cy, D455["depth_factor"])
+    gpu = DynaDetect(bgr[1], bgr[0], *Kd); ref = O.DynaDetect(bgr[1], bgr[0], *Kd)
+    gd, gl = gpu.DetectDynaArea(bgr[2], depth[2], 2); rd, rl = ref.detect(bgr[2], depth[2])
+    g = gpu.debug(); r = ref.debug()
+    ff = np.stack([r["flow_full"][..., 0], r["flow_full"][..., 1]])
+    assert np.array_equal(g["flow_full"].view(np.uint32), ff.view(np.uint32))
+    assert np.array_equal(g["mask_high"], r["mask_high"]) and np.array_equal(g["occ1"], r["occ1"])
+    u = np.logical_or(gd == 255, rd == 255).sum()
+    assert u == 0 or np.logical_and(gd == 255, rd == 255).sum() / u >= 0.99
+    gray = O.bgr2gray(bgr[2]); mask = gpu.dilate15(gd)
+    k, d = ORBextractor(1000, 1.2, 8, 20, 7)(gray, mask); rk, rdesc = O.ORBextractor(1000, 1.2, 8, 20, 7).extract(gray, mask)
+    assert k.tobytes() == rk.tobytes() and np.array_equal(d, rdesc)
+    gpu.close()

@@ -9,7 +9,6 @@ namespace sind {
 #define KM_MAX_BLOCKS 64
 #define MORPH_MAX 16
 
-struct KmCenters { float c[KM_K][3]; };
 struct KmState { float ctr[KM_K][3], old[KM_K][3], base[3]; int cnt[KM_K]; int iter, done, phase, fix_k, max_k, maxCount, overflow; double eps2; unsigned long long far; };
 struct MorphElem { int n, ax, ay; int j1[MORPH_MAX], j2[MORPH_MAX]; };
 struct PeacBlockStats { double sx, sy, sz, sxx, syy, szz, sxy, syz, sxz; int N, valid; };
@@ -20,11 +19,8 @@ int launch_points(hipStream_t s, const uint16_t* depth, float* px, float* py, fl
 int launch_labels_grid(hipStream_t s, int* labels, int w, int h);
 int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw, int sh, int dw, int dh);
 int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh);
-int launch_kmeans_sums(hipStream_t s, const float* px, const float* py, const float* pz, const int* labels, int n, double* partial, double* sums);
-int launch_kmeans_assign(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, const KmCenters& C);
-int launch_kmeans_farthest(hipStream_t s, const float* px, const float* py, const float* pz, const int* labels, int n, int which, const float c[3], unsigned long long* best);
 int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, double* partial, KmState* st,
-                        int maxCount, double eps2, int fix_rounds);
+                        int maxCount, double eps2);
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n);
 int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h);
 int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out);

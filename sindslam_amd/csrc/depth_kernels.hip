@@ -60,70 +60,10 @@ __global__ void k_labels_resize(const T* __restrict__ src, int* __restrict__ dst
     dst[dy * dw + dx] = d_cvRound(r0 * b0 + r1 * b1);
 }
 
-// ---------------------------------------------------------------- k-means: per-workgroup partial sums, fixed-order final sum
-// partial[block][k][0..2] = sum of x,y,z (double), [3] = count.  Deterministic: LDS tree inside the block, blocks summed in order.
-__global__ void __launch_bounds__(256) k_kmeans_partial(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                        const int* __restrict__ labels, int n, double* __restrict__ partial) {
-    __shared__ double acc[KM_K][4][4];      // [cluster][component][wave]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double s[KM_K][4];
-    #pragma unroll
-    for (int k = 0; k < KM_K; k++) { s[k][0] = s[k][1] = s[k][2] = s[k][3] = 0.0; }
-    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
-        const int l = labels[i]; const double x = px[i], y = py[i], z = pz[i];
-        #pragma unroll
-        for (int k = 0; k < KM_K; k++) if (l == k) { s[k][0] += x; s[k][1] += y; s[k][2] += z; s[k][3] += 1.0; }
-    }
-    #pragma unroll
-    for (int k = 0; k < KM_K; k++)
-        #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            double v = s[k][c];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0) acc[k][c][wv] = v;
-        }
-    __syncthreads();
-    if (tid < KM_K * 4) { const int k = tid >> 2, c = tid & 3; partial[((size_t)blockIdx.x * KM_K + k) * 4 + c] = ((acc[k][c][0] + acc[k][c][1]) + acc[k][c][2]) + acc[k][c][3]; }
-}
-__global__ void k_kmeans_final(const double* __restrict__ partial, int nblocks, double* __restrict__ sums) {
-    const int t = threadIdx.x;
-    if (t >= KM_K * 4) return;
-    double v = 0; for (int b = 0; b < nblocks; b++) v += partial[(size_t)b * KM_K * 4 + t];
-    sums[t] = v;
-}
-// KMeansDistanceComputer<false>: nearest centre, squared L2 accumulated in float component by component, first minimum wins
-__global__ void k_kmeans_assign(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int* __restrict__ labels,
-                                int n, KmCenters C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = px[i], y = py[i], z = pz[i];
-    int best = 0; float md = 3.402823466e+38f;
-    #pragma unroll
-    for (int k = 0; k < KM_K; k++) {
-        float t = x - C.c[k][0]; float dist = 0.f; dist += t * t;
-        t = y - C.c[k][1]; dist += t * t;
-        t = z - C.c[k][2]; dist += t * t;
-        if (md > dist) { md = dist; best = k; }
-    }
-    labels[i] = best;
-}
-// empty-cluster repair helper: farthest point (max squared distance, ties -> largest index) of cluster `which` from centre c
-__global__ void __launch_bounds__(256) k_kmeans_farthest(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                         const int* __restrict__ labels, int n, int which, float c0, float c1, float c2,
-                                                         unsigned long long* __restrict__ best) {
-    unsigned long long b = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (labels[i] != which) continue;
-        float t = px[i] - c0; float d = 0.f; d += t * t; t = py[i] - c1; d += t * t; t = pz[i] - c2; d += t * t;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;   // d >= 0: bit order == value order
-        b = b > key ? b : key;
-    }
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(b, o); b = b > t ? b : t; }
-    if ((threadIdx.x & 63) == 0) atomicMax(best, b);
-}
-// ---------------------------------------------------------------- device-resident k-means control (no host round trip per iteration)
-// One KmState per tail.  k_km_update runs the centre step of cv::kmeans (sums -> centres, empty-cluster repair, shift test,
-// last-iteration decision) in a single thread, exactly like the host loop it replaces (same FP32/FP64 operations).
+// ---------------------------------------------------------------- k-means (cv::kmeans, KMEANS_USE_INITIAL_LABELS), device resident
+// Centre sums: per-workgroup partials in FP64 with a fixed-order final sum (deterministic; OpenCV sums sequentially in FP32, so
+// centres agree to ~1e-7 relative and labels on all but <=1e-3 of the pixels).  One KmState per pyramid level; k_km_update runs
+// the centre step (sums -> centres, empty-cluster repair, shift test, last-iteration decision) with cv::kmeans' operations.
 __device__ void km_try_finalize(KmState* st) {
     // look for an empty cluster; if there is one, request a farthest-point search and return
     for (int k = 0; k < KM_K; k++) {
@@ -413,22 +353,8 @@ int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw,
     hipLaunchKernelGGL(k_labels_resize<uint8_t>, dim3(divup(dw, 128), dh), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh)); return SIND_OK; }
 int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh) {
     hipLaunchKernelGGL(k_labels_resize<int>, dim3(divup(dw, 128), dh), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh)); return SIND_OK; }
-int launch_kmeans_sums(hipStream_t s, const float* px, const float* py, const float* pz, const int* labels, int n, double* partial, double* sums) {
-    const int nb = std::min(divup(n, 256), KM_MAX_BLOCKS);
-    hipLaunchKernelGGL(k_kmeans_partial, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, partial);
-    hipLaunchKernelGGL(k_kmeans_final, dim3(1), dim3(64), 0, s, partial, nb, sums);
-    return SIND_OK;
-}
-int launch_kmeans_assign(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, const KmCenters& C) {
-    hipLaunchKernelGGL(k_kmeans_assign, dim3(divup(n, 256)), dim3(256), 0, s, px, py, pz, labels, n, C); return SIND_OK; }
-int launch_kmeans_farthest(hipStream_t s, const float* px, const float* py, const float* pz, const int* labels, int n, int which, const float c[3], unsigned long long* best) {
-    HIP_TRY(hipMemsetAsync(best, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_kmeans_farthest, dim3(std::min(divup(n, 256), 256)), dim3(256), 0, s, px, py, pz, labels, n, which, c[0], c[1], c[2], best); return SIND_OK; }
-// whole cv::kmeans(K=12, USE_INITIAL_LABELS) loop of one pyramid level, enqueued without any host synchronisation.
-// `fix_rounds` empty-cluster repairs are provisioned per iteration; KmState::phase == 0 with fix_k >= 0 after the last
-// iteration's repairs means more were needed (the caller then falls back to the host-stepped loop).
 int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, double* partial, KmState* st,
-                        int maxCount, double eps2, int fix_rounds) {
+                        int maxCount, double eps2) {
     const int nb = std::min(divup(n, 256), KM_MAX_BLOCKS), iters = std::max(maxCount, 2);
     hipLaunchKernelGGL(k_km_reset, dim3(1), dim3(64), 0, s, st, maxCount, eps2);
     for (int it = 0; it < iters; it++) {
@@ -436,7 +362,6 @@ int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const f
         hipLaunchKernelGGL(k_km_update, dim3(1), dim3(1024), 0, s, partial, nb, st, px, py, pz, labels, n);
         if (it + 1 < iters) hipLaunchKernelGGL(k_km_assign_dev, dim3(divup(n, 256)), dim3(256), 0, s, px, py, pz, labels, n, st);
     }
-    (void)fix_rounds;
     return SIND_OK;
 }
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n) { hipLaunchKernelGGL(k_labels_to_u8, dim3(divup(n, 256)), dim3(256), 0, s, labels, out, n); return SIND_OK; }

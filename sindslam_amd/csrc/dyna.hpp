@@ -59,11 +59,10 @@ private:
     bool labelLastAny = false;
     // device workspaces
     DevBuf<uint16_t> dpyr[4], filt; DevBuf<float> px, py, pz; DevBuf<int> lab[4]; DevBuf<uint8_t> lab8, labPrev8, edge, edgeTmp, total, depthN, occ2_d, magu8, low_d, high_d;
-    DevBuf<double> kpart, ksums; DevBuf<unsigned long long> far_d, planes_d; DevBuf<unsigned> umax_d, maxbits; DevBuf<int> hist_d, rag_d; DevBuf<float> mag, grid_d;
+    DevBuf<double> kpart; DevBuf<unsigned long long> planes_d; DevBuf<unsigned> umax_d, maxbits; DevBuf<int> hist_d, rag_d; DevBuf<float> mag, grid_d;
     DevBuf<PeacBlockStats> blocks_d;
     int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high);
     int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
-    int kmeans_stepped(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
     DevBuf<KmState> kstate;
     int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2);
     int seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,

@@ -103,7 +103,7 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     SIND_TRY(filt.alloc(N)); SIND_TRY(px.alloc(N)); SIND_TRY(py.alloc(N)); SIND_TRY(pz.alloc(N)); SIND_TRY(lab8.alloc(N)); SIND_TRY(labPrev8.alloc(N));
     SIND_TRY(edge.alloc(N)); SIND_TRY(edgeTmp.alloc(N)); SIND_TRY(total.alloc(N)); SIND_TRY(depthN.alloc(N)); SIND_TRY(occ2_d.alloc(N));
     SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc(N)); SIND_TRY(high_d.alloc(N)); SIND_TRY(mag.alloc(N));
-    SIND_TRY(kpart.alloc((size_t)KM_MAX_BLOCKS * KM_K * 4)); SIND_TRY(ksums.alloc(KM_K * 4)); SIND_TRY(far_d.alloc(1)); SIND_TRY(umax_d.alloc(2)); SIND_TRY(maxbits.alloc(1));
+    SIND_TRY(kpart.alloc((size_t)KM_MAX_BLOCKS * KM_K * 4)); SIND_TRY(umax_d.alloc(2)); SIND_TRY(maxbits.alloc(1));
     SIND_TRY(hist_d.alloc(256)); SIND_TRY(grid_d.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
     return SIND_OK;
 }
@@ -206,62 +206,9 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     return SIND_OK;
 }
 
-// ---- DD:315-420: 4-level k-means, K = 12, criteria (EPS+COUNT, 4, 0.07), KMEANS_USE_INITIAL_LABELS
-int DynaTail::kmeans_stepped(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
-    const float scales[4] = {1.0f, 0.5f, 0.25f, 0.125f};
-    const uint16_t* dl[4] = {depth_dev, dpyr[1].p, dpyr[2].p, dpyr[3].p};
-    for (int l = 1; l < 4; l++) SIND_TRY(launch_depth_half(stream, dl[l - 1], dpyr[l].p, W >> l, H >> l));
-    const double eps2 = 0.07 * 0.07; const int maxCount = 4;
-    for (int level = 3; level >= 0; level--) {
-        const int hp = (int)(H * scales[level]), wp = (int)(W * scales[level]), n = hp * wp;
-        SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale));
-        if (level == 3) {
-            if (!labelLastAny) SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp));
-            else { HIP_TRY(hipMemcpyAsync(labPrev8.p, labelLast.data(), N, hipMemcpyHostToDevice, stream)); SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp)); }
-        } else SIND_TRY(launch_labels_resize_i32(stream, lab[level + 1].p, lab[level].p, wp / 2, hp / 2, wp, hp));
-        float ctr[KM_K][3] = {{0}}, old[KM_K][3] = {{0}}; int cnt[KM_K] = {0};
-        for (int iter = 0;;) {
-            double max_center_shift = iter == 0 ? DBL_MAX : 0.0;
-            std::memcpy(old, ctr, sizeof(ctr));
-            SIND_TRY(launch_kmeans_sums(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, ksums.p));
-            double sums[KM_K * 4];
-            HIP_TRY(hipMemcpyAsync(sums, ksums.p, sizeof(sums), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            for (int k = 0; k < KM_K; k++) { for (int j = 0; j < 3; j++) ctr[k][j] = (float)sums[k * 4 + j]; cnt[k] = (int)sums[k * 4 + 3]; }
-            for (int k = 0; k < KM_K; k++) {                  // empty cluster: split the farthest point off the biggest one
-                if (cnt[k] != 0) continue;
-                int max_k = 0; for (int k1 = 1; k1 < KM_K; k1++) if (cnt[max_k] < cnt[k1]) max_k = k1;
-                const float sc = 1.f / cnt[max_k]; float base[3]; for (int j = 0; j < 3; j++) base[j] = ctr[max_k][j] * sc;
-                SIND_TRY(launch_kmeans_farthest(stream, px.p, py.p, pz.p, lab[level].p, n, max_k, base, far_d.p));
-                unsigned long long key; HIP_TRY(hipMemcpyAsync(&key, far_d.p, 8, hipMemcpyDeviceToHost, stream)); HIP_TRY(hipStreamSynchronize(stream));
-                const int fi = (int)(key & 0xffffffffu); float smp[3];
-                HIP_TRY(hipMemcpy(&smp[0], px.p + fi, 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(&smp[1], py.p + fi, 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(&smp[2], pz.p + fi, 4, hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(lab[level].p + fi, &k, 4, hipMemcpyHostToDevice));
-                cnt[max_k]--; cnt[k]++;
-                for (int j = 0; j < 3; j++) { ctr[max_k][j] -= smp[j]; ctr[k][j] += smp[j]; }
-            }
-            for (int k = 0; k < KM_K; k++) {
-                const float sc = 1.f / cnt[k];
-                for (int j = 0; j < 3; j++) ctr[k][j] *= sc;
-                if (iter > 0) { double dist = 0; for (int j = 0; j < 3; j++) { const double t = ctr[k][j] - old[k][j]; dist += t * t; } max_center_shift = std::max(max_center_shift, dist); }
-            }
-            const bool isLast = (++iter == std::max(maxCount, 2) || max_center_shift <= eps2);
-            if (isLast) break;
-            KmCenters C; std::memcpy(C.c, ctr, sizeof(ctr));
-            SIND_TRY(launch_kmeans_assign(stream, px.p, py.p, pz.p, lab[level].p, n, C));
-        }
-        if (level == 0) { std::memcpy(centers, ctr, sizeof(ctr)); std::memcpy(counts, cnt, sizeof(cnt)); }
-    }
-    SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N));
-    label8.resize(N);
-    HIP_TRY(hipMemcpyAsync(label8.data(), lab8.p, N, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    return SIND_OK;
-}
-
-// Fast path of the same computation: the whole 4-level k-means is enqueued without a single host round trip (the centre
-// step, empty-cluster repair and the stop test run in k_km_update on the device); one D2H of the four KmStates + labels at the
-// end.  If an iteration needed more empty-cluster repairs than were provisioned, the host-stepped loop above redoes the frame.
+// ---- DD:315-420: 4-level k-means, K = 12, criteria (EPS+COUNT, 4, 0.07), KMEANS_USE_INITIAL_LABELS.
+// The whole loop is enqueued without a host round trip: the centre step, empty-cluster repair and the stop test of cv::kmeans
+// run in k_km_update (one workgroup) on the device; one D2H of the level-0 state + labels at the end.
 int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
     const float scales[4] = {1.0f, 0.5f, 0.25f, 0.125f};
     const uint16_t* dl[4] = {depth_dev, dpyr[1].p, dpyr[2].p, dpyr[3].p};
@@ -273,14 +220,13 @@ int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, fl
         SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale));
         if (level == 3) { if (!labelLastAny) SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp)); else SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp)); }
         else SIND_TRY(launch_labels_resize_i32(stream, lab[level + 1].p, lab[level].p, wp / 2, hp / 2, wp, hp));
-        SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, kstate.p + level, 4, 0.07 * 0.07, 2));
+        SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, kstate.p + level, 4, 0.07 * 0.07));
     }
     SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N));
     KmState st[4]; label8.resize(N);
     HIP_TRY(hipMemcpyAsync(st, kstate.p, sizeof(st), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(label8.data(), lab8.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    for (int l = 0; l < 4; l++) if (st[l].overflow || (st[l].phase == 0 && st[l].fix_k >= 0)) return kmeans_stepped(depth_dev, label8, centers, counts);
     std::memcpy(centers, st[0].ctr, sizeof(st[0].ctr)); std::memcpy(counts, st[0].cnt, sizeof(st[0].cnt));
     return SIND_OK;
 }

@@ -8,6 +8,11 @@ import numpy as np
 from ._lib import check, lib, ptr
 
 
+def set_sor_variant(mode: int = 1, fuse: int = 5, tile_w: int = 64):
+    """process-wide solver variant: mode 1 = fused register-resident SOR, 0 = one launch per colour (cross-check)"""
+    check(lib().sind_flow_set_sor(mode, fuse, tile_w), "sind_flow_set_sor")
+
+
 class FlowStage:
     def __init__(self, fw: int = 384, fh: int = 288, max_batch: int = 8, device: int = 0):
         self.fw, self.fh, self.max_batch = fw, fh, max_batch

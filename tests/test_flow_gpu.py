@@ -68,3 +68,17 @@ def test_deepflow_full_size(fs, frames):
     ru, rv = fs.refine(g0[None], g1[None], -u, -v)
     ou, ov = O.varref(g0.astype(np.float32), g1.astype(np.float32), -o[..., 0], -o[..., 1])
     assert np.array_equal(ru[0].view(np.uint32), ou.view(np.uint32)) and np.array_equal(rv[0].view(np.uint32), ov.view(np.uint32))
+
+
+def test_sor_variants_agree_bitwise(fs, frames):
+    """fused register-resident SOR (several fuse depths / tile widths) == one-launch-per-colour SOR, bit for bit"""
+    from sindslam_amd.flow import set_sor_variant
+    g0, g1 = _small_pair(frames, 384, 288)
+    i0 = np.stack([g0, g1]); i1 = np.stack([g1, g0])
+    try:
+        set_sor_variant(0, 5, 64); ru, rv = fs.deepflow(i0, i1)
+        for fuse, tw in [(5, 64), (3, 64), (7, 64), (5, 128), (1, 64)]:
+            set_sor_variant(1, fuse, tw); u, v = fs.deepflow(i0, i1)
+            assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32)), (fuse, tw)
+    finally:
+        set_sor_variant(1, 5, 64)

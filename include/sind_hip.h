@@ -141,6 +141,9 @@ int sind_pipe_flush(sind_pipe* p, uint8_t* dyna, uint8_t* label, uint8_t* mask_d
  * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */
 int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, double* sor_ms, double* sor_alg_bytes);
 
+/* helper of the rgbd_tum_noros-shaped harness (sindslam_amd/harness.py): PNG scanline reconstruction, raw = h x (1 + stride) bytes */
+int sind_png_unfilter(const uint8_t* raw, int h, int stride, int bytes_per_pixel, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

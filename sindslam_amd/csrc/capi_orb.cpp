@@ -1,4 +1,5 @@
 // C ABI: ORBextractor (include/sind_hip.h).
+#include <cstdlib>
 #include <cstring>
 #include "../../include/sind_hip.h"
 #include "orb.hpp"
@@ -97,6 +98,30 @@ int sind_orb_debug_selected(sind_orb* o, int frame, sind_keypoint* kps, int cap,
     if (kps) std::memcpy(kps, R.kps.data(), (size_t)n * sizeof(sind_keypoint));
     if (desc) std::memcpy(desc, R.desc.data(), (size_t)n * 32);
     return (int)R.kps.size();
+}
+
+// PNG scanline reconstruction (filters None / Sub / Up / Average / Paeth, PNG spec section 9) for the rgbd_tum_noros-shaped harness
+// (sindslam_amd/harness.py inflates with zlib and calls this for the byte-serial part).  raw: h rows of (1 + stride) bytes.
+int sind_png_unfilter(const uint8_t* raw, int h, int stride, int bpp, uint8_t* out) {
+    if (!raw || !out || h < 1 || stride < 1 || bpp < 1) return SIND_E_ARG;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* r = raw + (size_t)y * (stride + 1); const int ft = r[0]; r++;
+        uint8_t* o = out + (size_t)y * stride; const uint8_t* up = y ? o - stride : nullptr;
+        for (int x = 0; x < stride; x++) {
+            const int a = x >= bpp ? o[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+            int pred = 0;
+            switch (ft) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                default: sind_set_error("sind_png_unfilter: bad filter type %d in row %d", ft, y); return SIND_E_ARG;
+            }
+            o[x] = (uint8_t)(r[x] + pred);
+        }
+    }
+    return SIND_OK;
 }
 
 }  // extern "C"

@@ -39,15 +39,26 @@ def make_inputs(S, T, nsteps, seed=12345):
     return bgr, depth
 
 
-def cpu_baseline(n_pairs=4):
-    """Oracle ('port') DynaDetect + dilate + ORB on one host core over a bounded sample of the same workload."""
+def cpu_baseline(n_pairs, gpu_dyna, gpu_kps):
+    """Oracle ('port') DynaDetect + dilate + ORB on one host core over a bounded sample of the same workload: the first frame
+    pairs of stream 0 (the unmodified seed-12345 sequence), which the GPU pipeline processed in its first step -> also the
+    parity figures of the metric ("mask IoU vs CPU ref", ORB keypoints bit-exact)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from sindslam_amd.synth import SyntheticStream, TUM3
-    b, d = SyntheticStream().frames(0, n_pairs + 2)
-    t, st = O.baseline_run(b, d, TUM3)
-    return {"value": n_pairs / t, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-            "sample": f"{n_pairs} frame pairs of the synthetic 640x480 stream, {t:.1f} s (flow {st[0]:.1f} s, tail {st[1]:.1f} s, orb {st[2]:.1f} s)"}
+    n_timed = max(n_pairs, 10)              # ~10 s of single-core work
+    b, d = SyntheticStream().frames(0, n_timed + 2)
+    t, st, dyna, kps = O.baseline_run(b, d, TUM3, want_outputs=True)
+    ious = []
+    for i in range(n_pairs):
+        a, r = gpu_dyna[i] == 255, dyna[i] == 255; u = np.logical_or(a, r).sum()
+        ious.append(1.0 if u == 0 else float(np.logical_and(a, r).sum() / u))
+    kp_equal = sum(int(gpu_kps[i].tobytes() == kps[i].tobytes()) for i in range(n_pairs))
+    base = {"value": n_timed / t, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n_timed} frame pairs of the synthetic 640x480 stream, {t:.1f} s (flow {st[0]:.1f} s, tail {st[1]:.1f} s, orb {st[2]:.1f} s)"}
+    parity = {"mask_iou_mean": float(np.mean(ious)), "mask_iou_min": float(np.min(ious)), "orb_keypoints_bit_exact_frames": kp_equal, "frames": n_pairs,
+              "reference": "CPU oracle (parity unpinned: the reference ships no golden vectors and cannot be built here)"}
+    return base, parity
 
 
 def pmc_traffic(pairs_per_step):
@@ -103,8 +114,11 @@ def main():
             m = torch.from_numpy(pipe.dyna)
             gather_masks(m.cuda() if args.backend == "nccl" else m)
 
+    first_dyna = first_kps = None
     for i in range(Wm):                     # warm-up: synchronous steps
         pipe.process_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()); gather()
+        if i == 0:                          # stream 0's first T results, for the parity figures below
+            first_dyna = pipe.dyna[0].copy(); first_kps = [pipe.keypoints(0, t)[0].copy() for t in range(T)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -140,8 +154,8 @@ def main():
                          "alg_bytes_per_launch": (sor_bytes / sor_launches) if sor_launches else None},
             "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "total": stages[4] / K},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu_baseline and world == 1 and first_dyna is not None:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(min(T, 4), first_dyna, first_kps)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -129,10 +129,13 @@ void orc_orb_tables(void* p, float* scale, float* inv_scale, float* sigma2, floa
     for (int i = 0; i < 16; i++) umax[i] = o->umax[i];
 }
 
+static int put_kps(const std::vector<KeyPoint>& v, OrcKp* out, int cap);
 // ---------------------------------------------------------------- CPU baseline: frames through DynaDetect + dilate + ORB, seconds out
 // bgr: n frames (w*h*3 each), depth: n frames.  Frames 0,1 prime the detector; pairs = n-2.  Gray for ORB = BGR2GRAY (Camera.RGB: 0).
 double orc_baseline_run(const uint8_t* bgr, const uint16_t* depth, int n, int w, int h, float fx, float fy, float cx, float cy, float depthScale,
-                        int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, double* stage_seconds /*flow, tail, orb*/) {
+                        int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, double* stage_seconds /*flow, tail, orb*/,
+                        int orb_gray_rgb_order, uint8_t* dyna_out /* (n-2) x h x w or NULL */, int* nkp_out /* n-2 or NULL */,
+                        OrcKp* kps_out /* (n-2) x kp_cap or NULL */, int kp_cap) {
     const size_t fb = (size_t)w * h * 3, fd = (size_t)w * h;
     DynaDetect dd(wrap8(bgr + fb, w, h, 3), wrap8(bgr, w, h, 3), fx, fy, cx, cy, depthScale);
     ORBextractor orb(nfeatures, scaleFactor, nlevels, iniTh, minTh);
@@ -148,8 +151,11 @@ double orc_baseline_run(const uint8_t* bgr, const uint16_t* depth, int n, int w,
         dd.skip_flow = true; dd.DetectDynaArea(img, dp, dy, lb); dd.skip_flow = false;
         dilate_ellipse15(dy, dil);
         double c = now();
-        bgr2gray(img, gray); orb.extract(gray, dil, k, d);
+        bgr2gray(img, gray, orb_gray_rgb_order != 0); orb.extract(gray, dil, k, d);
         double e = now();
+        if (dyna_out) std::memcpy(dyna_out + fd * (i - 2), dy.d.data(), fd);
+        if (nkp_out) nkp_out[i - 2] = (int)k.size();
+        if (kps_out) put_kps(k, kps_out + (size_t)(i - 2) * kp_cap, kp_cap);
         tf += b - a; tt += c - b; to += e - c;
     }
     if (stage_seconds) { stage_seconds[0] = tf; stage_seconds[1] = tt; stage_seconds[2] = to; }

@@ -213,9 +213,15 @@ class ORBextractor:
         lib().orc_orb_tables(self.p, *[_p(t[k]) for k in ["scale", "inv_scale", "sigma2", "inv_sigma2", "per_level", "umax"]]); return t
 
 
-def baseline_run(bgr, depth, intr, nfeatures=1500, scale=1.2, nlevels=8):
+def baseline_run(bgr, depth, intr, nfeatures=1500, scale=1.2, nlevels=8, orb_gray_rgb_order=1, want_outputs=False, kp_cap=4096):
+    """frames 0,1 prime the detector; returns (seconds, stage seconds[, dyna masks (n-2,h,w), keypoints per pair])"""
     n, h, w, _ = bgr.shape; st = np.zeros(3)
+    dyna = np.zeros((n - 2, h, w), np.uint8) if want_outputs else None
+    nkp = np.zeros(n - 2, np.int32) if want_outputs else None
+    kps = np.zeros((n - 2, kp_cap), KP_DTYPE) if want_outputs else None
     t = lib().orc_baseline_run(_p(np.ascontiguousarray(bgr)), _p(np.ascontiguousarray(depth)), n, w, h, C.c_float(intr["fx"]), C.c_float(intr["fy"]),
                                C.c_float(intr["cx"]), C.c_float(intr["cy"]), C.c_float(intr["depth_factor"]), nfeatures, C.c_float(scale), nlevels,
-                               intr["ini_th"], intr["min_th"], _p(st))
+                               intr["ini_th"], intr["min_th"], _p(st), int(orb_gray_rgb_order), _p(dyna), _p(nkp), _p(kps), kp_cap)
+    if want_outputs:
+        return t, st, dyna, [kps[i, :nkp[i]] for i in range(n - 2)]
     return t, st

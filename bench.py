@@ -129,6 +129,8 @@ def main():
             pipe.process_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()); gather()
         elif pipe.submit_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()):
             gather()
+        if first_dyna is None and not args.pipelined:     # --warmup 0: take the parity sample from the first timed step (1.2 MB copy)
+            first_dyna = pipe.dyna[0].copy(); first_kps = [pipe.keypoints(0, t)[0].copy() for t in range(T)]
         st = pipe.stats()
         sor_ms += st["sor_ms"]; sor_bytes += st["sor_alg_bytes"]; sor_launches += st["sor_launches"]
         stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"]])

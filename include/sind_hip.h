@@ -141,6 +141,25 @@ int sind_pipe_flush(sind_pipe* p, uint8_t* dyna, uint8_t* label, uint8_t* mask_d
  * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */
 int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, double* sor_ms, double* sor_alg_bytes);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Frame post-ORB steps: what the reference's RGB-D Frame constructor does with the extractor's output
+ * (ORB_SLAM2/src/Frame.cc:143-170) for B frames at once:
+ *   UndistortKeyPoints()           src/Frame.cc:477-509  -> un_xy   [B][cap][2]  mvKeysUn[i].pt  (identity when k1 == 0)
+ *   ComputeStereoFromRGBD(imDepth) src/Frame.cc:714-735  -> depth_out / u_right [B][cap]  mvDepth / mvuRight (-1 when d <= 0)
+ *   ComputeImageBounds(imGray)     src/Frame.cc:511-541  -> bounds4 = {mnMinX, mnMaxX, mnMinY, mnMaxY}
+ *   AssignFeaturesToGrid()         src/Frame.cc:283-299  -> cell [B][cap] = x * 48 + y (-1: PosInGrid false) and mGrid as CSR:
+ *                                                           grid_start [B][3073], grid_idx [B][cap] (push_back order)
+ * calib: mK, mDistCoef (k1 k2 p1 p2 k3), Camera.bf, depth_map_factor = 1 / DepthMapFactor (src/Tracking.cc:262-263 converts the
+ * raw u16 depth with it).  kps [B][cap] / nkp [B]: the extractor's output (host).  depth: raw u16 [B][height][width], host or
+ * device pointer (depth_on_device).  Output pointers are host and may be NULL.
+ */
+typedef struct sind_frame sind_frame;
+typedef struct sind_frame_calib { float fx, fy, cx, cy, k1, k2, p1, p2, k3, bf, depth_map_factor; } sind_frame_calib;
+int sind_frame_create(const sind_frame_calib* calib, int width, int height, int max_batch, int cap, int device, sind_frame** out);
+int sind_frame_destroy(sind_frame* f);
+int sind_frame_post_orb(sind_frame* f, const sind_keypoint* kps, const int* nkp, int B, const uint16_t* depth, int depth_on_device,
+                        float* un_xy, float* u_right, float* depth_out, int* cell, int* grid_start, int* grid_idx, float* bounds4);
+
 /* helper of the rgbd_tum_noros-shaped harness (sindslam_amd/harness.py): PNG scanline reconstruction, raw = h x (1 + stride) bytes */
 int sind_png_unfilter(const uint8_t* raw, int h, int stride, int bytes_per_pixel, uint8_t* out);
 

@@ -3,6 +3,7 @@
 #include <chrono>
 #include "dynadetect.hpp"
 #include "orb.hpp"
+#include "frame.hpp"
 
 using namespace cvx;
 
@@ -127,6 +128,19 @@ void orc_orb_tables(void* p, float* scale, float* inv_scale, float* sigma2, floa
     ORBextractor* o = (ORBextractor*)p;
     for (int i = 0; i < o->nlevels; i++) { scale[i] = o->mvScaleFactor[i]; inv_scale[i] = o->mvInvScaleFactor[i]; sigma2[i] = o->mvLevelSigma2[i]; inv_sigma2[i] = o->mvInvLevelSigma2[i]; per_level[i] = o->mnFeaturesPerLevel[i]; }
     for (int i = 0; i < 16; i++) umax[i] = o->umax[i];
+}
+
+// ---------------------------------------------------------------- Frame post-ORB steps (Frame.cc:143-170)
+// calib = {fx, fy, cx, cy, k1, k2, p1, p2, k3, bf, depthMapFactor}; outputs sized N (grid_start 3073, grid_idx N); returns the grid entry count
+int orc_frame_post_orb(const float* calib11, const float* kx, const float* ky, int N, const uint16_t* depth, int w, int h,
+                       float* un_xy, float* u_right, float* depth_out, int* cell, int* grid_start, int* grid_idx, float* bounds4) {
+    FrameCalib c{calib11[0], calib11[1], calib11[2], calib11[3], calib11[4], calib11[5], calib11[6], calib11[7], calib11[8], calib11[9], calib11[10]};
+    FramePost o; frame_post_orb(c, kx, ky, N, depth, w, h, o);
+    for (int i = 0; i < N; i++) { un_xy[2 * i] = o.unx[i]; un_xy[2 * i + 1] = o.uny[i]; u_right[i] = o.uRight[i]; depth_out[i] = o.depth[i]; cell[i] = o.cell[i]; }
+    std::memcpy(grid_start, o.gridStart.data(), o.gridStart.size() * sizeof(int));
+    if (!o.gridIdx.empty()) std::memcpy(grid_idx, o.gridIdx.data(), o.gridIdx.size() * sizeof(int));
+    if (bounds4) frame_bounds(c, w, h, bounds4);
+    return (int)o.gridIdx.size();
 }
 
 static int put_kps(const std::vector<KeyPoint>& v, OrcKp* out, int cap);

@@ -15,6 +15,13 @@ import oracle_lib as O  # noqa: E402
 from sindslam_amd.synth import SyntheticStream, TUM3  # noqa: E402
 
 
+# fx fy cx cy k1 k2 p1 p2 k3 bf depthMapFactor (the reference's Examples/RGB-D/TUM3.yaml and TUM1.yaml values)
+FRAME_CALIBS = {
+    "tum3": [535.4, 539.2, 320.1, 247.6, 0.0, 0.0, 0.0, 0.0, 0.0, 40.0, 1.0 / 5000.0],
+    "tum1": [517.306408, 516.469215, 318.643040, 255.313989, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314, 40.0, 1.0 / 5000.0],
+}
+
+
 def main():
     s = SyntheticStream(seed=12345)
     bgr, depth = s.frames(0, 4)
@@ -42,8 +49,22 @@ def main():
     # 4. primitive vectors
     np.savez_compressed(os.path.join(HERE, "primitives.npz"), gray2=g[2][::8, ::8].copy(), gray_min=O.resize_u8(g[2], 384, 288)[::6, ::6].copy(),
                         rng=O.rng_gaussian(12345, 0.5, 64), blur=O.gaussian_blur_u8(g[2][:64, :64].copy()), pyr_sizes=np.array(O.deepflow_levels(384, 288)))
+    # 5. Frame post-ORB steps on the keypoints of (2): TUM3 (no distortion) and TUM1 (radial + tangential distortion) calibrations
+    frame_fixture(k0, depth[2])
     print("golden fixtures written to", HERE)
 
 
+def frame_fixture(kps, depth2):
+    fp = {}
+    for name, cal in FRAME_CALIBS.items():
+        r = O.frame_post_orb(cal, kps["x"], kps["y"], depth2)
+        for key, val in r.items():
+            fp[f"{name}_{key}"] = val
+    np.savez_compressed(os.path.join(HERE, "frame_post.npz"), **fp)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["frame"]:       # only (5), from the committed ORB fixture
+        frame_fixture(np.load(os.path.join(HERE, "orb_frame2.npz"))["kps"], SyntheticStream(seed=12345).frames(2, 1)[1][0])
+    else:
+        main()

@@ -225,3 +225,13 @@ def baseline_run(bgr, depth, intr, nfeatures=1500, scale=1.2, nlevels=8, orb_gra
     if want_outputs:
         return t, st, dyna, [kps[i, :nkp[i]] for i in range(n - 2)]
     return t, st
+
+
+def frame_post_orb(calib11, kx, ky, depth):
+    """calib11 = fx fy cx cy k1 k2 p1 p2 k3 bf depthMapFactor -> dict of the Frame members (oracle/frame.hpp)"""
+    c = np.asarray(calib11, np.float32); kx = np.ascontiguousarray(kx, np.float32); ky = np.ascontiguousarray(ky, np.float32)
+    depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape; n = len(kx)
+    un = np.zeros((max(n, 1), 2), np.float32); ur = np.zeros(max(n, 1), np.float32); dep = np.zeros(max(n, 1), np.float32)
+    cell = np.zeros(max(n, 1), np.int32); gs = np.zeros(64 * 48 + 1, np.int32); gi = np.zeros(max(n, 1), np.int32); b = np.zeros(4, np.float32)
+    m = lib().orc_frame_post_orb(_p(c), _p(kx), _p(ky), n, _p(depth), w, h, _p(un), _p(ur), _p(dep), _p(cell), _p(gs), _p(gi), _p(b))
+    return dict(keys_un=un[:n], u_right=ur[:n], depth=dep[:n], cell=cell[:n], grid_start=gs, grid_idx=gi[:m], bounds=b)

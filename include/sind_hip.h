@@ -160,6 +160,35 @@ int sind_frame_destroy(sind_frame* f);
 int sind_frame_post_orb(sind_frame* f, const sind_keypoint* kps, const int* nkp, int B, const uint16_t* depth, int depth_on_device,
                         float* un_xy, float* u_right, float* depth_out, int* cell, int* grid_start, int* grid_idx, float* bounds4);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Projection matcher.  Replaces, for B (CurrentFrame, LastFrame) pairs at once,
+ *   int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th, bool bMono)   src/ORBmatcher.cc:1328-1470
+ * including Frame::GetFeaturesInArea (src/Frame.cc:398-451), ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1665), the
+ * rotation histogram and ComputeThreeMaxima (:1601-1642).  The Frame / MapPoint object graph is passed as flat arrays:
+ *   last frame, per keypoint i:  x3Dw = pMP->GetWorldPos(), last_valid = (pMP && !mvbOutlier[i]), last_has_obs = pMP->Observations() > 0,
+ *                                last_octave = mvKeys[i].octave, last_angle = mvKeysUn[i].angle, last_desc = pMP->GetDescriptor() (32 B)
+ *   current frame, per keypoint: cur_un_xy / cur_octave / cur_angle = mvKeysUn, cur_u_right = mvuRight, cur_desc = mDescriptors rows,
+ *                                grid_start / grid_idx = mGrid (as sind_frame_post_orb returns it), cur_taken = mvpMapPoints[i2] &&
+ *                                Observations() > 0 on entry (NULL = all free, the TrackWithMotionModel case src/Tracking.cc:914)
+ * Output: match_of_cur[i2] = index i of the last-frame keypoint whose MapPoint the reference stores in
+ * CurrentFrame.mvpMapPoints[i2] (-1: none or removed by the orientation check); *nmatches = the function's return value.
+ * config: fx fy cx cy bf of the current frame, bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}, scale_factors = mvScaleFactors.
+ * mCheckOrientation is the matcher's constructor flag (src/ORBmatcher.cc:41); nnratio is not used by this overload.
+ */
+typedef struct sind_match sind_match;
+typedef struct sind_match_config { float fx, fy, cx, cy, bf; float bounds[4]; float scale_factors[16]; int nlevels, cap_last, cap_cur, max_batch, device; } sind_match_config;
+typedef struct sind_match_pair {
+    const float* Tcw_cur; const float* Tcw_last;                     /* 4x4 row-major poses (rows 0..2 are read) */
+    int n_last; const float* x3Dw; const uint8_t* last_valid; const uint8_t* last_has_obs; const int* last_octave; const float* last_angle; const uint8_t* last_desc;
+    int n_cur; const float* cur_un_xy; const int* cur_octave; const float* cur_angle; const float* cur_u_right; const uint8_t* cur_desc;
+    const int* grid_start; const int* grid_idx; const uint8_t* cur_taken;
+    int* match_of_cur; int* nmatches;                                /* outputs (host) */
+} sind_match_pair;
+int sind_match_create(const sind_match_config* cfg, sind_match** out);
+int sind_match_destroy(sind_match* m);
+int sind_match_by_projection(sind_match* m, const sind_match_pair* pairs, int B, float th, int mono, int check_orientation);
+int sind_match_last_rounds(sind_match* m);      /* resolution rounds the last call needed (see csrc/match_kernels.hip) */
+
 /* helper of the rgbd_tum_noros-shaped harness (sindslam_amd/harness.py): PNG scanline reconstruction, raw = h x (1 + stride) bytes */
 int sind_png_unfilter(const uint8_t* raw, int h, int stride, int bytes_per_pixel, uint8_t* out);
 

@@ -4,6 +4,7 @@
 #include "dynadetect.hpp"
 #include "orb.hpp"
 #include "frame.hpp"
+#include "matcher.hpp"
 
 using namespace cvx;
 
@@ -142,6 +143,22 @@ int orc_frame_post_orb(const float* calib11, const float* kx, const float* ky, i
     if (bounds4) frame_bounds(c, w, h, bounds4);
     return (int)o.gridIdx.size();
 }
+
+// ---------------------------------------------------------------- ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:1328-1470)
+// cam10 = {fx, fy, cx, cy, bf, mb, minX, maxX, minY, maxY}; Tcw: 4x4 row-major
+int orc_search_by_projection(const float* cam10, const float* scale, int nlevels, const float* TcwCur, const float* TcwLast, int nLast, const float* x3Dw,
+                             const uint8_t* lastValid, const uint8_t* lastHasObs, const int* lastOctave, const float* lastAngle, const uint8_t* lastDesc, int nCur,
+                             const float* curUnXY, const int* curOctave, const float* curAngle, const float* curURight, const uint8_t* curDesc, const int* gridStart,
+                             const int* gridIdx, const uint8_t* curTaken, float th, int mono, int checkOrientation, int* matchOfCur) {
+    MatchInput in{}; in.fx = cam10[0]; in.fy = cam10[1]; in.cx = cam10[2]; in.cy = cam10[3]; in.bf = cam10[4]; in.mb = cam10[5];
+    for (int i = 0; i < 4; i++) in.bounds[i] = cam10[6 + i];
+    in.scaleFactors = scale; in.nlevels = nlevels; std::memcpy(in.TcwCur, TcwCur, 48); std::memcpy(in.TcwLast, TcwLast, 48);
+    in.nLast = nLast; in.x3Dw = x3Dw; in.lastValid = lastValid; in.lastHasObs = lastHasObs; in.lastOctave = lastOctave; in.lastAngle = lastAngle; in.lastDesc = lastDesc;
+    in.nCur = nCur; in.curUnXY = curUnXY; in.curOctave = curOctave; in.curAngle = curAngle; in.curURight = curURight; in.curDesc = curDesc; in.gridStart = gridStart; in.gridIdx = gridIdx;
+    in.curTaken = curTaken; in.th = th; in.mono = mono != 0; in.checkOrientation = checkOrientation != 0;
+    return search_by_projection(in, matchOfCur);
+}
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
 
 static int put_kps(const std::vector<KeyPoint>& v, OrcKp* out, int cap);
 // ---------------------------------------------------------------- CPU baseline: frames through DynaDetect + dilate + ORB, seconds out

@@ -235,3 +235,17 @@ def frame_post_orb(calib11, kx, ky, depth):
     cell = np.zeros(max(n, 1), np.int32); gs = np.zeros(64 * 48 + 1, np.int32); gi = np.zeros(max(n, 1), np.int32); b = np.zeros(4, np.float32)
     m = lib().orc_frame_post_orb(_p(c), _p(kx), _p(ky), n, _p(depth), w, h, _p(un), _p(ur), _p(dep), _p(cell), _p(gs), _p(gi), _p(b))
     return dict(keys_un=un[:n], u_right=ur[:n], depth=dep[:n], cell=cell[:n], grid_start=gs, grid_idx=gi[:m], bounds=b)
+
+
+def search_by_projection(cam10, scale, Tcw_cur, Tcw_last, last, cur, th, mono=False, check_orientation=True):
+    """last: dict(x3Dw, valid, has_obs, octave, angle, desc); cur: dict(un_xy, octave, angle, u_right, desc, grid_start, grid_idx, taken|None)
+    -> (match_of_cur, nmatches)   (oracle/matcher.hpp)"""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32); u8 = lambda a: np.ascontiguousarray(a, np.uint8); i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    cam = f32(cam10); sc = f32(scale); tc = f32(Tcw_cur); tl = f32(Tcw_last)
+    L = [f32(last["x3Dw"]), u8(last["valid"]), u8(last["has_obs"]), i32(last["octave"]), f32(last["angle"]), u8(last["desc"])]
+    Cc = [f32(cur["un_xy"]), i32(cur["octave"]), f32(cur["angle"]), f32(cur["u_right"]), u8(cur["desc"]), i32(cur["grid_start"]), i32(cur["grid_idx"])]
+    tk = None if cur.get("taken") is None else u8(cur["taken"])
+    nl, nc = len(L[1]), len(Cc[1]); out = np.full(max(nc, 1), -1, np.int32)
+    n = lib().orc_search_by_projection(_p(cam), _p(sc), len(sc), _p(tc), _p(tl), nl, *[_p(a) for a in L], nc, *[_p(a) for a in Cc], _p(tk), C.c_float(th),
+                                       int(mono), int(check_orientation), _p(out))
+    return out[:nc], n

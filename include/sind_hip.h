@@ -189,6 +189,27 @@ int sind_match_destroy(sind_match* m);
 int sind_match_by_projection(sind_match* m, const sind_match_pair* pairs, int B, float th, int mono, int check_orientation);
 int sind_match_last_rounds(sind_match* m);      /* resolution rounds the last call needed (see csrc/match_kernels.hip) */
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Mapping consumer.  Replaces, for B key frames at once, the body of
+ *   generatePointCloud(imgRGB, imgDepth, imgDepthLast, imgDynaMask, imgDynaMaskLast, imgLabel, poseRelative, Twc)
+ *                                                                              octomap_pub/src/pubPointCloud.cc:471-668
+ * stride-2 back-projection, re-projection depth-consistency vote per cluster (:556-607, vecOcclusion), cluster rejection
+ * (vecOcclusion[i] * 9 <= 0.4 * countNonZero(imgLabel == i) keeps cluster i, :641-663) and pcl::transformPointCloud(.., Twc) (:665).
+ * Images are dense [B][height][width] (bgr x3), host or device pointers (inputs_on_device); pose_relative / Twc: [B][16] row-major
+ * doubles (Eigen::Matrix4d values).  points [B][cap] receives tempCloudOneFrame in the reference's order (cluster 0, then the kept
+ * clusters 1..11, raster order inside a cluster; masked / out-of-range pixels are NaN points, the cloud is not dense), n_points [B];
+ * occlusion / label_count / kept: [B][12], may be NULL.  The statistical outlier filter and the octree insertion that follow in the
+ * ROS node (:291-309) are PCL / octomap library calls and stay with the caller.
+ */
+typedef struct sind_cloud sind_cloud;
+typedef struct sind_cloud_point { float x, y, z; uint8_t b, g, r, a; } sind_cloud_point;       /* pcl::PointXYZRGB payload */
+int sind_cloud_create(double fx, double fy, double cx, double cy, double depth_scale, int width, int height, int max_batch, int device, sind_cloud** out);
+int sind_cloud_destroy(sind_cloud* c);
+int sind_cloud_max_points(sind_cloud* c);                    /* ceil(width / 2) * ceil(height / 2) */
+int sind_cloud_generate(sind_cloud* c, int B, const uint8_t* bgr, const uint16_t* depth, const uint16_t* depth_last, const uint8_t* dyna, const uint8_t* dyna_last,
+                        const uint8_t* label, const double* pose_relative, const double* Twc, int inputs_on_device, sind_cloud_point* points, int cap, int* n_points,
+                        int* occlusion, int* label_count, int* kept);
+
 /* helper of the rgbd_tum_noros-shaped harness (sindslam_amd/harness.py): PNG scanline reconstruction, raw = h x (1 + stride) bytes */
 int sind_png_unfilter(const uint8_t* raw, int h, int stride, int bytes_per_pixel, uint8_t* out);
 

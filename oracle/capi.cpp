@@ -5,6 +5,7 @@
 #include "orb.hpp"
 #include "frame.hpp"
 #include "matcher.hpp"
+#include "cloud.hpp"
 
 using namespace cvx;
 
@@ -159,6 +160,17 @@ int orc_search_by_projection(const float* cam10, const float* scale, int nlevels
     return search_by_projection(in, matchOfCur);
 }
 int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+
+// ---------------------------------------------------------------- octomap_pub generatePointCloud (pubPointCloud.cc:471-660)
+// cam5 = {fx, fy, cx, cy, depthScale} (doubles); returns the point count (points_out may be NULL to query it; 16 B per point)
+int orc_generate_point_cloud(const double* cam5, const uint8_t* bgr, const uint16_t* depth, const uint16_t* depthLast, const uint8_t* dyna, const uint8_t* dynaLast,
+                             const uint8_t* label, int w, int h, const double* poseRelative16, const double* Twc16, void* points_out, int cap, double* occlusion12,
+                             int* labelCount12, uint8_t* kept12) {
+    CloudParams P{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]}; std::vector<CloudPoint> out;
+    generate_point_cloud(P, bgr, depth, depthLast, dyna, dynaLast, label, w, h, poseRelative16, Twc16, out, occlusion12, labelCount12, kept12);
+    if (points_out) std::memcpy(points_out, out.data(), std::min(out.size(), (size_t)cap) * sizeof(CloudPoint));
+    return (int)out.size();
+}
 
 static int put_kps(const std::vector<KeyPoint>& v, OrcKp* out, int cap);
 // ---------------------------------------------------------------- CPU baseline: frames through DynaDetect + dilate + ORB, seconds out

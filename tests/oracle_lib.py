@@ -249,3 +249,18 @@ def search_by_projection(cam10, scale, Tcw_cur, Tcw_last, last, cur, th, mono=Fa
     n = lib().orc_search_by_projection(_p(cam), _p(sc), len(sc), _p(tc), _p(tl), nl, *[_p(a) for a in L], nc, *[_p(a) for a in Cc], _p(tk), C.c_float(th),
                                        int(mono), int(check_orientation), _p(out))
     return out[:nc], n
+
+
+CLOUD_POINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1")])
+
+
+def generate_point_cloud(cam5, bgr, depth, depth_last, dyna, dyna_last, label, pose_relative, Twc):
+    """oracle/cloud.hpp -> dict(points, occlusion, label_count, kept)"""
+    h, w = depth.shape; cam = np.asarray(cam5, np.float64)
+    a = [np.ascontiguousarray(bgr, np.uint8), np.ascontiguousarray(depth, np.uint16), np.ascontiguousarray(depth_last, np.uint16),
+         np.ascontiguousarray(dyna, np.uint8), np.ascontiguousarray(dyna_last, np.uint8), np.ascontiguousarray(label, np.uint8)]
+    pr = np.ascontiguousarray(pose_relative, np.float64); tw = np.ascontiguousarray(Twc, np.float64)
+    cap = ((w + 1) // 2) * ((h + 1) // 2); pts = np.zeros(cap, CLOUD_POINT_DTYPE)
+    occ = np.zeros(12, np.float64); cnt = np.zeros(12, np.int32); kept = np.zeros(12, np.uint8)
+    n = lib().orc_generate_point_cloud(_p(cam), *[_p(x) for x in a], w, h, _p(pr), _p(tw), _p(pts), cap, _p(occ), _p(cnt), _p(kept))
+    return dict(points=pts[:n].copy(), occlusion=occ.astype(np.int32), label_count=cnt, kept=kept.astype(np.int32))

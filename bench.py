@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelined", action="store_true", help="software-pipeline consecutive steps (submit/flush); off by default: measured slower on MI355X")
+    ap.add_argument("--host-threads", type=int, default=0, help="host worker pool size (0 = library default, the GPU box's CPU share)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
     args = ap.parse_args()
 
@@ -100,7 +101,7 @@ def main():
     nsteps = K + Wm
     bgr, depth = make_inputs(S, T, nsteps, seed=12345 + rank)
     pipe = Pipeline(S, T, 640, 480, TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"], 1500, 1.2, 8, TUM3["ini_th"], TUM3["min_th"],
-                    orb_gray_rgb_order=1, device=local)
+                    orb_gray_rgb_order=1, device=local, host_threads=args.host_threads)
     for s in range(S):
         pipe.prime(s, bgr[s, 1], bgr[s, 0])
     # inputs resident in HBM before the timed region, laid out [step][S][T]...

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 // error codes returned across the C ABI (include/sind_hip.h)
@@ -32,6 +34,14 @@ void sind_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
+
+// Host wait for a stream that does not burn a core.  hipStreamSynchronize spins (measured on MI355X: CPU time == wall time), and a
+// GPU box bounds the CPU share of a process (16 cores per GPU on this pool): a spinning waiter takes that share away from the host
+// stages of the other streams.  Short waits stay hot (a few queries), long ones sleep between queries.
+static inline hipError_t sind_stream_wait(hipStream_t s) {
+    for (int i = 0; i < 32; i++) { const hipError_t e = hipStreamQuery(s); if (e != hipErrorNotReady) return e; }
+    for (;;) { const hipError_t e = hipStreamQuery(s); if (e != hipErrorNotReady) return e; std::this_thread::sleep_for(std::chrono::microseconds(20)); }
+}
 
 // simple owning device buffer
 template <class T>

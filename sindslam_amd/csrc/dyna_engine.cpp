@@ -53,7 +53,7 @@ int DynaFront::dense_flow(const uint8_t* pool, const int* cur, const int* prev1,
     std::vector<unsigned> h_max(B); std::vector<int> h_hist((size_t)B * 256);
     HIP_TRY(hipMemcpyAsync(h_max.data(), maxbits.p, B * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h_hist.data(), hist.p, (size_t)B * 256 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     std::vector<int> flagged; std::vector<int> lm(B, 0);
     const float scale_element = 0.6f;
     for (int b = 0; b < B; b++) {
@@ -132,7 +132,7 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
         else pts.push_back({col, row, randomd + 0.4f});
     }
     std::sort(pts.begin(), pts.end(), [](const PW& a, const PW& b) { return a.weight > b.weight; });
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     std::vector<Pt2f> in, inLast;
     for (const PW& p : pts) {
         const int gi = (p.y / 10 - 1) * gx + (p.x / 10 - 1);
@@ -146,7 +146,7 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     unsigned mb; int hist[256];
     HIP_TRY(hipMemcpyAsync(&mb, maxbits.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(hist, hist_d.p, sizeof(hist), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     float maxErrorf; std::memcpy(&maxErrorf, &mb, 4);
     // cv::threshold(THRESH_OTSU / THRESH_TRIANGLE) return values from the 256-bin histogram (imgproc/thresh.cpp)
     auto otsu = [&]() {
@@ -200,7 +200,7 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     std::vector<uint8_t> l8(N), h8(N);
     HIP_TRY(hipMemcpyAsync(l8.data(), low_d.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h8.data(), high_d.p, N, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     low = BitImg::from_u8(l8.data(), W, H, W); high = BitImg::from_u8(h8.data(), W, H, W);
     if (keep_debug) { dbg.maskLow = l8; dbg.maskHigh = h8; }
     return SIND_OK;
@@ -226,7 +226,7 @@ int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, fl
     KmState st[4]; label8.resize(N);
     HIP_TRY(hipMemcpyAsync(st, kstate.p, sizeof(st), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(label8.data(), lab8.p, N, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     std::memcpy(centers, st[0].ctr, sizeof(st[0].ctr)); std::memcpy(counts, st[0].cnt, sizeof(st[0].cnt));
     return SIND_OK;
 }
@@ -245,7 +245,7 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     HIP_TRY(hipMemcpyAsync(e8.data(), edge.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(t8.data(), total.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(blocks.data(), blocks_d.p, blocks.size() * sizeof(PeacBlockStats), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     FLAP(0)
     const BitImg occ = BitImg::from_u8(e8.data(), W, H, W);
     totalArea = BitImg::from_u8(t8.data(), W, H, W);
@@ -353,7 +353,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     SIND_TRY(launch_rag_stats(stream, planes_d.p, C, W, H, wpr, occ2_d.p, depthN.p, ov_d, ovp_d, lj_d, la_d, hist_dd));
     std::vector<int> rag((size_t)3 * C * C + C + (size_t)C * 256);
     HIP_TRY(hipMemcpyAsync(rag.data(), rag_d.p, rag.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     FLAP(8)
     const int* ov = rag.data(); const int* ovp = ov + C * C; const int* ljo = ovp + C * C; const int* lja = ljo + C * C; const int* hst = lja + C;
     // cal_hist (DD:1685-1739) from the two masked histograms

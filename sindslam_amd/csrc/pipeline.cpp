@@ -5,7 +5,11 @@
 //   phase B (stateful, frame order inside a stream, streams in parallel on host threads + their own HIP streams):
 //            DynaDetect tail, dilation, dynamic-mask erasure of the ORB keypoints.
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include "../../include/sind_hip.h"
@@ -14,16 +18,49 @@
 
 using namespace sind;
 
+// Fixed pool of host workers shared by the CalOccluded tasks of the step in phase A and the stateful tails of the step in phase B.
+// The GPU boxes give a process a bounded CPU share (16 cores per GPU on this pool): one bounded pool instead of a thread set per
+// phase keeps the runnable threads under that share, which matters most in the pipelined mode where both kinds of task coexist.
+struct TaskGroup { std::mutex m; std::condition_variable cv; int left = 0; };
+class WorkerPool {
+public:
+    void start(int n, int device) {
+        for (int i = 0; i < n; i++) th.emplace_back([this, i, device] {
+            (void)hipSetDevice(device);
+            for (;;) {
+                std::pair<std::function<void(int)>, TaskGroup*> job;
+                { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return stop || !q.empty(); }); if (q.empty()) return; job = std::move(q.front()); q.pop_front(); }
+                job.first(i);
+                { std::lock_guard<std::mutex> lk(job.second->m); if (--job.second->left == 0) job.second->cv.notify_all(); }
+            } });
+    }
+    void push(TaskGroup& g, std::function<void(int)> fn) {
+        { std::lock_guard<std::mutex> lk(g.m); g.left++; }
+        { std::lock_guard<std::mutex> lk(m); q.emplace_back(std::move(fn), &g); }
+        cv.notify_one();
+    }
+    static void wait(TaskGroup& g) { std::unique_lock<std::mutex> lk(g.m); g.cv.wait(lk, [&g] { return g.left == 0; }); }
+    int size() const { return (int)th.size(); }
+    ~WorkerPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); }
+private:
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv; std::deque<std::pair<std::function<void(int)>, TaskGroup*>> q; bool stop = false;
+};
+
 struct sind_pipe {
     sind_pipe_config c{}; DynaConfig dc; int S = 0, T = 0, fw = 0, fh = 0;
     hipStream_t stream = nullptr; std::vector<hipStream_t> tail_streams;
     DynaFront front; OrbEngine orb; std::vector<std::unique_ptr<DynaTail>> tails;
+    std::vector<hipStream_t> occ_streams; std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
-    struct StepBuf { DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; std::vector<uint16_t> depth_h; std::vector<OrbFrameResult> orb; std::vector<OccResult> occ; bool pending = false; } sb[2];
+    struct StepBuf {
+        DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; std::vector<uint16_t> depth_h; std::vector<OrbFrameResult> orb; std::vector<OccResult> occ; bool pending = false;
+        TaskGroup occ_group, tail_group; std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
+    } sb[2];
     int cur = 0;
     std::vector<char> primed;
     double stage_ms[6] = {0}; double sor_ms = 0, sor_bytes = 0; long long sor_launches = 0;
+    WorkerPool workers;          // declared last: joined first
 };
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -37,6 +74,14 @@ static void dilate15_codes(const uint8_t* src, int W, int H, uint8_t* dst) {
     any.paint_u8(dst, W, 125); hi.paint_u8(dst, W, 255);
 }
 
+// Tail / CalOccluded streams are high priority: their small kernels overtake the batch stream's flow solver when both are in flight.
+// (A CU partition via hipExtStreamCreateWithCUMask was measured on MI355X: every masked stream ran 3-4x slower, see DESIGN.md.)
+static int make_stream(hipStream_t* out, bool high_priority) {
+    if (high_priority && !(getenv("SIND_TAIL_PRIORITY") && atoi(getenv("SIND_TAIL_PRIORITY")) == 0)) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIP_TRY(hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi)); }
+    else HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return SIND_OK;
+}
+
 extern "C" {
 
 int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
@@ -45,16 +90,23 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     std::unique_ptr<sind_pipe> p(new sind_pipe());
     p->c = *cfg; p->S = cfg->streams; p->T = cfg->frames_per_step;
     p->dc.W = cfg->width; p->dc.H = cfg->height; p->dc.fx = cfg->fx; p->dc.fy = cfg->fy; p->dc.cx = cfg->cx; p->dc.cy = cfg->cy; p->dc.depthScale = cfg->depth_scale; p->dc.device = cfg->device;
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    SIND_TRY(make_stream(&p->stream, false));
     const int B = p->S * p->T; const size_t np = (size_t)cfg->width * cfg->height;
     SIND_TRY(p->front.init(p->dc, B, p->stream));
     p->fw = p->front.fw; p->fh = p->front.fh;
     SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->stream));
     p->tail_streams.resize(p->S); p->tails.resize(p->S);
     for (int s = 0; s < p->S; s++) {
-        { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIP_TRY(hipStreamCreateWithPriority(&p->tail_streams[s], hipStreamNonBlocking, hi)); }   // tails' small kernels overtake the next step's flow
+        SIND_TRY(make_stream(&p->tail_streams[s], true));       // high priority: the tails' small kernels overtake the next step's flow
         p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->tail_streams[s]));
     }
+    const int nworkers = cfg->host_threads > 0 ? cfg->host_threads : 24;         // default: 1.5x the box's CPU share per GPU (workers sleep while they wait for the GPU)
+    p->occ_streams.resize(nworkers); p->occ_tails.resize(nworkers);
+    for (int w = 0; w < nworkers; w++) {
+        SIND_TRY(make_stream(&p->occ_streams[w], true));
+        p->occ_tails[w].reset(new DynaTail()); SIND_TRY(p->occ_tails[w]->init(p->dc, p->occ_streams[w]));
+    }
+    p->workers.start(nworkers, cfg->device);
     SIND_TRY(p->gray.alloc(np * B)); SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
     if (cfg->orb_gray_rgb_order) SIND_TRY(p->gray_orb.alloc(np * B));
     for (int k = 0; k < 2; k++) { SIND_TRY(p->sb[k].U.alloc(np * B)); SIND_TRY(p->sb[k].V.alloc(np * B)); SIND_TRY(p->sb[k].depth_dev.alloc(np * B)); p->sb[k].depth_h.resize(np * B); }
@@ -67,12 +119,13 @@ int sind_pipe_destroy(sind_pipe* p) {
         double t[6] = {0}; long n = 0;
         for (auto& tl : p->tails) { for (int i = 0; i < 6; i++) t[i] += tl->t_stage[i]; n += tl->n_frames; }
         double f[12] = {0}; for (auto& tl : p->tails) for (int i = 0; i < 12; i++) f[i] += tl->t_fine[i];
+        for (auto& tl : p->occ_tails) for (int i = 0; i < 12; i++) f[i] += tl->t_fine[i];
         if (n) fprintf(stderr, "[sind] cal_occluded: gpu+d2h %.2f pack %.2f endpoints %.2f peac %.2f contour-filter %.2f close %.2f | seg_merge: pieces %.2f planes+h2d %.2f rag %.2f merge %.2f\n", f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5] / n, f[6] / n, f[7] / n, f[8] / n, f[9] / n);
         if (n) fprintf(stderr, "[sind] tail ms/frame over %ld frames: flow_masks %.2f kmeans %.2f labels %.2f cal_occluded %.2f seg_merge %.2f fusion %.2f\n", n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n);
     }
     (void)hipSetDevice(p->c.device);
     (void)hipDeviceSynchronize();
-    std::vector<hipStream_t> ss = p->tail_streams; ss.push_back(p->stream);
+    std::vector<hipStream_t> ss = p->tail_streams; ss.push_back(p->stream); ss.insert(ss.end(), p->occ_streams.begin(), p->occ_streams.end());
     delete p;
     for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
     return SIND_OK;
@@ -85,7 +138,7 @@ int sind_pipe_prime(sind_pipe* p, int s, const uint8_t* last, const uint8_t* las
     HIP_TRY(hipMemcpyAsync(p->bgr_d.p, lastlast, np * 3, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(p->bgr_d.p + np * 3, last, np * 3, hipMemcpyHostToDevice, p->stream));
     SIND_TRY(p->front.gray_and_min(p->bgr_d.p, 2, p->gray.p, p->pool.p + fb * (size_t)s * (p->T + 2)));   // slots 0 (n-2), 1 (n-1)
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(sind_stream_wait(p->stream));
     p->tails[s]->reset(); p->primed[s] = 1;
     return SIND_OK;
 }
@@ -104,27 +157,22 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     // private copies of the depth frames: device (tail kernels of this step run while the caller may reuse its buffer) and host
     HIP_TRY(hipMemcpyAsync(sb.depth_dev.p, depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(sb.depth_h.data(), sb.depth_dev.p, np * B * sizeof(uint16_t), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(sind_stream_wait(p->stream));
     // CalOccluded of every frame (state free: depth only) on the streams' own host threads / HIP streams, concurrent with the
     // dense flow below (the host cores would otherwise idle while the GPU runs the flow solver)
     sb.occ.assign(B, OccResult());
-    std::vector<int> occ_rc(S, SIND_OK); std::vector<std::string> occ_err(S);
-    const int occ_threads = p->c.host_threads > 0 ? std::min(p->c.host_threads, S) : std::min(S, 16);
-    std::vector<std::thread> occ_th;
-    for (int i = 0; i < occ_threads; i++) occ_th.emplace_back([&, i] {
-        for (int s = i; s < S; s += occ_threads) for (int tt = 0; tt < T; tt++) {
-            const int k = s * T + tt;
-            const int r = p->tails[s]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
-            if (r != SIND_OK) { occ_rc[s] = r; occ_err[s] = sind_last_error(); break; }
-        } });
-    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{occ_th};
+    sb.occ_rc.assign(B, SIND_OK); sb.occ_err.assign(B, std::string());
+    struct Waiter { TaskGroup& g; ~Waiter() { WorkerPool::wait(g); } } waiter{sb.occ_group};       // no task may outlive this call's buffers on an error return
+    for (int k = 0; k < B; k++) p->workers.push(sb.occ_group, [p, &sb, k, np](int w) {
+        const int r = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
+        if (r != SIND_OK) { sb.occ_rc[k] = r; sb.occ_err[k] = sind_last_error(); } });
     t[1] = now_ms();
     // dense flow for every (n, n-2) pair, second pass for large-motion pairs, refinement, up-scale
     std::vector<int> cur(B), p1(B), p2(B);
     for (int s = 0; s < S; s++) for (int tt = 0; tt < T; tt++) { const int k = s * T + tt, base = s * (T + 2) + tt; cur[k] = base + 2; p1[k] = base + 1; p2[k] = base; }
     p->front.flow.sor_timer.enabled = true; p->front.flow.sor_timer.reset();
     SIND_TRY(p->front.dense_flow(p->pool.p, cur.data(), p1.data(), p2.data(), B, sb.U.p, sb.V.p, nullptr));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(sind_stream_wait(p->stream));
     p->sor_ms = p->front.flow.sor_timer.collect_ms(); p->sor_bytes = p->front.flow.sor_timer.alg_bytes; p->sor_launches = p->front.flow.sor_timer.launches;
     t[2] = now_ms();
     // ORB front (pyramid, FAST, octree, orientation, blur, BRIEF) for all frames
@@ -135,9 +183,9 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         if (T >= 2) { HIP_TRY(hipMemcpyAsync(base, base + fb * T, fb * 2, hipMemcpyDeviceToDevice, p->stream)); }
         else { HIP_TRY(hipMemcpyAsync(base, base + fb, fb, hipMemcpyDeviceToDevice, p->stream)); HIP_TRY(hipMemcpyAsync(base + fb, base + fb * 2, fb, hipMemcpyDeviceToDevice, p->stream)); }
     }
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    for (auto& x : occ_th) x.join();
-    for (int s = 0; s < S; s++) if (occ_rc[s] != SIND_OK) { sind_set_error("stream %d (CalOccluded): %s", s, occ_err[s].c_str()); return occ_rc[s]; }
+    HIP_TRY(sind_stream_wait(p->stream));
+    WorkerPool::wait(sb.occ_group);
+    for (int k = 0; k < B; k++) if (sb.occ_rc[k] != SIND_OK) { sind_set_error("stream %d (CalOccluded): %s", k / T, sb.occ_err[k].c_str()); return sb.occ_rc[k]; }
     t[3] = now_ms();
     sb.pending = true;
     return SIND_OK;
@@ -145,37 +193,34 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
 
 // ---- phase B of one step (stateful tails, one host thread per stream or a bounded pool, each on its own HIP stream)
 struct PipeOut { uint8_t *dyna, *label, *mask; sind_keypoint* kps; int cap; int* nkp; uint8_t* desc; };
-static int phase_b(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
+static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
     const int S = p->S, T = p->T, W = p->c.width, H = p->c.height; const size_t np = (size_t)W * H;
-    std::vector<int> rc(S, SIND_OK); std::vector<std::string> err(S);
-    const int nthreads = p->c.host_threads > 0 ? std::min(p->c.host_threads, S) : std::min(S, 16);   // default: the box's CPU share per GPU
-    std::vector<std::thread> th;
-    auto work = [&](int tid) {
-        for (int s = tid; s < S; s += nthreads) {
-            std::vector<uint8_t> dy(np), lb(np), dil(np);
-            for (int t = 0; t < T && rc[s] == SIND_OK; t++) {
-                const int k = s * T + t;
-                int r = p->tails[s]->process(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.U.p + np * k, sb.V.p + np * k, dy.data(), lb.data(), &sb.occ[k]);
-                if (r != SIND_OK) { rc[s] = r; err[s] = sind_last_error(); break; }
-                dilate15_codes(dy.data(), W, H, dil.data());
-                if (o.dyna) std::memcpy(o.dyna + np * k, dy.data(), np);
-                if (o.label) std::memcpy(o.label + np * k, lb.data(), np);
-                if (o.mask) std::memcpy(o.mask + np * k, dil.data(), np);
-                std::vector<OrbKeyPoint> kk; std::vector<uint8_t> dd;
-                p->orb.finish(sb.orb[k], dil.data(), W, kk, dd);
-                if ((int)kk.size() > o.cap && o.kps) { rc[s] = SIND_E_CAPACITY; err[s] = "keypoint capacity exceeded"; break; }
-                if (o.nkp) o.nkp[k] = (int)kk.size();
-                if (o.kps) std::memcpy(o.kps + (size_t)k * o.cap, kk.data(), kk.size() * sizeof(sind_keypoint));
-                if (o.desc) std::memcpy(o.desc + (size_t)k * o.cap * 32, dd.data(), dd.size());
-            }
-        }
-    };
-    for (int i = 0; i < nthreads; i++) th.emplace_back(work, i);
-    for (auto& t : th) t.join();
+    sb.tail_rc.assign(S, SIND_OK); sb.tail_err.assign(S, std::string());
+    for (int s = 0; s < S; s++) p->workers.push(sb.tail_group, [p, &sb, o, s, T, W, H, np](int) {
+        std::vector<uint8_t> dy(np), lb(np), dil(np);
+        for (int t = 0; t < T; t++) {
+            const int k = s * T + t;
+            int r = p->tails[s]->process(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.U.p + np * k, sb.V.p + np * k, dy.data(), lb.data(), &sb.occ[k]);
+            if (r != SIND_OK) { sb.tail_rc[s] = r; sb.tail_err[s] = sind_last_error(); break; }
+            dilate15_codes(dy.data(), W, H, dil.data());
+            if (o.dyna) std::memcpy(o.dyna + np * k, dy.data(), np);
+            if (o.label) std::memcpy(o.label + np * k, lb.data(), np);
+            if (o.mask) std::memcpy(o.mask + np * k, dil.data(), np);
+            std::vector<OrbKeyPoint> kk; std::vector<uint8_t> dd;
+            p->orb.finish(sb.orb[k], dil.data(), W, kk, dd);
+            if ((int)kk.size() > o.cap && o.kps) { sb.tail_rc[s] = SIND_E_CAPACITY; sb.tail_err[s] = "keypoint capacity exceeded"; break; }
+            if (o.nkp) o.nkp[k] = (int)kk.size();
+            if (o.kps) std::memcpy(o.kps + (size_t)k * o.cap, kk.data(), kk.size() * sizeof(sind_keypoint));
+            if (o.desc) std::memcpy(o.desc + (size_t)k * o.cap * 32, dd.data(), dd.size());
+        } });
+}
+static int phase_b_finish(sind_pipe* p, sind_pipe::StepBuf& sb) {
+    WorkerPool::wait(sb.tail_group);
     sb.pending = false;
-    for (int s = 0; s < S; s++) if (rc[s] != SIND_OK) { sind_set_error("stream %d: %s", s, err[s].c_str()); return rc[s]; }
+    for (int s = 0; s < p->S; s++) if (sb.tail_rc[s] != SIND_OK) { sind_set_error("stream %d: %s", s, sb.tail_err[s].c_str()); return sb.tail_rc[s]; }
     return SIND_OK;
 }
+static int phase_b(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) { phase_b_start(p, sb, o); return phase_b_finish(p, sb); }
 
 static int check_inputs(sind_pipe* p, const void* a, const void* b) {
     if (!p || !a || !b) { sind_set_error("sind_pipe: null input"); return SIND_E_ARG; }
@@ -207,14 +252,14 @@ int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* d
     const bool has_prev = p->sb[prev].pending;
     if (have_output) *have_output = has_prev ? 1 : 0;
     const PipeOut o{dyna, label, mask_dil, kps, cap, nkp, desc};
-    int rb = SIND_OK; std::string eb; double tb0 = now_ms(), tb1 = tb0;
-    std::thread bth;
-    if (has_prev) bth = std::thread([&] { (void)hipSetDevice(p->c.device); rb = phase_b(p, p->sb[prev], o); if (rb != SIND_OK) eb = sind_last_error(); tb1 = now_ms(); });
+    const double tb0 = now_ms(); double tb1 = tb0;
+    if (has_prev) phase_b_start(p, p->sb[prev], o);            // queued ahead of this step's CalOccluded tasks
     double t[4]; const double t0 = now_ms();
     const int ra = phase_a(p, p->sb[p->cur], bgr_dev, depth_dev, t);
-    if (bth.joinable()) bth.join();
+    int rb = SIND_OK;
+    if (has_prev) { rb = phase_b_finish(p, p->sb[prev]); tb1 = now_ms(); }
     const double t4 = now_ms();
-    if (rb != SIND_OK) { sind_set_error("%s", eb.c_str()); return rb; }
+    if (rb != SIND_OK) return rb;
     SIND_TRY(ra);
     p->stage_ms[0] = t[1] - t[0]; p->stage_ms[1] = t[2] - t[1]; p->stage_ms[2] = t[3] - t[2]; p->stage_ms[3] = 0; p->stage_ms[4] = tb1 - tb0; p->stage_ms[5] = t4 - t0;
     p->cur ^= 1;

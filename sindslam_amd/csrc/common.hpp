@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <thread>
@@ -38,9 +39,15 @@ static inline int divup(int a, int b) { return (a + b - 1) / b; }
 // Host wait for a stream that does not burn a core.  hipStreamSynchronize spins (measured on MI355X: CPU time == wall time), and a
 // GPU box bounds the CPU share of a process (16 cores per GPU on this pool): a spinning waiter takes that share away from the host
 // stages of the other streams.  Short waits stay hot (a few queries), long ones sleep between queries.
+extern std::atomic<long long> g_sind_wait_ns, g_sind_wait_calls;      // statistics of sind_stream_wait (SIND_TAIL_TIMING report)
 static inline hipError_t sind_stream_wait(hipStream_t s) {
-    for (int i = 0; i < 32; i++) { const hipError_t e = hipStreamQuery(s); if (e != hipErrorNotReady) return e; }
-    for (;;) { const hipError_t e = hipStreamQuery(s); if (e != hipErrorNotReady) return e; std::this_thread::sleep_for(std::chrono::microseconds(20)); }
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipErrorNotReady;
+    for (int i = 0; i < 32 && e == hipErrorNotReady; i++) e = hipStreamQuery(s);
+    while (e == hipErrorNotReady) { std::this_thread::sleep_for(std::chrono::microseconds(20)); e = hipStreamQuery(s); }
+    g_sind_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+    g_sind_wait_calls.fetch_add(1, std::memory_order_relaxed);
+    return e;
 }
 
 // simple owning device buffer
@@ -56,6 +63,23 @@ struct DevBuf {
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
     ~DevBuf() { release(); }
     DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// page-locked host buffer: D2H / H2D on it go through the SDMA engines and never wait behind compute kernels of other streams
+// (pageable copies are staged by blit kernels, which queue up behind the flow solver when tails and the next step overlap)
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr; size_t n = 0;
+    int alloc(size_t count) {
+        if (count <= n && p) return SIND_OK;
+        release();
+        if (hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault) != hipSuccess) { p = nullptr; n = 0; sind_set_error("hipHostMalloc(%zu bytes) failed", count * sizeof(T)); return SIND_E_ALLOC; }
+        n = count; return SIND_OK;
+    }
+    void release() { if (p) { (void)hipHostFree(p); p = nullptr; n = 0; } }
+    T* data() { return p; } const T* data() const { return p; }
+    ~PinnedBuf() { release(); }
+    PinnedBuf() = default; PinnedBuf(const PinnedBuf&) = delete; PinnedBuf& operator=(const PinnedBuf&) = delete;
 };
 
 #ifdef __HIPCC__

@@ -61,6 +61,9 @@ private:
     DevBuf<uint16_t> dpyr[4], filt; DevBuf<float> px, py, pz; DevBuf<int> lab[4]; DevBuf<uint8_t> lab8, labPrev8, edge, edgeTmp, total, depthN, occ2_d, magu8, low_d, high_d;
     DevBuf<double> kpart; DevBuf<unsigned long long> planes_d; DevBuf<unsigned> umax_d, maxbits; DevBuf<int> hist_d, rag_d; DevBuf<float> mag, grid_d;
     DevBuf<PeacBlockStats> blocks_d;
+    // page-locked staging of everything that crosses PCIe in a tail
+    PinnedBuf<float> h_grid; PinnedBuf<int> h_hist, h_rag; PinnedBuf<uint8_t> h_a8, h_b8, h_lab8; PinnedBuf<KmState> h_kstate; PinnedBuf<PeacBlockStats> h_blocks;
+    PinnedBuf<unsigned long long> h_planes;
     int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high);
     int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
     DevBuf<KmState> kstate;

@@ -104,6 +104,12 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     SIND_TRY(edge.alloc(N)); SIND_TRY(edgeTmp.alloc(N)); SIND_TRY(total.alloc(N)); SIND_TRY(depthN.alloc(N)); SIND_TRY(occ2_d.alloc(N));
     SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc(N)); SIND_TRY(high_d.alloc(N)); SIND_TRY(mag.alloc(N));
     SIND_TRY(kpart.alloc((size_t)KM_MAX_BLOCKS * KM_K * 4)); SIND_TRY(umax_d.alloc(2)); SIND_TRY(maxbits.alloc(1));
+    SIND_TRY(h_grid.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(h_hist.alloc(257)); SIND_TRY(h_a8.alloc(N)); SIND_TRY(h_b8.alloc(N)); SIND_TRY(h_lab8.alloc(N));
+    SIND_TRY(h_kstate.alloc(4)); SIND_TRY(h_blocks.alloc((size_t)(W / 16) * (H / 16)));
+    { // RAG workspaces for up to 64 pieces up front: a later (re)allocation synchronises the whole device, i.e. waits for the
+      // flow solver of the next step when tails and dense flow overlap
+      const size_t cap = 64, pw = (size_t)H * (W / 64), nr = 3 * cap * cap + cap + cap * 256;
+      SIND_TRY(h_planes.alloc(3 * cap * pw)); SIND_TRY(planes_d.alloc(3 * cap * pw)); SIND_TRY(h_rag.alloc(nr)); SIND_TRY(rag_d.alloc(nr)); }
     SIND_TRY(hist_d.alloc(256)); SIND_TRY(grid_d.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
     return SIND_OK;
 }
@@ -114,8 +120,8 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     const int numCluster = KM_K;
     SIND_TRY(launch_gather_grid(stream, U, V, grid_d.p, W, H, 10));
     const int gx = (W - 1) / 10, gy = (H - 1) / 10;
-    std::vector<float> gridFlow((size_t)2 * gx * gy);
-    HIP_TRY(hipMemcpyAsync(gridFlow.data(), grid_d.p, gridFlow.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    float* gridFlow = h_grid.p;
+    HIP_TRY(hipMemcpyAsync(gridFlow, grid_d.p, (size_t)2 * gx * gy * sizeof(float), hipMemcpyDeviceToHost, stream));
     // previous-frame dynamic ratio per cluster (DD:1169-1177)
     std::vector<float> clusterWeight(numCluster, 0.0f);
     { int nC[256] = {0}, nD[256] = {0};
@@ -143,10 +149,10 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     double Hm[9];
     find_homography_prosac(in, inLast, Hm);
     SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, maxbits.p, hist_d.p, magu8.p, W, H));
-    unsigned mb; int hist[256];
-    HIP_TRY(hipMemcpyAsync(&mb, maxbits.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(hist, hist_d.p, sizeof(hist), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_hist.p + 256, maxbits.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_hist.p, hist_d.p, 256 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
+    unsigned mb; std::memcpy(&mb, h_hist.p + 256, 4); int hist[256]; std::memcpy(hist, h_hist.p, sizeof(hist));
     float maxErrorf; std::memcpy(&maxErrorf, &mb, 4);
     // cv::threshold(THRESH_OTSU / THRESH_TRIANGLE) return values from the 256-bin histogram (imgproc/thresh.cpp)
     auto otsu = [&]() {
@@ -197,12 +203,11 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     }
     dbg.thr_low = lo; dbg.thr_high = hi;
     SIND_TRY(launch_threshold_masks(stream, magu8.p, lo, hi, low_d.p, high_d.p, N));
-    std::vector<uint8_t> l8(N), h8(N);
-    HIP_TRY(hipMemcpyAsync(l8.data(), low_d.p, N, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(h8.data(), high_d.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_a8.p, low_d.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_b8.p, high_d.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
-    low = BitImg::from_u8(l8.data(), W, H, W); high = BitImg::from_u8(h8.data(), W, H, W);
-    if (keep_debug) { dbg.maskLow = l8; dbg.maskHigh = h8; }
+    low = BitImg::from_u8(h_a8.p, W, H, W); high = BitImg::from_u8(h_b8.p, W, H, W);
+    if (keep_debug) { dbg.maskLow.assign(h_a8.p, h_a8.p + N); dbg.maskHigh.assign(h_b8.p, h_b8.p + N); }
     return SIND_OK;
 }
 
@@ -214,7 +219,7 @@ int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, fl
     const uint16_t* dl[4] = {depth_dev, dpyr[1].p, dpyr[2].p, dpyr[3].p};
     SIND_TRY(kstate.alloc(4));
     for (int l = 1; l < 4; l++) SIND_TRY(launch_depth_half(stream, dl[l - 1], dpyr[l].p, W >> l, H >> l));
-    if (labelLastAny) HIP_TRY(hipMemcpyAsync(labPrev8.p, labelLast.data(), N, hipMemcpyHostToDevice, stream));
+    if (labelLastAny) { std::memcpy(h_lab8.p, labelLast.data(), N); HIP_TRY(hipMemcpyAsync(labPrev8.p, h_lab8.p, N, hipMemcpyHostToDevice, stream)); }
     for (int level = 3; level >= 0; level--) {
         const int hp = (int)(H * scales[level]), wp = (int)(W * scales[level]), n = hp * wp;
         SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale));
@@ -223,10 +228,11 @@ int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, fl
         SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, kstate.p + level, 4, 0.07 * 0.07));
     }
     SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N));
-    KmState st[4]; label8.resize(N);
-    HIP_TRY(hipMemcpyAsync(st, kstate.p, sizeof(st), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(label8.data(), lab8.p, N, hipMemcpyDeviceToHost, stream));
+    label8.resize(N);
+    HIP_TRY(hipMemcpyAsync(h_kstate.p, kstate.p, 4 * sizeof(KmState), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_a8.p, lab8.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
+    const KmState* st = h_kstate.p; std::memcpy(label8.data(), h_a8.p, N);
     std::memcpy(centers, st[0].ctr, sizeof(st[0].ctr)); std::memcpy(counts, st[0].cnt, sizeof(st[0].cnt));
     return SIND_OK;
 }
@@ -241,14 +247,14 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     SIND_TRY(launch_morph(stream, edge.p, edgeTmp.p, W, H, 4, false));      // MORPH_OPEN, element4 = erode then dilate
     SIND_TRY(launch_morph(stream, edgeTmp.p, edge.p, W, H, 4, true));
     SIND_TRY(launch_peac_block_stats(stream, depth_dev, W, H, 16, 16, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale, blocks_d.p));
-    std::vector<uint8_t> e8(N), t8(N); std::vector<PeacBlockStats> blocks((size_t)(W / 16) * (H / 16));
-    HIP_TRY(hipMemcpyAsync(e8.data(), edge.p, N, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(t8.data(), total.p, N, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(blocks.data(), blocks_d.p, blocks.size() * sizeof(PeacBlockStats), hipMemcpyDeviceToHost, stream));
+    PinnedBuf<PeacBlockStats>& blocks = h_blocks;
+    HIP_TRY(hipMemcpyAsync(h_a8.p, edge.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_b8.p, total.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(blocks.data(), blocks_d.p, blocks.n * sizeof(PeacBlockStats), hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
     FLAP(0)
-    const BitImg occ = BitImg::from_u8(e8.data(), W, H, W);
-    totalArea = BitImg::from_u8(t8.data(), W, H, W);
+    const BitImg occ = BitImg::from_u8(h_a8.p, W, H, W);
+    totalArea = BitImg::from_u8(h_b8.p, W, H, W);
     FLAP(1)
     // end points: edge pixels with at most 4 of the 12 radius-2 ring pixels set (DD:498-532), greedy NMS radius 6 in scan order
     static const int ring[12][2] = {{0,-2},{1,-2},{2,-1},{2,0},{2,1},{1,2},{0,2},{-1,2},{-2,1},{-2,0},{-2,-1},{-1,-2}};
@@ -281,7 +287,7 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     BitImg u = occ; u |= acc; occ1 = u.closed(e3);
     FLAP(5)
     #undef FLAP
-    if (keep_debug) { dbg.gradEdge = e8; dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
+    if (keep_debug) { dbg.gradEdge.assign(h_a8.p, h_a8.p + N); dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
     return SIND_OK;
 }
 
@@ -336,23 +342,27 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     for (int i = 0; i < C; i++) all[i].img.paint_u8(total.data(), W, (uint8_t)i);
     // ---- RAG statistics on the GPU: upload the 3*C bit planes, one pass over the frame
     const int wpr = W / 64; const size_t pw = (size_t)H * wpr;
-    std::vector<unsigned long long> planes((size_t)3 * C * pw, 0);
+    SIND_TRY(h_planes.alloc((size_t)3 * C * pw)); SIND_TRY(h_rag.alloc((size_t)3 * C * C + C + (size_t)C * 256));
+    unsigned long long* planes = h_planes.p; const size_t planes_n = (size_t)3 * C * pw;
+    for (int i = 0; i < C; i++) if (!all[i].hasLianjie) std::memset(&planes[((size_t)2 * C + i) * pw], 0, pw * 8);
     for (int i = 0; i < C; i++) {
         std::memcpy(&planes[((size_t)0 * C + i) * pw], all[i].img.d.data(), pw * 8);
         std::memcpy(&planes[((size_t)1 * C + i) * pw], all[i].dil.d.data(), pw * 8);
         if (all[i].hasLianjie) std::memcpy(&planes[((size_t)2 * C + i) * pw], all[i].lianjie.d.data(), pw * 8);
     }
-    SIND_TRY(planes_d.alloc(planes.size())); SIND_TRY(rag_d.alloc((size_t)3 * C * C + C + (size_t)C * 256));
-    HIP_TRY(hipMemcpyAsync(planes_d.p, planes.data(), planes.size() * 8, hipMemcpyHostToDevice, stream));
-    std::vector<uint8_t> o2(N); occ2.to_u8(o2.data(), W, 255);
-    HIP_TRY(hipMemcpyAsync(occ2_d.p, o2.data(), N, hipMemcpyHostToDevice, stream));
+    FLAP(10)
+    SIND_TRY(planes_d.alloc(planes_n)); SIND_TRY(rag_d.alloc((size_t)3 * C * C + C + (size_t)C * 256));
+    FLAP(11)
+    HIP_TRY(hipMemcpyAsync(planes_d.p, planes, planes_n * 8, hipMemcpyHostToDevice, stream));
+    occ2.to_u8(h_b8.p, W, 255);
+    HIP_TRY(hipMemcpyAsync(occ2_d.p, h_b8.p, N, hipMemcpyHostToDevice, stream));
     FLAP(7)
     SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1));
     SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, depthN.p, N));
     int* ov_d = rag_d.p; int* ovp_d = ov_d + C * C; int* lj_d = ovp_d + C * C; int* la_d = lj_d + C * C; int* hist_dd = la_d + C;
     SIND_TRY(launch_rag_stats(stream, planes_d.p, C, W, H, wpr, occ2_d.p, depthN.p, ov_d, ovp_d, lj_d, la_d, hist_dd));
-    std::vector<int> rag((size_t)3 * C * C + C + (size_t)C * 256);
-    HIP_TRY(hipMemcpyAsync(rag.data(), rag_d.p, rag.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    PinnedBuf<int>& rag = h_rag;
+    HIP_TRY(hipMemcpyAsync(rag.data(), rag_d.p, ((size_t)3 * C * C + C + (size_t)C * 256) * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
     FLAP(8)
     const int* ov = rag.data(); const int* ovp = ov + C * C; const int* ljo = ovp + C * C; const int* lja = ljo + C * C; const int* hst = lja + C;

@@ -47,8 +47,9 @@ int sind_flow_varref_f32(sind_flow* f, const float* i0, const float* i1, int w, 
 int sind_flow_deepflow_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v);   /* device pointers, async */
 int sind_flow_refine_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v);
 int sind_flow_sync(sind_flow* f);
-/* solver variant (process-wide): mode 1 = fused register-resident SOR (default), 0 = one launch per colour (cross-check);
- * fuse = iterations per launch on tiled levels (default 5); tile_w = 64 (default) or 128 */
+/* solver variant (process-wide): mode 1 = fused register-resident SOR, 1x8 strips, IEEE division (default), 2 = fused, 1x4 strips +
+ * reciprocal (Markstein) division, 0 = one launch per colour (cross-check); fuse = iterations per launch on tiled levels (default 5);
+ * tile_w = 64 (default) or 128 (mode 1 only) */
 int sind_flow_set_sor(int mode, int fuse, int tile_w);
 /* HIP-event timing of everything enqueued on the handle's stream between begin and end (bench.py roofline leg) */
 int sind_flow_timer_begin(sind_flow* f);

@@ -94,7 +94,7 @@ int sind_flow_refine_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int
     return f->eng.refine(i0, i1, B, u, v);
 }
 int sind_flow_set_sor(int mode, int fuse, int tile_w) {
-    if (mode < 0 || mode > 1 || fuse < 1 || fuse > 12 || (tile_w != 64 && tile_w != 128)) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }
+    if (mode < 0 || mode > 2 || fuse < 1 || fuse > 12 || (tile_w != 64 && tile_w != 128)) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }
     sind::g_sor_mode = mode; sind::g_sor_fuse = fuse; sind::g_sor_tile_w = tile_w; return SIND_OK;
 }
 int sind_flow_sync(sind_flow* f) { if (!f) return SIND_E_ARG; HIP_TRY(hipStreamSynchronize(f->stream)); return SIND_OK; }

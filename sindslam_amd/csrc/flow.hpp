@@ -34,7 +34,7 @@ int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w,
 int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img);
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb);
-extern int g_sor_mode, g_sor_fuse, g_sor_tile_w;
+extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd;
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch);
 int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr);
 int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, unsigned* maxbits, int* hist, uint8_t* out_u8, int n, int B);

@@ -20,9 +20,10 @@ static std::vector<std::pair<int, int>> deepflow_sizes(int w, int h) {
 
 int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     fw = fw_; fh = fh_; maxB = maxB_; stream = s;
-    if (const char* e = getenv("SIND_SOR_MODE")) g_sor_mode = atoi(e);       // 0: per-colour launches, 1: fused (default)
+    if (const char* e = getenv("SIND_SOR_MODE")) g_sor_mode = atoi(e);       // 0: per-colour launches, 1: fused 1x8 strips (default), 2: fused 1x4 strips + reciprocal division
     if (const char* e = getenv("SIND_SOR_TILEW")) g_sor_tile_w = atoi(e) == 64 ? 64 : 128;
     if (const char* e = getenv("SIND_SOR_FUSE")) g_sor_fuse = std::max(1, std::min(atoi(e), 12));
+    if (const char* e = getenv("SIND_SOR_XCD")) g_sor_xcd = atoi(e) != 0;
     levels = deepflow_sizes(fw, fh);
     level_off.clear(); pyr_pixels = 0;
     for (auto& l : levels) { level_off.push_back(pyr_pixels); pyr_pixels += (size_t)l.first * l.second; }

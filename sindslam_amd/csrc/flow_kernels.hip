@@ -208,7 +208,7 @@ __device__ __forceinline__ void ld8(const float* __restrict__ p, float (&d)[SOR_
     const F4u a = *reinterpret_cast<const F4u*>(p), c = *reinterpret_cast<const F4u*>(p + 4);
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = c.x; d[5] = c.y; d[6] = c.z; d[7] = c.w;
 }
-__global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo, int ntx, int iters, float omega,
+__global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo_x, int halo, int ntx, int iters, int xcd_remap, float omega,
                                                       const float* __restrict__ gA11, const float* __restrict__ gA12, const float* __restrict__ gA22,
                                                       const float* __restrict__ gB1, const float* __restrict__ gB2, const float* __restrict__ gW,
                                                       const float* __restrict__ gUin, const float* __restrict__ gVin, float* __restrict__ gUout,
@@ -223,8 +223,16 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
     const int tid = threadIdx.x;
     const int idx = tid < half ? tid : tid - half;
     const int j = idx % SW, ly = 2 * (idx / SW) + (tid < half ? 0 : 1);
-    const int tile = blockIdx.x, tx = tile % ntx, ty = tile / ntx, b = blockIdx.y;
-    const int ex0 = tx * IW - halo, ey0 = ty * IH - halo;           // E origin in image coordinates (may be negative)
+    // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (each with its own L2) in linear-id order, so neighbouring ids never
+    // share an L2.  Re-map id -> (image, tile) such that XCD q walks the q-th eighth of all tiles in order: tiles that overlap in their
+    // halos then run on the same XCD at about the same time and the halo is fetched from HBM once.
+    int tile = blockIdx.x, b = blockIdx.y;
+    {
+        const long long ntile = gridDim.x, lin = blockIdx.x + (long long)blockIdx.y * ntile, per = ntile * gridDim.y / 8;
+        if (xcd_remap && lin < per * 8) { const long long logical = (lin & 7) * per + (lin >> 3); b = (int)(logical / ntile); tile = (int)(logical - (long long)b * ntile); }
+    }
+    const int tx = tile % ntx, ty = tile / ntx;
+    const int ex0 = tx * IW - halo_x, ey0 = ty * IH - halo;         // E origin in image coordinates (may be negative)
     const int gy = ey0 + ly, gx0 = ex0 + SOR_PX * j;
     const size_t base = (size_t)b * w * h;
     const int off = (ex0 + ey0) & 1;             // local parity of the globally "red" pixels
@@ -310,6 +318,126 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
         if (gy >= iy0 && gy < iy0 + IH) {
             #pragma unroll
             for (int i = 0; i < SOR_PX; i++) {
+                const int gx = gx0 + i;
+                if (((valid >> i) & 1u) && gx >= ix0 && gx < ix0 + IW) { const size_t g = base + (size_t)gy * w + gx; gUout[g] = du[i]; gVout[g] = dv[i]; }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Second generation of the fused kernel for the tiled levels: 1x4 pixel strips (1024 threads per 64x64 tile) leave room in the
+// 128-VGPR budget for the RECIPROCALS of A11 / A22, so the two IEEE divisions of a pixel update (~14 VALU operations each, and the
+// kernel is VALU-bound once the coefficients come from L2) become Markstein's three-operation sequence
+//     q0 = n * r;  e = fma(-a, q0, n);  q = fma(e, r, q0)        with r = RN(1 / a)
+// which returns the correctly rounded quotient RN(n / a) for a correctly rounded reciprocal (Markstein 1990; no overflow /
+// underflow: the system is O(1)).  Same LDS scheme as above with float2 instead of float4 (two pixels per colour and strip).
+// tests/test_flow_gpu.py::test_sor_variants_agree_bitwise holds this kernel to the per-colour reference kernel bit for bit.
+#define SOR4_PX 4
+__device__ __forceinline__ float sor_div(float n, float a, float r) { const float q0 = n * r; const float e = fmaf(-a, q0, n); return fmaf(e, r, q0); }
+__global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int EH, int IW, int IH, int halo_x, int halo, int ntx, int iters, int xcd_remap, float omega,
+                                                     const float* __restrict__ gA11, const float* __restrict__ gA12, const float* __restrict__ gA22,
+                                                     const float* __restrict__ gB1, const float* __restrict__ gB2, const float* __restrict__ gW,
+                                                     const float* __restrict__ gUin, const float* __restrict__ gVin, float* __restrict__ gUout,
+                                                     float* __restrict__ gVout) {
+    extern __shared__ float4 lds4[];
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
+    float* lds = reinterpret_cast<float*>(lds4);
+    const int SW = EW / SOR4_PX;                 // strips per row
+    const int RS2 = EW / 4 + 2;                  // LDS row stride in float2 (one guard float2 on each side)
+    const int half = blockDim.x >> 1;
+    const int NR = 2 * (half / SW);
+    const int PL2 = (NR + 2) * RS2;
+    const int tid = threadIdx.x;
+    const int idx = tid < half ? tid : tid - half;
+    const int j = idx % SW, ly = 2 * (idx / SW) + (tid < half ? 0 : 1);
+    int tile = blockIdx.x, b = blockIdx.y;
+    {
+        const long long ntile = gridDim.x, lin = blockIdx.x + (long long)blockIdx.y * ntile, per = ntile * gridDim.y / 8;
+        if (xcd_remap && lin < per * 8) { const long long logical = (lin & 7) * per + (lin >> 3); b = (int)(logical / ntile); tile = (int)(logical - (long long)b * ntile); }
+    }
+    const int tx = tile % ntx, ty = tile / ntx;
+    const int ex0 = tx * IW - halo_x, ey0 = ty * IH - halo;
+    const int gy = ey0 + ly, gx0 = ex0 + SOR4_PX * j;
+    const size_t base = (size_t)b * w * h;
+    const int off = (ex0 + ey0) & 1;
+
+    for (int i = tid; i < 4 * PL2; i += blockDim.x) lds2[i] = make_float2(0.f, 0.f);
+    float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], wu[4], du[4], dv[4], r11[4], r22[4];
+    float wl0 = 0.f;
+    unsigned valid = 0;
+    const bool row_ok = ly < EH && gy >= 0 && gy < h;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) { a11[i] = 1.f; a12[i] = 0.f; a22[i] = 1.f; b1[i] = 0.f; b2[i] = 0.f; wp[i] = 0.f; wu[i] = 0.f; du[i] = 0.f; dv[i] = 0.f; }
+    #define LD4(P, D) { const F4u t_ = *reinterpret_cast<const F4u*>(P); D[0] = t_.x; D[1] = t_.y; D[2] = t_.z; D[3] = t_.w; }
+    if (row_ok && gx0 >= 0 && gx0 + 4 <= w) {
+        const size_t g = base + (size_t)gy * w + gx0;
+        valid = 0xfu;
+        LD4(gA11 + g, a11) LD4(gA12 + g, a12) LD4(gA22 + g, a22) LD4(gB1 + g, b1) LD4(gB2 + g, b2) LD4(gW + g, wp) LD4(gUin + g, du) LD4(gVin + g, dv)
+        if (gy > 0) LD4(gW + g - w, wu)
+    } else if (row_ok) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int gx = gx0 + i;
+            if (gx >= 0 && gx < w) {
+                const size_t g = base + (size_t)gy * w + gx;
+                valid |= 1u << i;
+                a11[i] = gA11[g]; a12[i] = gA12[g]; a22[i] = gA22[g]; b1[i] = gB1[g]; b2[i] = gB2[g]; wp[i] = gW[g];
+                wu[i] = gy > 0 ? gW[g - w] : 0.f;
+                du[i] = gUin[g]; dv[i] = gVin[g];
+            }
+        }
+    }
+    #undef LD4
+    if (row_ok && gx0 - 1 >= 0 && gx0 - 1 < w) wl0 = gW[base + (size_t)gy * w + gx0 - 1];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) { r11[i] = 1.0f / a11[i]; r22[i] = 1.0f / a22[i]; }          // correctly rounded (IEEE divide flag of the build)
+    __syncthreads();
+    const int ro2 = (ly + 1) * RS2 + 1 + j;
+    const int s0 = ly & 1;
+    {
+        const int pe = s0 == 0 ? 0 : 2, po = s0 == 0 ? 2 : 0;
+        lds2[(pe + 0) * PL2 + ro2] = make_float2(du[0], du[2]); lds2[(pe + 1) * PL2 + ro2] = make_float2(dv[0], dv[2]);
+        lds2[(po + 0) * PL2 + ro2] = make_float2(du[1], du[3]); lds2[(po + 1) * PL2 + ro2] = make_float2(dv[1], dv[3]);
+    }
+    __syncthreads();
+
+    #define SOR4_HALF(START, Q)                                                                                                   \
+        {                                                                                                                         \
+            const int oq = (Q) ^ 1;                                                                                               \
+            const float2 t0 = lds2[(oq * 2 + 0) * PL2 + ro2 - RS2], t1 = lds2[(oq * 2 + 1) * PL2 + ro2 - RS2];                    \
+            const float2 t2 = lds2[(oq * 2 + 0) * PL2 + ro2 + RS2], t3 = lds2[(oq * 2 + 1) * PL2 + ro2 + RS2];                    \
+            const float uu[2] = {t0.x, t0.y}, vu[2] = {t1.x, t1.y}, ud[2] = {t2.x, t2.y}, vd[2] = {t3.x, t3.y};                   \
+            const float eu = lds[2 * ((oq * 2 + 0) * PL2 + ro2) + ((START) == 0 ? -1 : 2)];                                       \
+            const float ev = lds[2 * ((oq * 2 + 1) * PL2 + ro2) + ((START) == 0 ? -1 : 2)];                                       \
+            _Pragma("unroll")                                                                                                     \
+            for (int k = 0; k < 2; k++) {                                                                                         \
+                const int i = (START) + 2 * k;                                                                                    \
+                const float wl = i == 0 ? wl0 : wp[i == 0 ? 0 : i - 1];                                                           \
+                const float ul = i == 0 ? eu : du[i == 0 ? 0 : i - 1], vl = i == 0 ? ev : dv[i == 0 ? 0 : i - 1];                \
+                const float ur = i == 3 ? eu : du[i == 3 ? 3 : i + 1], vr = i == 3 ? ev : dv[i == 3 ? 3 : i + 1];                \
+                const float sigmaU = wl * ul + wp[i] * ur + wu[i] * uu[k] + wp[i] * ud[k];                                        \
+                const float sigmaV = wl * vl + wp[i] * vr + wu[i] * vu[k] + wp[i] * vd[k];                                        \
+                float nu = du[i], nv = dv[i];                                                                                     \
+                nu += omega * (sor_div(sigmaU + b1[i] - nv * a12[i], a11[i], r11[i]) - nu);                                       \
+                nv += omega * (sor_div(sigmaV + b2[i] - nu * a12[i], a22[i], r22[i]) - nv);                                       \
+                const bool ok = (valid >> i) & 1u;                                                                                \
+                du[i] = ok ? nu : 0.f; dv[i] = ok ? nv : 0.f;                                                                     \
+            }                                                                                                                     \
+            lds2[((Q) * 2 + 0) * PL2 + ro2] = make_float2(du[START], du[(START) + 2]);                                            \
+            lds2[((Q) * 2 + 1) * PL2 + ro2] = make_float2(dv[START], dv[(START) + 2]);                                            \
+        }
+    if ((off ^ s0) == 0) {
+        for (int it = 0; it < iters; it++) { SOR4_HALF(0, off) __syncthreads(); SOR4_HALF(1, off ^ 1) __syncthreads(); }
+    } else {
+        for (int it = 0; it < iters; it++) { SOR4_HALF(1, off) __syncthreads(); SOR4_HALF(0, off ^ 1) __syncthreads(); }
+    }
+    #undef SOR4_HALF
+    if (row_ok) {
+        const int ix0 = tx * IW, iy0 = ty * IH;
+        if (gy >= iy0 && gy < iy0 + IH) {
+            #pragma unroll
+            for (int i = 0; i < 4; i++) {
                 const int gx = gx0 + i;
                 if (((valid >> i) & 1u) && gx >= ix0 && gx < ix0 + IW) { const size_t g = base + (size_t)gy * w + gx; gUout[g] = du[i]; gVout[g] = dv[i]; }
             }
@@ -457,8 +585,10 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 // `total` red-black SOR iterations on the level's system.  Small levels: the whole image is one tile and all iterations run
 // in one launch; larger levels: 64 x 64 tiles, SOR_FUSE iterations per launch with a 2*SOR_FUSE halo, ping-pong between the
 // two increment buffers (a tile reads its halo from neighbours that another workgroup of the same launch rewrites).
-int g_sor_mode = 1;          // 1 = fused kernel (default), 0 = one launch per colour (kept for A/B timing and as a cross-check)
+int g_sor_mode = 1;          // 1 = fused, 1x8 strips, IEEE division (default, fastest); 2 = fused, 1x4 strips + reciprocal division on the tiled levels;
+                             // 0 = one launch per colour (kept for A/B timing and as a cross-check)
 int g_sor_fuse = 5;
+int g_sor_xcd = 1;           // XCD-aware tile order of the fused kernel (0 = plain blockIdx order, for A/B timing)
 int g_sor_tile_w = 64;       // 128 x 64 tiles (1024 threads) or 64 x 64 (512 threads)
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch) {
     if (g_sor_mode == 0) {
@@ -477,16 +607,31 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     if (threads_for(EWw, h) <= SOR_NT) {               // whole image in one workgroup: every iteration in one launch, in place
         const int EW = EWw, EH = h, nt = threads_for(EW, EH);
         const size_t shm = sor_lds_bytes(EW, nt);
-        hipLaunchKernelGGL(k_sor_fused, dim3(1, B), dim3(nt), shm, s, w, h, EW, EH, EW, EH, 0, 1, total, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt,
+        hipLaunchKernelGGL(k_sor_fused, dim3(1, B), dim3(nt), shm, s, w, h, EW, EH, EW, EH, 0, 0, 1, total, 0, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt,
                            P.dWu, P.dWv, P.dWu, P.dWv);
         *nlaunch += 1; return SIND_OK;
+    }
+    if (g_sor_mode == 2) {                             // 1x4 strips + reciprocal division (k_sor_fused4), 64 x 64 tiles, 1024 threads
+        static bool attr4 = false;
+        if (!attr4) { HIP_TRY(hipFuncSetAttribute((const void*)k_sor_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr4 = true; }
+        const int EW = 64, EH = 64, nt = 1024;
+        const size_t shm = (size_t)4 * (EH + 2) * (EW / 4 + 2) * sizeof(float2);
+        for (int done = 0; done < total;) {
+            const int k = std::min(g_sor_fuse, total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
+            const int ntx = divup(w, IW), nty = divup(h, IH);
+            hipLaunchKernelGGL(k_sor_fused4, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
+                               P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
+            std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);
+            done += k; *nlaunch += 1;
+        }
+        return SIND_OK;
     }
     const int EW = g_sor_tile_w, EH = 64, nt = threads_for(EW, EH);
     const size_t shm = sor_lds_bytes(EW, nt);
     for (int done = 0; done < total;) {
-        const int k = std::min(g_sor_fuse, total - done), halo = 2 * k, IW = EW - 2 * halo, IH = EH - 2 * halo;
+        const int k = std::min(g_sor_fuse, total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
         const int ntx = divup(w, IW), nty = divup(h, IH);
-        hipLaunchKernelGGL(k_sor_fused, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo, ntx, k, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
+        hipLaunchKernelGGL(k_sor_fused, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
                            P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
         std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);
         done += k; *nlaunch += 1;

@@ -9,7 +9,8 @@ from ._lib import check, lib, ptr
 
 
 def set_sor_variant(mode: int = 1, fuse: int = 5, tile_w: int = 64):
-    """process-wide solver variant: mode 1 = fused register-resident SOR, 0 = one launch per colour (cross-check)"""
+    """process-wide solver variant: mode 1 = fused register-resident SOR, 1x8 strips, IEEE division (default), 2 = fused with 1x4
+    strips and reciprocal (Markstein) division, 0 = one launch per colour (cross-check)"""
     check(lib().sind_flow_set_sor(mode, fuse, tile_w), "sind_flow_set_sor")
 
 

@@ -71,14 +71,15 @@ def test_deepflow_full_size(fs, frames):
 
 
 def test_sor_variants_agree_bitwise(fs, frames):
-    """fused register-resident SOR (several fuse depths / tile widths) == one-launch-per-colour SOR, bit for bit"""
+    """both fused register-resident SOR kernels (IEEE division / reciprocal division; several fuse depths and tile widths)
+    == one-launch-per-colour SOR, bit for bit"""
     from sindslam_amd.flow import set_sor_variant
     g0, g1 = _small_pair(frames, 384, 288)
     i0 = np.stack([g0, g1]); i1 = np.stack([g1, g0])
     try:
         set_sor_variant(0, 5, 64); ru, rv = fs.deepflow(i0, i1)
-        for fuse, tw in [(5, 64), (3, 64), (7, 64), (5, 128), (1, 64)]:
-            set_sor_variant(1, fuse, tw); u, v = fs.deepflow(i0, i1)
-            assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32)), (fuse, tw)
+        for mode, fuse, tw in [(2, 5, 64), (2, 3, 64), (2, 7, 64), (2, 1, 64), (1, 5, 64), (1, 3, 64), (1, 7, 64), (1, 5, 128), (1, 1, 64)]:
+            set_sor_variant(mode, fuse, tw); u, v = fs.deepflow(i0, i1)
+            assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32)), (mode, fuse, tw)
     finally:
         set_sor_variant(1, 5, 64)

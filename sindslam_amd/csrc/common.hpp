@@ -43,7 +43,7 @@ extern std::atomic<long long> g_sind_wait_ns, g_sind_wait_calls;      // statist
 static inline hipError_t sind_stream_wait(hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipErrorNotReady;
-    for (int i = 0; i < 32 && e == hipErrorNotReady; i++) e = hipStreamQuery(s);
+    for (int i = 0; i < 8 && e == hipErrorNotReady; i++) e = hipStreamQuery(s);
     while (e == hipErrorNotReady) { std::this_thread::sleep_for(std::chrono::microseconds(20)); e = hipStreamQuery(s); }
     g_sind_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
     g_sind_wait_calls.fetch_add(1, std::memory_order_relaxed);

@@ -52,7 +52,7 @@ public:
     int compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out);
     void reset();
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; long n_frames = 0;
-    double t_fine[12] = {0};       // cal_occluded: gpu+d2h, pack, endpoints, peac, contour filter, close | seg_merge: pieces, planes+h2d, rag gpu, merge    // flow masks, k-means, label prep, CalOccluded, SegAndMerge, fusion (ms, SIND_TAIL_TIMING=1)
+    double t_fine[40] = {0};       // cal_occluded: gpu+d2h, pack, endpoints, peac, contour filter, close | seg_merge: pieces, planes+h2d, rag gpu, merge    // flow masks, k-means, label prep, CalOccluded, SegAndMerge, fusion (ms, SIND_TAIL_TIMING=1)
 private:
     int W = 0, H = 0, N = 0;
     std::vector<uint8_t> dynaLast, labelLast, highLast;       // host state images (DynaDetect.h:172-178)

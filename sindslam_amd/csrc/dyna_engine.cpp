@@ -122,6 +122,8 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     const int gx = (W - 1) / 10, gy = (H - 1) / 10;
     float* gridFlow = h_grid.p;
     HIP_TRY(hipMemcpyAsync(gridFlow, grid_d.p, (size_t)2 * gx * gy * sizeof(float), hipMemcpyDeviceToHost, stream));
+    double tq = tick_ms();
+    #define QLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; }
     // previous-frame dynamic ratio per cluster (DD:1169-1177)
     std::vector<float> clusterWeight(numCluster, 0.0f);
     { int nC[256] = {0}, nD[256] = {0};
@@ -137,8 +139,10 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
         else if ((unsigned)(dl - 20) <= 230 - 20) { const int label = labelLast[(size_t)row * W + col]; pts.push_back({col, row, randomd + 1.2f * (1.0f - clusterWeight[label])}); }
         else pts.push_back({col, row, randomd + 0.4f});
     }
+    QLAP(20)
     std::sort(pts.begin(), pts.end(), [](const PW& a, const PW& b) { return a.weight > b.weight; });
     HIP_TRY(sind_stream_wait(stream));
+    QLAP(21)
     std::vector<Pt2f> in, inLast;
     for (const PW& p : pts) {
         const int gi = (p.y / 10 - 1) * gx + (p.x / 10 - 1);
@@ -147,7 +151,9 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
         if ((unsigned)r <= (unsigned)H && (unsigned)c <= (unsigned)W) { in.push_back({ptCol, ptRow}); inLast.push_back({ptCol - fxv, ptRow - fyv}); }
     }
     double Hm[9];
+    tq = tick_ms();
     find_homography_prosac(in, inLast, Hm);
+    QLAP(22)
     SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, maxbits.p, hist_d.p, magu8.p, W, H));
     HIP_TRY(hipMemcpyAsync(h_hist.p + 256, maxbits.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h_hist.p, hist_d.p, 256 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -206,7 +212,10 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     HIP_TRY(hipMemcpyAsync(h_a8.p, low_d.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h_b8.p, high_d.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
+    tq = tick_ms();
     low = BitImg::from_u8(h_a8.p, W, H, W); high = BitImg::from_u8(h_b8.p, W, H, W);
+    QLAP(23)
+    #undef QLAP
     if (keep_debug) { dbg.maskLow.assign(h_a8.p, h_a8.p + N); dbg.maskHigh.assign(h_b8.p, h_b8.p + N); }
     return SIND_OK;
 }
@@ -303,15 +312,21 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     const float depth_weight = 1.5f;
     for (int i = 0; i + 1 < (int)allLabels.size(); i++) {
         const BitImg& orig = allLabels[i];
+        double tq = tick_ms();
+        #define QLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; }
         BitImg each = orig; each.andnot(occ1); each = each.opened(e4);
+        QLAP(12)
         std::vector<Contour> contours; find_contours(each, contours, true);
+        QLAP(13)
         for (const Contour& c : contours) {
             if (!(c.size() > 50 && contour_area(c) > 80)) continue;
+            tq = tick_ms();
             const Rect bb = contour_bbox(c);
             Piece p; BitImg temp(W, H); draw_filled(temp, c);
             temp = temp.dilated(e9, bb.y0, bb.y1); temp &= orig;
             p.img = temp; p.area = (float)temp.count();
             p.dil = temp.dilated(e7, bb.y0 - 5, bb.y1 + 5);
+            QLAP(14)
             BitImg t1(W, H); draw_thick2(t1, c); t1.andnot(occDil); t1 &= labelForSegEdge;
             if (t1.count() > 20) {
                 std::vector<Contour> c2; const Rect r2{std::max(bb.x0 - 2, 0), std::max(bb.y0 - 2, 0), std::min(bb.x1 + 2, W - 1), std::min(bb.y1 + 2, H - 1)};
@@ -319,6 +334,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
                 std::vector<const Contour*> kept; for (const Contour& q : c2) if (q.size() >= 30) kept.push_back(&q);
                 if (!kept.empty()) { p.lianjie.create(W, H); draw_filled(p.lianjie, kept); p.hasLianjie = true; }
             }
+            QLAP(15)
             // myCluster::calCenterPoint (DD:256-293): float sums in row-major order; only z is used afterwards
             { float f3 = 0.f; const Rect ib = p.img.bbox();
               for (int y = ib.y0; y <= ib.y1; y++) { const uint64_t* r = p.img.row(y);
@@ -327,6 +343,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
                     float pzv = 0.f; if (!((float)d / cfg.depthScale >= (float)(uint16_t)6 || d == 0)) { const float depth2 = (float)d * (1.0f / cfg.depthScale); pzv = (float)(depth2 * depth_weight); }
                     f3 += pzv; } } }
               p.cz = f3 / p.area; }
+            QLAP(16)
             all.push_back(std::move(p));
         }
     }
@@ -487,15 +504,19 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     std::vector<uint8_t> label3(N, 0);
     if (!allLabels.empty()) SIND_TRY(seg_and_merge(allLabels, occ1, occ2, labelForSegEdge, depth_host, depth_dev, label3));
     LAP(4)
+    double tq = tick_ms();
+    #define QLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; }
     int maxNum = 0; for (uint8_t v : label3) maxNum = std::max<int>(maxNum, v);
     if (keep_debug) { dbg.occ1.resize(N); occ1.to_u8(dbg.occ1.data(), W, 255); dbg.occ2.resize(N); occ2.to_u8(dbg.occ2.data(), W, 255); dbg.totalArea.resize(N); totalArea.to_u8(dbg.totalArea.data(), W, 255); }
     // fusion (DD:1553-1636)
     BitImg low = BitImg::from_u8(highLast.data(), W, H, W); low |= maskLow; low &= totalArea;
     low = low.dilated(EllipseElem(5));
     const BitImg notLow = low.inverted();
+    QLAP(25)
     BitImg dyna(W, H);
     std::vector<BitImg> clusters(maxNum + 1); for (auto& m : clusters) m.create(W, H);
     for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const int l = label3[(size_t)y * W + x]; if (l) clusters[l].set(x, y); }
+    QLAP(26)
     for (int n = 1; n <= maxNum; n++) {
         const BitImg& one = clusters[n]; const int oneCnt = one.count();
         BitImg blocked = one.inverted(), filled(W, H);
@@ -511,6 +532,7 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
         }
         if (filled.count() > 0.5 * oneCnt) dyna |= one; else dyna |= filled;
     }
+    QLAP(27)
     dyna = dyna.dilated(EllipseElem(9));
     std::vector<uint8_t> out(N, 0);
     totalArea.paint_u8(out.data(), W, 125); dyna.paint_u8(out.data(), W, 255);
@@ -518,6 +540,8 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     // roll the state (DD:1660-1664)
     dynaLast = out; labelLast = label3; maskHigh.to_u8(highLast.data(), W, 255);
     labelLastAny = false; for (uint8_t v : label3) if (v) { labelLastAny = true; break; }
+    QLAP(28)
+    #undef QLAP
     LAP(5)
     #undef LAP
     return SIND_OK;

@@ -48,9 +48,9 @@ private:
 
 struct sind_pipe {
     sind_pipe_config c{}; DynaConfig dc; int S = 0, T = 0, fw = 0, fh = 0;
-    hipStream_t stream = nullptr; std::vector<hipStream_t> tail_streams;
+    hipStream_t stream = nullptr; std::vector<hipStream_t> worker_streams;      // one HIP stream per pool worker, shared by the tasks it runs
     DynaFront front; OrbEngine orb; std::vector<std::unique_ptr<DynaTail>> tails;
-    std::vector<hipStream_t> occ_streams; std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
+    std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
     struct StepBuf {
@@ -95,17 +95,15 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     SIND_TRY(p->front.init(p->dc, B, p->stream));
     p->fw = p->front.fw; p->fh = p->front.fh;
     SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->stream));
-    p->tail_streams.resize(p->S); p->tails.resize(p->S);
-    for (int s = 0; s < p->S; s++) {
-        SIND_TRY(make_stream(&p->tail_streams[s], true));       // high priority: the tails' small kernels overtake the next step's flow
-        p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->tail_streams[s]));
-    }
     const int nworkers = cfg->host_threads > 0 ? cfg->host_threads : 24;         // default: 1.5x the box's CPU share per GPU (workers sleep while they wait for the GPU)
-    p->occ_streams.resize(nworkers); p->occ_tails.resize(nworkers);
+    // A task leaves its stream idle (every GPU section ends in a wait), so the HIP streams belong to the workers, not to the camera
+    // streams: their number does not grow with S.
+    p->worker_streams.resize(nworkers); p->occ_tails.resize(nworkers); p->tails.resize(p->S);
     for (int w = 0; w < nworkers; w++) {
-        SIND_TRY(make_stream(&p->occ_streams[w], true));
-        p->occ_tails[w].reset(new DynaTail()); SIND_TRY(p->occ_tails[w]->init(p->dc, p->occ_streams[w]));
+        SIND_TRY(make_stream(&p->worker_streams[w], true));
+        p->occ_tails[w].reset(new DynaTail()); SIND_TRY(p->occ_tails[w]->init(p->dc, p->worker_streams[w]));
     }
+    for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers])); }
     p->workers.start(nworkers, cfg->device);
     SIND_TRY(p->gray.alloc(np * B)); SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
     if (cfg->orb_gray_rgb_order) SIND_TRY(p->gray_orb.alloc(np * B));
@@ -118,15 +116,17 @@ int sind_pipe_destroy(sind_pipe* p) {
     if (getenv("SIND_TAIL_TIMING")) {
         double t[6] = {0}; long n = 0;
         for (auto& tl : p->tails) { for (int i = 0; i < 6; i++) t[i] += tl->t_stage[i]; n += tl->n_frames; }
-        double f[12] = {0}; for (auto& tl : p->tails) for (int i = 0; i < 12; i++) f[i] += tl->t_fine[i];
-        for (auto& tl : p->occ_tails) for (int i = 0; i < 12; i++) f[i] += tl->t_fine[i];
+        double f[40] = {0}; for (auto& tl : p->tails) for (int i = 0; i < 40; i++) f[i] += tl->t_fine[i];
+        for (auto& tl : p->occ_tails) for (int i = 0; i < 40; i++) f[i] += tl->t_fine[i];
         if (n) fprintf(stderr, "[sind] cal_occluded: gpu+d2h %.2f pack %.2f endpoints %.2f peac %.2f contour-filter %.2f close %.2f | seg_merge: pieces %.2f sort+paint+pack %.2f alloc %.2f h2d-enqueue %.2f rag %.2f merge %.2f\n", f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5] / n, f[6] / n, f[10] / n, f[11] / n, f[7] / n, f[8] / n, f[9] / n);
+        if (n) fprintf(stderr, "[sind] pieces: open %.2f contours %.2f masks %.2f lianjie %.2f centre %.2f | flow_masks host: weights %.2f sort+wait %.2f homography %.2f pack %.2f | fusion: low %.2f clusters %.2f fill %.2f out+state %.2f\n",
+                       f[12] / n, f[13] / n, f[14] / n, f[15] / n, f[16] / n, f[20] / n, f[21] / n, f[22] / n, f[23] / n, f[25] / n, f[26] / n, f[27] / n, f[28] / n);
         if (n) fprintf(stderr, "[sind] stream waits: %.2f ms and %.1f calls per frame (occ + tail + batch stream)\n", g_sind_wait_ns.load() / 1e6 / n, (double)g_sind_wait_calls.load() / n);
         if (n) fprintf(stderr, "[sind] tail ms/frame over %ld frames: flow_masks %.2f kmeans %.2f labels %.2f cal_occluded %.2f seg_merge %.2f fusion %.2f\n", n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n);
     }
     (void)hipSetDevice(p->c.device);
     (void)hipDeviceSynchronize();
-    std::vector<hipStream_t> ss = p->tail_streams; ss.push_back(p->stream); ss.insert(ss.end(), p->occ_streams.begin(), p->occ_streams.end());
+    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream);
     delete p;
     for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
     return SIND_OK;
@@ -194,26 +194,34 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
 
 // ---- phase B of one step (stateful tails, one host thread per stream or a bounded pool, each on its own HIP stream)
 struct PipeOut { uint8_t *dyna, *label, *mask; sind_keypoint* kps; int cap; int* nkp; uint8_t* desc; };
+// One task = one frame of one stream; it queues the stream's next frame when it is done.  Frames of a stream stay in order, and the
+// pool always sees up to S runnable tasks, so the workers stay busy until the end of the phase (a task per stream left the second
+// "round" of 32 streams on 24 workers half empty).
+static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker) {
+    p->tails[s]->stream = p->worker_streams[worker];
+    const int T = p->T, W = p->c.width, H = p->c.height; const size_t np = (size_t)W * H;
+    static thread_local std::vector<uint8_t> dy, lb, dil;
+    dy.resize(np); lb.resize(np); dil.resize(np);
+    const int k = s * T + t;
+    int r = p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k]);
+    if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return; }
+    dilate15_codes(dy.data(), W, H, dil.data());
+    if (o.dyna) std::memcpy(o.dyna + np * k, dy.data(), np);
+    if (o.label) std::memcpy(o.label + np * k, lb.data(), np);
+    if (o.mask) std::memcpy(o.mask + np * k, dil.data(), np);
+    std::vector<OrbKeyPoint> kk; std::vector<uint8_t> dd;
+    p->orb.finish(sb->orb[k], dil.data(), W, kk, dd);
+    if ((int)kk.size() > o.cap && o.kps) { sb->tail_rc[s] = SIND_E_CAPACITY; sb->tail_err[s] = "keypoint capacity exceeded"; return; }
+    if (o.nkp) o.nkp[k] = (int)kk.size();
+    if (o.kps) std::memcpy(o.kps + (size_t)k * o.cap, kk.data(), kk.size() * sizeof(sind_keypoint));
+    if (o.desc) std::memcpy(o.desc + (size_t)k * o.cap * 32, dd.data(), dd.size());
+    if (t + 1 < T) p->workers.push(sb->tail_group, [p, sb, o, s, t](int w) { tail_task(p, sb, o, s, t + 1, w); });
+}
 static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
-    const int S = p->S, T = p->T, W = p->c.width, H = p->c.height; const size_t np = (size_t)W * H;
+    const int S = p->S;
     sb.tail_rc.assign(S, SIND_OK); sb.tail_err.assign(S, std::string());
-    for (int s = 0; s < S; s++) p->workers.push(sb.tail_group, [p, &sb, o, s, T, W, H, np](int) {
-        std::vector<uint8_t> dy(np), lb(np), dil(np);
-        for (int t = 0; t < T; t++) {
-            const int k = s * T + t;
-            int r = p->tails[s]->process(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.U.p + np * k, sb.V.p + np * k, dy.data(), lb.data(), &sb.occ[k]);
-            if (r != SIND_OK) { sb.tail_rc[s] = r; sb.tail_err[s] = sind_last_error(); break; }
-            dilate15_codes(dy.data(), W, H, dil.data());
-            if (o.dyna) std::memcpy(o.dyna + np * k, dy.data(), np);
-            if (o.label) std::memcpy(o.label + np * k, lb.data(), np);
-            if (o.mask) std::memcpy(o.mask + np * k, dil.data(), np);
-            std::vector<OrbKeyPoint> kk; std::vector<uint8_t> dd;
-            p->orb.finish(sb.orb[k], dil.data(), W, kk, dd);
-            if ((int)kk.size() > o.cap && o.kps) { sb.tail_rc[s] = SIND_E_CAPACITY; sb.tail_err[s] = "keypoint capacity exceeded"; break; }
-            if (o.nkp) o.nkp[k] = (int)kk.size();
-            if (o.kps) std::memcpy(o.kps + (size_t)k * o.cap, kk.data(), kk.size() * sizeof(sind_keypoint));
-            if (o.desc) std::memcpy(o.desc + (size_t)k * o.cap * 32, dd.data(), dd.size());
-        } });
+    sind_pipe::StepBuf* sbp = &sb;
+    for (int s = 0; s < S; s++) p->workers.push(sb.tail_group, [p, sbp, o, s](int w) { tail_task(p, sbp, o, s, 0, w); });
 }
 static int phase_b_finish(sind_pipe* p, sind_pipe::StepBuf& sb) {
     WorkerPool::wait(sb.tail_group);

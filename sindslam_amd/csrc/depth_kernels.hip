@@ -88,17 +88,22 @@ __device__ void km_try_finalize(KmState* st) {
 // Centre step of one k-means iteration in ONE workgroup: reduce the per-block partial sums, repair every empty cluster
 // (block-wide farthest-point search over the biggest cluster, as cv::kmeans does, repeated until no cluster is empty), scale,
 // shift test, stop decision.  No host round trip and no provisioning limit.
-__global__ void __launch_bounds__(1024) k_km_update(const double* __restrict__ partial, int nblocks, KmState* __restrict__ st,
+__global__ void __launch_bounds__(1024) k_km_update(const double* __restrict__ partial, int nblocks, KmState* __restrict__ gst,
                                                     const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                     int* __restrict__ labels, int n) {
     __shared__ double sums[KM_K * 4];
     __shared__ double stage[KM_MAX_BLOCKS * KM_K * 4];
     __shared__ unsigned long long wbest[16];
     __shared__ int s_fix;
-    if (st->done) return;
+    __shared__ KmState S;                                  // the state lives in LDS while the centre step runs: the serial part below touches it
+                                                           // ~100 times, and every touch of the global copy would be a dependent ~1 us round trip
+    static_assert(sizeof(KmState) % 4 == 0, "KmState is copied word by word");
+    if (gst->done) return;
     const int t = threadIdx.x;
+    for (int i = t; i < (int)(sizeof(KmState) / 4); i += blockDim.x) reinterpret_cast<unsigned*>(&S)[i] = reinterpret_cast<const unsigned*>(gst)[i];
     for (int i = t; i < nblocks * KM_K * 4; i += blockDim.x) stage[i] = partial[i];     // parallel fetch, then a fixed-order (deterministic) sum
     __syncthreads();
+    KmState* st = &S;
     if (t < KM_K * 4) { double v = 0; for (int b = 0; b < nblocks; b++) v += stage[b * KM_K * 4 + t]; sums[t] = v; }
     __syncthreads();
     if (t == 0) {
@@ -133,6 +138,7 @@ __global__ void __launch_bounds__(1024) k_km_update(const double* __restrict__ p
         __threadfence_block();
         __syncthreads();
     }
+    for (int i = t; i < (int)(sizeof(KmState) / 4); i += blockDim.x) reinterpret_cast<unsigned*>(gst)[i] = reinterpret_cast<const unsigned*>(&S)[i];
 }
 __global__ void __launch_bounds__(256) k_km_partial_dev(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                         const int* __restrict__ labels, int n, double* __restrict__ partial, const KmState* __restrict__ st) {
@@ -154,21 +160,40 @@ __global__ void __launch_bounds__(256) k_km_partial_dev(const float* __restrict_
     __syncthreads();
     if (tid < KM_K * 4) { const int k = tid >> 2, c = tid & 3; partial[((size_t)blockIdx.x * KM_K + k) * 4 + c] = ((acc[k][c][0] + acc[k][c][1]) + acc[k][c][2]) + acc[k][c][3]; }
 }
-__global__ void k_km_assign_dev(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int* __restrict__ labels,
-                                int n, const KmState* __restrict__ st) {
+// re-assignment to the nearest centre fused with the centre sums of the next iteration (cv::kmeans' assignment step followed by the sums of
+// k_km_partial_dev: one pass over the points and one launch instead of two)
+__global__ void __launch_bounds__(256) k_km_assign_partial(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                           int* __restrict__ labels, int n, double* __restrict__ partial, const KmState* __restrict__ st) {
     if (st->done || st->phase != 1) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = px[i], y = py[i], z = pz[i];
-    int best = 0; float md = 3.402823466e+38f;
+    __shared__ double acc[KM_K][4][4];
+    __shared__ float ctr[KM_K][3];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < KM_K * 3) ctr[tid / 3][tid % 3] = st->ctr[tid / 3][tid % 3];
+    __syncthreads();
+    double s[KM_K][4];
     #pragma unroll
-    for (int k = 0; k < KM_K; k++) {
-        float t = x - st->ctr[k][0]; float dist = 0.f; dist += t * t;
-        t = y - st->ctr[k][1]; dist += t * t;
-        t = z - st->ctr[k][2]; dist += t * t;
-        if (md > dist) { md = dist; best = k; }
+    for (int k = 0; k < KM_K; k++) { s[k][0] = s[k][1] = s[k][2] = s[k][3] = 0.0; }
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        const float xf = px[i], yf = py[i], zf = pz[i];
+        int best = 0; float md = 3.402823466e+38f;
+        #pragma unroll
+        for (int k = 0; k < KM_K; k++) {
+            float t = xf - ctr[k][0]; float dist = 0.f; dist += t * t;
+            t = yf - ctr[k][1]; dist += t * t;
+            t = zf - ctr[k][2]; dist += t * t;
+            if (md > dist) { md = dist; best = k; }
+        }
+        labels[i] = best;
+        const double x = xf, y = yf, z = zf;
+        #pragma unroll
+        for (int k = 0; k < KM_K; k++) if (best == k) { s[k][0] += x; s[k][1] += y; s[k][2] += z; s[k][3] += 1.0; }
     }
-    labels[i] = best;
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++)
+        #pragma unroll
+        for (int c = 0; c < 4; c++) { double v = s[k][c]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); if (lane == 0) acc[k][c][wv] = v; }
+    __syncthreads();
+    if (tid < KM_K * 4) { const int k = tid >> 2, c = tid & 3; partial[((size_t)blockIdx.x * KM_K + k) * 4 + c] = ((acc[k][c][0] + acc[k][c][1]) + acc[k][c][2]) + acc[k][c][3]; }
 }
 __global__ void k_km_reset(KmState* st, int maxCount, double eps2) {
     if (threadIdx.x == 0) { st->iter = 0; st->done = 0; st->phase = 0; st->overflow = 0; st->fix_k = -1; st->max_k = 0; st->far = 0ull; st->maxCount = maxCount; st->eps2 = eps2;
@@ -357,10 +382,11 @@ int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const f
                         int maxCount, double eps2) {
     const int nb = std::min(divup(n, 256), KM_MAX_BLOCKS), iters = std::max(maxCount, 2);
     hipLaunchKernelGGL(k_km_reset, dim3(1), dim3(64), 0, s, st, maxCount, eps2);
-    for (int it = 0; it < iters; it++) {
-        hipLaunchKernelGGL(k_km_partial_dev, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, partial, st);
+    hipLaunchKernelGGL(k_km_partial_dev, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, partial, st);
+    hipLaunchKernelGGL(k_km_update, dim3(1), dim3(1024), 0, s, partial, nb, st, px, py, pz, labels, n);
+    for (int it = 1; it < iters; it++) {           // every later kernel is a no-op once the centre step has set st->done
+        hipLaunchKernelGGL(k_km_assign_partial, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, partial, st);
         hipLaunchKernelGGL(k_km_update, dim3(1), dim3(1024), 0, s, partial, nb, st, px, py, pz, labels, n);
-        if (it + 1 < iters) hipLaunchKernelGGL(k_km_assign_dev, dim3(divup(n, 256)), dim3(256), 0, s, px, py, pz, labels, n, st);
     }
     return SIND_OK;
 }
@@ -391,9 +417,13 @@ int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax
 int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int w, int h, int wpr, const uint8_t* occ2, const uint8_t* depthN,
                      int* overlap, int* overlapPlane, int* ljOverlap, int* ljArea, int* hist) {
     if (C < 1 || C > 254) { sind_set_error("rag_stats: %d pieces unsupported (1..254)", C); return SIND_E_ARG; }
-    HIP_TRY(hipMemsetAsync(overlap, 0, (size_t)C * C * sizeof(int), s)); HIP_TRY(hipMemsetAsync(overlapPlane, 0, (size_t)C * C * sizeof(int), s));
-    HIP_TRY(hipMemsetAsync(ljOverlap, 0, (size_t)C * C * sizeof(int), s)); HIP_TRY(hipMemsetAsync(ljArea, 0, (size_t)C * sizeof(int), s));
-    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)C * 256 * sizeof(int), s));
+    if (overlapPlane == overlap + C * C && ljOverlap == overlapPlane + C * C && ljArea == ljOverlap + C * C && hist == ljArea + C)
+        HIP_TRY(hipMemsetAsync(overlap, 0, ((size_t)3 * C * C + C + (size_t)C * 256) * sizeof(int), s));        // the caller's five outputs are one block: one fill
+    else {
+        HIP_TRY(hipMemsetAsync(overlap, 0, (size_t)C * C * sizeof(int), s)); HIP_TRY(hipMemsetAsync(overlapPlane, 0, (size_t)C * C * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(ljOverlap, 0, (size_t)C * C * sizeof(int), s)); HIP_TRY(hipMemsetAsync(ljArea, 0, (size_t)C * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(hist, 0, (size_t)C * 256 * sizeof(int), s));
+    }
     if (C <= 64) {
         const size_t shm = ((size_t)C * 256 + 3 * (size_t)C * C + C) * sizeof(int);      // <= 64 KB + 48 KB + 256 B of the 160 KB LDS
         static bool attr_set = false;

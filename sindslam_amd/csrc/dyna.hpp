@@ -43,6 +43,7 @@ class DynaTail {
 public:
     DynaConfig cfg; hipStream_t stream = nullptr; DynaDebug dbg; bool keep_debug = false;
     int init(const DynaConfig& c, hipStream_t s);
+    ~DynaTail() { for (auto& g : kmGraph) if (g) (void)hipGraphExecDestroy(g); }
     // depth_host: H x W u16 (host); depth_dev: same on the device; U/V: device full-resolution flow of this frame.
     // dyna_out / label_out: host H x W u8 (0 invalid / 125 static / 255 dynamic ; 0 invalid, 1..n clusters).
     int process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out,
@@ -54,19 +55,20 @@ public:
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; long n_frames = 0;
     double t_fine[40] = {0};       // cal_occluded: gpu+d2h, pack, endpoints, peac, contour filter, close | seg_merge: pieces, planes+h2d, rag gpu, merge    // flow masks, k-means, label prep, CalOccluded, SegAndMerge, fusion (ms, SIND_TAIL_TIMING=1)
 private:
-    int W = 0, H = 0, N = 0;
-    std::vector<uint8_t> dynaLast, labelLast, highLast;       // host state images (DynaDetect.h:172-178)
-    bool labelLastAny = false;
+    int W = 0, H = 0, N = 0, zInvalidFrom = 65536; float invDepthScale = 0.f;
+    std::vector<uint8_t> dynaLast, labelLast; BitImg highLast;       // host state images (DynaDetect.h:172-178)
+    bool labelLastAny = false; int lastCnt[256] = {0}, lastDyn[256] = {0};
     // device workspaces
-    DevBuf<uint16_t> dpyr[4], filt; DevBuf<float> px, py, pz; DevBuf<int> lab[4]; DevBuf<uint8_t> lab8, labPrev8, edge, edgeTmp, total, depthN, occ2_d, magu8, low_d, high_d;
-    DevBuf<double> kpart; DevBuf<unsigned long long> planes_d; DevBuf<unsigned> umax_d, maxbits; DevBuf<int> hist_d, rag_d; DevBuf<float> mag, grid_d;
+    DevBuf<uint16_t> dpyr[4], filt; DevBuf<float> px, py, pz; DevBuf<int> lab[4]; DevBuf<uint8_t> lab8, labPrev8, edge, edgeTmp, total, depthN, occ2_d, magu8, low_d;
+    DevBuf<double> kpart; DevBuf<unsigned long long> planes_d; DevBuf<unsigned> umax_d; DevBuf<int> hist_d, rag_d; DevBuf<float> mag, grid_d;
     DevBuf<PeacBlockStats> blocks_d;
     // page-locked staging of everything that crosses PCIe in a tail
-    PinnedBuf<float> h_grid; PinnedBuf<int> h_hist, h_rag; PinnedBuf<uint8_t> h_a8, h_b8, h_lab8; PinnedBuf<KmState> h_kstate; PinnedBuf<PeacBlockStats> h_blocks;
+    PinnedBuf<float> h_grid; PinnedBuf<int> h_hist, h_rag; PinnedBuf<uint8_t> h_ab, h_lab8; PinnedBuf<KmState> h_kstate; PinnedBuf<PeacBlockStats> h_blocks;
     PinnedBuf<unsigned long long> h_planes;
     int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high);
     int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
-    DevBuf<KmState> kstate;
+    DevBuf<KmState> kstate; DevBuf<uint16_t> depth_fix; hipGraphExec_t kmGraph[2] = {nullptr, nullptr};
+    int kmeans_enqueue(const uint16_t* depth0, bool prevLabels);
     int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2);
     int seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,
                       const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew);

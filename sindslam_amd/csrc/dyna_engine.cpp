@@ -96,24 +96,33 @@ int DynaFront::dense_flow(const uint8_t* pool, const int* cur, const int* prev1,
 // ======================================================================================================= tail
 int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     cfg = c; stream = s; W = c.W; H = c.H; N = W * H;
+    invDepthScale = 1.0f / cfg.depthScale; zInvalidFrom = 65536;
+    for (int d = 65535; d >= 0; d--) { if ((float)(uint16_t)d / cfg.depthScale >= (float)(uint16_t)6) zInvalidFrom = d; else break; }
     if (W % 64 != 0 || W % 8 != 0 || H % 8 != 0) { sind_set_error("DynaTail: width must be a multiple of 64 and height of 8 (got %dx%d)", W, H); return SIND_E_ARG; }
     reset();
     for (int l = 1; l < 4; l++) SIND_TRY(dpyr[l].alloc((size_t)N >> (2 * l)));
     for (int l = 0; l < 4; l++) SIND_TRY(lab[l].alloc((size_t)N >> (2 * l)));
     SIND_TRY(filt.alloc(N)); SIND_TRY(px.alloc(N)); SIND_TRY(py.alloc(N)); SIND_TRY(pz.alloc(N)); SIND_TRY(lab8.alloc(N)); SIND_TRY(labPrev8.alloc(N));
     SIND_TRY(edge.alloc(N)); SIND_TRY(edgeTmp.alloc(N)); SIND_TRY(total.alloc(N)); SIND_TRY(depthN.alloc(N)); SIND_TRY(occ2_d.alloc(N));
-    SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc(N)); SIND_TRY(high_d.alloc(N)); SIND_TRY(mag.alloc(N));
-    SIND_TRY(kpart.alloc((size_t)KM_MAX_BLOCKS * KM_K * 4)); SIND_TRY(umax_d.alloc(2)); SIND_TRY(maxbits.alloc(1));
-    SIND_TRY(h_grid.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(h_hist.alloc(257)); SIND_TRY(h_a8.alloc(N)); SIND_TRY(h_b8.alloc(N)); SIND_TRY(h_lab8.alloc(N));
+    SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc((size_t)2 * N)); SIND_TRY(mag.alloc(N));       // low_d: low mask, then high mask (one D2H)
+    SIND_TRY(kpart.alloc((size_t)KM_MAX_BLOCKS * KM_K * 4)); SIND_TRY(umax_d.alloc(2));
+    SIND_TRY(h_grid.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(h_hist.alloc(257)); SIND_TRY(h_ab.alloc((size_t)2 * N)); SIND_TRY(h_lab8.alloc(N));
     SIND_TRY(h_kstate.alloc(4)); SIND_TRY(h_blocks.alloc((size_t)(W / 16) * (H / 16)));
     { // RAG workspaces for up to 64 pieces up front: a later (re)allocation synchronises the whole device, i.e. waits for the
       // flow solver of the next step when tails and dense flow overlap
       const size_t cap = 64, pw = (size_t)H * (W / 64), nr = 3 * cap * cap + cap + cap * 256;
       SIND_TRY(h_planes.alloc(3 * cap * pw)); SIND_TRY(planes_d.alloc(3 * cap * pw)); SIND_TRY(h_rag.alloc(nr)); SIND_TRY(rag_d.alloc(nr)); }
-    SIND_TRY(hist_d.alloc(256)); SIND_TRY(grid_d.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
+    SIND_TRY(kstate.alloc(4)); SIND_TRY(depth_fix.alloc(N));
+    SIND_TRY(hist_d.alloc(257));       // [256] = residual maximum (float bits)
+    SIND_TRY(grid_d.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
+    // every kernel operand of the tail must exist before the first launch (a missing workspace would be a wild device write)
+    const void* ws[] = {dpyr[1].p, dpyr[2].p, dpyr[3].p, lab[0].p, lab[1].p, lab[2].p, lab[3].p, filt.p, px.p, py.p, pz.p, lab8.p, labPrev8.p, edge.p, edgeTmp.p, total.p,
+                        depthN.p, occ2_d.p, magu8.p, low_d.p, mag.p, kpart.p, umax_d.p, h_grid.p, h_hist.p, h_ab.p, h_lab8.p, h_kstate.p, h_blocks.p, h_planes.p, planes_d.p,
+                        h_rag.p, rag_d.p, kstate.p, depth_fix.p, hist_d.p, grid_d.p, blocks_d.p};
+    for (const void* q : ws) if (!q) { sind_set_error("DynaTail::init: a workspace was not allocated"); return SIND_E_STATE; }
     return SIND_OK;
 }
-void DynaTail::reset() { dynaLast.assign(N, 0); labelLast.assign(N, 0); highLast.assign(N, 0); labelLastAny = false; }
+void DynaTail::reset() { dynaLast.assign(N, 0); labelLast.assign(N, 0); highLast.create(W, H); labelLastAny = false; std::memset(lastCnt, 0, sizeof(lastCnt)); std::memset(lastDyn, 0, sizeof(lastDyn)); }
 
 // ---- DD:1163-1367: sample weights -> PROSAC pairs -> homography -> residual -> Otsu / Triangle thresholds -> masks
 int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& high) {
@@ -126,9 +135,7 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     #define QLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; }
     // previous-frame dynamic ratio per cluster (DD:1169-1177)
     std::vector<float> clusterWeight(numCluster, 0.0f);
-    { int nC[256] = {0}, nD[256] = {0};
-      for (int k = 0; k < N; k++) { const int l = labelLast[k]; nC[l]++; nD[l] += dynaLast[k] == 255; }
-      for (int i = 1; i < numCluster; i++) clusterWeight[i] = (float)nD[i] / (float)(nC[i] + 1.0f); }
+    for (int i = 1; i < numCluster; i++) clusterWeight[i] = (float)lastDyn[i] / (float)(lastCnt[i] + 1.0f);       // counts of the previous frame's labels (see process())
     struct PW { int x, y; float weight; };
     std::vector<PW> pts; pts.reserve((size_t)gx * gy);
     CvRng rng(12345);
@@ -154,9 +161,8 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     tq = tick_ms();
     find_homography_prosac(in, inLast, Hm);
     QLAP(22)
-    SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, maxbits.p, hist_d.p, magu8.p, W, H));
-    HIP_TRY(hipMemcpyAsync(h_hist.p + 256, maxbits.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(h_hist.p, hist_d.p, 256 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, (unsigned*)(hist_d.p + 256), hist_d.p, magu8.p, W, H));
+    HIP_TRY(hipMemcpyAsync(h_hist.p, hist_d.p, 257 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
     unsigned mb; std::memcpy(&mb, h_hist.p + 256, 4); int hist[256]; std::memcpy(hist, h_hist.p, sizeof(hist));
     float maxErrorf; std::memcpy(&maxErrorf, &mb, 4);
@@ -208,40 +214,61 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
         lo = thred2; hi = thred1;
     }
     dbg.thr_low = lo; dbg.thr_high = hi;
-    SIND_TRY(launch_threshold_masks(stream, magu8.p, lo, hi, low_d.p, high_d.p, N));
-    HIP_TRY(hipMemcpyAsync(h_a8.p, low_d.p, N, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(h_b8.p, high_d.p, N, hipMemcpyDeviceToHost, stream));
+    SIND_TRY(launch_threshold_masks(stream, magu8.p, lo, hi, low_d.p, (low_d.p + N), N));
+    HIP_TRY(hipMemcpyAsync(h_ab.p, low_d.p, (size_t)2 * N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
     tq = tick_ms();
-    low = BitImg::from_u8(h_a8.p, W, H, W); high = BitImg::from_u8(h_b8.p, W, H, W);
+    low = BitImg::from_u8(h_ab.p, W, H, W); high = BitImg::from_u8((h_ab.p + N), W, H, W);
     QLAP(23)
     #undef QLAP
-    if (keep_debug) { dbg.maskLow.assign(h_a8.p, h_a8.p + N); dbg.maskHigh.assign(h_b8.p, h_b8.p + N); }
+    if (keep_debug) { dbg.maskLow.assign(h_ab.p, h_ab.p + N); dbg.maskHigh.assign((h_ab.p + N), (h_ab.p + N) + N); }
     return SIND_OK;
 }
 
 // ---- DD:315-420: 4-level k-means, K = 12, criteria (EPS+COUNT, 4, 0.07), KMEANS_USE_INITIAL_LABELS.
 // The whole loop is enqueued without a host round trip: the centre step, empty-cluster repair and the stop test of cv::kmeans
 // run in k_km_update (one workgroup) on the device; one D2H of the level-0 state + labels at the end.
-int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
+// The ~50 launches of a frame's k-means are recorded once per tail as a HIP graph (two variants: grid labels for the very first
+// frame, previous-frame labels afterwards) and replayed with one hipGraphLaunch: the packets reach the queue in one go instead of
+// one host submission per kernel.  The graph reads the depth frame from a fixed per-tail buffer.
+int DynaTail::kmeans_enqueue(const uint16_t* depth0, bool prevLabels) {
     const float scales[4] = {1.0f, 0.5f, 0.25f, 0.125f};
-    const uint16_t* dl[4] = {depth_dev, dpyr[1].p, dpyr[2].p, dpyr[3].p};
-    SIND_TRY(kstate.alloc(4));
+    const uint16_t* dl[4] = {depth0, dpyr[1].p, dpyr[2].p, dpyr[3].p};
     for (int l = 1; l < 4; l++) SIND_TRY(launch_depth_half(stream, dl[l - 1], dpyr[l].p, W >> l, H >> l));
-    if (labelLastAny) { std::memcpy(h_lab8.p, labelLast.data(), N); HIP_TRY(hipMemcpyAsync(labPrev8.p, h_lab8.p, N, hipMemcpyHostToDevice, stream)); }
     for (int level = 3; level >= 0; level--) {
         const int hp = (int)(H * scales[level]), wp = (int)(W * scales[level]), n = hp * wp;
         SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale));
-        if (level == 3) { if (!labelLastAny) SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp)); else SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp)); }
+        if (level == 3) { if (!prevLabels) SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp)); else SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp)); }
         else SIND_TRY(launch_labels_resize_i32(stream, lab[level + 1].p, lab[level].p, wp / 2, hp / 2, wp, hp));
         SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, kstate.p + level, 4, 0.07 * 0.07));
     }
     SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N));
+    return SIND_OK;
+}
+int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
+    static const bool use_graph = !(getenv("SIND_KM_GRAPH") && atoi(getenv("SIND_KM_GRAPH")) == 0);
+    if (labelLastAny) { std::memcpy(h_lab8.p, labelLast.data(), N); HIP_TRY(hipMemcpyAsync(labPrev8.p, h_lab8.p, N, hipMemcpyHostToDevice, stream)); }
+    if (!use_graph) SIND_TRY(kmeans_enqueue(depth_dev, labelLastAny));
+    else {
+        const int v = labelLastAny ? 1 : 0;
+        if (!kmGraph[v]) {
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            const int rc = kmeans_enqueue(depth_fix.p, v != 0);
+            const hipError_t ec = hipStreamEndCapture(stream, &g);
+            if (rc != SIND_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            HIP_TRY(ec);
+            HIP_TRY(hipGraphInstantiate(&kmGraph[v], g, nullptr, nullptr, 0));
+            HIP_TRY(hipGraphDestroy(g));
+        }
+        HIP_TRY(hipMemcpyAsync(depth_fix.p, depth_dev, (size_t)N * sizeof(uint16_t), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipGraphLaunch(kmGraph[v], stream));
+    }
     label8.resize(N);
     HIP_TRY(hipMemcpyAsync(h_kstate.p, kstate.p, 4 * sizeof(KmState), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(h_a8.p, lab8.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_ab.p, lab8.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
-    const KmState* st = h_kstate.p; std::memcpy(label8.data(), h_a8.p, N);
+    const KmState* st = h_kstate.p; std::memcpy(label8.data(), h_ab.p, N);
     std::memcpy(centers, st[0].ctr, sizeof(st[0].ctr)); std::memcpy(counts, st[0].cnt, sizeof(st[0].cnt));
     return SIND_OK;
 }
@@ -257,13 +284,13 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     SIND_TRY(launch_morph(stream, edgeTmp.p, edge.p, W, H, 4, true));
     SIND_TRY(launch_peac_block_stats(stream, depth_dev, W, H, 16, 16, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale, blocks_d.p));
     PinnedBuf<PeacBlockStats>& blocks = h_blocks;
-    HIP_TRY(hipMemcpyAsync(h_a8.p, edge.p, N, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(h_b8.p, total.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_ab.p, edge.p, N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync((h_ab.p + N), total.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(blocks.data(), blocks_d.p, blocks.n * sizeof(PeacBlockStats), hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
     FLAP(0)
-    const BitImg occ = BitImg::from_u8(h_a8.p, W, H, W);
-    totalArea = BitImg::from_u8(h_b8.p, W, H, W);
+    const BitImg occ = BitImg::from_u8(h_ab.p, W, H, W);
+    totalArea = BitImg::from_u8((h_ab.p + N), W, H, W);
     FLAP(1)
     // end points: edge pixels with at most 4 of the 12 radius-2 ring pixels set (DD:498-532), greedy NMS radius 6 in scan order
     static const int ring[12][2] = {{0,-2},{1,-2},{2,-1},{2,0},{2,1},{1,2},{0,2},{-1,2},{-2,1},{-2,0},{-2,-1},{-1,-2}};
@@ -296,7 +323,7 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     BitImg u = occ; u |= acc; occ1 = u.closed(e3);
     FLAP(5)
     #undef FLAP
-    if (keep_debug) { dbg.gradEdge.assign(h_a8.p, h_a8.p + N); dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
+    if (keep_debug) { dbg.gradEdge.assign(h_ab.p, h_ab.p + N); dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
     return SIND_OK;
 }
 
@@ -314,7 +341,8 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
         const BitImg& orig = allLabels[i];
         double tq = tick_ms();
         #define QLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; }
-        BitImg each = orig; each.andnot(occ1); each = each.opened(e4);
+        BitImg each = orig; each.andnot(occ1);
+        { const Rect eb = each.bbox(); if (eb.empty()) continue; each = each.opened_rows(e4, eb.y0, eb.y1); }
         QLAP(12)
         std::vector<Contour> contours; find_contours(each, contours, true);
         QLAP(13)
@@ -322,13 +350,13 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
             if (!(c.size() > 50 && contour_area(c) > 80)) continue;
             tq = tick_ms();
             const Rect bb = contour_bbox(c);
-            Piece p; BitImg temp(W, H); draw_filled(temp, c);
-            temp = temp.dilated(e9, bb.y0, bb.y1); temp &= orig;
-            p.img = temp; p.area = (float)temp.count();
-            p.dil = temp.dilated(e7, bb.y0 - 5, bb.y1 + 5);
+            Piece p; p.img.create(W, H); draw_filled(p.img, c);
+            p.img = p.img.dilated(e9, bb.y0, bb.y1); p.img.and_rows(orig, bb.y0 - 4, bb.y1 + 4);       // the 9x9 element reaches 4 rows up and down
+            p.area = (float)p.img.count_rows(bb.y0 - 4, bb.y1 + 4);
+            p.dil = p.img.dilated(e7, bb.y0 - 4, bb.y1 + 4);
             QLAP(14)
-            BitImg t1(W, H); draw_thick2(t1, c); t1.andnot(occDil); t1 &= labelForSegEdge;
-            if (t1.count() > 20) {
+            BitImg t1(W, H); draw_thick2(t1, c); t1.andnot_rows(occDil, bb.y0 - 1, bb.y1 + 1); t1.and_rows(labelForSegEdge, bb.y0 - 1, bb.y1 + 1);
+            if (t1.count_rows(bb.y0 - 1, bb.y1 + 1) > 20) {
                 std::vector<Contour> c2; const Rect r2{std::max(bb.x0 - 2, 0), std::max(bb.y0 - 2, 0), std::min(bb.x1 + 2, W - 1), std::min(bb.y1 + 2, H - 1)};
                 find_contours(t1, c2, true, &r2);
                 std::vector<const Contour*> kept; for (const Contour& q : c2) if (q.size() >= 30) kept.push_back(&q);
@@ -340,7 +368,8 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
               for (int y = ib.y0; y <= ib.y1; y++) { const uint64_t* r = p.img.row(y);
                 for (int k = 0; k < p.img.wpr; k++) { uint64_t m = r[k]; while (m) { const int x = (k << 6) + __builtin_ctzll(m); m &= m - 1;
                     const uint16_t d = depth_host[(size_t)y * W + x];
-                    float pzv = 0.f; if (!((float)d / cfg.depthScale >= (float)(uint16_t)6 || d == 0)) { const float depth2 = (float)d * (1.0f / cfg.depthScale); pzv = (float)(depth2 * depth_weight); }
+                    // (float)d / depthScale >= 6 is monotonic in d: compared against the first raw value that satisfies it (zInvalidFrom, init())
+                    float pzv = 0.f; if (!((int)d >= zInvalidFrom || d == 0)) { const float depth2 = (float)d * invDepthScale; pzv = (float)(depth2 * depth_weight); }
                     f3 += pzv; } } }
               p.cz = f3 / p.area; }
             QLAP(16)
@@ -371,8 +400,8 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     SIND_TRY(planes_d.alloc(planes_n)); SIND_TRY(rag_d.alloc((size_t)3 * C * C + C + (size_t)C * 256));
     FLAP(11)
     HIP_TRY(hipMemcpyAsync(planes_d.p, planes, planes_n * 8, hipMemcpyHostToDevice, stream));
-    occ2.to_u8(h_b8.p, W, 255);
-    HIP_TRY(hipMemcpyAsync(occ2_d.p, h_b8.p, N, hipMemcpyHostToDevice, stream));
+    occ2.to_u8((h_ab.p + N), W, 255);
+    HIP_TRY(hipMemcpyAsync(occ2_d.p, (h_ab.p + N), N, hipMemcpyHostToDevice, stream));
     FLAP(7)
     SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1));
     SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, depthN.p, N));
@@ -484,8 +513,7 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     float depth_vals[KM_K]; int order[KM_K];
     for (int i = 0; i < KM_K; i++) { depth_vals[i] = centers[i][2]; if (depth_vals[i] < 0.2) depth_vals[i] += 20.0f; order[i] = i; }
     std::stable_sort(order, order + KM_K, [&](int a, int b) { return depth_vals[a] < depth_vals[b]; });
-    std::vector<BitImg> labelMask(KM_K); for (auto& m : labelMask) m.create(W, H);
-    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const int l = label8[(size_t)y * W + x]; if (l < KM_K) labelMask[l].set(x, y); }
+    std::vector<BitImg> labelMask(KM_K); BitImg::split_labels(label8.data(), W, H, W, 0, KM_K, labelMask.data());
     std::vector<BitImg> allLabels; BitImg labelForSegEdge(W, H);
     float ratioArea = 0.0f; const float TotalArea = (float)(H * W); int count0 = 0;
     for (int i = 0; i < KM_K; i++) {
@@ -509,13 +537,13 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     int maxNum = 0; for (uint8_t v : label3) maxNum = std::max<int>(maxNum, v);
     if (keep_debug) { dbg.occ1.resize(N); occ1.to_u8(dbg.occ1.data(), W, 255); dbg.occ2.resize(N); occ2.to_u8(dbg.occ2.data(), W, 255); dbg.totalArea.resize(N); totalArea.to_u8(dbg.totalArea.data(), W, 255); }
     // fusion (DD:1553-1636)
-    BitImg low = BitImg::from_u8(highLast.data(), W, H, W); low |= maskLow; low &= totalArea;
+    BitImg low = highLast; low |= maskLow; low &= totalArea;
     low = low.dilated(EllipseElem(5));
     const BitImg notLow = low.inverted();
     QLAP(25)
     BitImg dyna(W, H);
-    std::vector<BitImg> clusters(maxNum + 1); for (auto& m : clusters) m.create(W, H);
-    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const int l = label3[(size_t)y * W + x]; if (l) clusters[l].set(x, y); }
+    std::vector<BitImg> clusters(maxNum + 1); clusters[0].create(W, H);
+    if (maxNum > 0) BitImg::split_labels(label3.data(), W, H, W, 1, maxNum, clusters.data() + 1);
     QLAP(26)
     for (int n = 1; n <= maxNum; n++) {
         const BitImg& one = clusters[n]; const int oneCnt = one.count();
@@ -534,12 +562,13 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     }
     QLAP(27)
     dyna = dyna.dilated(EllipseElem(9));
-    std::vector<uint8_t> out(N, 0);
-    totalArea.paint_u8(out.data(), W, 125); dyna.paint_u8(out.data(), W, 255);
-    std::memcpy(dyna_out, out.data(), N); std::memcpy(label_out, label3.data(), N);
+    totalArea.to_u8(dyna_out, W, 125); dyna.paint_u8(dyna_out, W, 255);
+    std::memcpy(label_out, label3.data(), N);
     // roll the state (DD:1660-1664)
-    dynaLast = out; labelLast = label3; maskHigh.to_u8(highLast.data(), W, 255);
-    labelLastAny = false; for (uint8_t v : label3) if (v) { labelLastAny = true; break; }
+    std::memcpy(dynaLast.data(), dyna_out, N); labelLast.swap(label3); highLast = maskHigh;
+    labelLastAny = maxNum > 0;
+    std::memset(lastCnt, 0, sizeof(lastCnt)); std::memset(lastDyn, 0, sizeof(lastDyn));       // per-label pixel / dynamic-pixel counts for the next frame's sample weights
+    for (int n = 1; n <= maxNum && n < 256; n++) { lastCnt[n] = clusters[n].count(); lastDyn[n] = BitImg::and_count(clusters[n], dyna); }
     QLAP(28)
     #undef QLAP
     LAP(5)

@@ -675,8 +675,8 @@ int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, 
 }
 int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h) {
     HMat Hm; for (int i = 0; i < 9; i++) Hm.h[i] = H[i];
-    HIP_TRY(hipMemsetAsync(maxbits, 0, sizeof(unsigned), s));
-    HIP_TRY(hipMemsetAsync(hist, 0, 256 * sizeof(int), s));
+    if ((const void*)maxbits == (const void*)(hist + 256)) HIP_TRY(hipMemsetAsync(hist, 0, 257 * sizeof(int), s));       // histogram and maximum in one block: one fill
+    else { HIP_TRY(hipMemsetAsync(maxbits, 0, sizeof(unsigned), s)); HIP_TRY(hipMemsetAsync(hist, 0, 256 * sizeof(int), s)); }
     hipLaunchKernelGGL(k_residual_mag, dim3(divup(w, 128), h), dim3(128), 0, s, u, v, Hm, mag, maxbits, w, h);
     const int n = w * h, gx = std::min(divup(n, 256), 64);
     hipLaunchKernelGGL(k_mag_hist, dim3(gx, 1), dim3(256), 0, s, mag, maxbits, hist, magu8, n);

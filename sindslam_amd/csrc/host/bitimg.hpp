@@ -10,8 +10,27 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <emmintrin.h>      // SSE2 (x86-64 baseline): byte image <-> bit image conversions, 16 pixels per instruction
 
 namespace sind {
+
+// 64 consecutive bytes -> one word: bit i = (s[i] != 0) / (s[i] == v)
+static inline uint64_t pack64_nonzero(const uint8_t* s) {
+    const __m128i z = _mm_setzero_si128(); uint64_t m = 0;
+    for (int q = 0; q < 4; q++) m |= (uint64_t)(uint16_t)~_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(s + 16 * q)), z)) << (16 * q);
+    return m;
+}
+static inline uint64_t pack64_equal(const uint8_t* s, uint8_t v) {
+    const __m128i c = _mm_set1_epi8((char)v); uint64_t m = 0;
+    for (int q = 0; q < 4; q++) m |= (uint64_t)(uint16_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(s + 16 * q)), c)) << (16 * q);
+    return m;
+}
+// 8 bits -> 8 bytes of 0x00 / 0xFF
+static inline uint64_t spread8(unsigned b) {
+    uint64_t x = (uint64_t)b * 0x0101010101010101ull & 0x8040201008040201ull;      // byte k holds bit k (at position k)
+    x = ((x + 0x7f7f7f7f7f7f7f7full) | x) & 0x8080808080808080ull;                // any bit in the byte -> 0x80
+    return (x >> 7) * 0xffull;
+}
 
 struct Rect { int x0, y0, x1, y1; bool empty() const { return x1 < x0 || y1 < y0; } };   // inclusive
 
@@ -41,18 +60,33 @@ public:
 
     static BitImg from_u8(const uint8_t* p, int w, int h, int stride) {
         BitImg b(w, h);
+        const int full = w >> 6;
         for (int y = 0; y < h; y++) { const uint8_t* s = p + (size_t)y * stride; uint64_t* r = b.row(y);
-            for (int x = 0; x < w; x++) if (s[x]) r[x >> 6] |= 1ull << (x & 63); }
+            for (int k = 0; k < full; k++) r[k] = pack64_nonzero(s + 64 * k);
+            for (int x = full << 6; x < w; x++) if (s[x]) r[x >> 6] |= 1ull << (x & 63); }
         return b;
     }
     static BitImg from_equal(const uint8_t* p, int w, int h, int stride, uint8_t v) {
         BitImg b(w, h);
+        const int full = w >> 6;
         for (int y = 0; y < h; y++) { const uint8_t* s = p + (size_t)y * stride; uint64_t* r = b.row(y);
-            for (int x = 0; x < w; x++) if (s[x] == v) r[x >> 6] |= 1ull << (x & 63); }
+            for (int k = 0; k < full; k++) r[k] = pack64_equal(s + 64 * k, v);
+            for (int x = full << 6; x < w; x++) if (s[x] == v) r[x >> 6] |= 1ull << (x & 63); }
         return b;
     }
+    // one bit image per byte value v in [0, n): out[v] = (src == v); n passes of 16-pixel compares instead of a per-pixel scatter
+    static void split_labels(const uint8_t* p, int w, int h, int stride, int first, int n, BitImg* out) {
+        for (int v = 0; v < n; v++) out[v].create(w, h);
+        const int full = w >> 6;
+        for (int y = 0; y < h; y++) { const uint8_t* s = p + (size_t)y * stride;
+            for (int k = 0; k < full; k++) for (int v = 0; v < n; v++) out[v].row(y)[k] = pack64_equal(s + 64 * k, (uint8_t)(first + v));
+            for (int x = full << 6; x < w; x++) { const int v = (int)s[x] - first; if (v >= 0 && v < n) out[v].row(y)[x >> 6] |= 1ull << (x & 63); } }
+    }
     void to_u8(uint8_t* out, int stride, uint8_t on, uint8_t off = 0) const {
-        for (int y = 0; y < h; y++) { const uint64_t* r = row(y); uint8_t* o = out + (size_t)y * stride; for (int x = 0; x < w; x++) o[x] = ((r[x >> 6] >> (x & 63)) & 1) ? on : off; }
+        const int full = w >> 6; const uint64_t on8 = on * 0x0101010101010101ull, off8 = off * 0x0101010101010101ull;
+        for (int y = 0; y < h; y++) { const uint64_t* r = row(y); uint8_t* o = out + (size_t)y * stride;
+            for (int k = 0; k < full; k++) { const uint64_t m = r[k]; for (int q = 0; q < 8; q++) { const uint64_t f = spread8((unsigned)(m >> (8 * q)) & 0xffu), v = (f & on8) | (~f & off8); std::memcpy(o + 64 * k + 8 * q, &v, 8); } }
+            for (int x = full << 6; x < w; x++) o[x] = ((r[x >> 6] >> (x & 63)) & 1) ? on : off; }
     }
     void paint_u8(uint8_t* out, int stride, uint8_t v) const {       // out[p] = v where the bit is set
         for (int y = 0; y < h; y++) { const uint64_t* r = row(y); uint8_t* o = out + (size_t)y * stride;
@@ -81,46 +115,61 @@ public:
     }
 
     // dilation by an elliptical element; rows outside [ry0, ry1] of the SOURCE are known to be empty (bbox hint)
-    BitImg dilated(const EllipseElem& e, int ry0 = 0, int ry1 = -1) const {
-        if (ry1 < 0) ry1 = h - 1;
-        ry0 = std::max(ry0, 0); ry1 = std::min(ry1, h - 1);
+    // word range [k0, k1] that holds the set pixels of rows [y0, y1] (k1 < k0: none)
+    void word_extent(int y0, int y1, int& k0, int& k1) const {
+        k0 = wpr; k1 = -1;
+        for (int y = y0; y <= y1; y++) { const uint64_t* s = row(y); for (int q = 0; q < wpr; q++) if (s[q]) { k0 = std::min(k0, q); k1 = std::max(k1, q); } }
+    }
+    // Dilation of the source rows [ry0, ry1].  Only the word window [kw0, kw1] is read and written: the caller guarantees that the
+    // result is needed there only and that nothing outside the window can reach it except through the window's first / last word
+    // (an element is far narrower than a word), or that the window edge is the image edge.
+    BitImg dilated_win(const EllipseElem& e, int ry0, int ry1, int kw0, int kw1) const {
         BitImg out(w, h);
-        if (ry1 < ry0) return out;
+        kw0 = std::max(kw0, 0); kw1 = std::min(kw1, wpr - 1);
+        if (ry1 < ry0 || kw1 < kw0) return out;
+        const int nw = kw1 - kw0 + 1; const bool has_tail = kw1 == wpr - 1;
         // distinct horizontal runs of the element
         std::vector<std::pair<int, int>> runs; std::vector<int> run_of(e.n, -1);
         for (int i = 0; i < e.n; i++) { if (e.j2[i] <= e.j1[i]) continue; std::pair<int, int> r(e.j1[i], e.j2[i]);
             size_t k = 0; for (; k < runs.size(); k++) if (runs[k] == r) break; if (k == runs.size()) runs.push_back(r); run_of[i] = (int)k; }
         const int nr = ry1 - ry0 + 1; const uint64_t tm = tail_mask();
-        std::vector<std::vector<uint64_t>> H(runs.size(), std::vector<uint64_t>((size_t)nr * wpr, 0));
-        std::vector<uint64_t> acc(wpr), tmp(wpr);
+        std::vector<uint64_t> Hbuf(runs.size() * (size_t)nr * nw, 0), acc(nw), tmp(nw);
         for (size_t k = 0; k < runs.size(); k++) {
             const int a = runs[k].first - e.ax, L = runs[k].second - runs[k].first;     // shifts a .. a+L-1
             for (int y = ry0; y <= ry1; y++) {
-                const uint64_t* s = row(y);
-                bool nz = false; for (int q = 0; q < wpr; q++) nz |= s[q] != 0;
+                const uint64_t* s = row(y) + kw0;
+                bool nz = false; for (int q = 0; q < nw; q++) nz |= s[q] != 0;
                 if (!nz) continue;
                 // every run of an elliptical element contains the anchor column (a <= 0 <= a+L-1): build the window as
                 // OR_{t=0..mp} src[x+t]  |  OR_{t=0..mn} src[x-t], each by doubling, so partial windows at the borders survive
-                uint64_t* hrow = &H[k][(size_t)(y - ry0) * wpr];
+                uint64_t* hrow = &Hbuf[(k * nr + (size_t)(y - ry0)) * nw];
                 for (int dir = 0; dir < 2; dir++) {
                     const int m = dir == 0 ? a + L - 1 : -a, sgn = dir == 0 ? 1 : -1;
-                    std::copy(s, s + wpr, acc.begin());
+                    std::copy(s, s + nw, acc.begin());
                     int p = 1;                                          // acc covers t = 0..p-1
-                    while (p * 2 <= m + 1) { std::copy(acc.begin(), acc.end(), tmp.begin()); or_shift(acc.data(), tmp.data(), wpr, sgn * p); p *= 2; }
-                    if (p < m + 1) { std::copy(acc.begin(), acc.end(), tmp.begin()); or_shift(acc.data(), tmp.data(), wpr, sgn * (m + 1 - p)); }
-                    for (int q = 0; q < wpr; q++) hrow[q] |= acc[q];
+                    while (p * 2 <= m + 1) { std::copy(acc.begin(), acc.end(), tmp.begin()); or_shift(acc.data(), tmp.data(), nw, sgn * p); p *= 2; }
+                    if (p < m + 1) { std::copy(acc.begin(), acc.end(), tmp.begin()); or_shift(acc.data(), tmp.data(), nw, sgn * (m + 1 - p)); }
+                    for (int q = 0; q < nw; q++) hrow[q] |= acc[q];
                 }
-                hrow[wpr - 1] &= tm;
+                if (has_tail) hrow[nw - 1] &= tm;
             }
         }
         for (int i = 0; i < e.n; i++) {
             if (run_of[i] < 0) continue;
             const int dy = i - e.ay;                               // dst(y) takes src(y + dy)  ->  src row ys feeds dst row ys - dy
             for (int ys = ry0; ys <= ry1; ys++) { const int yd = ys - dy; if (yd < 0 || yd >= h) continue;
-                const uint64_t* hrow = &H[run_of[i]][(size_t)(ys - ry0) * wpr]; uint64_t* o = out.row(yd);
-                for (int q = 0; q < wpr; q++) o[q] |= hrow[q]; }
+                const uint64_t* hrow = &Hbuf[((size_t)run_of[i] * nr + (size_t)(ys - ry0)) * nw]; uint64_t* o = out.row(yd) + kw0;
+                for (int q = 0; q < nw; q++) o[q] |= hrow[q]; }
         }
         return out;
+    }
+    BitImg dilated(const EllipseElem& e, int ry0 = 0, int ry1 = -1) const {
+        if (ry1 < 0) ry1 = h - 1;
+        ry0 = std::max(ry0, 0); ry1 = std::min(ry1, h - 1);
+        if (ry1 < ry0) return BitImg(w, h);
+        int k0, k1; word_extent(ry0, ry1, k0, k1);
+        if (k1 < k0) return BitImg(w, h);
+        return dilated_win(e, ry0, ry1, k0 - 1, k1 + 1);          // a dilation grows by less than a word: one spare word on each side
     }
     // erosion: positions outside the image are ignored, i.e. erode(X) = ~dilate(~X) inside the image
     BitImg eroded(const EllipseElem& e) const { return inverted().dilated(e).inverted(); }
@@ -130,12 +179,21 @@ public:
         y0 = std::max(y0, 0); y1 = std::min(y1, h - 1);
         BitImg out(w, h);
         if (y1 < y0) return out;
-        const BitImg d = inverted().dilated(e, y0 - e.n, y1 + e.n);
+        int k0, k1; word_extent(y0, y1, k0, k1);
+        if (k1 < k0) return out;
+        // the erosion is a subset of the source: only the words [k0, k1] of rows [y0, y1] are needed from the dilated complement
+        const BitImg d = inverted().dilated_win(e, std::max(y0 - e.n, 0), std::min(y1 + e.n, h - 1), k0 - 1, k1 + 1);
         const uint64_t tm = tail_mask();
-        for (int y = y0; y <= y1; y++) { const uint64_t* p = d.row(y); uint64_t* o = out.row(y); for (int k = 0; k < wpr; k++) o[k] = ~p[k]; o[wpr - 1] &= tm; }
+        for (int y = y0; y <= y1; y++) { const uint64_t* p = d.row(y); uint64_t* o = out.row(y); for (int k = k0; k <= k1; k++) o[k] = ~p[k]; o[wpr - 1] &= tm; }
         return out;
     }
     BitImg opened(const EllipseElem& e) const { return eroded(e).dilated(e); }
+    // opening of an image whose set pixels all lie in rows [y0, y1] (the result is a subset of the source)
+    BitImg opened_rows(const EllipseElem& e, int y0, int y1) const { return eroded_rows(e, y0, y1).dilated(e, y0, y1); }
+    // row-range variants of the set operations (everything outside [y0, y1] is left untouched)
+    void and_rows(const BitImg& o, int y0, int y1) { y0 = std::max(y0, 0); y1 = std::min(y1, h - 1); for (size_t i = (size_t)y0 * wpr; i < (size_t)(y1 + 1) * wpr; i++) d[i] &= o.d[i]; }
+    void andnot_rows(const BitImg& o, int y0, int y1) { y0 = std::max(y0, 0); y1 = std::min(y1, h - 1); for (size_t i = (size_t)y0 * wpr; i < (size_t)(y1 + 1) * wpr; i++) d[i] &= ~o.d[i]; }
+    int count_rows(int y0, int y1) const { y0 = std::max(y0, 0); y1 = std::min(y1, h - 1); int n = 0; for (size_t i = (size_t)y0 * wpr; i < (size_t)(y1 + 1) * wpr; i++) n += __builtin_popcountll(d[i]); return n; }
     BitImg closed(const EllipseElem& e) const { return dilated(e).eroded(e); }
 };
 

@@ -94,10 +94,7 @@ inline void draw_thick2(BitImg& img, const Contour& c) {
 }
 // FILLED drawing of one or several contours sharing one edge table: boundary + even-odd interior per scanline
 inline void draw_filled(BitImg& img, const std::vector<const Contour*>& cs) {
-    int y0 = 1 << 30, y1 = -1;
-    for (const Contour* c : cs) for (const PtI& p : *c) { y0 = std::min(y0, p.y); y1 = std::max(y1, p.y); }
-    if (y1 < y0) return;
-    std::vector<std::vector<int>> cross(y1 - y0 + 1);
+    std::vector<uint32_t> cross;                 // (row << 16 | column + 1) of every edge crossing, sorted = rows in order, columns ascending
     for (const Contour* cp : cs) {
         const Contour& c = *cp; const size_t n = c.size();
         for (size_t i = 0; i < n; i++) {
@@ -105,18 +102,17 @@ inline void draw_filled(BitImg& img, const std::vector<const Contour*>& cs) {
             img.set_safe(p.x, p.y);
             if (p.y == q.y) continue;
             const PtI& top = p.y < q.y ? p : q;
-            cross[top.y - y0].push_back(top.x);
+            if (top.y >= 0 && top.y < img.h) cross.push_back(((uint32_t)top.y << 16) | (uint32_t)(std::min(std::max(top.x, -1), 65533) + 1));
         }
     }
-    for (int y = y0; y <= y1; y++) {
-        if (y < 0 || y >= img.h) continue;
-        std::vector<int>& xs = cross[y - y0];
-        if (xs.size() < 2) continue;
-        std::sort(xs.begin(), xs.end());
-        for (size_t k = 0; k + 1 < xs.size(); k += 2) {
-            const int a = std::max(xs[k], 0), b = std::min(xs[k + 1], img.w - 1);
+    std::sort(cross.begin(), cross.end());
+    for (size_t i = 0; i < cross.size();) {
+        size_t j = i; const uint32_t yk = cross[i] >> 16;
+        while (j < cross.size() && (cross[j] >> 16) == yk) j++;
+        const int y = (int)yk; uint64_t* r = img.row(y);
+        for (size_t k = i; k + 1 < j; k += 2) {
+            const int a = std::max((int)(cross[k] & 0xffffu) - 1, 0), b = std::min((int)(cross[k + 1] & 0xffffu) - 1, img.w - 1);
             if (b < a) continue;
-            uint64_t* r = img.row(y);
             const int ka = a >> 6, kb = b >> 6;
             for (int q = ka; q <= kb; q++) {
                 uint64_t m = ~0ull;
@@ -125,25 +121,68 @@ inline void draw_filled(BitImg& img, const std::vector<const Contour*>& cs) {
                 r[q] |= m;
             }
         }
+        i = j;
     }
 }
 inline void draw_filled(BitImg& img, const Contour& c) { std::vector<const Contour*> one(1, &c); draw_filled(img, one); }
 
 // floodFill(FLOODFILL_MASK_ONLY, 8-connected) on a two-valued image: `same` holds the pixels whose value equals the
 // seed's value, `blocked` the non-zero mask pixels; newly filled pixels are added to `filled` and to `blocked`.
+// Span version: the filled set of a flood fill does not depend on the visiting order, so rows are filled run by run on the bit
+// words (allowed = same & ~blocked) and only run end points are pushed; cost ~ number of runs instead of number of pixels.
 inline int flood_fill(const BitImg& same, BitImg& blocked, BitImg& filled, PtI seed) {
-    if (seed.x < 0 || seed.y < 0 || seed.x >= same.w || seed.y >= same.h) return 0;
+    const int W = same.w, H = same.h, wpr = same.wpr;
+    if (seed.x < 0 || seed.y < 0 || seed.x >= W || seed.y >= H) return 0;
     if (blocked.get(seed.x, seed.y)) return 0;
-    std::deque<PtI> q; q.push_back(seed); blocked.set(seed.x, seed.y); filled.set(seed.x, seed.y);
-    int area = 0;
-    while (!q.empty()) {
-        const PtI p = q.front(); q.pop_front(); area++;
-        for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
-            if (!dx && !dy) continue;
-            const int x = p.x + dx, y = p.y + dy;
-            if (x < 0 || y < 0 || x >= same.w || y >= same.h) continue;
-            if (blocked.get(x, y) || !same.get(x, y)) continue;
-            blocked.set(x, y); filled.set(x, y); q.push_back({x, y});
+    auto allowed_word = [&](int y, int k) -> uint64_t { uint64_t a = same.row(y)[k] & ~blocked.row(y)[k]; if (k == wpr - 1) a &= same.tail_mask(); return a; };
+    // first allowed pixel in [x, xmax] of row y, or -1
+    auto next_allowed = [&](int y, int x, int xmax) -> int {
+        for (int k = x >> 6; k <= (xmax >> 6); k++) {
+            uint64_t a = allowed_word(y, k); if (k == (x >> 6)) a &= ~0ull << (x & 63);
+            if (a) { const int p = (k << 6) + __builtin_ctzll(a); return p <= xmax ? p : -1; }
+        }
+        return -1;
+    };
+    // last pixel of the allowed run that contains x (x is allowed), scanning right / left
+    auto run_right = [&](int y, int x) -> int {
+        for (int k = x >> 6; k < wpr; k++) {
+            uint64_t na = ~allowed_word(y, k); if (k == (x >> 6)) na &= ~0ull << (x & 63);
+            if (k == wpr - 1) na |= ~same.tail_mask();
+            if (na) return (k << 6) + __builtin_ctzll(na) - 1;
+        }
+        return W - 1;
+    };
+    auto run_left = [&](int y, int x) -> int {
+        for (int k = x >> 6; k >= 0; k--) {
+            uint64_t na = ~allowed_word(y, k); if (k == (x >> 6)) na &= (x & 63) == 63 ? ~0ull : ((1ull << ((x & 63) + 1)) - 1);
+            if (na) return (k << 6) + 64 - __builtin_clzll(na);
+        }
+        return 0;
+    };
+    auto mark = [&](int y, int a, int b) {
+        uint64_t* bl = blocked.row(y); uint64_t* fl = filled.row(y);
+        for (int k = a >> 6; k <= (b >> 6); k++) {
+            uint64_t m = ~0ull; if (k == (a >> 6)) m &= ~0ull << (a & 63); if (k == (b >> 6)) m &= (b & 63) == 63 ? ~0ull : ((1ull << ((b & 63) + 1)) - 1);
+            bl[k] |= m; fl[k] |= m;
+        }
+    };
+    struct Span { int y, a, b; };
+    std::vector<Span> st; int area = 0;
+    // the seed pixel is filled unconditionally (like the queue version), then its row neighbourhood is scanned
+    { uint64_t* bl = blocked.row(seed.y); uint64_t* fl = filled.row(seed.y); bl[seed.x >> 6] |= 1ull << (seed.x & 63); fl[seed.x >> 6] |= 1ull << (seed.x & 63); area++; }
+    st.push_back({seed.y, seed.x - 1, seed.x + 1});
+    if (seed.y > 0) st.push_back({seed.y - 1, seed.x - 1, seed.x + 1});
+    if (seed.y + 1 < H) st.push_back({seed.y + 1, seed.x - 1, seed.x + 1});
+    while (!st.empty()) {
+        const Span s = st.back(); st.pop_back();
+        int x = std::max(s.a, 0); const int xmax = std::min(s.b, W - 1);
+        while (x <= xmax) {
+            const int p = next_allowed(s.y, x, xmax); if (p < 0) break;
+            const int l = run_left(s.y, p), r = run_right(s.y, p);
+            mark(s.y, l, r); area += r - l + 1;
+            if (s.y > 0) st.push_back({s.y - 1, l - 1, r + 1});
+            if (s.y + 1 < H) st.push_back({s.y + 1, l - 1, r + 1});
+            x = r + 2;
         }
     }
     return area;

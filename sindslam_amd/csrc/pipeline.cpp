@@ -70,8 +70,7 @@ static void dilate15_codes(const uint8_t* src, int W, int H, uint8_t* dst) {
     const EllipseElem e15(15);
     BitImg hi = BitImg::from_equal(src, W, H, W, 255), any = BitImg::from_u8(src, W, H, W);
     hi = hi.dilated(e15); any = any.dilated(e15);
-    std::memset(dst, 0, (size_t)W * H);
-    any.paint_u8(dst, W, 125); hi.paint_u8(dst, W, 255);
+    any.to_u8(dst, W, 125); hi.paint_u8(dst, W, 255);
 }
 
 // Tail / CalOccluded streams are high priority: their small kernels overtake the batch stream's flow solver when both are in flight.

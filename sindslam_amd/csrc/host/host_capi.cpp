@@ -14,6 +14,24 @@ void sindh_morph(const uint8_t* src, int w, int h, int n, int op, uint8_t* out) 
     const BitImg r = op == 0 ? b.dilated(e) : op == 1 ? b.eroded(e) : op == 2 ? b.opened(e) : b.closed(e);
     r.to_u8(out, w, 255);
 }
+// row-restricted variants used on sparse masks (ops 4 = eroded_rows, 5 = opened_rows over the mask's own row range)
+void sindh_morph_rows(const uint8_t* src, int w, int h, int n, int op, uint8_t* out) {
+    const BitImg b = BitImg::from_u8(src, w, h, w); const EllipseElem e(n); const Rect bb = b.bbox();
+    BitImg r(w, h);
+    if (!bb.empty()) r = op == 4 ? b.eroded_rows(e, bb.y0, bb.y1) : op == 5 ? b.opened_rows(e, bb.y0, bb.y1) : b.dilated(e, bb.y0, bb.y1);
+    r.to_u8(out, w, 255);
+}
+// floodFill(FLOODFILL_MASK_ONLY) stand-in: same / blocked as byte images, returns the filled area and the filled mask
+int sindh_flood_fill(const uint8_t* same, const uint8_t* blocked, int w, int h, int sx, int sy, uint8_t* filled_out, uint8_t* blocked_out) {
+    const BitImg s = BitImg::from_u8(same, w, h, w); BitImg b = BitImg::from_u8(blocked, w, h, w), f(w, h);
+    const int area = flood_fill(s, b, f, PtI{sx, sy});
+    f.to_u8(filled_out, w, 255); b.to_u8(blocked_out, w, 255);
+    return area;
+}
+// byte image <-> bit image round trip and per-value split (SSE2 paths)
+void sindh_pack_roundtrip(const uint8_t* src, int w, int h, uint8_t v, uint8_t* nonzero_out, uint8_t* equal_out) {
+    BitImg::from_u8(src, w, h, w).to_u8(nonzero_out, w, 200, 3); BitImg::from_equal(src, w, h, w, v).to_u8(equal_out, w, 255);
+}
 int sindh_find_contours(const uint8_t* src, int w, int h, int external_only, int* pts_xy, int cap_pts, int* lens, int cap_contours) {
     std::vector<Contour> cs; find_contours(BitImg::from_u8(src, w, h, w), cs, external_only != 0);
     int np = 0, nc = 0;

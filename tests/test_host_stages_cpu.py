@@ -97,3 +97,51 @@ def test_octree_identical(H, frames):
         n = H.sindh_octree(P(xyr), len(xyr), 16, w - 16, 16, h - 16, int(per[lv]), P(out), 4000)
         assert n == len(sel)
         assert np.array_equal(out[:n, 0] + 16, sel["x"]) and np.array_equal(out[:n, 1] + 16, sel["y"]) and np.array_equal(out[:n, 2], sel["response"])
+
+
+def _blobs(rng, w, h, n):
+    img = np.zeros((h, w), np.uint8)
+    for _ in range(n):
+        cx, cy, rx, ry = rng.integers(0, w), rng.integers(0, h), rng.integers(3, 60), rng.integers(3, 30)
+        y0, y1, x0, x1 = max(cy - ry, 0), min(cy + ry, h - 1), max(cx - rx, 0), min(cx + rx, w - 1)
+        img[y0:y1 + 1, x0:x1 + 1] = (rng.random((y1 - y0 + 1, x1 - x0 + 1)) < 0.9) * 255
+    return img
+
+
+@pytest.mark.parametrize("w", [640, 200, 64])
+def test_window_restricted_morphology_equals_full_frame_oracle(H, w):
+    """eroded_rows / opened_rows / dilated(rows) evaluate only the mask's own rows and words; the result must equal the full-frame op"""
+    import oracle_lib as O
+    rng = np.random.default_rng(w)
+    for trial in range(6):
+        img = _blobs(rng, w, 90, 1 + trial % 3)
+        for n in (3, 4, 7, 9, 10):
+            for op_rows, op_full in ((4, "erode"), (5, "open"), (6, "dilate")):
+                out = np.zeros_like(img); H.sindh_morph_rows(P(img), w, 90, n, op_rows, P(out))
+                assert np.array_equal(out, O.morph(img, n, op_full)), (trial, n, op_rows)
+
+
+def test_span_flood_fill_equals_connected_component(H):
+    from scipy import ndimage
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        w, h = int(rng.choice([64, 100, 640])), 70
+        same = ((rng.random((h, w)) < rng.uniform(0.4, 0.8)) * 255).astype(np.uint8); blocked = ((rng.random((h, w)) < 0.15) * 255).astype(np.uint8)
+        sx, sy = int(rng.integers(0, w)), int(rng.integers(0, h))
+        filled = np.zeros_like(same); bl2 = np.zeros_like(same)
+        area = H.sindh_flood_fill(P(same), P(blocked), w, h, sx, sy, P(filled), P(bl2))
+        if blocked[sy, sx]:
+            assert area == 0 and not filled.any(); continue
+        allowed = (same > 0) & (blocked == 0); allowed[sy, sx] = True          # the seed is filled unconditionally
+        lab, _ = ndimage.label(allowed, structure=np.ones((3, 3)))
+        want = lab == lab[sy, sx]
+        assert np.array_equal(filled > 0, want) and area == want.sum() and np.array_equal(bl2 > 0, (blocked > 0) | want)
+
+
+def test_sse_bit_packing_round_trip(H):
+    rng = np.random.default_rng(9)
+    for w in (640, 100, 64, 200):
+        img = rng.choice(np.array([0, 7, 125, 255], np.uint8), size=(37, w))
+        a = np.zeros_like(img); b = np.zeros_like(img)
+        H.sindh_pack_roundtrip(P(img), w, 37, 125, P(a), P(b))
+        assert np.array_equal(a, np.where(img > 0, 200, 3)) and np.array_equal(b, np.where(img == 125, 255, 0))

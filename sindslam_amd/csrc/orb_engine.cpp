@@ -104,7 +104,7 @@ int OrbEngine::extract_all(const uint8_t* gray, int B, std::vector<OrbFrameResul
     HIP_TRY(hipMemcpyAsync(h_total.data(), frame_total.p, B * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h_off.data(), cell_offsets.p, (size_t)B * nc * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h_cnt.data(), counts.p, (size_t)B * nc * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     int max_total = 0;
     for (int b = 0; b < B; b++) {
         if (h_total[b] > dense_cap) { sind_set_error("OrbEngine: %d FAST keypoints exceed the dense capacity %d", h_total[b], dense_cap); return SIND_E_CAPACITY; }
@@ -115,7 +115,7 @@ int OrbEngine::extract_all(const uint8_t* gray, int B, std::vector<OrbFrameResul
     if (max_total > 0)
         HIP_TRY(hipMemcpy2DAsync(h_dense.data(), (size_t)max_total * sizeof(OrbRawKp), dense.p, (size_t)dense_cap * sizeof(OrbRawKp),
                                  (size_t)max_total * sizeof(OrbRawKp), B, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     // ---- host octree per frame and level
     out.assign(B, OrbFrameResult());
     dbg_fast.assign(B, std::vector<std::vector<OctKp>>(nlevels));
@@ -161,7 +161,7 @@ int OrbEngine::extract_all(const uint8_t* gray, int B, std::vector<OrbFrameResul
         HIP_TRY(hipMemcpy2DAsync(h_angle.data(), (size_t)sel_cap * 4, angle_dev.p, (size_t)sel_cap * 4, (size_t)max_sel * 4, B, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpy2DAsync(h_desc.data(), (size_t)sel_cap * 32, desc_dev.p, (size_t)sel_cap * 32, (size_t)max_sel * 32, B, hipMemcpyDeviceToHost, stream));
     }
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(sind_stream_wait(stream));
     HIP_TRY(hipGetLastError());
     for (int b = 0; b < B; b++) {
         OrbFrameResult& R = out[b]; R.kps.resize(h_nsel[b]); R.desc.resize((size_t)h_nsel[b] * 32);

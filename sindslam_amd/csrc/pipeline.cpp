@@ -48,7 +48,7 @@ private:
 
 struct sind_pipe {
     sind_pipe_config c{}; DynaConfig dc; int S = 0, T = 0, fw = 0, fh = 0;
-    hipStream_t stream = nullptr; std::vector<hipStream_t> worker_streams;      // one HIP stream per pool worker, shared by the tasks it runs
+    hipStream_t stream = nullptr, orb_stream = nullptr; hipEvent_t ev_gray = nullptr; std::vector<hipStream_t> worker_streams;      // one HIP stream per pool worker, shared by the tasks it runs
     DynaFront front; OrbEngine orb; std::vector<std::unique_ptr<DynaTail>> tails;
     std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
@@ -89,11 +89,11 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     std::unique_ptr<sind_pipe> p(new sind_pipe());
     p->c = *cfg; p->S = cfg->streams; p->T = cfg->frames_per_step;
     p->dc.W = cfg->width; p->dc.H = cfg->height; p->dc.fx = cfg->fx; p->dc.fy = cfg->fy; p->dc.cx = cfg->cx; p->dc.cy = cfg->cy; p->dc.depthScale = cfg->depth_scale; p->dc.device = cfg->device;
-    SIND_TRY(make_stream(&p->stream, false));
+    SIND_TRY(make_stream(&p->stream, false)); SIND_TRY(make_stream(&p->orb_stream, false)); HIP_TRY(hipEventCreateWithFlags(&p->ev_gray, hipEventDisableTiming));
     const int B = p->S * p->T; const size_t np = (size_t)cfg->width * cfg->height;
     SIND_TRY(p->front.init(p->dc, B, p->stream));
     p->fw = p->front.fw; p->fh = p->front.fh;
-    SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->stream));
+    SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->orb_stream));
     const int nworkers = cfg->host_threads > 0 ? cfg->host_threads : 24;         // default: 1.5x the box's CPU share per GPU (workers sleep while they wait for the GPU)
     // A task leaves its stream idle (every GPU section ends in a wait), so the HIP streams belong to the workers, not to the camera
     // streams: their number does not grow with S.
@@ -125,7 +125,8 @@ int sind_pipe_destroy(sind_pipe* p) {
     }
     (void)hipSetDevice(p->c.device);
     (void)hipDeviceSynchronize();
-    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream);
+    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream); ss.push_back(p->orb_stream);
+    if (p->ev_gray) (void)hipEventDestroy(p->ev_gray);
     delete p;
     for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
     return SIND_OK;
@@ -154,6 +155,16 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         SIND_TRY(launch_resize_u8(p->stream, p->gray.p + np * (size_t)s * T, p->pool.p + fb * ((size_t)s * (T + 2) + 2), W, H, p->fw, p->fh, T, W, p->fw, np, fb));
     const uint8_t* gray_for_orb = p->gray.p;
     if (p->c.orb_gray_rgb_order) { SIND_TRY(launch_bgr2gray(p->stream, bgr_dev, p->gray_orb.p, np * B, true)); gray_for_orb = p->gray_orb.p; }
+    // ORB front (pyramid, FAST, octree, orientation, blur, BRIEF) of all frames: independent of the flow, so it runs on its own HIP
+    // stream and host thread underneath the dense flow instead of after it
+    HIP_TRY(hipEventRecord(p->ev_gray, p->stream));
+    int orb_rc = SIND_OK; std::string orb_err;
+    std::thread orb_thread([&] {
+        (void)hipSetDevice(p->c.device);
+        if (hipStreamWaitEvent(p->orb_stream, p->ev_gray, 0) != hipSuccess) { orb_rc = SIND_E_HIP; orb_err = "hipStreamWaitEvent failed"; return; }
+        orb_rc = p->orb.extract_all(gray_for_orb, B, sb.orb);
+        if (orb_rc != SIND_OK) orb_err = sind_last_error(); });
+    struct OrbJoin { std::thread& t; ~OrbJoin() { if (t.joinable()) t.join(); } } orb_join{orb_thread};
     // private copies of the depth frames: device (tail kernels of this step run while the caller may reuse its buffer) and host
     HIP_TRY(hipMemcpyAsync(sb.depth_dev.p, depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(sb.depth_h.data(), sb.depth_dev.p, np * B * sizeof(uint16_t), hipMemcpyDeviceToHost, p->stream));
@@ -175,8 +186,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     HIP_TRY(sind_stream_wait(p->stream));
     p->sor_ms = p->front.flow.sor_timer.collect_ms(); p->sor_bytes = p->front.flow.sor_timer.alg_bytes; p->sor_launches = p->front.flow.sor_timer.launches;
     t[2] = now_ms();
-    // ORB front (pyramid, FAST, octree, orientation, blur, BRIEF) for all frames
-    SIND_TRY(p->orb.extract_all(gray_for_orb, B, sb.orb));
+    orb_thread.join();
+    if (orb_rc != SIND_OK) { sind_set_error("ORB front: %s", orb_err.c_str()); return orb_rc; }
     // roll the gray history: the last two frames of every stream become slots 0, 1
     for (int s = 0; s < S; s++) {
         uint8_t* base = p->pool.p + fb * (size_t)s * (T + 2);

@@ -109,7 +109,7 @@ __global__ void k_derivs(const float* __restrict__ avg, const float* __restrict_
 __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gIx, const float* __restrict__ gIy, const float* __restrict__ gIz,
                        const float* __restrict__ gIxx, const float* __restrict__ gIxy, const float* __restrict__ gIyy,
                        const float* __restrict__ gIxz, const float* __restrict__ gIyz, const float* __restrict__ gWu,
-                       const float* __restrict__ gWv, const float* __restrict__ gtWu, const float* __restrict__ gtWv,
+                       const float* __restrict__ gWv,
                        const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
                        float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
@@ -137,12 +137,16 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gIx,
     b1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
     b2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
 
-    const float* tU = gtWu + base; const float* tV = gtWv + base; const float* WU = gWu + base; const float* WV = gWv + base;
+    // tempW = W + dW is formed on the fly (OpenCV keeps it in a buffer that it refreshes after every fixed-point iteration with this
+    // very addition): two planes less to read here and no k_add_flow pass between the iterations.  Before the first iteration
+    // dW = 0, and W + 0 differs from W only in the sign of a zero, which the squared differences below cannot see.
+    const float* WU = gWu + base; const float* WV = gWv + base; const float* DU = gdWu + base; const float* DV = gdWv + base;
     auto wgt_at = [&](int yy, int xx) {
         const int xn = min(xx + 1, w - 1), yn = min(yy + 1, h - 1);
-        const float c_u = tU[yy * w + xx], c_v = tV[yy * w + xx];
-        const float ux = tU[yy * w + xn] - c_u, vx = tV[yy * w + xn] - c_v;
-        const float uy = tU[yn * w + xx] - c_u, vy = tV[yn * w + xx] - c_v;
+        const int ic = yy * w + xx, ix = yy * w + xn, iy = yn * w + xx;
+        const float c_u = WU[ic] + DU[ic], c_v = WV[ic] + DV[ic];
+        const float ux = (WU[ix] + DU[ix]) - c_u, vx = (WV[ix] + DV[ix]) - c_v;
+        const float uy = (WU[iy] + DU[iy]) - c_u, vy = (WV[iy] + DV[iy]) - c_v;
         return alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
     };
     const float wp = wgt_at(y, x);
@@ -446,8 +450,8 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 }
 
 // tempW = W + dW (end of a fixed-point iteration); with commit != 0 also W = tempW (end of the level)
-__global__ void k_add_flow(const float* __restrict__ Wu, const float* __restrict__ Wv, const float* __restrict__ dWu,
-                           const float* __restrict__ dWv, float* __restrict__ tWu, float* __restrict__ tWv, size_t n) {
+__global__ void k_add_flow(const float* Wu, const float* Wv, const float* __restrict__ dWu,
+                           const float* __restrict__ dWv, float* tWu, float* tWv, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     tWu[i] = Wu[i] + dWu[i]; tWv[i] = Wv[i] + dWv[i];
@@ -647,20 +651,16 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     hipLaunchKernelGGL(k_derivs, g, blk, 0, s, P.avg, P.Iz, P.Ix, P.Iy, P.Ixx, P.Ixy, P.Iyy, P.Ixz, P.Iyz, w, h);
     HIP_TRY(hipMemsetAsync(P.dWu, 0, n * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(P.dWv, 0, n * sizeof(float), s));
-    HIP_TRY(hipMemcpyAsync(P.tWu, P.Wu, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(P.tWv, P.Wv, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (int it = 0; it < V.fixedPointIterations; it++) {
-        hipLaunchKernelGGL(k_coef, g, blk, 0, s, V, w, h, P.Ix, P.Iy, P.Iz, P.Ixx, P.Ixy, P.Iyy, P.Ixz, P.Iyz, P.Wu, P.Wv, P.tWu, P.tWv,
+        hipLaunchKernelGGL(k_coef, g, blk, 0, s, V, w, h, P.Ix, P.Iy, P.Iz, P.Ixx, P.Ixy, P.Iyy, P.Ixz, P.Iyz, P.Wu, P.Wv,
                            P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt);
         if (timer) timer->begin(s);
         long long nlaunch = 0;
         SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch));
         // algorithmic bytes: 44 B per pixel per red+black iteration (9 reads + 2 writes of f32), SURVEY.md §8d
         if (timer) timer->end(s, nlaunch, 44.0 * (double)w * h * B * V.sorIterations);
-        hipLaunchKernelGGL(k_add_flow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.tWu, P.tWv, n);
     }
-    HIP_TRY(hipMemcpyAsync(P.Wu, P.tWu, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(P.Wv, P.tWv, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_add_flow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.Wu, P.Wv, n);      // W = W + dW, in place
     HIP_TRY(hipGetLastError());
     return SIND_OK;
 }

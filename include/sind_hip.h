@@ -141,6 +141,10 @@ int sind_pipe_flush(sind_pipe* p, uint8_t* dyna, uint8_t* label, uint8_t* mask_d
  * plus HIP-event statistics of the flow solver: sor_launches, sor_ms (sum of event-bracketed SOR launch groups),
  * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */
 int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, double* sor_ms, double* sor_alg_bytes);
+/* flow-solver statistics of the last step when the batch is cut into concurrent slices (one HIP stream each): launches and algorithmic
+ * bytes of all slices, sum_ms = sum of the event-bracketed launch groups, union_ms = time during which at least one slice had solver
+ * launches in flight (union of those intervals on a common event time base), slices = number of concurrent streams */
+int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Frame post-ORB steps: what the reference's RGB-D Frame constructor does with the extractor's output

@@ -27,6 +27,8 @@ struct SorTimer {
     void end(hipStream_t s, long long n_launches, double bytes) { if (!enabled) return; (void)hipEventRecord(ev[used + 1], s); used += 2; launches += n_launches; alg_bytes += bytes; }
     void reset() { used = 0; alg_bytes = 0; launches = 0; }
     double collect_ms() { double t = 0; for (size_t i = 0; i + 1 < used; i += 2) { float ms = 0; if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) t += ms; } return t; }
+    // [start, end] of every bracketed launch group in ms after `base` (an event with timing, recorded earlier on any stream)
+    void intervals(hipEvent_t base, std::vector<std::pair<double, double>>& out) { for (size_t i = 0; i + 1 < used; i += 2) { float a = 0, b = 0; if (hipEventElapsedTime(&a, base, ev[i]) == hipSuccess && hipEventElapsedTime(&b, base, ev[i + 1]) == hipSuccess) out.emplace_back(a, b); } }
     ~SorTimer() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
 

@@ -78,7 +78,7 @@ static void dilate15_codes(const uint8_t* src, int W, int H, uint8_t* dst) {
 // Tail / CalOccluded streams are high priority: their small kernels overtake the batch stream's flow solver when both are in flight.
 // (A CU partition via hipExtStreamCreateWithCUMask was measured on MI355X: every masked stream ran 3-4x slower, see DESIGN.md.)
 static int make_stream(hipStream_t* out, bool high_priority) {
-    if (high_priority && !(getenv("SIND_TAIL_PRIORITY") && atoi(getenv("SIND_TAIL_PRIORITY")) == 0)) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIP_TRY(hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi)); }
+    if (high_priority) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIP_TRY(hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi)); }
     else HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
     return SIND_OK;
 }
@@ -91,7 +91,8 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     std::unique_ptr<sind_pipe> p(new sind_pipe());
     p->c = *cfg; p->S = cfg->streams; p->T = cfg->frames_per_step;
     p->dc.W = cfg->width; p->dc.H = cfg->height; p->dc.fx = cfg->fx; p->dc.fy = cfg->fy; p->dc.cx = cfg->cx; p->dc.cy = cfg->cy; p->dc.depthScale = cfg->depth_scale; p->dc.device = cfg->device;
-    SIND_TRY(make_stream(&p->stream, false)); SIND_TRY(make_stream(&p->orb_stream, false)); HIP_TRY(hipEventCreateWithFlags(&p->ev_gray, hipEventDisableTiming));
+    const bool flow_hi = getenv("SIND_FLOW_PRIORITY") && atoi(getenv("SIND_FLOW_PRIORITY")) != 0;
+    SIND_TRY(make_stream(&p->stream, flow_hi)); SIND_TRY(make_stream(&p->orb_stream, false)); HIP_TRY(hipEventCreateWithFlags(&p->ev_gray, hipEventDisableTiming));
     const int B = p->S * p->T; const size_t np = (size_t)cfg->width * cfg->height;
     // dense-flow slices: three concurrent streams keep the GPU busy through the launch tails and the small pyramid levels of each other
     // (measured at B = 256: 270 -> 253 ms per step); small batches stay in one piece
@@ -99,7 +100,7 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     SIND_TRY(p->front.init(p->dc, nsplit > 1 ? std::max(Bs, 2) : B, p->stream));
     HIP_TRY(hipEventCreate(&p->ev_pool));                   // with timing: also the time base of the solver intervals
     for (int i = 1; i < nsplit; i++) {
-        hipStream_t st = nullptr; SIND_TRY(make_stream(&st, false)); p->extra_streams.push_back(st);
+        hipStream_t st = nullptr; SIND_TRY(make_stream(&st, flow_hi)); p->extra_streams.push_back(st);
         p->extra_fronts.emplace_back(new DynaFront()); SIND_TRY(p->extra_fronts.back()->init(p->dc, Bs, st));
     }
     p->fw = p->front.fw; p->fh = p->front.fh;
@@ -109,7 +110,7 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     // streams: their number does not grow with S.
     p->worker_streams.resize(nworkers); p->occ_tails.resize(nworkers); p->tails.resize(p->S);
     for (int w = 0; w < nworkers; w++) {
-        SIND_TRY(make_stream(&p->worker_streams[w], true));
+        SIND_TRY(make_stream(&p->worker_streams[w], !(getenv("SIND_TAIL_PRIORITY") && atoi(getenv("SIND_TAIL_PRIORITY")) == 0)));
         p->occ_tails[w].reset(new DynaTail()); SIND_TRY(p->occ_tails[w]->init(p->dc, p->worker_streams[w]));
     }
     for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers])); }

@@ -58,3 +58,24 @@ def test_1280x720_d455():
     k, d = ORBextractor(1000, 1.2, 8, 20, 7)(gray, mask); rk, rdesc = O.ORBextractor(1000, 1.2, 8, 20, 7).extract(gray, mask)
     assert k.tobytes() == rk.tobytes() and np.array_equal(d, rdesc)
     gpu.close()
+
+
+def test_bonn_configuration():
+    """BASELINE.json configs[2]: Bonn intrinsics (Examples/RGB-D/Bonn.yaml), FAST 20/7, through DynaDetect -> dilate -> ORB for four frames"""
+    from sindslam_amd.dyna import DynaDetect
+    from sindslam_amd.orb import ORBextractor
+    from sindslam_amd.synth import BONN
+    s = SyntheticStream(seed=4242, intr=BONN, motion_scale=1.5)
+    bgr, depth = s.frames(0, 6)
+    Kb = (s.fx, s.fy, s.cx, s.cy, BONN["depth_factor"])
+    gpu = DynaDetect(bgr[1], bgr[0], *Kb); ref = O.DynaDetect(bgr[1], bgr[0], *Kb)
+    orb = ORBextractor(1000, 1.2, 8, BONN["ini_th"], BONN["min_th"]); rorb = O.ORBextractor(1000, 1.2, 8, BONN["ini_th"], BONN["min_th"])
+    for t in range(2, 6):
+        gd, gl = gpu.DetectDynaArea(bgr[t], depth[t], t); rd, rl = ref.detect(bgr[t], depth[t])
+        u = np.logical_or(gd == 255, rd == 255).sum()
+        assert u == 0 or np.logical_and(gd == 255, rd == 255).sum() / u >= 0.99          # IoU bar of BASELINE.json
+        assert np.array_equal(gd == 0, rd == 0) and (gl != rl).mean() <= 1e-3
+        gray = O.bgr2gray(bgr[t]); mask = gpu.dilate15(gd)
+        k, d = orb(gray, mask); rk, rdesc = rorb.extract(gray, O.dilate15(rd))
+        assert k.tobytes() == rk.tobytes() and np.array_equal(d, rdesc)
+    gpu.close(); orb.close()

@@ -36,7 +36,7 @@ struct DynaDebug {           // stage outputs of the last tail call (parity test
     float centers[KM_K][3] = {{0}}; int nClusters = 0;
 };
 
-struct OccResult { BitImg totalArea, occ1, occ2; bool ready = false; };     // CalOccluded outputs of one frame (state free)
+struct OccResult { BitImg totalArea, occ1, occ2; bool ready = false; const float* gridFlow = nullptr; };     // state-free per-frame results computed ahead of the tail: CalOccluded outputs, flow at the 10-px sample grid (host)
 
 // ---- stateful tail of one stream (reference DynaDetect.cc:1377-1666 minus the dense flow) ---------------------------------
 class DynaTail {
@@ -65,7 +65,7 @@ private:
     // page-locked staging of everything that crosses PCIe in a tail
     PinnedBuf<float> h_grid; PinnedBuf<int> h_hist, h_rag; PinnedBuf<uint8_t> h_ab, h_lab8; PinnedBuf<KmState> h_kstate; PinnedBuf<PeacBlockStats> h_blocks;
     PinnedBuf<unsigned long long> h_planes;
-    int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high);
+    int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high, const float* gridFlowPre = nullptr);
     int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
     DevBuf<KmState> kstate; DevBuf<uint16_t> depth_fix; hipGraphExec_t kmGraph[2] = {nullptr, nullptr};
     int kmeans_enqueue(const uint16_t* depth0, bool prevLabels);

@@ -125,12 +125,15 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
 void DynaTail::reset() { dynaLast.assign(N, 0); labelLast.assign(N, 0); highLast.create(W, H); labelLastAny = false; std::memset(lastCnt, 0, sizeof(lastCnt)); std::memset(lastDyn, 0, sizeof(lastDyn)); }
 
 // ---- DD:1163-1367: sample weights -> PROSAC pairs -> homography -> residual -> Otsu / Triangle thresholds -> masks
-int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& high) {
+int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& high, const float* gridFlowPre) {
     const int numCluster = KM_K;
-    SIND_TRY(launch_gather_grid(stream, U, V, grid_d.p, W, H, 10));
     const int gx = (W - 1) / 10, gy = (H - 1) / 10;
-    float* gridFlow = h_grid.p;
-    HIP_TRY(hipMemcpyAsync(gridFlow, grid_d.p, (size_t)2 * gx * gy * sizeof(float), hipMemcpyDeviceToHost, stream));
+    const float* gridFlow = gridFlowPre;                      // the pipeline gathers the sample grid of all frames right after the dense flow
+    if (!gridFlow) {
+        SIND_TRY(launch_gather_grid(stream, U, V, grid_d.p, W, H, 10));
+        HIP_TRY(hipMemcpyAsync(h_grid.p, grid_d.p, (size_t)2 * gx * gy * sizeof(float), hipMemcpyDeviceToHost, stream));
+        gridFlow = h_grid.p;
+    }
     double tq = tick_ms();
     #define QLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; }
     // previous-frame dynamic ratio per cluster (DD:1169-1177)
@@ -148,7 +151,7 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     }
     QLAP(20)
     std::sort(pts.begin(), pts.end(), [](const PW& a, const PW& b) { return a.weight > b.weight; });
-    HIP_TRY(sind_stream_wait(stream));
+    if (!gridFlowPre) HIP_TRY(sind_stream_wait(stream));
     QLAP(21)
     std::vector<Pt2f> in, inLast;
     for (const PW& p : pts) {
@@ -502,7 +505,7 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     BitImg maskLow, maskHigh;
     double tk = tick_ms(); n_frames++;
     #define LAP(i) { const double t_ = tick_ms(); t_stage[i] += t_ - tk; tk = t_; }
-    SIND_TRY(flow_masks(U, V, maskLow, maskHigh));
+    SIND_TRY(flow_masks(U, V, maskLow, maskHigh, pre ? pre->gridFlow : nullptr));
     LAP(0)
     // k-means (DD:1410-1414)
     std::vector<uint8_t> label8; float centers[KM_K][3]; int counts[KM_K];

@@ -527,10 +527,11 @@ __global__ void k_threshold_masks(const uint8_t* __restrict__ magu8, float thr_l
 // gather flow at the 63x47 sample grid (DD:1182-1204) so the host can build the PROSAC-ordered pairs
 __global__ void k_gather_grid(const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ out, int w, int h, int step) {
     const int gx = (w - 1) / step, gy = (h - 1) / step;   // points at step, 2*step, ... < w
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;      // blockIdx.y = frame of a batch (dense [B][h][w] planes)
     if (i >= gx * gy) return;
     const int r = (i / gx + 1) * step, c = (i % gx + 1) * step;
-    out[2 * i] = u[r * w + c]; out[2 * i + 1] = v[r * w + c];
+    const size_t fo = (size_t)b * w * h;
+    out[((size_t)b * gx * gy + i) * 2] = u[fo + r * w + c]; out[((size_t)b * gx * gy + i) * 2 + 1] = v[fo + r * w + c];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -686,9 +687,9 @@ int launch_threshold_masks(hipStream_t s, const uint8_t* magu8, float lo, float 
     hipLaunchKernelGGL(k_threshold_masks, dim3(divup(n, 256)), dim3(256), 0, s, magu8, lo, hi, low, high, n);
     return SIND_OK;
 }
-int launch_gather_grid(hipStream_t s, const float* u, const float* v, float* out, int w, int h, int step) {
+int launch_gather_grid(hipStream_t s, const float* u, const float* v, float* out, int w, int h, int step, int B) {
     const int cnt = ((w - 1) / step) * ((h - 1) / step);
-    hipLaunchKernelGGL(k_gather_grid, dim3(divup(cnt, 256)), dim3(256), 0, s, u, v, out, w, h, step);
+    hipLaunchKernelGGL(k_gather_grid, dim3(divup(cnt, 256), B), dim3(256), 0, s, u, v, out, w, h, step);
     return SIND_OK;
 }
 int launch_scale2(hipStream_t s, float* a, float* b, float sc, size_t n) {

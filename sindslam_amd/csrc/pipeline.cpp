@@ -57,6 +57,7 @@ struct sind_pipe {
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
     struct StepBuf {
         DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; std::vector<uint16_t> depth_h; std::vector<OrbFrameResult> orb; std::vector<OccResult> occ; bool pending = false;
+        DevBuf<float> grid_dev; PinnedBuf<float> grid_h;       // flow at the 10-px sample grid of every frame (DD:1182-1204), gathered right after the dense flow
         TaskGroup occ_group, tail_group; std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
     } sb[2];
     int cur = 0;
@@ -196,6 +197,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     {   // the batch may be cut into slices that run the whole flow pyramid concurrently on their own streams (SIND_FLOW_SPLIT):
         // launches of different slices overlap on the GPU, so one slice's load phase can hide under another slice's iterations
         const int nsl = 1 + (int)p->extra_fronts.size(), Bs = (B + nsl - 1) / nsl;
+        const size_t gsz = (size_t)2 * ((W - 1) / 10) * ((H - 1) / 10);
+        SIND_TRY(sb.grid_dev.alloc(gsz * B)); SIND_TRY(sb.grid_h.alloc(gsz * B));
         std::vector<DynaFront*> fr(1, &p->front); for (auto& f : p->extra_fronts) fr.push_back(f.get());
         HIP_TRY(hipEventRecord(p->ev_pool, p->stream));
         std::vector<int> rc(nsl, SIND_OK); std::vector<std::string> er(nsl); std::vector<std::thread> th;
@@ -204,6 +207,10 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
             DynaFront& f = *fr[i]; f.flow.sor_timer.enabled = true; f.flow.sor_timer.reset();
             if (i > 0 && hipStreamWaitEvent(f.stream, p->ev_pool, 0) != hipSuccess) { rc[i] = SIND_E_HIP; er[i] = "hipStreamWaitEvent failed"; return; }
             rc[i] = f.dense_flow(p->pool.p, cur.data() + b0, p1.data() + b0, p2.data() + b0, nb, sb.U.p + np * b0, sb.V.p + np * b0, nullptr);
+            if (rc[i] == SIND_OK) {       // sample grid of the slice's frames for the tails' PROSAC pairs: one launch + one copy instead of one each per frame
+                rc[i] = launch_gather_grid(f.stream, sb.U.p + np * b0, sb.V.p + np * b0, sb.grid_dev.p + gsz * b0, W, H, 10, nb);
+                if (rc[i] == SIND_OK && hipMemcpyAsync(sb.grid_h.p + gsz * b0, sb.grid_dev.p + gsz * b0, gsz * nb * sizeof(float), hipMemcpyDeviceToHost, f.stream) != hipSuccess) rc[i] = SIND_E_HIP;
+            }
             if (rc[i] == SIND_OK && sind_stream_wait(f.stream) != hipSuccess) rc[i] = SIND_E_HIP;
             if (rc[i] != SIND_OK) er[i] = sind_last_error();
         };
@@ -211,6 +218,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         run(0);
         for (auto& t : th) t.join();
         for (int i = 0; i < nsl; i++) if (rc[i] != SIND_OK) { sind_set_error("dense flow slice %d: %s", i, er[i].c_str()); return rc[i]; }
+        for (int k = 0; k < B; k++) sb.occ[k].gridFlow = sb.grid_h.p + gsz * k;
         p->sor_ms = 0; p->sor_bytes = 0; p->sor_launches = 0; p->sor_slices = nsl;
         std::vector<std::pair<double, double>> iv;
         for (DynaFront* f : fr) { p->sor_ms += f->flow.sor_timer.collect_ms(); p->sor_bytes += f->flow.sor_timer.alg_bytes; p->sor_launches += f->flow.sor_timer.launches; f->flow.sor_timer.intervals(p->ev_pool, iv); }

@@ -36,7 +36,8 @@ struct DynaDebug {           // stage outputs of the last tail call (parity test
     float centers[KM_K][3] = {{0}}; int nClusters = 0;
 };
 
-struct OccResult { BitImg totalArea, occ1, occ2; bool ready = false; const float* gridFlow = nullptr; };     // state-free per-frame results computed ahead of the tail: CalOccluded outputs, flow at the 10-px sample grid (host)
+struct OccResult { BitImg totalArea, occ1, occ2; bool ready = false; const float* gridFlow = nullptr;
+                   uint8_t* occ2_dev = nullptr; uint8_t* depthN_dev = nullptr; };          // optional device slots the producer fills: plane-edge mask and 8-bit normalised depth for the RAG statistics     // state-free per-frame results computed ahead of the tail: CalOccluded outputs, flow at the 10-px sample grid (host)
 
 // ---- stateful tail of one stream (reference DynaDetect.cc:1377-1666 minus the dense flow) ---------------------------------
 class DynaTail {
@@ -71,7 +72,7 @@ private:
     int kmeans_enqueue(const uint16_t* depth0, bool prevLabels);
     int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2);
     int seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,
-                      const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew);
+                      const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew, const OccResult* pre = nullptr);
 };
 
 }  // namespace sind

@@ -332,7 +332,7 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
 
 // ---- DD:653-1018: split every depth cluster on edges into pieces, region-adjacency statistics on the GPU, greedy merge on the host
 int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,
-                            const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew) {
+                            const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew, const OccResult* pre) {
     struct Piece { BitImg img, dil, lianjie; bool hasLianjie = false; float area = 0, score = -10, cz = 0; };
     std::vector<Piece> all;
     double tf = tick_ms();
@@ -403,13 +403,13 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     SIND_TRY(planes_d.alloc(planes_n)); SIND_TRY(rag_d.alloc((size_t)3 * C * C + C + (size_t)C * 256));
     FLAP(11)
     HIP_TRY(hipMemcpyAsync(planes_d.p, planes, planes_n * 8, hipMemcpyHostToDevice, stream));
-    occ2.to_u8((h_ab.p + N), W, 255);
-    HIP_TRY(hipMemcpyAsync(occ2_d.p, (h_ab.p + N), N, hipMemcpyHostToDevice, stream));
+    const uint8_t* occ2_use = pre && pre->occ2_dev ? pre->occ2_dev : occ2_d.p;
+    if (!(pre && pre->occ2_dev)) { occ2.to_u8((h_ab.p + N), W, 255); HIP_TRY(hipMemcpyAsync(occ2_d.p, (h_ab.p + N), N, hipMemcpyHostToDevice, stream)); }
     FLAP(7)
-    SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1));
-    SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, depthN.p, N));
+    const uint8_t* depthN_use = pre && pre->depthN_dev ? pre->depthN_dev : depthN.p;
+    if (!(pre && pre->depthN_dev)) { SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1)); SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, depthN.p, N)); }
     int* ov_d = rag_d.p; int* ovp_d = ov_d + C * C; int* lj_d = ovp_d + C * C; int* la_d = lj_d + C * C; int* hist_dd = la_d + C;
-    SIND_TRY(launch_rag_stats(stream, planes_d.p, C, W, H, wpr, occ2_d.p, depthN.p, ov_d, ovp_d, lj_d, la_d, hist_dd));
+    SIND_TRY(launch_rag_stats(stream, planes_d.p, C, W, H, wpr, occ2_use, depthN_use, ov_d, ovp_d, lj_d, la_d, hist_dd));
     PinnedBuf<int>& rag = h_rag;
     HIP_TRY(hipMemcpyAsync(rag.data(), rag_d.p, ((size_t)3 * C * C + C + (size_t)C * 256) * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
@@ -495,7 +495,10 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
 // ---- DD:1377-1666
 int DynaTail::compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out) {
     HIP_TRY(hipSetDevice(cfg.device));
+    // the depth-only inputs of the RAG statistics go first so that they are finished by the time cal_occluded waits on the stream
+    if (out.depthN_dev) { SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1)); SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, out.depthN_dev, N)); }
     SIND_TRY(cal_occluded(depth_host, depth_dev, out.totalArea, out.occ1, out.occ2));
+    if (out.occ2_dev) { out.occ2.to_u8(h_ab.p + N, W, 255); HIP_TRY(hipMemcpyAsync(out.occ2_dev, h_ab.p + N, N, hipMemcpyHostToDevice, stream)); HIP_TRY(sind_stream_wait(stream)); }
     out.ready = true; return SIND_OK;
 }
 
@@ -533,7 +536,7 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     else SIND_TRY(cal_occluded(depth_host, depth_dev, totalArea, occ1, occ2));
     LAP(3)
     std::vector<uint8_t> label3(N, 0);
-    if (!allLabels.empty()) SIND_TRY(seg_and_merge(allLabels, occ1, occ2, labelForSegEdge, depth_host, depth_dev, label3));
+    if (!allLabels.empty()) SIND_TRY(seg_and_merge(allLabels, occ1, occ2, labelForSegEdge, depth_host, depth_dev, label3, pre && pre->ready ? pre : nullptr));
     LAP(4)
     double tq = tick_ms();
     #define QLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; }

@@ -57,6 +57,7 @@ struct sind_pipe {
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
     struct StepBuf {
         DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; std::vector<uint16_t> depth_h; std::vector<OrbFrameResult> orb; std::vector<OccResult> occ; bool pending = false;
+        DevBuf<uint8_t> occ2_dev, depthN_dev;                  // per frame: plane-edge mask and normalised depth for the tails' RAG statistics (filled by the CalOccluded tasks)
         DevBuf<float> grid_dev; PinnedBuf<float> grid_h;       // flow at the 10-px sample grid of every frame (DD:1182-1204), gathered right after the dense flow
         TaskGroup occ_group, tail_group; std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
     } sb[2];
@@ -185,6 +186,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     // CalOccluded of every frame (state free: depth only) on the streams' own host threads / HIP streams, concurrent with the
     // dense flow below (the host cores would otherwise idle while the GPU runs the flow solver)
     sb.occ.assign(B, OccResult());
+    SIND_TRY(sb.occ2_dev.alloc(np * B)); SIND_TRY(sb.depthN_dev.alloc(np * B));
+    for (int k = 0; k < B; k++) { sb.occ[k].occ2_dev = sb.occ2_dev.p + np * k; sb.occ[k].depthN_dev = sb.depthN_dev.p + np * k; }
     sb.occ_rc.assign(B, SIND_OK); sb.occ_err.assign(B, std::string());
     struct Waiter { TaskGroup& g; ~Waiter() { WorkerPool::wait(g); } } waiter{sb.occ_group};       // no task may outlive this call's buffers on an error return
     for (int k = 0; k < B; k++) p->workers.push(sb.occ_group, [p, &sb, k, np](int w) {

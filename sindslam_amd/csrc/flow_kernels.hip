@@ -241,18 +241,19 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
     const size_t base = (size_t)b * w * h;
     const int off = (ex0 + ey0) & 1;             // local parity of the globally "red" pixels
 
-    for (int i = tid; i < 4 * PL4; i += blockDim.x) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);      // also zeroes the guard ring
-    float a11[SOR_PX], a12[SOR_PX], a22[SOR_PX], b1[SOR_PX], b2[SOR_PX], wp[SOR_PX], wu[SOR_PX], du[SOR_PX], dv[SOR_PX];
+    for (int i = tid; i < 6 * PL4; i += blockDim.x) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);      // also zeroes the guard ring (planes 4, 5: smoothness weights)
+    float a11[SOR_PX], a12[SOR_PX], a22[SOR_PX], b1[SOR_PX], b2[SOR_PX], wp[SOR_PX], du[SOR_PX], dv[SOR_PX];
+    float wtop[SOR_PX];                          // weights of the image row above the tile, loaded by the tile's first row only
     float wl0 = 0.f;
     unsigned valid = 0;
     const bool row_ok = ly < EH && gy >= 0 && gy < h;
     #pragma unroll
-    for (int i = 0; i < SOR_PX; i++) { a11[i] = 1.f; a12[i] = 0.f; a22[i] = 1.f; b1[i] = 0.f; b2[i] = 0.f; wp[i] = 0.f; wu[i] = 0.f; du[i] = 0.f; dv[i] = 0.f; }
+    for (int i = 0; i < SOR_PX; i++) { a11[i] = 1.f; a12[i] = 0.f; a22[i] = 1.f; b1[i] = 0.f; b2[i] = 0.f; wp[i] = 0.f; wtop[i] = 0.f; du[i] = 0.f; dv[i] = 0.f; }
     if (row_ok && gx0 >= 0 && gx0 + SOR_PX <= w) {        // whole strip inside the image: 16-byte loads
         const size_t g = base + (size_t)gy * w + gx0;
         valid = 0xffu;
         ld8(gA11 + g, a11); ld8(gA12 + g, a12); ld8(gA22 + g, a22); ld8(gB1 + g, b1); ld8(gB2 + g, b2); ld8(gW + g, wp); ld8(gUin + g, du); ld8(gVin + g, dv);
-        if (gy > 0) ld8(gW + g - w, wu);
+        if (ly == 0 && gy > 0) ld8(gW + g - w, wtop);
     } else if (row_ok) {
         #pragma unroll
         for (int i = 0; i < SOR_PX; i++) {
@@ -261,12 +262,11 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
                 const size_t g = base + (size_t)gy * w + gx;
                 valid |= 1u << i;
                 a11[i] = gA11[g]; a12[i] = gA12[g]; a22[i] = gA22[g]; b1[i] = gB1[g]; b2[i] = gB2[g]; wp[i] = gW[g];
-                wu[i] = gy > 0 ? gW[g - w] : 0.f;
+                if (ly == 0 && gy > 0) wtop[i] = gW[g - w];
                 du[i] = gUin[g]; dv[i] = gVin[g];
             }
         }
     }
-    if (row_ok && gx0 - 1 >= 0 && gx0 - 1 < w) wl0 = gW[base + (size_t)gy * w + gx0 - 1];
     __syncthreads();
     // LDS addressing (float4 units): plane(parity q, component c) at (q*2 + c)*PL4; strip j of row ly at (ly+1)*RS4 + 1 + j
     const int ro4 = (ly + 1) * RS4 + 1 + j;
@@ -277,8 +277,19 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
         const int pe = s0 == 0 ? 0 : 2, po = s0 == 0 ? 2 : 0;      // plane pair receiving the i-even / i-odd pixels
         lds4[(pe + 0) * PL4 + ro4] = au; lds4[(pe + 1) * PL4 + ro4] = av;
         lds4[(po + 0) * PL4 + ro4] = bu; lds4[(po + 1) * PL4 + ro4] = bv;
+        // smoothness weights, same checkerboard split (plane 4 + parity): a pixel's upper weight is read back from the row above, so the
+        // w_up plane is neither loaded from memory (one ninth of the tile's load requests) nor held in registers
+        lds4[(4 + (pe >> 1)) * PL4 + ro4] = make_float4(wp[0], wp[2], wp[4], wp[6]);
+        lds4[(4 + (po >> 1)) * PL4 + ro4] = make_float4(wp[1], wp[3], wp[5], wp[7]);
+        if (ly == 0) {                           // guard row = image row above the tile: pixel parities are those of local row -1
+            lds4[(4 + (po >> 1)) * PL4 + ro4 - RS4] = make_float4(wtop[0], wtop[2], wtop[4], wtop[6]);
+            lds4[(4 + (pe >> 1)) * PL4 + ro4 - RS4] = make_float4(wtop[1], wtop[3], wtop[5], wtop[7]);
+        }
     }
     __syncthreads();
+    // weight of the pixel left of the strip = last pixel of the neighbouring strip (LDS); at the tile's left edge it reads the zero
+    // guard, which only touches the outermost halo ring (never part of the written interior) or lies outside the image (weight 0)
+    wl0 = lds[4 * ((4 + (s0 ^ 1)) * PL4 + ro4) - 1];
 
     // one half-sweep over the strip pixels START, START+2, START+4, START+6 (compile-time START keeps register indices static);
     // Q = local parity being updated.  Invalid pixels (outside the image / surplus rows) keep du = dv = 0.
@@ -289,6 +300,7 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
             const float4 t2 = lds4[(oq * 2 + 0) * PL4 + ro4 + RS4], t3 = lds4[(oq * 2 + 1) * PL4 + ro4 + RS4];                    \
             const float uu[4] = {t0.x, t0.y, t0.z, t0.w}, vu[4] = {t1.x, t1.y, t1.z, t1.w};                                       \
             const float ud[4] = {t2.x, t2.y, t2.z, t2.w}, vd[4] = {t3.x, t3.y, t3.z, t3.w};                                       \
+            const float4 tw = lds4[(4 + oq) * PL4 + ro4 - RS4]; const float wu[4] = {tw.x, tw.y, tw.z, tw.w};                     \
             /* strip-edge horizontal neighbour: left of pixel 0 (START == 0) or right of pixel 7 (START == 1) */                   \
             const float eu = lds[4 * ((oq * 2 + 0) * PL4 + ro4) + ((START) == 0 ? -1 : 4)];                                       \
             const float ev = lds[4 * ((oq * 2 + 1) * PL4 + ro4) + ((START) == 0 ? -1 : 4)];                                       \
@@ -298,8 +310,8 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
                 const float wl = i == 0 ? wl0 : wp[i == 0 ? 0 : i - 1];                                                           \
                 const float ul = i == 0 ? eu : du[i == 0 ? 0 : i - 1], vl = i == 0 ? ev : dv[i == 0 ? 0 : i - 1];                \
                 const float ur = i == 7 ? eu : du[i == 7 ? 7 : i + 1], vr = i == 7 ? ev : dv[i == 7 ? 7 : i + 1];                \
-                const float sigmaU = wl * ul + wp[i] * ur + wu[i] * uu[k] + wp[i] * ud[k];                                        \
-                const float sigmaV = wl * vl + wp[i] * vr + wu[i] * vu[k] + wp[i] * vd[k];                                        \
+                const float sigmaU = wl * ul + wp[i] * ur + wu[k] * uu[k] + wp[i] * ud[k];                                        \
+                const float sigmaV = wl * vl + wp[i] * vr + wu[k] * vu[k] + wp[i] * vd[k];                                        \
                 float nu = du[i], nv = dv[i];                                                                                     \
                 nu += omega * ((sigmaU + b1[i] - nv * a12[i]) / a11[i] - nu);                                                     \
                 nv += omega * ((sigmaV + b2[i] - nu * a12[i]) / a22[i] - nv);                                                     \
@@ -605,8 +617,8 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         *nlaunch += 2LL * total; return SIND_OK;
     }
     static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_sor_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
-    auto sor_lds_bytes = [](int EW, int nt) { const int NR = 2 * ((nt / 2) / (EW / SOR_PX)); return (size_t)4 * (NR + 2) * (EW / 8 + 2) * sizeof(float4); };
+    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_sor_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+    auto sor_lds_bytes = [](int EW, int nt) { const int NR = 2 * ((nt / 2) / (EW / SOR_PX)); return (size_t)6 * (NR + 2) * (EW / 8 + 2) * sizeof(float4); };
     auto threads_for = [](int EW, int EH) { const int halfn = (EW / SOR_PX) * ((EH + 1) / 2); return 2 * ((halfn + 63) / 64 * 64); };
     const int EWw = (w + SOR_PX - 1) / SOR_PX * SOR_PX;
     if (threads_for(EWw, h) <= SOR_NT) {               // whole image in one workgroup: every iteration in one launch, in place

@@ -10,9 +10,9 @@ struct VarParams {      // cv::VariationalRefinement parameters (variational_ref
 };
 struct HMat { double h[9]; };
 
-// per-level working planes, each [B][h][w] float, allocated once for the finest level
+// per-level working planes (16), each [B][h][w] float, allocated once for the finest level
 struct FlowPlanes {
-    float *avg, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz;   // warped-average image and its derivatives
+    float *avg, *Iz;                                          // warped-average image and temporal difference (k_coef derives the Sobel images from them)
     float *A11, *A12, *A22, *b1, *b2, *wgt;                   // linear system + smoothness weights
     float *Wu, *Wv, *dWu, *dWv, *tWu, *tWv;                    // level flow, increment, W + dW
     float *dWu2, *dWv2;                                       // ping-pong partner of the increment (tiled fused SOR)

@@ -28,9 +28,10 @@ int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     level_off.clear(); pyr_pixels = 0;
     for (auto& l : levels) { level_off.push_back(pyr_pixels); pyr_pixels += (size_t)l.first * l.second; }
     const size_t n0 = (size_t)fw * fh * maxB;
-    SIND_TRY(plane_store.alloc(n0 * 23));
+    static_assert(sizeof(FlowPlanes) == 16 * sizeof(float*), "FlowPlanes is filled as an array of 16 plane pointers");
+    SIND_TRY(plane_store.alloc(n0 * 16));
     float** f = reinterpret_cast<float**>(&planes);
-    for (int i = 0; i < 23; i++) f[i] = plane_store.p + n0 * i;
+    for (int i = 0; i < 16; i++) f[i] = plane_store.p + n0 * i;
     SIND_TRY(pyr0.alloc(pyr_pixels * maxB));
     SIND_TRY(pyr1.alloc(pyr_pixels * maxB));
     return SIND_OK;

@@ -80,35 +80,10 @@ __global__ void k_warp_avg_iz(const float* __restrict__ I0, const float* __restr
     Iz[base + i] = wv - i0;
 }
 
-// prepareBuffers, part 2: the seven Sobel(ksize=1, BORDER_REPLICATE) derivative images.  Second derivatives are
-// differences of first-derivative values at replicated positions, recomputed here from avg with clamped indices
-// (same float operations as differencing the stored Ix / Iy images).
-__global__ void k_derivs(const float* __restrict__ avg, const float* __restrict__ Iz, float* __restrict__ Ix, float* __restrict__ Iy,
-                         float* __restrict__ Ixx, float* __restrict__ Ixy, float* __restrict__ Iyy, float* __restrict__ Ixz,
-                         float* __restrict__ Iyz, int w, int h) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    if (x >= w) return;
-    const size_t base = (size_t)b * w * h; const int i = y * w + x;
-    const float* A = avg + base; const float* Z = Iz + base;
-    auto cx = [&](int v) { return min(max(v, 0), w - 1); };
-    auto cy = [&](int v) { return min(max(v, 0), h - 1); };
-    auto dX = [&](const float* P, int yy, int xx) { return P[yy * w + cx(xx + 1)] - P[yy * w + cx(xx - 1)]; };
-    auto dY = [&](const float* P, int yy, int xx) { return P[cy(yy + 1) * w + xx] - P[cy(yy - 1) * w + xx]; };
-    Ix[base + i] = dX(A, y, x);
-    Iy[base + i] = dY(A, y, x);
-    Ixz[base + i] = dX(Z, y, x);
-    Iyz[base + i] = dY(Z, y, x);
-    Ixx[base + i] = dX(A, y, cx(x + 1)) - dX(A, y, cx(x - 1));
-    Ixy[base + i] = dX(A, cy(y + 1), x) - dX(A, cy(y - 1), x);
-    Iyy[base + i] = dY(A, cy(y + 1), x) - dY(A, cy(y - 1), x);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // One fixed-point iteration set-up: ComputeDataTerm + ComputeSmoothnessTerm{Hor,Vert}Pass gathered per pixel.
 // The four smoothness contributions are added in the order OpenCV's red/black passes produce for the pixel's colour.
-__global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gIx, const float* __restrict__ gIy, const float* __restrict__ gIz,
-                       const float* __restrict__ gIxx, const float* __restrict__ gIxy, const float* __restrict__ gIyy,
-                       const float* __restrict__ gIxz, const float* __restrict__ gIyz, const float* __restrict__ gWu,
+__global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
                        const float* __restrict__ gWv,
                        const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
                        float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt) {
@@ -116,8 +91,19 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gIx,
     if (x >= w) return;
     const size_t base = (size_t)b * w * h; const int i = y * w + x;
     const float zeta2 = P.zeta * P.zeta, eps2 = P.epsilon * P.epsilon, gamma2 = P.gamma / 2, delta2 = P.delta / 2, alpha2 = P.alpha / 2;
-    const float Ix = gIx[base + i], Iy = gIy[base + i], Iz = gIz[base + i], Ixx = gIxx[base + i], Ixy = gIxy[base + i],
-                Iyy = gIyy[base + i], Ixz = gIxz[base + i], Iyz = gIyz[base + i], dU = gdWu[base + i], dV = gdWv[base + i];
+    // The seven Sobel(ksize = 1, BORDER_REPLICATE) derivative images of prepareBuffers are formed here from the warped average and
+    // the temporal difference (the float operations k_derivs used to store, evaluated at the same replicated positions): two planes
+    // are read through the cache instead of eight from memory, in each of the five fixed-point iterations of a level.
+    const float* A = gAvg + base; const float* Z = gIz + base;
+    auto cx = [&](int v) { return min(max(v, 0), w - 1); };
+    auto cy = [&](int v) { return min(max(v, 0), h - 1); };
+    auto dX = [&](const float* Pp, int yy, int xx) { return Pp[yy * w + cx(xx + 1)] - Pp[yy * w + cx(xx - 1)]; };
+    auto dY = [&](const float* Pp, int yy, int xx) { return Pp[cy(yy + 1) * w + xx] - Pp[cy(yy - 1) * w + xx]; };
+    const float Ix = dX(A, y, x), Iy = dY(A, y, x), Iz = Z[i], Ixz = dX(Z, y, x), Iyz = dY(Z, y, x);
+    const float Ixx = dX(A, y, cx(x + 1)) - dX(A, y, cx(x - 1));
+    const float Ixy = dX(A, cy(y + 1), x) - dX(A, cy(y - 1), x);
+    const float Iyy = dY(A, cy(y + 1), x) - dY(A, cy(y - 1), x);
+    const float dU = gdWu[base + i], dV = gdWv[base + i];
     float derivNorm = Ix * Ix + Iy * Iy + zeta2;
     const float Ik1z = Iz + Ix * dU + Iy * dV;
     float weight = (delta2 / sqrtf(Ik1z * Ik1z / derivNorm + eps2)) / derivNorm;
@@ -661,11 +647,10 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     const size_t n = (size_t)w * h * B;
     const dim3 g = grid2d(w, h, B), blk(128);
     hipLaunchKernelGGL(k_warp_avg_iz, g, blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, w, h);
-    hipLaunchKernelGGL(k_derivs, g, blk, 0, s, P.avg, P.Iz, P.Ix, P.Iy, P.Ixx, P.Ixy, P.Iyy, P.Ixz, P.Iyz, w, h);
     HIP_TRY(hipMemsetAsync(P.dWu, 0, n * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(P.dWv, 0, n * sizeof(float), s));
     for (int it = 0; it < V.fixedPointIterations; it++) {
-        hipLaunchKernelGGL(k_coef, g, blk, 0, s, V, w, h, P.Ix, P.Iy, P.Iz, P.Ixx, P.Ixy, P.Iyy, P.Ixz, P.Iyz, P.Wu, P.Wv,
+        hipLaunchKernelGGL(k_coef, g, blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
                            P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt);
         if (timer) timer->begin(s);
         long long nlaunch = 0;

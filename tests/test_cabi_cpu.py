@@ -45,6 +45,10 @@ def test_bad_arguments():
     assert lib().sind_flow_create(8, 8, 1, 0, C.byref(h)) == -1
     assert lib().sind_orb_create(0, C.c_float(1.2), 8, 15, 5, 0, C.byref(h)) == -1
     assert lib().sind_pipe_create(None, C.byref(h)) == -1
+    assert lib().sind_frame_create(None, 640, 480, 1, 16, 0, C.byref(h)) == -1
+    assert lib().sind_match_create(None, C.byref(h)) == -1
+    assert lib().sind_cloud_create(C.c_double(0.0), C.c_double(1.0), C.c_double(0.0), C.c_double(0.0), C.c_double(5000.0), 640, 480, 1, 0, C.byref(h)) == -1
+    assert lib().sind_flow_set_sor(7, 5, 64) == -1 and lib().sind_flow_set_sor(1, 5, 64) == 0
 
 
 def test_product_never_touches_the_oracle():

@@ -68,7 +68,7 @@ private:
     PinnedBuf<unsigned long long> h_planes;
     int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high, const float* gridFlowPre = nullptr);
     int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
-    DevBuf<KmState> kstate; DevBuf<uint16_t> depth_fix; hipGraphExec_t kmGraph[2] = {nullptr, nullptr};
+    DevBuf<KmState> kstate; DevBuf<uint16_t> depth_fix; hipGraphExec_t kmGraph[2] = {nullptr, nullptr}; bool kmGraphBroken = false;
     int kmeans_enqueue(const uint16_t* depth0, bool prevLabels);
     int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2);
     int seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,

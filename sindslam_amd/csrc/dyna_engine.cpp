@@ -251,22 +251,26 @@ int DynaTail::kmeans_enqueue(const uint16_t* depth0, bool prevLabels) {
 int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
     static const bool use_graph = !(getenv("SIND_KM_GRAPH") && atoi(getenv("SIND_KM_GRAPH")) == 0);
     if (labelLastAny) { std::memcpy(h_lab8.p, labelLast.data(), N); HIP_TRY(hipMemcpyAsync(labPrev8.p, h_lab8.p, N, hipMemcpyHostToDevice, stream)); }
-    if (!use_graph) SIND_TRY(kmeans_enqueue(depth_dev, labelLastAny));
-    else {
+    bool graphed = false;
+    if (use_graph && !kmGraphBroken) {
         const int v = labelLastAny ? 1 : 0;
-        if (!kmGraph[v]) {
+        if (!kmGraph[v]) {                       // record once; any failure here only means "launch kernel by kernel from now on" (still the GPU path)
             hipGraph_t g = nullptr;
-            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            const int rc = kmeans_enqueue(depth_fix.p, v != 0);
-            const hipError_t ec = hipStreamEndCapture(stream, &g);
-            if (rc != SIND_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-            HIP_TRY(ec);
-            HIP_TRY(hipGraphInstantiate(&kmGraph[v], g, nullptr, nullptr, 0));
-            HIP_TRY(hipGraphDestroy(g));
+            if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = kmeans_enqueue(depth_fix.p, v != 0);
+                const hipError_t ec = hipStreamEndCapture(stream, &g);
+                if (rc != SIND_OK || ec != hipSuccess || hipGraphInstantiate(&kmGraph[v], g, nullptr, nullptr, 0) != hipSuccess) { kmGraph[v] = nullptr; kmGraphBroken = true; }
+                if (g) (void)hipGraphDestroy(g);
+            } else kmGraphBroken = true;
+            if (kmGraphBroken) { const hipError_t le = hipGetLastError(); fprintf(stderr, "[sind] k-means HIP graph unavailable (%s); launching the chain kernel by kernel\n", hipGetErrorString(le)); }
         }
-        HIP_TRY(hipMemcpyAsync(depth_fix.p, depth_dev, (size_t)N * sizeof(uint16_t), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipGraphLaunch(kmGraph[v], stream));
+        if (!kmGraphBroken) {
+            HIP_TRY(hipMemcpyAsync(depth_fix.p, depth_dev, (size_t)N * sizeof(uint16_t), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipGraphLaunch(kmGraph[v], stream));
+            graphed = true;
+        }
     }
+    if (!graphed) SIND_TRY(kmeans_enqueue(depth_dev, labelLastAny));
     label8.resize(N);
     HIP_TRY(hipMemcpyAsync(h_kstate.p, kstate.p, 4 * sizeof(KmState), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h_ab.p, lab8.p, N, hipMemcpyDeviceToHost, stream));

@@ -110,10 +110,18 @@ def main():
     torch.cuda.synchronize()
     from sindslam_amd.parallel import gather_masks
 
+    gbuf = {}
+
     def gather():
-        if world > 1:   # RCCL gather of the per-frame dynamic masks over xGMI
-            m = torch.from_numpy(pipe.dyna)
-            gather_masks(m.cuda() if args.backend == "nccl" else m)
+        if world > 1:   # RCCL gather of the per-frame dynamic masks over xGMI (page-locked source, persistent device buffers)
+            m = pipe.dyna_pinned if pipe.dyna_pinned is not None else torch.from_numpy(pipe.dyna)
+            if args.backend == "nccl":
+                if "dev" not in gbuf:
+                    gbuf["dev"] = torch.empty_like(m, device="cuda"); gbuf["out"] = torch.empty((world,) + tuple(m.shape), dtype=m.dtype, device="cuda")
+                gbuf["dev"].copy_(m, non_blocking=True)
+                gather_masks(gbuf["dev"], out=gbuf["out"])
+            else:
+                gather_masks(m)
 
     first_dyna = first_kps = None
     for i in range(Wm):                     # warm-up: synchronous steps

@@ -13,12 +13,14 @@ def shard_streams(total_streams: int, rank: int, world: int):
     return list(range(lo, lo + base + (1 if rank < extra else 0)))
 
 
-def gather_masks(local_masks, group=None):
-    """local_masks: torch u8 tensor [S_local, T, H, W] (equal shape on every rank) -> [world, S_local, T, H, W] on every rank."""
+def gather_masks(local_masks, group=None, out=None):
+    """local_masks: torch u8 tensor [S_local, T, H, W] (equal shape on every rank) -> [world, S_local, T, H, W] on every rank.
+    out: optional preallocated result tensor (reused every step by the bench)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(local_masks.shape), dtype=local_masks.dtype, device=local_masks.device)
+    if out is None:
+        out = torch.empty((world,) + tuple(local_masks.shape), dtype=local_masks.dtype, device=local_masks.device)
     if dist.get_backend(group) == "gloo":
         parts = [torch.empty_like(local_masks) for _ in range(world)]
         dist.all_gather(parts, local_masks.contiguous(), group=group)

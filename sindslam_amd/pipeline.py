@@ -28,8 +28,17 @@ class Pipeline:
         check(lib().sind_pipe_create(C.byref(cfg), C.byref(h)), "sind_pipe_create")
         self._h = h
         B = streams * frames_per_step
-        self.dyna = np.zeros((streams, frames_per_step, height, width), np.uint8)
-        self.label = np.zeros_like(self.dyna); self.mask = np.zeros_like(self.dyna)
+        # outputs live in page-locked memory when torch is there (plumbing only): the multi-GPU gather uploads the masks every step
+        shape = (streams, frames_per_step, height, width)
+        self.dyna_pinned = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                self.dyna_pinned = torch.zeros(shape, dtype=torch.uint8).pin_memory()
+        except ImportError:
+            pass
+        self.dyna = self.dyna_pinned.numpy() if self.dyna_pinned is not None else np.zeros(shape, np.uint8)
+        self.label = np.zeros(shape, np.uint8); self.mask = np.zeros(shape, np.uint8)
         self.kps = np.zeros((B, self.cap), KP_DTYPE); self.nkp = np.zeros(B, np.int32); self.desc = np.zeros((B, self.cap, 32), np.uint8)
 
     def close(self):

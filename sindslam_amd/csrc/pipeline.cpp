@@ -2,7 +2,7 @@
 // Examples/RGB-D/rgbd_tum_noros.cc:110-170 (DetectDynaArea -> 15x15 dilate -> ORBextractor via Frame::ExtractORB2) for
 // S independent streams x T frames per step.
 //   phase A (state free, one batch of S*T frames on the shared HIP stream): gray, 0.6 resize, dense flow, ORB front
-//   phase B (stateful, frame order inside a stream, streams in parallel on host threads + their own HIP streams):
+//   phase B (stateful, frame order inside a stream; one task per frame on a fixed worker pool, one HIP stream per worker):
 //            DynaDetect tail, dilation, dynamic-mask erasure of the ORB keypoints.
 #include <algorithm>
 #include <chrono>
@@ -248,7 +248,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     return SIND_OK;
 }
 
-// ---- phase B of one step (stateful tails, one host thread per stream or a bounded pool, each on its own HIP stream)
+// ---- phase B of one step (stateful tails on the worker pool)
 struct PipeOut { uint8_t *dyna, *label, *mask; sind_keypoint* kps; int cap; int* nkp; uint8_t* desc; };
 // One task = one frame of one stream; it queues the stream's next frame when it is done.  Frames of a stream stay in order, and the
 // pool always sees up to S runnable tasks, so the workers stay busy until the end of the phase (a task per stream left the second

@@ -85,6 +85,31 @@ __device__ void km_try_finalize(KmState* st) {
     st->phase = 1;                                        // centres of this iteration are final
     if (st->iter == (st->maxCount > 2 ? st->maxCount : 2) || max_center_shift <= st->eps2) st->done = 1;
 }
+// Wave-level sum of the 48 per-lane accumulators (12 clusters x {x, y, z, count}) as a reduce-scatter: in every step a lane hands half
+// of its values to its partner and keeps the other half, so 51 shuffles replace 48 x 6; after the xor-4 step three values are left per
+// lane, finished by two plain exchange steps.  Lane l (l % 4 == 0) ends up with the sums of accumulators j + 3*b2 + 6*b3 + 12*b4 + 24*b5
+// (b = bits of l), which it writes to acc[...][wave].  Fixed order, hence deterministic.
+__device__ __forceinline__ void km_wave_reduce_store(double (&s)[KM_K][4], double (*acc)[4][4], int lane, int wv) {
+    double v[48];
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++) { v[4 * k] = s[k][0]; v[4 * k + 1] = s[k][1]; v[4 * k + 2] = s[k][2]; v[4 * k + 3] = s[k][3]; }
+    #define KM_STEP(HALF, MASK)                                                                               \
+        _Pragma("unroll")                                                                                     \
+        for (int j = 0; j < (HALF); j++) {                                                                    \
+            const bool up = (lane & (MASK)) != 0;                                                             \
+            const double send = up ? v[j] : v[j + (HALF)], keep = up ? v[j + (HALF)] : v[j];                  \
+            v[j] = keep + __shfl_xor(send, (MASK));                                                           \
+        }
+    KM_STEP(24, 32) KM_STEP(12, 16) KM_STEP(6, 8) KM_STEP(3, 4)
+    #undef KM_STEP
+    #pragma unroll
+    for (int j = 0; j < 3; j++) { v[j] += __shfl_xor(v[j], 2); v[j] += __shfl_xor(v[j], 1); }
+    if ((lane & 3) == 0) {
+        const int base = ((lane >> 2) & 1) * 3 + ((lane >> 3) & 1) * 6 + ((lane >> 4) & 1) * 12 + ((lane >> 5) & 1) * 24;
+        #pragma unroll
+        for (int j = 0; j < 3; j++) { const int a = base + j; acc[a >> 2][a & 3][wv] = v[j]; }
+    }
+}
 // Centre step of one k-means iteration in ONE workgroup: reduce the per-block partial sums, repair every empty cluster
 // (block-wide farthest-point search over the biggest cluster, as cv::kmeans does, repeated until no cluster is empty), scale,
 // shift test, stop decision.  No host round trip and no provisioning limit.
@@ -116,12 +141,22 @@ __global__ void __launch_bounds__(1024) k_km_update(const double* __restrict__ p
     while (s_fix >= 0) {                                   // uniform: s_fix is shared
         const int which = st->max_k; const float c0 = st->base[0], c1 = st->base[1], c2 = st->base[2];
         unsigned long long b = 0;
-        for (int i = t; i < n; i += blockDim.x) {
-            if (labels[i] != which) continue;
-            float d0 = px[i] - c0; float d = 0.f; d += d0 * d0; d0 = py[i] - c1; d += d0 * d0; d0 = pz[i] - c2; d += d0 * d0;
+        // four points per lane and step with 16-byte loads: the scan is one workgroup walking the whole level, so its cost is the number
+        // of dependent memory round trips (it was ~280 us at 640x480 with scalar loads, and empty clusters are not rare)
+        auto consider = [&](int l, float x, float y, float z, int i) {
+            if (l != which) return;
+            float d0 = x - c0; float d = 0.f; d += d0 * d0; d0 = y - c1; d += d0 * d0; d0 = z - c2; d += d0 * d0;
             const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;      // ties -> largest index ("max_dist <= dist")
             b = b > key ? b : key;
+        };
+        const int n4 = n >> 2;
+        #pragma unroll 2
+        for (int q = t; q < n4; q += blockDim.x) {
+            const int4 L = reinterpret_cast<const int4*>(labels)[q];
+            const float4 X = reinterpret_cast<const float4*>(px)[q], Y = reinterpret_cast<const float4*>(py)[q], Z = reinterpret_cast<const float4*>(pz)[q];
+            consider(L.x, X.x, Y.x, Z.x, 4 * q); consider(L.y, X.y, Y.y, Z.y, 4 * q + 1); consider(L.z, X.z, Y.z, Z.z, 4 * q + 2); consider(L.w, X.w, Y.w, Z.w, 4 * q + 3);
         }
+        for (int i = (n4 << 2) + t; i < n; i += blockDim.x) consider(labels[i], px[i], py[i], pz[i], i);
         for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(b, o); b = b > v ? b : v; }
         if ((t & 63) == 0) wbest[t >> 6] = b;
         __syncthreads();
@@ -153,10 +188,7 @@ __global__ void __launch_bounds__(256) k_km_partial_dev(const float* __restrict_
         #pragma unroll
         for (int k = 0; k < KM_K; k++) if (l == k) { s[k][0] += x; s[k][1] += y; s[k][2] += z; s[k][3] += 1.0; }
     }
-    #pragma unroll
-    for (int k = 0; k < KM_K; k++)
-        #pragma unroll
-        for (int c = 0; c < 4; c++) { double v = s[k][c]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); if (lane == 0) acc[k][c][wv] = v; }
+    km_wave_reduce_store(s, acc, lane, wv);
     __syncthreads();
     if (tid < KM_K * 4) { const int k = tid >> 2, c = tid & 3; partial[((size_t)blockIdx.x * KM_K + k) * 4 + c] = ((acc[k][c][0] + acc[k][c][1]) + acc[k][c][2]) + acc[k][c][3]; }
 }
@@ -188,10 +220,7 @@ __global__ void __launch_bounds__(256) k_km_assign_partial(const float* __restri
         #pragma unroll
         for (int k = 0; k < KM_K; k++) if (best == k) { s[k][0] += x; s[k][1] += y; s[k][2] += z; s[k][3] += 1.0; }
     }
-    #pragma unroll
-    for (int k = 0; k < KM_K; k++)
-        #pragma unroll
-        for (int c = 0; c < 4; c++) { double v = s[k][c]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); if (lane == 0) acc[k][c][wv] = v; }
+    km_wave_reduce_store(s, acc, lane, wv);
     __syncthreads();
     if (tid < KM_K * 4) { const int k = tid >> 2, c = tid & 3; partial[((size_t)blockIdx.x * KM_K + k) * 4 + c] = ((acc[k][c][0] + acc[k][c][1]) + acc[k][c][2]) + acc[k][c][3]; }
 }

@@ -362,14 +362,24 @@ __global__ void __launch_bounds__(256) k_rag_stats(const unsigned long long* __r
     const int n = w * h;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int y = i / w, x = i - y * w; const size_t widx = (size_t)y * wpr + (x >> 6); const int bit = x & 63;
+        // The 64 lanes of a wave sit on the 64 pixels of ONE plane word (w % 64 == 0 and every stride is a multiple of 64): lane c fetches
+        // the three words of piece c once, and each lane then picks its own bit out of the words broadcast with readlane -- 3 loads per
+        // 64 pieces instead of 3*C dependent loads per pixel, which is what this kernel's time used to be.
         unsigned long long mi[4] = {0, 0, 0, 0}, md[4] = {0, 0, 0, 0}, ml[4] = {0, 0, 0, 0};
-        for (int c = 0; c < C; c++) {
-            const unsigned long long bi = (planes[((size_t)0 * C + c) * pw + widx] >> bit) & 1ull;
-            const unsigned long long bd = (planes[((size_t)1 * C + c) * pw + widx] >> bit) & 1ull;
-            const unsigned long long bl = (planes[((size_t)2 * C + c) * pw + widx] >> bit) & 1ull;
-            const int k = c >> 6, sft = c & 63;
-            #pragma unroll
-            for (int q = 0; q < 4; q++) if (q == k) { mi[q] |= bi << sft; md[q] |= bd << sft; ml[q] |= bl << sft; }
+        const int lane = threadIdx.x & 63;
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q >= NW) break;
+            const int c = (q << 6) + lane;
+            unsigned long long wi = 0, wd = 0, wl = 0;
+            if (c < C) { wi = planes[((size_t)0 * C + c) * pw + widx]; wd = planes[((size_t)1 * C + c) * pw + widx]; wl = planes[((size_t)2 * C + c) * pw + widx]; }
+            const int cnt = min(64, C - (q << 6));
+            for (int cc = 0; cc < cnt; cc++) {
+                const unsigned long long a = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wi >> 32), cc) << 32) | (unsigned)__builtin_amdgcn_readlane((int)wi, cc);
+                const unsigned long long d = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wd >> 32), cc) << 32) | (unsigned)__builtin_amdgcn_readlane((int)wd, cc);
+                const unsigned long long l = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wl >> 32), cc) << 32) | (unsigned)__builtin_amdgcn_readlane((int)wl, cc);
+                mi[q] |= ((a >> bit) & 1ull) << cc; md[q] |= ((d >> bit) & 1ull) << cc; ml[q] |= ((l >> bit) & 1ull) << cc;
+            }
         }
         const int dv = depthN[i];
         if (dv < 255) {

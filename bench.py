@@ -39,24 +39,32 @@ def make_inputs(S, T, nsteps, seed=12345):
     return bgr, depth
 
 
-def cpu_baseline(n_pairs, gpu_dyna, gpu_kps):
-    """Oracle ('port') DynaDetect + dilate + ORB on one host core over a bounded sample of the same workload: the first frame
-    pairs of stream 0 (the unmodified seed-12345 sequence), which the GPU pipeline processed in its first step -> also the
-    parity figures of the metric ("mask IoU vs CPU ref", ORB keypoints bit-exact)."""
+def cpu_baseline(n_par, bgr, depth, gpu_dyna, gpu_kps, threads=8, n_timed=10):
+    """Oracle ('port') DynaDetect + dilate + ORB on the host over a bounded sample of the same workload: the first `n_timed` frame
+    pairs of the bench's first `threads` streams, one scalar oracle instance per thread (the reference pins its own loops to
+    omp_set_num_threads(8), DynaDetect.cc:268) -> also the parity figures of the metric ("mask IoU vs CPU ref", ORB keypoints
+    bit-exact) on the first n_par frames of each of those streams, which the GPU pipeline processed in its first step."""
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from sindslam_amd.synth import SyntheticStream, TUM3
-    n_timed = max(n_pairs, 10)              # ~10 s of single-core work
-    b, d = SyntheticStream().frames(0, n_timed + 2)
-    t, st, dyna, kps = O.baseline_run(b, d, TUM3, want_outputs=True)
-    ious = []
-    for i in range(n_pairs):
-        a, r = gpu_dyna[i] == 255, dyna[i] == 255; u = np.logical_or(a, r).sum()
-        ious.append(1.0 if u == 0 else float(np.logical_and(a, r).sum() / u))
-    kp_equal = sum(int(gpu_kps[i].tobytes() == kps[i].tobytes()) for i in range(n_pairs))
-    base = {"value": n_timed / t, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-            "sample": f"{n_timed} frame pairs of the synthetic 640x480 stream, {t:.1f} s (flow {st[0]:.1f} s, tail {st[1]:.1f} s, orb {st[2]:.1f} s)"}
-    parity = {"mask_iou_mean": float(np.mean(ious)), "mask_iou_min": float(np.min(ious)), "orb_keypoints_bit_exact_frames": kp_equal, "frames": n_pairs,
+    from sindslam_amd.synth import TUM3
+    threads = max(1, min(threads, bgr.shape[0], os.cpu_count() or 1)); n_timed = min(max(n_par, n_timed), bgr.shape[1] - 2)
+    O.lib()                                  # load before the clock starts; ctypes calls release the GIL
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(lambda s: O.baseline_run(bgr[s, :n_timed + 2], depth[s, :n_timed + 2], TUM3, want_outputs=True), range(threads)))
+    wall = time.perf_counter() - t0
+    ious = []; kp_equal = 0; st = np.zeros(3); cpu_s = 0.0
+    for s, (t, stage, dyna, kps) in enumerate(res):
+        st += stage; cpu_s += t
+        for i in range(n_par):
+            a, r = gpu_dyna[s][i] == 255, dyna[i] == 255; u = np.logical_or(a, r).sum()
+            ious.append(1.0 if u == 0 else float(np.logical_and(a, r).sum() / u))
+            kp_equal += int(gpu_kps[s][i].tobytes() == kps[i].tobytes())
+    base = {"value": threads * n_timed / wall, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} streams x {n_timed} frame pairs of the synthetic 640x480 workload, one oracle instance per thread: {wall:.1f} s wall, "
+                      f"{cpu_s:.1f} core-seconds (flow {st[0]:.1f}, tail {st[1]:.1f}, orb {st[2]:.1f}) = {threads * n_timed / cpu_s:.2f} pairs/s per core"}
+    parity = {"mask_iou_mean": float(np.mean(ious)), "mask_iou_min": float(np.min(ious)), "orb_keypoints_bit_exact_frames": kp_equal, "frames": len(ious),
               "reference": "CPU oracle (parity unpinned: the reference ships no golden vectors and cannot be built here)"}
     return base, parity
 
@@ -79,6 +87,8 @@ def main():
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the cpu_baseline leg (one oracle instance and one stream each)")
+    ap.add_argument("--host-input", action="store_true", help="hand over HOST buffers each step (sind_pipe_process, PCIe-inclusive rate; DESIGN.md 6) instead of HBM-resident inputs")
     ap.add_argument("--pipelined", action="store_true", help="software-pipeline consecutive steps (submit/flush); off by default: measured slower on MI355X")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker pool size (0 = library default, the GPU box's CPU share)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
@@ -123,26 +133,37 @@ def main():
             else:
                 gather_masks(m)
 
+    NPS = min(S, args.cpu_threads) if (world == 1 and not args.no_cpu_baseline) else 0
+
+    def parity_sample():
+        return [pipe.dyna[s].copy() for s in range(NPS)], [[pipe.keypoints(s, t)[0].copy() for t in range(T)] for s in range(NPS)]
+
+    host_b = host_d = None
+    if args.host_input:
+        host_b = [np.ascontiguousarray(bgr[:, 2 + i * T: 2 + (i + 1) * T]) for i in range(nsteps)]
+        host_d = [np.ascontiguousarray(depth[:, 2 + i * T: 2 + (i + 1) * T]) for i in range(nsteps)]
     first_dyna = first_kps = None
     for i in range(Wm):                     # warm-up: synchronous steps
         pipe.process_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()); gather()
-        if i == 0:                          # stream 0's first T results, for the parity figures below
-            first_dyna = pipe.dyna[0].copy(); first_kps = [pipe.keypoints(0, t)[0].copy() for t in range(T)]
+        if i == 0:                          # the first streams' first T results, for the parity figures below
+            first_dyna, first_kps = parity_sample()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sor_ms = sor_bytes = sor_union = 0.0; sor_launches = 0; sor_slices = 1; stages = np.zeros(5)
+    sor_ms = sor_bytes = sor_union = 0.0; sor_launches = 0; sor_slices = 1; stages = np.zeros(6)
     for i in range(Wm, Wm + K):             # timed: software-pipelined steps (phase A of step i overlaps the tails of step i-1)
-        if not args.pipelined:
+        if args.host_input:
+            pipe.process(host_b[i], host_d[i]); gather()
+        elif not args.pipelined:
             pipe.process_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()); gather()
         elif pipe.submit_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()):
             gather()
-        if first_dyna is None and not args.pipelined:     # --warmup 0: take the parity sample from the first timed step (1.2 MB copy)
-            first_dyna = pipe.dyna[0].copy(); first_kps = [pipe.keypoints(0, t)[0].copy() for t in range(T)]
+        if first_dyna is None and not args.pipelined:     # --warmup 0: take the parity sample from the first timed step (a few MB copied)
+            first_dyna, first_kps = parity_sample()
         st = pipe.stats()
         sor_ms += st["sor_ms"]; sor_bytes += st["sor_alg_bytes"]; sor_launches += st["sor_launches"]; sor_union += st["sor_union_ms"]; sor_slices = st["sor_slices"]
-        stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"]])
+        stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"], st["upload_ms"]])
     if args.pipelined and pipe.flush():      # drain the last step inside the timed region
         gather()
     torch.cuda.synchronize()
@@ -164,15 +185,16 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "TUM fr3/walking_xyz-shaped synthetic RGB-D stream, 640x480, TUM3 intrinsics, FAST 15/5, 1500 features",
-                       "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world, "parallelism": f"stream-sharded x{world}", "pipelined": bool(args.pipelined)},
+                       "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world, "parallelism": f"stream-sharded x{world}", "pipelined": bool(args.pipelined),
+                       "inputs": "host buffers, H2D inside the timed region" if args.host_input else "resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": pmc_traffic(S * T / max(sor_slices, 1)),
                          "kernel": "k_sor_fused", "launches": sor_launches, "avg_launch_us": (sor_ms * 1e3 / sor_launches) if sor_launches else None,
                          "alg_bytes_per_launch": (sor_bytes / sor_launches) if sor_launches else None,
                          "concurrent_launches": sor_slices, "achieved_per_launch": per_launch, "solver_busy_ms_per_step": sor_union / K},
-            "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "total": stages[4] / K},
+            "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "host_upload": stages[5] / K, "total": stages[4] / K},
         }
         if not args.no_cpu_baseline and world == 1 and first_dyna is not None:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(min(T, 4), first_dyna, first_kps)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(min(T, 4), bgr, depth, first_dyna, first_kps, threads=NPS)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

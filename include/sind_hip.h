@@ -137,7 +137,7 @@ int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* d
                          sind_keypoint* kps, int cap, int* nkp, uint8_t* desc, int* have_output);
 int sind_pipe_flush(sind_pipe* p, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated, sind_keypoint* kps, int cap, int* nkp, uint8_t* desc,
                     int* have_output);
-/* per-stage wall times of the last step in milliseconds: {front_gray, dense_flow, orb_front, depth_copy, tails, total},
+/* per-stage wall times of the last step in milliseconds: {front_gray, dense_flow, orb_front, host_upload (sind_pipe_process only, else 0), tails, total},
  * plus HIP-event statistics of the flow solver: sor_launches, sor_ms (sum of event-bracketed SOR launch groups),
  * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */
 int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, double* sor_ms, double* sor_alg_bytes);

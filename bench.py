@@ -69,6 +69,28 @@ def cpu_baseline(n_par, bgr, depth, gpu_dyna, gpu_kps, threads=8, n_timed=10):
     return base, parity
 
 
+def thread_cpu_seconds():
+    """CPU seconds (user + system) of this process's live threads, summed by thread name (/proc/self/task/*/stat)."""
+    tick = os.sysconf("SC_CLK_TCK"); acc = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            st = open(f"/proc/self/task/{tid}/stat").read()
+        except OSError:
+            continue
+        name = st[st.index("(") + 1: st.rindex(")")]; f = st[st.rindex(")") + 2:].split()
+        acc[name] = acc.get(name, 0.0) + (int(f[11]) + int(f[12])) / tick
+    return acc
+
+
+def cgroup_throttle():
+    """(periods, throttled periods, throttled microseconds) of this container's CPU quota (cgroup v2 cpu.stat), or None"""
+    try:
+        kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines())
+        return int(kv["nr_periods"]), int(kv["nr_throttled"]), int(kv["throttled_usec"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def pmc_traffic(pairs_per_step):
     """HBM bytes per k_sor_fused launch from the committed rocprofv3 PMC passes (profiles/r01/v8_pmc_k_sor_fused.json: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction), scaled to this batch; None if absent."""
@@ -89,6 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the cpu_baseline leg (one oracle instance and one stream each)")
     ap.add_argument("--host-input", action="store_true", help="hand over HOST buffers each step (sind_pipe_process, PCIe-inclusive rate; DESIGN.md 6) instead of HBM-resident inputs")
+    ap.add_argument("--thread-cpu", action="store_true", help="print the CPU seconds the live threads used inside the timed region, by thread name (stderr)")
     ap.add_argument("--pipelined", action="store_true", help="software-pipeline consecutive steps (submit/flush); off by default: measured slower on MI355X")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker pool size (0 = library default, the GPU box's CPU share)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
@@ -150,7 +173,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    thr0 = cgroup_throttle()
+    t0 = time.perf_counter(); c0 = time.process_time(); th0 = thread_cpu_seconds() if args.thread_cpu else None
     sor_ms = sor_bytes = sor_union = 0.0; sor_launches = 0; sor_slices = 1; stages = np.zeros(6)
     for i in range(Wm, Wm + K):             # timed: software-pipelined steps (phase A of step i overlaps the tails of step i-1)
         if args.host_input:
@@ -169,10 +193,17 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    th1 = thread_cpu_seconds() if args.thread_cpu else None
+    thr1 = cgroup_throttle()
+    dt = time.perf_counter() - t0; cpu_busy = (time.process_time() - c0) / dt      # host cores this rank kept busy (all threads)
     if world > 1:
         tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     pairs = S * T * K * world
+    if args.thread_cpu and rank == 0:       # short-lived threads (flow slices, ORB, octree) that ended before the second sample are not listed
+        for name in sorted(th1, key=lambda n: -(th1[n] - th0.get(n, 0.0))):
+            print(f"[thread-cpu] {name:16s} {(th1[name] - th0.get(name, 0.0)) / K * 1e3:9.1f} core-ms per step", file=sys.stderr)
+        live = sum(th1[n] - th0.get(n, 0.0) for n in th1)
+        print(f"[thread-cpu] {'(exited threads)':16s} {(cpu_busy * dt - live) / K * 1e3:9.1f} core-ms per step   total {cpu_busy * dt / K * 1e3:.1f}", file=sys.stderr)
     if rank == 0:
         # The batch runs as `sor_slices` slices on concurrent HIP streams, so solver launches overlap on the GPU.  achieved = algorithmic
         # bytes of all launches / time with at least one solver launch in flight (union of the HIP-event intervals of all slices on a
@@ -192,6 +223,8 @@ def main():
                          "alg_bytes_per_launch": (sor_bytes / sor_launches) if sor_launches else None,
                          "concurrent_launches": sor_slices, "achieved_per_launch": per_launch, "solver_busy_ms_per_step": sor_union / K},
             "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "host_upload": stages[5] / K, "total": stages[4] / K},
+            "host_cores_busy": cpu_busy,
+            "cpu_quota": None if not (thr0 and thr1) else {"periods": thr1[0] - thr0[0], "throttled_periods": thr1[1] - thr0[1], "throttled_ms": (thr1[2] - thr0[2]) / 1e3},
         }
         if not args.no_cpu_baseline and world == 1 and first_dyna is not None:
             out["cpu_baseline"], out["parity"] = cpu_baseline(min(T, 4), bgr, depth, first_dyna, first_kps, threads=NPS)

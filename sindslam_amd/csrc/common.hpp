@@ -50,6 +50,13 @@ static inline hipError_t sind_stream_wait(hipStream_t s) {
     return e;
 }
 
+// Same for an event: used to bound how far a launching thread runs ahead of the GPU (a HIP launch into a full queue spins)
+static inline hipError_t sind_event_wait(hipEvent_t ev) {
+    hipError_t e = hipEventQuery(ev);
+    while (e == hipErrorNotReady) { std::this_thread::sleep_for(std::chrono::microseconds(50)); e = hipEventQuery(ev); }
+    return e;
+}
+
 // simple owning device buffer
 template <class T>
 struct DevBuf {

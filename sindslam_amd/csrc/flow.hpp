@@ -62,8 +62,11 @@ public:
     int varref_f32(const float* I0, const float* I1, int w, int h, int B, float* u, float* v, const VarParams& V);
     FlowPlanes planes{};
     SorTimer sor_timer;
+    int launch_ahead = 3;                        // pyramid levels the launching thread may be ahead of the GPU (0 = unbounded)
+    ~FlowEngine() { for (hipEvent_t e : level_done) (void)hipEventDestroy(e); }
 private:
     DevBuf<float> plane_store, pyr0, pyr1;
+    std::vector<hipEvent_t> level_done;          // one event per pyramid level
     float* level_ptr(DevBuf<float>& pyr, int l, int B) { return pyr.p + level_off[l] * (size_t)B; }
 };
 

@@ -24,6 +24,7 @@ int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     if (const char* e = getenv("SIND_SOR_TILEW")) g_sor_tile_w = atoi(e) == 64 ? 64 : 128;
     if (const char* e = getenv("SIND_SOR_FUSE")) g_sor_fuse = std::max(1, std::min(atoi(e), 12));
     if (const char* e = getenv("SIND_SOR_XCD")) g_sor_xcd = atoi(e) != 0;
+    if (const char* e = getenv("SIND_LAUNCH_AHEAD")) launch_ahead = std::max(0, atoi(e));       // 0: unbounded
     levels = deepflow_sizes(fw, fh);
     level_off.clear(); pyr_pixels = 0;
     for (auto& l : levels) { level_off.push_back(pyr_pixels); pyr_pixels += (size_t)l.first * l.second; }
@@ -56,9 +57,15 @@ int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, 
     const size_t nc = (size_t)levels[L - 1].first * levels[L - 1].second * B;
     HIP_TRY(hipMemsetAsync(P.Wu, 0, nc * sizeof(float), stream));
     HIP_TRY(hipMemsetAsync(P.Wv, 0, nc * sizeof(float), stream));
+    // One level is ~36 launches.  A thread that enqueues the whole pyramid runs far ahead of the GPU, fills the queue and then SPINS inside
+    // the launch call for the rest of the solve (measured: a slice thread burnt a full core, 215 ms per step); so the thread stays at
+    // most `launch_ahead` levels ahead and sleeps on the level events instead.
+    while ((int)level_done.size() < L) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); level_done.push_back(e); }
     for (int l = L - 1; l >= 0; --l) {
         const int w = levels[l].first, h = levels[l].second;
+        if (launch_ahead > 0 && l + launch_ahead < L) HIP_TRY(sind_event_wait(level_done[l + launch_ahead]));
         SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V, &sor_timer));
+        HIP_TRY(hipEventRecord(level_done[l], stream));
         if (l > 0) {
             const int nw = levels[l - 1].first, nh = levels[l - 1].second;
             SIND_TRY(launch_resize_f32(stream, P.Wu, P.tWu, w, h, nw, nh, B, inv_scale, true));

@@ -11,7 +11,8 @@
 #include <limits>
 #include <map>
 #include <queue>
-#include <set>
+#include <algorithm>
+#include <iterator>
 #include "host.hpp"
 
 namespace sind {
@@ -51,7 +52,7 @@ void jacobi3(const double K[3][3], double s[3], double V[3][3]) {
 struct Seg {
     double sx = 0, sy = 0, sz = 0, sxx = 0, syy = 0, szz = 0, sxy = 0, syz = 0, sxz = 0; int N = 0;
     int rid = 0; double mse = 0, center[3] = {0, 0, 0}, normal[3] = {0, 0, 0}; bool nouse = false;
-    std::set<int> nbs;
+    std::vector<int> nbs;                    // neighbour node indices, ascending (the iteration order of the candidate loop)
     void fit() {
         const double sc = 1.0 / N;
         center[0] = sx * sc; center[1] = sy * sc; center[2] = sz * sc;
@@ -67,39 +68,37 @@ struct Seg {
 };
 
 struct Fitter {
-    const PeacInput& in; Params P; const int W, H, bw = 16, bh = 16, minSupport = 2000, maxStep = 100000;
+    const PeacInput& in; Params P; const int W, H; static constexpr int bw = 16, bh = 16, minSupport = 2000, maxStep = 100000;
     std::vector<Seg> pool; std::vector<int> dsParent, dsSize; std::vector<int> extracted;
-    explicit Fitter(const PeacInput& i) : in(i), W(i.w), H(i.h) {}
+    const float invScale;
+    explicit Fitter(const PeacInput& i) : in(i), W(i.w), H(i.h), invScale(1.0f / i.depthScale) {}
     struct QCmp { const std::vector<Seg>* pool; bool operator()(int a, int b) const { return (*pool)[b].mse < (*pool)[a].mse; } };
     typedef std::priority_queue<int, std::vector<int>, QCmp> Queue;
 
     int find(int x) { if (dsParent[x] != x) dsParent[x] = find(dsParent[x]); return dsParent[x]; }
     void unite(int x, int y) { int a = find(x), b = find(y); if (a == b) return; if (dsSize[a] < dsSize[b]) { dsParent[a] = b; dsSize[b] += dsSize[a]; } else { dsParent[b] = a; dsSize[a] += dsSize[b]; } }
-    void link(int a, int b) { pool[a].nbs.insert(b); pool[b].nbs.insert(a); }
-    void unlink_all(int a) { for (int nb : pool[a].nbs) pool[nb].nbs.erase(a); pool[a].nbs.clear(); }
-    std::vector<float> cloud;     // organised cloud (x, y, z) of the frame, z = NaN-equivalent flag -1 for missing depth
-    void build_cloud() {
-        cloud.resize((size_t)W * H * 3);
-        const float inv = 1.0f / in.depthScale;
-        for (int row = 0; row < H; row++) { const uint16_t* dr = in.depth + (size_t)row * W; float* c = &cloud[(size_t)row * W * 3];
-            for (int col = 0; col < W; col++) { const float d = (float)dr[col];
-                if (d < 1e-3f) { c[3 * col + 2] = -1.f; continue; }
-                const float z = d * inv; c[3 * col] = (col - in.cx) * z / in.fx; c[3 * col + 1] = (row - in.cy) * z / in.fy; c[3 * col + 2] = z; } }
-    }
+    static void set_insert(std::vector<int>& v, int x) { auto it = std::lower_bound(v.begin(), v.end(), x); if (it == v.end() || *it != x) v.insert(it, x); }
+    static void set_erase(std::vector<int>& v, int x) { auto it = std::lower_bound(v.begin(), v.end(), x); if (it != v.end() && *it == x) v.erase(it); }
+    void link(int a, int b) { set_insert(pool[a].nbs, b); set_insert(pool[b].nbs, a); }
+    void unlink_all(int a) { for (int nb : pool[a].nbs) set_erase(pool[nb].nbs, a); pool[a].nbs.clear(); }
+    // point of the organised cloud (float arithmetic of the reference's cloud construction), computed where the region grow needs it:
+    // the grow looks at ~2/3 of the pixels once, a materialised cloud would cost a pass over all of them plus 3.7 MB of traffic
     bool point(int row, int col, double p[3]) const {
-        const float* c = &cloud[((size_t)row * W + col) * 3];
-        if (c[2] < 0.f) return false;
-        p[0] = (double)c[0]; p[1] = (double)c[1]; p[2] = (double)c[2];
+        const float d = (float)in.depth[(size_t)row * W + col];
+        if (d < 1e-3f) return false;
+        const float z = d * invScale;
+        p[0] = (double)((col - in.cx) * z / in.fx); p[1] = (double)((row - in.cy) * z / in.fy); p[2] = (double)z;
         return true;
     }
 
+    std::vector<int> nbv;
     int cluster(Queue& q) {
         int step = 0;
         while (!q.empty() && step <= maxStep) {
             const int p = q.top(); q.pop();
             if (pool[p].nouse) continue;
             int cand = -1, cand_nb = -1;
-            const std::vector<int> nbv(pool[p].nbs.begin(), pool[p].nbs.end());   // pool may reallocate while candidates are appended
+            nbv = pool[p].nbs;                                                      // pool may reallocate while candidates are appended
             for (int nb : nbv) {
                 if (pool[p].similarity(pool[nb]) < P.simMerge) continue;
                 Seg m; const Seg &a = pool[p], &b = pool[nb];
@@ -110,9 +109,12 @@ struct Fitter {
             if (cand >= 0 && pool[cand].mse < P.mse_merge(pool[cand].center[2])) {
                 q.push(cand);
                 unite(pool[p].rid, pool[cand_nb].rid);
-                std::set<int> u = pool[p].nbs; u.insert(pool[cand_nb].nbs.begin(), pool[cand_nb].nbs.end()); u.erase(p); u.erase(cand_nb);
+                std::vector<int> u; u.reserve(pool[p].nbs.size() + pool[cand_nb].nbs.size());
+                std::set_union(pool[p].nbs.begin(), pool[p].nbs.end(), pool[cand_nb].nbs.begin(), pool[cand_nb].nbs.end(), std::back_inserter(u));
+                set_erase(u, p); set_erase(u, cand_nb);
                 unlink_all(p); unlink_all(cand_nb);
-                pool[cand].nbs = u; for (int nb : u) pool[nb].nbs.insert(cand);
+                for (int nb : u) set_insert(pool[nb].nbs, cand);
+                pool[cand].nbs.swap(u);
                 pool[p].nouse = pool[cand_nb].nouse = true;
             } else {
                 if (pool[p].N >= minSupport) extracted.push_back(p);
@@ -158,12 +160,14 @@ struct Fitter {
             else --i;
         }
         cluster(q);
-        build_cloud();
         // ---- refineDetails: block erosion, seeds, region grow, last merge
         std::vector<int> planes = extracted; extracted.clear();
         std::map<int, int> rid2pl; for (int k = 0; k < (int)planes.size(); k++) rid2pl.insert({pool[planes[k]].rid, k});
-        std::vector<int> member((size_t)W * H, -1), blkMap(NB, -1); std::vector<char> valid(planes.size(), 0);
-        std::vector<std::pair<int, int>> seeds;
+        // per-pixel plane index, or -1 - (number of failed tries), stops at -6; 16 bits keep the grow's working set small (at most W*H/minSupport planes)
+        std::vector<int16_t> member((size_t)W * H, -1); std::vector<int> blkMap(NB, -1); std::vector<char> valid(planes.size(), 0);
+        struct Seed { uint16_t x, y; int pl; };
+        std::vector<Seed> seeds; seeds.reserve((size_t)W * H);
+        auto seed_at = [&](int idx, int pl) { const int y = idx / W; seeds.push_back({(uint16_t)(idx - y * W), (uint16_t)y, pl}); };
         auto nb4 = [](int i, int j, int Hh, int Ww, int out[4]) { const int id = i * Ww + j; int c = 0; if (j > 0) out[c++] = id - 1; if (j < Ww - 1) out[c++] = id + 1; if (i > 0) out[c++] = id - Ww; if (i < Hh - 1) out[c++] = id + Ww; return c; };
         for (int i = 0, b = 0; i < Nh; ++i) for (int j = 0; j < Nw; ++j, ++b) {
             const int set = find(b), sz = dsSize[set] * bw * bh;
@@ -171,39 +175,55 @@ struct Fitter {
                 int nb[4]; const int nn = nb4(i, j, Nh, Nw, nb); bool same = true;
                 for (int k = 0; k < nn; k++) if (find(nb[k]) != set) { same = false; break; }
                 const int pl = rid2pl[set];
-                if (same) { blkMap[b] = pl; valid[pl] = 1; for (int y = i * bh; y < (i + 1) * bh; y++) for (int x = j * bw; x < (j + 1) * bw; x++) member[(size_t)y * W + x] = pl; }
+                if (same) { blkMap[b] = pl; valid[pl] = 1; for (int y = i * bh; y < (i + 1) * bh; y++) std::fill_n(&member[(size_t)y * W + j * bw], bw, (int16_t)pl); }
             }
             if (blkMap[b] < 0) {
-                if (i > 0 && blkMap[b - Nw] >= 0) { const int s = (i * bh - 1) * W + j * bw; for (int k = 1; k < bw; ++k) seeds.push_back({s + k, blkMap[b - Nw]}); }
-                if (j > 0 && blkMap[b - 1] >= 0) { const int s = (i * bh) * W + j * bw - 1; for (int k = 0; k < bh - 1; ++k) seeds.push_back({s + k * W, blkMap[b - 1]}); }
+                if (i > 0 && blkMap[b - Nw] >= 0) { const int s = (i * bh - 1) * W + j * bw; for (int k = 1; k < bw; ++k) seed_at(s + k, blkMap[b - Nw]); }
+                if (j > 0 && blkMap[b - 1] >= 0) { const int s = (i * bh) * W + j * bw - 1; for (int k = 0; k < bh - 1; ++k) seed_at(s + k * W, blkMap[b - 1]); }
             } else {
                 const int pl = blkMap[b];
-                if (i > 0 && blkMap[b - Nw] != pl) { const int s = (i * bh) * W + j * bw; for (int k = 0; k < bw - 1; ++k) seeds.push_back({s + k, pl}); }
-                if (j > 0 && blkMap[b - 1] != pl) { const int s = (i * bh) * W + j * bw; for (int k = 1; k < bh; ++k) seeds.push_back({s + k * W, pl}); }
+                if (i > 0 && blkMap[b - Nw] != pl) { const int s = (i * bh) * W + j * bw; for (int k = 0; k < bw - 1; ++k) seed_at(s + k, pl); }
+                if (j > 0 && blkMap[b - 1] != pl) { const int s = (i * bh) * W + j * bw; for (int k = 1; k < bh; ++k) seed_at(s + k * W, pl); }
             }
         }
+        // region grow along the plane borders (FIFO, order-defined).  Per plane: the distance test's constants; per plane pair: whether
+        // the refine link has been decided already (normals do not change here, so the first decision is final)
+        const int nPl = (int)planes.size();
+        struct PlaneC { double n[3], c[3], thr; };
+        std::vector<PlaneC> pc(nPl);
+        for (int k = 0; k < nPl; k++) { const Seg& S = pool[planes[k]]; for (int q = 0; q < 3; q++) { pc[k].n[q] = S.normal[q]; pc[k].c[q] = S.center[q]; } pc[k].thr = 9 * S.mse + 1e-5; }
+        std::vector<char> linkSeen((size_t)nPl * nPl, 0);
         std::vector<float> distMap((size_t)W * H, std::numeric_limits<float>::max());
+        auto visit = [&](int cx, int cy, int pl, const PlaneC& S) {
+            const int c = cy * W + cx; int16_t& trail = member[c];
+            if (trail <= -6) return;
+            if (trail == pl) return;
+            const int by = cy / bh, bx = cx / bw;
+            if (by < Nh && bx < Nw && blkMap[by * Nw + bx] >= 0) return;
+            double pt[3]; float cdist = -1;
+            const bool has_pt = point(cy, cx, pt);
+            if (has_pt) cdist = (float)std::fabs(S.n[0] * (pt[0] - S.c[0]) + S.n[1] * (pt[1] - S.c[1]) + S.n[2] * (pt[2] - S.c[2]));
+            if (has_pt && (double)cdist * (double)cdist < S.thr) {
+                if (trail >= 0 && !linkSeen[(size_t)pl * nPl + trail]) {
+                    linkSeen[(size_t)pl * nPl + trail] = linkSeen[(size_t)trail * nPl + pl] = 1;
+                    if (pool[planes[pl]].similarity(pool[planes[trail]]) >= P.simRefine) link(planes[trail], planes[pl]);
+                }
+                float& od = distMap[c];
+                if (cdist < od) { trail = (int16_t)pl; od = cdist; seeds.push_back({(uint16_t)cx, (uint16_t)cy, pl}); }
+                else if (trail < 0) trail -= 1;
+            } else if (trail < 0) trail -= 1;
+        };
         for (size_t k = 0; k < seeds.size(); ++k) {
-            const int sIdx = seeds[k].first, sy = sIdx / W, sx = sIdx - sy * W, pl = seeds[k].second;
-            const Seg& S = pool[planes[pl]];
-            int nb[4]; const int nn = nb4(sy, sx, H, W, nb);
-            for (int t = 0; t < nn; ++t) {
-                const int c = nb[t]; int& trail = member[c];
-                if (trail <= -6) continue;
-                if (trail >= 0 && trail == pl) continue;
-                const int cy = c / W, cx = c - cy * W, by = cy / bh, bx = cx / bw;
-                const int blk = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
-                if (blk >= 0 && blkMap[blk] >= 0) continue;
-                double pt[3]; float cdist = -1;
-                const bool has_pt = point(cy, cx, pt);
-                if (has_pt) cdist = (float)std::fabs(S.dist(pt));
-                if (has_pt && (double)cdist * (double)cdist < 9 * S.mse + 1e-5) {
-                    if (trail >= 0) { Seg& O = pool[planes[trail]]; if (S.similarity(O) >= P.simRefine) link(planes[trail], planes[pl]); }
-                    float& od = distMap[c];
-                    if (cdist < od) { trail = pl; od = cdist; seeds.push_back({c, pl}); }
-                    else if (trail < 0) trail -= 1;
-                } else if (trail < 0) trail -= 1;
+            if (k + 12 < seeds.size()) {      // the FIFO jumps between all growing borders: fetch the rows a later seed will look at
+                const Seed f = seeds[k + 12]; const size_t c = (size_t)f.y * W + f.x;
+                __builtin_prefetch(&member[c]); if (f.y > 0) __builtin_prefetch(&member[c - W]); if (f.y < H - 1) __builtin_prefetch(&member[c + W]);
+                __builtin_prefetch(&in.depth[c]); __builtin_prefetch(&distMap[c]);
             }
+            const Seed sd = seeds[k]; const int sx = sd.x, sy = sd.y; const PlaneC& S = pc[sd.pl];
+            if (sx > 0) visit(sx - 1, sy, sd.pl, S);
+            if (sx < W - 1) visit(sx + 1, sy, sd.pl, S);
+            if (sy > 0) visit(sx, sy - 1, sd.pl, S);
+            if (sy < H - 1) visit(sx, sy + 1, sd.pl, S);
         }
         Queue q2(QCmp{&pool});
         for (int k = 0; k < (int)planes.size(); k++) if (valid[k]) q2.push(planes[k]);
@@ -217,10 +237,21 @@ struct Fitter {
         }
         const int nOut = (int)extracted.size();
         std::vector<BitImg> masks(nOut); for (auto& m : masks) m.create(W, H);
-        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const int pl = member[(size_t)y * W + x]; if (pl >= 0 && plmap[pl] >= 0 && plmap[pl] < nOut) masks[plmap[pl]].set(x, y); }
+        std::vector<int> yLo(nOut, H), yHi(nOut, -1);
+        for (int y = 0; y < H; y++) {                                  // runs of equal membership -> bit ranges
+            const int16_t* m = &member[(size_t)y * W];
+            for (int x = 0; x < W;) {
+                const int pl = m[x], x0 = x; while (x < W && m[x] == pl) x++;
+                if (pl < 0 || plmap[pl] < 0 || plmap[pl] >= nOut) continue;
+                const int o = plmap[pl]; uint64_t* r = masks[o].row(y); const int a = x0, b = x - 1, ka = a >> 6, kb = b >> 6;
+                for (int q = ka; q <= kb; q++) { uint64_t v = ~0ull; if (q == ka) v &= ~0ull << (a & 63); if (q == kb) v &= (b & 63) == 63 ? ~0ull : ((1ull << ((b & 63) + 1)) - 1); r[q] |= v; }
+                yLo[o] = std::min(yLo[o], y); yHi[o] = y;
+            }
+        }
         const EllipseElem e3(3);
-        for (const BitImg& m : masks) {
-            const BitImg c = m.closed(e3);
+        for (int o = 0; o < nOut; o++) {
+            if (yHi[o] < 0) continue;
+            const BitImg c = masks[o].dilated(e3, yLo[o], yHi[o]).eroded_rows(e3, yLo[o] - 1, yHi[o] + 1);     // closing, evaluated on the mask's rows only
             std::vector<Contour> cs; find_contours(c, cs, true);
             for (const Contour& k : cs) draw_thick2(planeContours, k);
         }

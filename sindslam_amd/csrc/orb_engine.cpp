@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <thread>
+#include <pthread.h>
 #include "orb.hpp"
 
 namespace sind {
@@ -147,7 +148,7 @@ int OrbEngine::extract_all(const uint8_t* gray, int B, std::vector<OrbFrameResul
     {   // the quadtree of a frame is serial, frames are independent: spread them over host threads
         const int nth = std::max(1, std::min<int>(B, std::min<int>(12, (int)std::thread::hardware_concurrency())));
         std::vector<std::thread> th;
-        for (int t = 0; t < nth; t++) th.emplace_back([&, t] { for (int b = t; b < B; b += nth) octree_frame(b); });
+        for (int t = 0; t < nth; t++) th.emplace_back([&, t] { (void)pthread_setname_np(pthread_self(), "sind-octree"); for (int b = t; b < B; b += nth) octree_frame(b); });
         for (auto& t : th) t.join();
     }
     for (int b = 0; b < B; b++) { if (frame_rc[b] != SIND_OK) { sind_set_error("OrbEngine: more than %d selected keypoints", sel_cap); return frame_rc[b]; } max_sel = std::max(max_sel, h_nsel[b]); }

@@ -13,6 +13,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <pthread.h>
+#include <ctime>
+#include <cstdio>
 #include "../../include/sind_hip.h"
 #include "dyna.hpp"
 #include "orb.hpp"
@@ -22,11 +25,16 @@ using namespace sind;
 // Fixed pool of host workers shared by the CalOccluded tasks of the step in phase A and the stateful tails of the step in phase B.
 // The GPU boxes give a process a bounded CPU share (16 cores per GPU on this pool): one bounded pool instead of a thread set per
 // phase keeps the runnable threads under that share, which matters most in the pipelined mode where both kinds of task coexist.
+// CPU time (user + system) of the calling thread in ms, for the SIND_TAIL_TIMING report of the short-lived phase-A threads
+static double thread_cpu_ms() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static std::atomic<long long> g_cpu_us_flow{0}, g_cpu_us_orb{0}, g_cpu_steps{0};
+
 struct TaskGroup { std::mutex m; std::condition_variable cv; int left = 0; };
 class WorkerPool {
 public:
     void start(int n, int device) {
         for (int i = 0; i < n; i++) th.emplace_back([this, i, device] {
+            (void)pthread_setname_np(pthread_self(), "sind-worker");      // names show up in /proc/<pid>/task/*/comm (bench.py --thread-cpu)
             (void)hipSetDevice(device);
             for (;;) {
                 std::pair<std::function<void(int)>, TaskGroup*> job;
@@ -60,9 +68,10 @@ struct sind_pipe {
         DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; std::vector<uint16_t> depth_h; std::vector<OrbFrameResult> orb; std::vector<OccResult> occ; bool pending = false;
         DevBuf<uint8_t> occ2_dev, depthN_dev;                  // per frame: plane-edge mask and normalised depth for the tails' RAG statistics (filled by the CalOccluded tasks)
         DevBuf<float> grid_dev; PinnedBuf<float> grid_h;       // flow at the 10-px sample grid of every frame (DD:1182-1204), gathered right after the dense flow
+        std::atomic<int> occ_next{0};                          // next frame for the CalOccluded runner tasks
         TaskGroup occ_group, tail_group; std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
     } sb[2];
-    int cur = 0;
+    int cur = 0; int occ_workers = 24;
     std::vector<char> primed;
     double stage_ms[6] = {0}; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;
     WorkerPool workers;          // declared last: joined first
@@ -108,7 +117,12 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     }
     p->fw = p->front.fw; p->fh = p->front.fh;
     SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->orb_stream));
-    const int nworkers = cfg->host_threads > 0 ? cfg->host_threads : 24;         // default: 1.5x the box's CPU share per GPU (workers sleep while they wait for the GPU)
+    // CPU share of this process: the container's quota (cgroup v2 cpu.max, 16 cores per GPU on the MI355X boxes), else the machine's cores
+    int cpu_share = (int)std::thread::hardware_concurrency(); if (cpu_share <= 0) cpu_share = 16;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { long long q = 0, per = 0; if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) cpu_share = (int)std::max<long long>(1, std::min<long long>(cpu_share, q / per)); fclose(f); }
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int lw = atoi(e); if (lw > 1) cpu_share = std::max(2, cpu_share / lw); }      // ranks of one node (torch.distributed.run) share the quota
+    cpu_share = std::min(cpu_share, 16);                                          // more host threads than this per GPU bring nothing (measured)
+    const int nworkers = cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 3 / 2);      // default: 1.5x the CPU share (workers sleep while they wait for the GPU)
     // A task leaves its stream idle (every GPU section ends in a wait), so the HIP streams belong to the workers, not to the camera
     // streams: their number does not grow with S.
     p->worker_streams.resize(nworkers); p->occ_tails.resize(nworkers); p->tails.resize(p->S);
@@ -117,6 +131,8 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
         p->occ_tails[w].reset(new DynaTail()); SIND_TRY(p->occ_tails[w]->init(p->dc, p->worker_streams[w]));
     }
     for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers])); }
+    p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads
+    if (const char* e = getenv("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
     p->workers.start(nworkers, cfg->device);
     SIND_TRY(p->gray.alloc(np * B)); SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
     if (cfg->orb_gray_rgb_order) SIND_TRY(p->gray_orb.alloc(np * B));
@@ -134,6 +150,7 @@ int sind_pipe_destroy(sind_pipe* p) {
         if (n) fprintf(stderr, "[sind] cal_occluded: gpu+d2h %.2f pack %.2f endpoints %.2f peac %.2f contour-filter %.2f close %.2f | seg_merge: pieces %.2f sort+paint+pack %.2f alloc %.2f h2d-enqueue %.2f rag %.2f merge %.2f\n", f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5] / n, f[6] / n, f[10] / n, f[11] / n, f[7] / n, f[8] / n, f[9] / n);
         if (n) fprintf(stderr, "[sind] pieces: open %.2f contours %.2f masks %.2f lianjie %.2f centre %.2f | flow_masks host: weights %.2f sort+wait %.2f homography %.2f pack %.2f | fusion: low %.2f clusters %.2f fill %.2f out+state %.2f\n",
                        f[12] / n, f[13] / n, f[14] / n, f[15] / n, f[16] / n, f[20] / n, f[21] / n, f[22] / n, f[23] / n, f[25] / n, f[26] / n, f[27] / n, f[28] / n);
+        if (g_cpu_steps.load()) fprintf(stderr, "[sind] phase-A thread CPU per step: flow slices %.1f ms, ORB thread %.1f ms (octree threads not included)\n", g_cpu_us_flow.load() / 1e3 / g_cpu_steps.load(), g_cpu_us_orb.load() / 1e3 / g_cpu_steps.load());
         if (n) fprintf(stderr, "[sind] stream waits: %.2f ms and %.1f calls per frame (occ + tail + batch stream)\n", g_sind_wait_ns.load() / 1e6 / n, (double)g_sind_wait_calls.load() / n);
         if (n) fprintf(stderr, "[sind] tail ms/frame over %ld frames: flow_masks %.2f kmeans %.2f labels %.2f cal_occluded %.2f seg_merge %.2f fusion %.2f\n", n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n);
     }
@@ -175,10 +192,12 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     HIP_TRY(hipEventRecord(p->ev_gray, p->stream));
     int orb_rc = SIND_OK; std::string orb_err;
     std::thread orb_thread([&] {
+        (void)pthread_setname_np(pthread_self(), "sind-orb");
         (void)hipSetDevice(p->c.device);
         if (hipStreamWaitEvent(p->orb_stream, p->ev_gray, 0) != hipSuccess) { orb_rc = SIND_E_HIP; orb_err = "hipStreamWaitEvent failed"; return; }
         orb_rc = p->orb.extract_all(gray_for_orb, B, sb.orb);
-        if (orb_rc != SIND_OK) orb_err = sind_last_error(); });
+        if (orb_rc != SIND_OK) orb_err = sind_last_error();
+        g_cpu_us_orb += (long long)(thread_cpu_ms() * 1e3); });
     struct OrbJoin { std::thread& t; ~OrbJoin() { if (t.joinable()) t.join(); } } orb_join{orb_thread};
     // private copies of the depth frames: device (tail kernels of this step run while the caller may reuse its buffer) and host
     HIP_TRY(hipMemcpyAsync(sb.depth_dev.p, depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToDevice, p->stream));
@@ -191,9 +210,15 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     for (int k = 0; k < B; k++) { sb.occ[k].occ2_dev = sb.occ2_dev.p + np * k; sb.occ[k].depthN_dev = sb.depthN_dev.p + np * k; }
     sb.occ_rc.assign(B, SIND_OK); sb.occ_err.assign(B, std::string());
     struct Waiter { TaskGroup& g; ~Waiter() { WorkerPool::wait(g); } } waiter{sb.occ_group};       // no task may outlive this call's buffers on an error return
-    for (int k = 0; k < B; k++) p->workers.push(sb.occ_group, [p, &sb, k, np](int w) {
-        const int r = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
-        if (r != SIND_OK) { sb.occ_rc[k] = r; sb.occ_err[k] = sind_last_error(); } });
+    // `occ_workers` runner tasks share the frames through a counter: CalOccluded is host-heavy (PEAC region grow), and more runnable
+    // threads than the CPU quota of the box (cgroup cpu.max, 16 cores per GPU) only burn the quota early in a period and stall EVERY
+    // thread of the process, the flow's launch threads included, until the period ends
+    sb.occ_next.store(0);
+    for (int r = 0; r < std::min(p->occ_workers, B); r++) p->workers.push(sb.occ_group, [p, &sb, B, np](int w) {
+        for (int k; (k = sb.occ_next.fetch_add(1)) < B;) {
+            const int rc = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
+            if (rc != SIND_OK) { sb.occ_rc[k] = rc; sb.occ_err[k] = sind_last_error(); }
+        } });
     t[1] = now_ms();
     // dense flow for every (n, n-2) pair, second pass for large-motion pairs, refinement, up-scale
     std::vector<int> cur(B), p1(B), p2(B);
@@ -218,8 +243,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
             if (rc[i] == SIND_OK && sind_stream_wait(f.stream) != hipSuccess) rc[i] = SIND_E_HIP;
             if (rc[i] != SIND_OK) er[i] = sind_last_error();
         };
-        for (int i = 1; i < nsl; i++) th.emplace_back([&, i] { (void)hipSetDevice(p->c.device); run(i); });
-        run(0);
+        for (int i = 1; i < nsl; i++) th.emplace_back([&, i] { (void)pthread_setname_np(pthread_self(), "sind-flow"); (void)hipSetDevice(p->c.device); run(i); g_cpu_us_flow += (long long)(thread_cpu_ms() * 1e3); });
+        { const double c0 = thread_cpu_ms(); run(0); g_cpu_us_flow += (long long)((thread_cpu_ms() - c0) * 1e3); g_cpu_steps++; }
         for (auto& t : th) t.join();
         for (int i = 0; i < nsl; i++) if (rc[i] != SIND_OK) { sind_set_error("dense flow slice %d: %s", i, er[i].c_str()); return rc[i]; }
         for (int k = 0; k < B; k++) sb.occ[k].gridFlow = sb.grid_h.p + gsz * k;

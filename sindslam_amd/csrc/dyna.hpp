@@ -40,6 +40,10 @@ struct OccResult { BitImg totalArea, occ1, occ2; bool ready = false; const float
                    uint8_t* occ2_dev = nullptr; uint8_t* depthN_dev = nullptr; };          // optional device slots the producer fills: plane-edge mask and 8-bit normalised depth for the RAG statistics     // state-free per-frame results computed ahead of the tail: CalOccluded outputs, flow at the 10-px sample grid (host)
 
 // ---- stateful tail of one stream (reference DynaDetect.cc:1377-1666 minus the dense flow) ---------------------------------
+// Output of the flow-independent half of a frame (k-means on the depth, CalOccluded, SegAndMerge): everything the flow-dependent
+// half (flow masks, fusion) needs from it.  The pipeline computes it for all frames of a step while the dense flow is on the GPU.
+struct DepthStageOut { std::vector<uint8_t> label3; int maxNum = 0; BitImg totalArea; bool ready = false; };
+
 class DynaTail {
 public:
     DynaConfig cfg; hipStream_t stream = nullptr; DynaDebug dbg; bool keep_debug = false;
@@ -49,6 +53,10 @@ public:
     // dyna_out / label_out: host H x W u8 (0 invalid / 125 static / 255 dynamic ; 0 invalid, 1..n clusters).
     int process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out,
                 const OccResult* precomputed = nullptr);
+    // process() = depth_stage() + flow_stage().  The two halves keep separate state (the k-means warm labels belong to the depth half,
+    // the sample weights / previous masks to the flow half), so the depth half of the next frames may run ahead of the flow half.
+    int depth_stage(const uint16_t* depth_host, const uint16_t* depth_dev, const OccResult* precomputed, DepthStageOut& out);
+    int flow_stage(const float* U, const float* V, const DepthStageOut& d, uint8_t* dyna_out, uint8_t* label_out, const float* gridFlowPre = nullptr);
     // CalOccluded (DD:429-642) depends on the depth frame only: the pipeline runs it on this tail's stream while the dense flow
     // of the step is still on the GPU and the host cores are idle
     int compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out);
@@ -57,8 +65,9 @@ public:
     double t_fine[40] = {0};       // cal_occluded: gpu+d2h, pack, endpoints, peac, contour filter, close | seg_merge: pieces, planes+h2d, rag gpu, merge    // flow masks, k-means, label prep, CalOccluded, SegAndMerge, fusion (ms, SIND_TAIL_TIMING=1)
 private:
     int W = 0, H = 0, N = 0, zInvalidFrom = 65536; float invDepthScale = 0.f;
-    std::vector<uint8_t> dynaLast, labelLast; BitImg highLast;       // host state images (DynaDetect.h:172-178)
-    bool labelLastAny = false; int lastCnt[256] = {0}, lastDyn[256] = {0};
+    std::vector<uint8_t> dynaLast, labelLast; BitImg highLast;       // host state images (DynaDetect.h:172-178) as seen by the flow half
+    int lastCnt[256] = {0}, lastDyn[256] = {0};
+    std::vector<uint8_t> kmLabelLast; bool kmLabelLastAny = false;   // imgLabelLast as seen by the depth half (k-means warm labels, DD:374-395)
     // device workspaces
     DevBuf<uint16_t> dpyr[4], filt; DevBuf<float> px, py, pz; DevBuf<int> lab[4]; DevBuf<uint8_t> lab8, labPrev8, edge, edgeTmp, total, depthN, occ2_d, magu8, low_d;
     DevBuf<double> kpart; DevBuf<unsigned long long> planes_d; DevBuf<unsigned> umax_d; DevBuf<int> hist_d, rag_d; DevBuf<float> mag, grid_d;
@@ -67,6 +76,7 @@ private:
     PinnedBuf<float> h_grid; PinnedBuf<int> h_hist, h_rag; PinnedBuf<uint8_t> h_ab, h_lab8; PinnedBuf<KmState> h_kstate; PinnedBuf<PeacBlockStats> h_blocks;
     PinnedBuf<unsigned long long> h_planes;
     int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high, const float* gridFlowPre = nullptr);
+    int fuse(const BitImg& maskLow, const BitImg& maskHigh, const DepthStageOut& d, uint8_t* dyna_out, uint8_t* label_out);
     int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
     DevBuf<KmState> kstate; DevBuf<uint16_t> depth_fix; hipGraphExec_t kmGraph[2] = {nullptr, nullptr}; bool kmGraphBroken = false;
     int kmeans_enqueue(const uint16_t* depth0, bool prevLabels);

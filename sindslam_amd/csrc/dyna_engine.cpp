@@ -122,7 +122,7 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     for (const void* q : ws) if (!q) { sind_set_error("DynaTail::init: a workspace was not allocated"); return SIND_E_STATE; }
     return SIND_OK;
 }
-void DynaTail::reset() { dynaLast.assign(N, 0); labelLast.assign(N, 0); highLast.create(W, H); labelLastAny = false; std::memset(lastCnt, 0, sizeof(lastCnt)); std::memset(lastDyn, 0, sizeof(lastDyn)); }
+void DynaTail::reset() { dynaLast.assign(N, 0); labelLast.assign(N, 0); kmLabelLast.assign(N, 0); highLast.create(W, H); kmLabelLastAny = false; std::memset(lastCnt, 0, sizeof(lastCnt)); std::memset(lastDyn, 0, sizeof(lastDyn)); }
 
 // ---- DD:1163-1367: sample weights -> PROSAC pairs -> homography -> residual -> Otsu / Triangle thresholds -> masks
 int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& high, const float* gridFlowPre) {
@@ -250,10 +250,10 @@ int DynaTail::kmeans_enqueue(const uint16_t* depth0, bool prevLabels) {
 }
 int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
     static const bool use_graph = !(getenv("SIND_KM_GRAPH") && atoi(getenv("SIND_KM_GRAPH")) == 0);
-    if (labelLastAny) { std::memcpy(h_lab8.p, labelLast.data(), N); HIP_TRY(hipMemcpyAsync(labPrev8.p, h_lab8.p, N, hipMemcpyHostToDevice, stream)); }
+    if (kmLabelLastAny) { std::memcpy(h_lab8.p, kmLabelLast.data(), N); HIP_TRY(hipMemcpyAsync(labPrev8.p, h_lab8.p, N, hipMemcpyHostToDevice, stream)); }
     bool graphed = false;
     if (use_graph && !kmGraphBroken) {
-        const int v = labelLastAny ? 1 : 0;
+        const int v = kmLabelLastAny ? 1 : 0;
         if (!kmGraph[v]) {                       // record once; any failure here only means "launch kernel by kernel from now on" (still the GPU path)
             hipGraph_t g = nullptr;
             if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -270,7 +270,7 @@ int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, fl
             graphed = true;
         }
     }
-    if (!graphed) SIND_TRY(kmeans_enqueue(depth_dev, labelLastAny));
+    if (!graphed) SIND_TRY(kmeans_enqueue(depth_dev, kmLabelLastAny));
     label8.resize(N);
     HIP_TRY(hipMemcpyAsync(h_kstate.p, kstate.p, 4 * sizeof(KmState), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h_ab.p, lab8.p, N, hipMemcpyDeviceToHost, stream));
@@ -508,13 +508,21 @@ int DynaTail::compute_occluded(const uint16_t* depth_host, const uint16_t* depth
 
 int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out,
                       const OccResult* pre) {
+    // same stage order as the reference (flow masks, clustering, fusion); the order also matters for throughput: a pool of tails that
+    // all start with the 50-launch k-means chain was measured 20 ms per step slower than one that starts with the host-side pair sorting
     HIP_TRY(hipSetDevice(cfg.device));
-    BitImg maskLow, maskHigh;
-    double tk = tick_ms(); n_frames++;
+    BitImg maskLow, maskHigh; n_frames++;
+    { const double t0 = tick_ms(); SIND_TRY(flow_masks(U, V, maskLow, maskHigh, pre ? pre->gridFlow : nullptr)); t_stage[0] += tick_ms() - t0; }
+    DepthStageOut d;
+    SIND_TRY(depth_stage(depth_host, depth_dev, pre, d));
+    return fuse(maskLow, maskHigh, d, dyna_out, label_out);
+}
+
+// flow-independent half: k-means (DD:1410-1414), cluster order (DD:1428-1491), CalOccluded (DD:1493), SegAndMerge (DD:1495-1551)
+int DynaTail::depth_stage(const uint16_t* depth_host, const uint16_t* depth_dev, const OccResult* pre, DepthStageOut& out) {
+    HIP_TRY(hipSetDevice(cfg.device));
+    double tk = tick_ms();
     #define LAP(i) { const double t_ = tick_ms(); t_stage[i] += t_ - tk; tk = t_; }
-    SIND_TRY(flow_masks(U, V, maskLow, maskHigh, pre ? pre->gridFlow : nullptr));
-    LAP(0)
-    // k-means (DD:1410-1414)
     std::vector<uint8_t> label8; float centers[KM_K][3]; int counts[KM_K];
     SIND_TRY(kmeans(depth_dev, label8, centers, counts));
     if (keep_debug) { dbg.kmeansLabel = label8; std::memcpy(dbg.centers, centers, sizeof(centers)); }
@@ -534,18 +542,38 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
         if (count0 <= 5 && ratioArea < 0.6f) { labelForSegEdge |= labelMask[idx]; ++count0; }
     }
     labelForSegEdge = labelForSegEdge.dilated(EllipseElem(7));
-    BitImg totalArea, occ1, occ2;
+    BitImg occ1, occ2;
     LAP(2)
-    if (pre && pre->ready) { totalArea = pre->totalArea; occ1 = pre->occ1; occ2 = pre->occ2; }
-    else SIND_TRY(cal_occluded(depth_host, depth_dev, totalArea, occ1, occ2));
+    if (pre && pre->ready) { out.totalArea = pre->totalArea; occ1 = pre->occ1; occ2 = pre->occ2; }
+    else SIND_TRY(cal_occluded(depth_host, depth_dev, out.totalArea, occ1, occ2));
     LAP(3)
-    std::vector<uint8_t> label3(N, 0);
-    if (!allLabels.empty()) SIND_TRY(seg_and_merge(allLabels, occ1, occ2, labelForSegEdge, depth_host, depth_dev, label3, pre && pre->ready ? pre : nullptr));
+    out.label3.assign(N, 0);
+    if (!allLabels.empty()) SIND_TRY(seg_and_merge(allLabels, occ1, occ2, labelForSegEdge, depth_host, depth_dev, out.label3, pre && pre->ready ? pre : nullptr));
     LAP(4)
+    #undef LAP
+    int maxNum = 0; for (uint8_t v : out.label3) maxNum = std::max<int>(maxNum, v);
+    out.maxNum = maxNum; out.ready = true;
+    if (keep_debug) { dbg.occ1.resize(N); occ1.to_u8(dbg.occ1.data(), W, 255); dbg.occ2.resize(N); occ2.to_u8(dbg.occ2.data(), W, 255); dbg.totalArea.resize(N); out.totalArea.to_u8(dbg.totalArea.data(), W, 255); }
+    kmLabelLast = out.label3; kmLabelLastAny = maxNum > 0;          // imgLabelLast for the next frame's k-means (DD:1660-1664)
+    return SIND_OK;
+}
+
+// flow-dependent half: flow masks (DD:1163-1367) and fusion (DD:1553-1636), then the state roll (DD:1660-1664)
+int DynaTail::flow_stage(const float* U, const float* V, const DepthStageOut& d, uint8_t* dyna_out, uint8_t* label_out, const float* gridFlowPre) {
+    HIP_TRY(hipSetDevice(cfg.device));
+    if (!d.ready) { sind_set_error("DynaTail::flow_stage: the depth stage of this frame has not run"); return SIND_E_STATE; }
+    BitImg maskLow, maskHigh; n_frames++;
+    { const double t0 = tick_ms(); SIND_TRY(flow_masks(U, V, maskLow, maskHigh, gridFlowPre)); t_stage[0] += tick_ms() - t0; }
+    return fuse(maskLow, maskHigh, d, dyna_out, label_out);
+}
+
+// fusion (DD:1553-1636) and the state roll (DD:1660-1664)
+int DynaTail::fuse(const BitImg& maskLow, const BitImg& maskHigh, const DepthStageOut& d, uint8_t* dyna_out, uint8_t* label_out) {
+    double tk = tick_ms();
+    #define LAP(i) { const double t_ = tick_ms(); t_stage[i] += t_ - tk; tk = t_; }
+    const std::vector<uint8_t>& label3 = d.label3; const int maxNum = d.maxNum; const BitImg& totalArea = d.totalArea;
     double tq = tick_ms();
     #define QLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; }
-    int maxNum = 0; for (uint8_t v : label3) maxNum = std::max<int>(maxNum, v);
-    if (keep_debug) { dbg.occ1.resize(N); occ1.to_u8(dbg.occ1.data(), W, 255); dbg.occ2.resize(N); occ2.to_u8(dbg.occ2.data(), W, 255); dbg.totalArea.resize(N); totalArea.to_u8(dbg.totalArea.data(), W, 255); }
     // fusion (DD:1553-1636)
     BitImg low = highLast; low |= maskLow; low &= totalArea;
     low = low.dilated(EllipseElem(5));
@@ -575,8 +603,7 @@ int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, con
     totalArea.to_u8(dyna_out, W, 125); dyna.paint_u8(dyna_out, W, 255);
     std::memcpy(label_out, label3.data(), N);
     // roll the state (DD:1660-1664)
-    std::memcpy(dynaLast.data(), dyna_out, N); labelLast.swap(label3); highLast = maskHigh;
-    labelLastAny = maxNum > 0;
+    std::memcpy(dynaLast.data(), dyna_out, N); labelLast = label3; highLast = maskHigh;
     std::memset(lastCnt, 0, sizeof(lastCnt)); std::memset(lastDyn, 0, sizeof(lastDyn));       // per-label pixel / dynamic-pixel counts for the next frame's sample weights
     for (int n = 1; n <= maxNum && n < 256; n++) { lastCnt[n] = clusters[n].count(); lastDyn[n] = BitImg::and_count(clusters[n], dyna); }
     QLAP(28)

@@ -57,7 +57,7 @@ private:
 
 struct sind_pipe {
     sind_pipe_config c{}; DynaConfig dc; int S = 0, T = 0, fw = 0, fh = 0;
-    hipStream_t stream = nullptr, orb_stream = nullptr; hipEvent_t ev_gray = nullptr; std::vector<hipStream_t> worker_streams;      // one HIP stream per pool worker, shared by the tasks it runs
+    hipStream_t stream = nullptr, orb_stream = nullptr; hipEvent_t ev_gray = nullptr; std::vector<hipStream_t> worker_streams, worker_streams_lo;      // one HIP stream per pool worker, shared by the tasks it runs
     DynaFront front; std::vector<std::unique_ptr<DynaFront>> extra_fronts; std::vector<hipStream_t> extra_streams; hipEvent_t ev_pool = nullptr;      // batch slices 1.. of the dense flow (slice 0 = front)
     OrbEngine orb; std::vector<std::unique_ptr<DynaTail>> tails;
     std::vector<std::unique_ptr<PinnedBuf<uint8_t>>> upload_stage;        // page-locked staging of sind_pipe_process (host-buffer entry point), two 4 MB buffers per uploading worker
@@ -69,6 +69,10 @@ struct sind_pipe {
         DevBuf<uint8_t> occ2_dev, depthN_dev;                  // per frame: plane-edge mask and normalised depth for the tails' RAG statistics (filled by the CalOccluded tasks)
         DevBuf<float> grid_dev; PinnedBuf<float> grid_h;       // flow at the 10-px sample grid of every frame (DD:1182-1204), gathered right after the dense flow
         std::atomic<int> occ_next{0};                          // next frame for the CalOccluded runner tasks
+        // depth half of the tails (k-means, SegAndMerge) run ahead, underneath the dense flow (synchronous steps only): per-frame results,
+        // and a gate per frame that opens when both its CalOccluded result and the stream's previous depth stage are there
+        bool depth_ahead = false; std::vector<DepthStageOut> dout; std::unique_ptr<std::atomic<int>[]> gate; TaskGroup depth_group;
+        std::vector<int> depth_rc; std::vector<std::string> depth_err;
         TaskGroup occ_group, tail_group; std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
     } sb[2];
     int cur = 0; int occ_workers = 24;
@@ -122,13 +126,21 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { long long q = 0, per = 0; if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) cpu_share = (int)std::max<long long>(1, std::min<long long>(cpu_share, q / per)); fclose(f); }
     if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int lw = atoi(e); if (lw > 1) cpu_share = std::max(2, cpu_share / lw); }      // ranks of one node (torch.distributed.run) share the quota
     cpu_share = std::min(cpu_share, 16);                                          // more host threads than this per GPU bring nothing (measured)
-    const int nworkers = cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 3 / 2);      // default: 1.5x the CPU share (workers sleep while they wait for the GPU)
+    const int nworkers = cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 2);         // default: 2x the CPU share (workers sleep while they wait for the GPU)
     // A task leaves its stream idle (every GPU section ends in a wait), so the HIP streams belong to the workers, not to the camera
     // streams: their number does not grow with S.
     p->worker_streams.resize(nworkers); p->occ_tails.resize(nworkers); p->tails.resize(p->S);
+    // Two streams per worker: phase-B tasks use a high-priority stream; phase-A tasks (CalOccluded, optional depth stages) have their own
+    // stream, high priority by default as well.  Measured on MI355X: at normal priority these small kernels starve behind the solver's
+    // workgroups (dense flow 230 -> 221 ms, but 65-90 ms of CalOccluded / depth-stage work is then left over when the flow ends); at high
+    // priority they cost the solver about what they would cost alone.  Either way the small kernels of a step are worth ~90 ms of GPU time.
+    p->worker_streams_lo.resize(nworkers);
+    const bool phase_a_hi = !(getenv("SIND_PHASEA_PRIORITY") && atoi(getenv("SIND_PHASEA_PRIORITY")) == 0);
     for (int w = 0; w < nworkers; w++) {
         SIND_TRY(make_stream(&p->worker_streams[w], !(getenv("SIND_TAIL_PRIORITY") && atoi(getenv("SIND_TAIL_PRIORITY")) == 0)));
-        p->occ_tails[w].reset(new DynaTail()); SIND_TRY(p->occ_tails[w]->init(p->dc, p->worker_streams[w]));
+        if (phase_a_hi) p->worker_streams_lo[w] = p->worker_streams[w];      // same stream (extra streams would also change how the runtime spreads the workers' streams over its hardware queues)
+        else SIND_TRY(make_stream(&p->worker_streams_lo[w], false));
+        p->occ_tails[w].reset(new DynaTail()); SIND_TRY(p->occ_tails[w]->init(p->dc, p->worker_streams_lo[w]));
     }
     for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers])); }
     p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads
@@ -156,7 +168,8 @@ int sind_pipe_destroy(sind_pipe* p) {
     }
     (void)hipSetDevice(p->c.device);
     (void)hipDeviceSynchronize();
-    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream); ss.push_back(p->orb_stream); ss.insert(ss.end(), p->extra_streams.begin(), p->extra_streams.end());
+    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream);
+    for (size_t w = 0; w < p->worker_streams_lo.size(); w++) if (w >= p->worker_streams.size() || p->worker_streams_lo[w] != p->worker_streams[w]) ss.push_back(p->worker_streams_lo[w]); ss.push_back(p->orb_stream); ss.insert(ss.end(), p->extra_streams.begin(), p->extra_streams.end());
     if (p->ev_pool) (void)hipEventDestroy(p->ev_pool);
     if (p->ev_gray) (void)hipEventDestroy(p->ev_gray);
     delete p;
@@ -177,7 +190,8 @@ int sind_pipe_prime(sind_pipe* p, int s, const uint8_t* last, const uint8_t* las
 }
 
 // ---- phase A of one step (state free, batched over S*T frames, shared HIP stream): fills a StepBuf
-static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev, const uint16_t* depth_dev, double t[4]) {
+static void depth_task(sind_pipe* p, sind_pipe::StepBuf* sb, int k, int worker);
+static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev, const uint16_t* depth_dev, double t[4], bool depth_ahead = false) {
     const int S = p->S, T = p->T, B = S * T, W = p->c.width, H = p->c.height;
     const size_t np = (size_t)W * H, fb = (size_t)p->fw * p->fh;
     t[0] = now_ms();
@@ -209,7 +223,14 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     SIND_TRY(sb.occ2_dev.alloc(np * B)); SIND_TRY(sb.depthN_dev.alloc(np * B));
     for (int k = 0; k < B; k++) { sb.occ[k].occ2_dev = sb.occ2_dev.p + np * k; sb.occ[k].depthN_dev = sb.depthN_dev.p + np * k; }
     sb.occ_rc.assign(B, SIND_OK); sb.occ_err.assign(B, std::string());
-    struct Waiter { TaskGroup& g; ~Waiter() { WorkerPool::wait(g); } } waiter{sb.occ_group};       // no task may outlive this call's buffers on an error return
+    struct Waiter { TaskGroup& g; ~Waiter() { WorkerPool::wait(g); } };       // no task may outlive this call's buffers on an error return
+    Waiter depth_waiter{sb.depth_group}, waiter{sb.occ_group};                // destroyed in reverse order: CalOccluded runners first (they open the last gates), then the depth chains
+    sb.depth_ahead = depth_ahead;
+    if (depth_ahead) {
+        sb.dout.assign(B, DepthStageOut()); sb.depth_rc.assign(B, SIND_OK); sb.depth_err.assign(B, std::string());
+        if (!sb.gate) sb.gate.reset(new std::atomic<int>[B]);
+        for (int k = 0; k < B; k++) sb.gate[k].store(k % T == 0 ? 1 : 0);       // the first frame of a stream only waits for its CalOccluded
+    }
     // `occ_workers` runner tasks share the frames through a counter: CalOccluded is host-heavy (PEAC region grow), and more runnable
     // threads than the CPU quota of the box (cgroup cpu.max, 16 cores per GPU) only burn the quota early in a period and stall EVERY
     // thread of the process, the flow's launch threads included, until the period ends
@@ -218,6 +239,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         for (int k; (k = sb.occ_next.fetch_add(1)) < B;) {
             const int rc = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
             if (rc != SIND_OK) { sb.occ_rc[k] = rc; sb.occ_err[k] = sind_last_error(); }
+            if (sb.depth_ahead && sb.gate[k].fetch_add(1) == 1) { sind_pipe::StepBuf* sbp = &sb; p->workers.push(sb.depth_group, [p, sbp, k](int w2) { depth_task(p, sbp, k, w2); }); }
         } });
     t[1] = now_ms();
     // dense flow for every (n, n-2) pair, second pass for large-motion pairs, refinement, up-scale
@@ -268,7 +290,9 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     }
     HIP_TRY(sind_stream_wait(p->stream));
     WorkerPool::wait(sb.occ_group);
+    WorkerPool::wait(sb.depth_group);           // every chain has been started by now (a gate is opened from inside a running task of either group)
     for (int k = 0; k < B; k++) if (sb.occ_rc[k] != SIND_OK) { sind_set_error("stream %d (CalOccluded): %s", k / T, sb.occ_err[k].c_str()); return sb.occ_rc[k]; }
+    if (depth_ahead) for (int k = 0; k < B; k++) if (sb.depth_rc[k] != SIND_OK) { sind_set_error("stream %d (depth stage): %s", k / T, sb.depth_err[k].c_str()); return sb.depth_rc[k]; }
     t[3] = now_ms();
     sb.pending = true;
     return SIND_OK;
@@ -279,13 +303,23 @@ struct PipeOut { uint8_t *dyna, *label, *mask; sind_keypoint* kps; int cap; int*
 // One task = one frame of one stream; it queues the stream's next frame when it is done.  Frames of a stream stay in order, and the
 // pool always sees up to S runnable tasks, so the workers stay busy until the end of the phase (a task per stream left the second
 // "round" of 32 streams on 24 workers half empty).
+// Depth half of frame k = (stream s, frame t) of a synchronous step: runs while the dense flow is on the GPU, in frame order per stream
+// (the k-means warm labels are the previous frame's merged labels).  It opens the gate of the stream's next frame when it is done.
+static void depth_task(sind_pipe* p, sind_pipe::StepBuf* sb, int k, int worker) {
+    const int T = p->T, s = k / T, t = k % T; const size_t np = (size_t)p->c.width * p->c.height;
+    p->tails[s]->stream = p->worker_streams_lo[worker];
+    const int r = p->tails[s]->depth_stage(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, &sb->occ[k], sb->dout[k]);
+    if (r != SIND_OK) { sb->depth_rc[k] = r; sb->depth_err[k] = sind_last_error(); }
+    if (t + 1 < T && sb->gate[k + 1].fetch_add(1) == 1) p->workers.push(sb->depth_group, [p, sb, k](int w) { depth_task(p, sb, k + 1, w); });
+}
 static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker) {
     p->tails[s]->stream = p->worker_streams[worker];
     const int T = p->T, W = p->c.width, H = p->c.height; const size_t np = (size_t)W * H;
     static thread_local std::vector<uint8_t> dy, lb, dil;
     dy.resize(np); lb.resize(np); dil.resize(np);
     const int k = s * T + t;
-    int r = p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k]);
+    int r = sb->depth_ahead ? p->tails[s]->flow_stage(sb->U.p + np * k, sb->V.p + np * k, sb->dout[k], dy.data(), lb.data(), sb->occ[k].gridFlow)
+                            : p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k]);
     if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return; }
     dilate15_codes(dy.data(), W, H, dil.data());
     if (o.dyna) std::memcpy(o.dyna + np * k, dy.data(), np);
@@ -326,7 +360,11 @@ int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* 
     SIND_TRY(check_inputs(p, bgr_dev, depth_dev));
     if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_process: a submitted step is still pending, call sind_pipe_flush first"); return SIND_E_STATE; }
     double t[4]; const double t0 = now_ms();
-    SIND_TRY(phase_a(p, p->sb[0], bgr_dev, depth_dev, t));
+    // Optional: run the depth half of the tails (k-means, SegAndMerge) underneath the dense flow.  Parity-tested, off by default: the tails
+    // phase shrinks from ~75 to ~23 ms, but the solver loses as much to the ~13 k extra small launches it then shares the GPU with
+    // (dense flow 232 -> 287 ms at high stream priority; at normal priority the chains starve and drain after the flow instead).
+    static const bool depth_ahead = getenv("SIND_DEPTH_AHEAD") && atoi(getenv("SIND_DEPTH_AHEAD")) != 0;
+    SIND_TRY(phase_a(p, p->sb[0], bgr_dev, depth_dev, t, depth_ahead));
     const PipeOut o{dyna, label, mask_dil, kps, cap, nkp, desc};
     SIND_TRY(phase_b(p, p->sb[0], o));
     const double t4 = now_ms();

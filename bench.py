@@ -92,9 +92,9 @@ def cgroup_throttle():
 
 
 def pmc_traffic(pairs_per_step):
-    """HBM bytes per k_sor_fused launch from the committed rocprofv3 PMC passes (profiles/r01/v8_pmc_k_sor_fused.json: separate
+    """HBM bytes per k_sor_fused launch from the committed rocprofv3 PMC passes (profiles/r01/v11_pmc_k_sor_fused.json: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction), scaled to this batch; None if absent."""
-    f = os.path.join(ROOT, "profiles", "r01", "v8_pmc_k_sor_fused.json")
+    f = os.path.join(ROOT, "profiles", "r01", "v11_pmc_k_sor_fused.json")
     if not os.path.exists(f):
         return None
     d = json.load(open(f))

@@ -137,6 +137,10 @@ int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* d
                          sind_keypoint* kps, int cap, int* nkp, uint8_t* desc, int* have_output);
 int sind_pipe_flush(sind_pipe* p, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated, sind_keypoint* kps, int cap, int* nkp, uint8_t* desc,
                     int* have_output);
+/* Schedule of the synchronous step (sind_pipe_process / _process_dev): on != 0 runs the flow-independent half of every tail (depth
+ * k-means, SegAndMerge; reference DynaDetect.cc:1410-1551) underneath the dense flow instead of after it.  Results are identical;
+ * default off (environment SIND_DEPTH_AHEAD=1 turns it on at create), see DESIGN.md 3.1 item 7 for the measurement. */
+int sind_pipe_set_depth_ahead(sind_pipe* p, int on);
 /* per-stage wall times of the last step in milliseconds: {front_gray, dense_flow, orb_front, host_upload (sind_pipe_process only, else 0), tails, total},
  * plus HIP-event statistics of the flow solver: sor_launches, sor_ms (sum of event-bracketed SOR launch groups),
  * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */

@@ -76,6 +76,10 @@ struct sind_pipe {
         TaskGroup occ_group, tail_group; std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
     } sb[2];
     int cur = 0; int occ_workers = 24;
+    // Optional schedule of the synchronous step: run the depth half of the tails (k-means, SegAndMerge) underneath the dense flow.
+    // Parity-tested, off by default: the tails phase shrinks from ~75 to ~23 ms, but the solver loses as much to the ~13 k extra small
+    // launches it then shares the GPU with (dense flow 232 -> 287 ms at high stream priority; at normal priority the chains starve).
+    bool depth_ahead = false;
     std::vector<char> primed;
     double stage_ms[6] = {0}; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;
     WorkerPool workers;          // declared last: joined first
@@ -145,6 +149,7 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers])); }
     p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads
     if (const char* e = getenv("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
+    p->depth_ahead = getenv("SIND_DEPTH_AHEAD") && atoi(getenv("SIND_DEPTH_AHEAD")) != 0;
     p->workers.start(nworkers, cfg->device);
     SIND_TRY(p->gray.alloc(np * B)); SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
     if (cfg->orb_gray_rgb_order) SIND_TRY(p->gray_orb.alloc(np * B));
@@ -360,11 +365,7 @@ int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* 
     SIND_TRY(check_inputs(p, bgr_dev, depth_dev));
     if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_process: a submitted step is still pending, call sind_pipe_flush first"); return SIND_E_STATE; }
     double t[4]; const double t0 = now_ms();
-    // Optional: run the depth half of the tails (k-means, SegAndMerge) underneath the dense flow.  Parity-tested, off by default: the tails
-    // phase shrinks from ~75 to ~23 ms, but the solver loses as much to the ~13 k extra small launches it then shares the GPU with
-    // (dense flow 232 -> 287 ms at high stream priority; at normal priority the chains starve and drain after the flow instead).
-    static const bool depth_ahead = getenv("SIND_DEPTH_AHEAD") && atoi(getenv("SIND_DEPTH_AHEAD")) != 0;
-    SIND_TRY(phase_a(p, p->sb[0], bgr_dev, depth_dev, t, depth_ahead));
+    SIND_TRY(phase_a(p, p->sb[0], bgr_dev, depth_dev, t, p->depth_ahead));
     const PipeOut o{dyna, label, mask_dil, kps, cap, nkp, desc};
     SIND_TRY(phase_b(p, p->sb[0], o));
     const double t4 = now_ms();
@@ -440,6 +441,12 @@ int sind_pipe_process(sind_pipe* p, const uint8_t* bgr, const uint16_t* depth, u
     const int rc = sind_pipe_process_dev(p, p->bgr_d.p, p->depth_d.p, dyna, label, mask_dil, kps, cap, nkp, desc);
     p->stage_ms[3] = t_up; p->stage_ms[5] += t_up;
     return rc;
+}
+
+int sind_pipe_set_depth_ahead(sind_pipe* p, int on) {
+    if (!p) return SIND_E_ARG;
+    if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_set_depth_ahead: a submitted step is still pending"); return SIND_E_STATE; }
+    p->depth_ahead = on != 0; return SIND_OK;
 }
 
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices) {

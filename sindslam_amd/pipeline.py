@@ -75,6 +75,10 @@ class Pipeline:
                                     C.byref(have)), "sind_pipe_flush")
         return bool(have.value)
 
+    def set_depth_ahead(self, on: bool):
+        """schedule of the synchronous step: depth half of the tails underneath the dense flow (same results)"""
+        check(lib().sind_pipe_set_depth_ahead(self._h, int(bool(on))), "sind_pipe_set_depth_ahead")
+
     def keypoints(self, s: int, t: int):
         k = s * self.T + t; n = self.nkp[k]; return self.kps[k, :n], self.desc[k, :n]
 

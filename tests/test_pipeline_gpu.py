@@ -70,3 +70,25 @@ def test_pipelined_submit_equals_sync(frames):
         for k in range(S * T):
             n = e[3][k]; assert e[4][k, :n].tobytes() == g[4][k, :n].tobytes() and np.array_equal(e[5][k, :n], g[5][k, :n])
     ref.close(); pip.close()
+
+
+def test_depth_ahead_schedule_equals_default(frames):
+    """the depth half of the tails run underneath the dense flow (sind_pipe_set_depth_ahead) returns bit-identical results"""
+    from sindslam_amd.pipeline import Pipeline
+    bgr, depth = frames
+    S, T = 3, 2
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    sb = np.stack([bgr, bgr[:, ::-1], bgr[:, :, ::-1]]); sd = np.stack([depth, depth[:, ::-1], depth[:, :, ::-1]])
+    ref = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5); pip = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5)
+    pip.set_depth_ahead(True)
+    for s in range(S):
+        ref.prime(s, sb[s, 1], sb[s, 0]); pip.prime(s, sb[s, 1], sb[s, 0])
+    for step in range(2):                     # the second step starts from rolled state (k-means warm labels, previous masks)
+        lo = 2 + step * T
+        ref.process(sb[:, lo:lo + T], sd[:, lo:lo + T]); pip.process(sb[:, lo:lo + T], sd[:, lo:lo + T])
+        assert np.array_equal(ref.dyna, pip.dyna) and np.array_equal(ref.label, pip.label) and np.array_equal(ref.mask, pip.mask)
+        assert np.array_equal(ref.nkp, pip.nkp)
+        for k in range(S * T):
+            n = ref.nkp[k]; assert ref.kps[k, :n].tobytes() == pip.kps[k, :n].tobytes() and np.array_equal(ref.desc[k, :n], pip.desc[k, :n])
+        assert (ref.label > 0).any()
+    ref.close(); pip.close()

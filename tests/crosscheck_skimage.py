@@ -4,8 +4,10 @@ independent implementation whose semantics coincide with OpenCV's for these case
 oracle restates the OpenCV primitive correctly.
 
 usage: python3.9 crosscheck_skimage.py <in.npz> <out.npz>
-in : gray (u8 image), fast_img (u8, the padded ORB level image), otsu_imgs (k, h, w) u8, resize_src (f32), resize_shape (2,)
-out: score (int16 map: largest FAST-9 threshold at which the pixel is still a corner, -1 = never), otsu (k,), triangle (k,), resized
+in : fast_img (u8, the padded ORB level image), otsu_imgs (k, h, w) u8, resize_src (f32), resize_shape (2,),
+     brief_img (u8, blurred level image), brief_rc (n, 2) keypoint rows / columns, brief_angle (n,) radians
+out: score (int16 map: largest FAST-9 threshold at which the pixel is still a corner, -1 = never), otsu (k,), triangle (k,), resized,
+     pattern (256, 4) scikit-image's copy of the learned rBRIEF pattern, brief (n, 32) steered-BRIEF descriptors, OpenCV bit order
 """
 import sys
 
@@ -33,5 +35,13 @@ out["triangle"] = np.array([threshold_triangle(im) for im in d["otsu_imgs"]], np
 
 dh, dw = [int(v) for v in d["resize_shape"]]
 out["resized"] = resize(d["resize_src"].astype(np.float64), (dh, dw), order=1, mode="edge", anti_aliasing=False, preserve_range=True)
+
+# rBRIEF: scikit-image ships the same learned 256-pair pattern as OpenCV and steers it with the keypoint angle like OpenCV does
+# (row offset = x sin + y cos, column offset = x cos - y sin, rounded); bit = I(p0) < I(p1)
+from skimage.feature.orb_cy import _orb_loop
+from skimage.feature._orb_descriptor_positions import POS
+out["pattern"] = np.asarray(POS, np.int32)
+desc = _orb_loop(np.ascontiguousarray(d["brief_img"].astype(np.float64)), np.ascontiguousarray(d["brief_rc"].astype(np.intp)), np.ascontiguousarray(d["brief_angle"].astype(np.float64)))
+out["brief"] = np.packbits(np.asarray(desc).astype(np.uint8), axis=1, bitorder="little")
 
 np.savez(sys.argv[2], **out)

@@ -116,8 +116,12 @@ def test_fast_scores_otsu_and_resize_against_scikit_image(frames, tmp_path):
         otsu_imgs.append(np.clip(np.where(sel, b, a), 0, 255).astype(np.uint8))
     otsu_imgs = np.stack(otsu_imgs)
     src = rng.uniform(0, 255, (60, 80)).astype(np.float32)
+    kps, desc = orb.extract(gray)
+    l0 = kps["octave"] == 0; k0 = kps[l0]; d0 = desc[l0]
+    blurred = O.gaussian_blur_u8(gray, 7, 2.0)             # ORBextractor.cc:1145: the level image is cloned, then blurred
     fin, fout = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
-    np.savez(fin, fast_img=pad, otsu_imgs=otsu_imgs, resize_src=src, resize_shape=np.array([57, 76]))
+    np.savez(fin, fast_img=pad, otsu_imgs=otsu_imgs, resize_src=src, resize_shape=np.array([57, 76]), brief_img=blurred,
+             brief_rc=np.stack([np.rint(k0["y"]), np.rint(k0["x"])], 1).astype(np.int64), brief_angle=np.deg2rad(k0["angle"].astype(np.float64)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
     subprocess.check_call([CONDA_PY, os.path.join(HERE, "crosscheck_skimage.py"), fin, fout], env=env, timeout=600)
     r = np.load(fout)
@@ -138,3 +142,13 @@ def test_fast_scores_otsu_and_resize_against_scikit_image(frames, tmp_path):
         assert O.otsu(hist) == r["otsu"][k], k
         assert abs(O.triangle(hist) - r["triangle"][k]) <= 2, (k, O.triangle(hist), r["triangle"][k])
     assert np.abs(O.resize_f32(src, 76, 57) - r["resized"]).max() < 2e-3
+    # rBRIEF: the 256 x 4 pattern table is scikit-image's copy of OpenCV's; steering it by the oracle's keypoint angle over the oracle's
+    # blurred image reproduces the oracle's level-0 descriptors (a handful of bits may differ where a rotated offset falls on x.5:
+    # C round() vs cvRound, and float vs double trigonometry)
+    import re
+    hdr = open(os.path.join(os.path.dirname(HERE), "include", "sind_brief_pattern.h")).read()
+    table = np.array([int(v) for v in re.findall(r"-?\d+", hdr[hdr.index("{"):])], np.int32).reshape(256, 4)
+    assert np.array_equal(table, r["pattern"])
+    assert len(k0) > 300
+    diff_bits = np.unpackbits(d0 ^ r["brief"], axis=1).sum()
+    assert diff_bits <= 2e-4 * d0.size * 8, (int(diff_bits), d0.size * 8)

@@ -5,9 +5,11 @@ oracle restates the OpenCV primitive correctly.
 
 usage: python3.9 crosscheck_skimage.py <in.npz> <out.npz>
 in : fast_img (u8, the padded ORB level image), otsu_imgs (k, h, w) u8, resize_src (f32), resize_shape (2,),
-     brief_img (u8, blurred level image), brief_rc (n, 2) keypoint rows / columns, brief_angle (n,) radians
+     brief_img (u8, blurred level image), brief_rc (n, 2) keypoint rows / columns, brief_angle (n,) radians,
+     angle_img (u8, padded unblurred level image), angle_rc (n, 2)
 out: score (int16 map: largest FAST-9 threshold at which the pixel is still a corner, -1 = never), otsu (k,), triangle (k,), resized,
-     pattern (256, 4) scikit-image's copy of the learned rBRIEF pattern, brief (n, 32) steered-BRIEF descriptors, OpenCV bit order
+     pattern (256, 4) scikit-image's copy of the learned rBRIEF pattern, brief (n, 32) steered-BRIEF descriptors, OpenCV bit order,
+     angle (n,) intensity-centroid orientation in radians
 """
 import sys
 
@@ -43,5 +45,10 @@ from skimage.feature._orb_descriptor_positions import POS
 out["pattern"] = np.asarray(POS, np.int32)
 desc = _orb_loop(np.ascontiguousarray(d["brief_img"].astype(np.float64)), np.ascontiguousarray(d["brief_rc"].astype(np.intp)), np.ascontiguousarray(d["brief_angle"].astype(np.float64)))
 out["brief"] = np.packbits(np.asarray(desc).astype(np.uint8), axis=1, bitorder="little")
+
+# orientation by intensity centroid over the radius-15 disc (scikit-image builds the disc from the same u_max table as OpenCV's ORB)
+from skimage.feature import corner_orientations
+from skimage.feature.orb import OFAST_MASK
+out["angle"] = corner_orientations(d["angle_img"].astype(np.float64), np.ascontiguousarray(d["angle_rc"].astype(np.intp)), OFAST_MASK)
 
 np.savez(sys.argv[2], **out)

@@ -99,8 +99,14 @@ def test_external_contours_are_the_8_connected_components():
             cid = ids.pop(); assert cid not in seen; seen.add(cid)
             ys, xs = np.nonzero(lab == cid); first = np.lexsort((xs, ys))[0]
             assert c[0].tolist() == [xs[first], ys[first]]                                        # starts at the raster-first pixel
-            # every border pixel of the component (a pixel with a background 4-neighbour or on the image edge) is on the contour when the component has no hole
         assert seen == set(range(1, n + 1))
+        # without holes, the traced pixels are exactly the inner boundary: foreground pixels with a background (or outside) 4-neighbour
+        filled = ndimage.binary_fill_holes(m > 0, structure=np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]]))
+        inner = filled & ~ndimage.binary_erosion(filled, structure=np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]]), border_value=0)
+        traced = np.zeros_like(filled)
+        for c in O.find_contours(filled.astype(np.uint8) * 255, True):
+            traced[c[:, 1], c[:, 0]] = True
+        assert np.array_equal(traced, inner)
 
 
 @pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="the image's conda interpreter (scikit-image) is not present")
@@ -121,7 +127,8 @@ def test_fast_scores_otsu_and_resize_against_scikit_image(frames, tmp_path):
     blurred = O.gaussian_blur_u8(gray, 7, 2.0)             # ORBextractor.cc:1145: the level image is cloned, then blurred
     fin, fout = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
     np.savez(fin, fast_img=pad, otsu_imgs=otsu_imgs, resize_src=src, resize_shape=np.array([57, 76]), brief_img=blurred,
-             brief_rc=np.stack([np.rint(k0["y"]), np.rint(k0["x"])], 1).astype(np.int64), brief_angle=np.deg2rad(k0["angle"].astype(np.float64)))
+             brief_rc=np.stack([np.rint(k0["y"]), np.rint(k0["x"])], 1).astype(np.int64), brief_angle=np.deg2rad(k0["angle"].astype(np.float64)),
+             angle_img=orb.level_padded(0), angle_rc=np.stack([np.rint(k0["y"]) + 19, np.rint(k0["x"]) + 19], 1).astype(np.int64))
     env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
     subprocess.check_call([CONDA_PY, os.path.join(HERE, "crosscheck_skimage.py"), fin, fout], env=env, timeout=600)
     r = np.load(fout)
@@ -152,3 +159,6 @@ def test_fast_scores_otsu_and_resize_against_scikit_image(frames, tmp_path):
     assert len(k0) > 300
     diff_bits = np.unpackbits(d0 ^ r["brief"], axis=1).sum()
     assert diff_bits <= 2e-4 * d0.size * 8, (int(diff_bits), d0.size * 8)
+    # IC_Angle: atan2 of the first-order moments over the radius-15 disc; the oracle goes through cv::fastAtan2 (about 0.3 degrees accurate)
+    da = np.abs((np.rad2deg(r["angle"]) % 360.0) - k0["angle"]); da = np.minimum(da, 360.0 - da)
+    assert da.max() < 0.5, float(da.max())

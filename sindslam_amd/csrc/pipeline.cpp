@@ -167,6 +167,7 @@ int sind_pipe_destroy(sind_pipe* p) {
         if (n) fprintf(stderr, "[sind] cal_occluded: gpu+d2h %.2f pack %.2f endpoints %.2f peac %.2f contour-filter %.2f close %.2f | seg_merge: pieces %.2f sort+paint+pack %.2f alloc %.2f h2d-enqueue %.2f rag %.2f merge %.2f\n", f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5] / n, f[6] / n, f[10] / n, f[11] / n, f[7] / n, f[8] / n, f[9] / n);
         if (n) fprintf(stderr, "[sind] pieces: open %.2f contours %.2f masks %.2f lianjie %.2f centre %.2f | flow_masks host: weights %.2f sort+wait %.2f homography %.2f pack %.2f | fusion: low %.2f clusters %.2f fill %.2f out+state %.2f\n",
                        f[12] / n, f[13] / n, f[14] / n, f[15] / n, f[16] / n, f[20] / n, f[21] / n, f[22] / n, f[23] / n, f[25] / n, f[26] / n, f[27] / n, f[28] / n);
+        if (n) fprintf(stderr, "[sind] after the tail: dilate15 %.2f output copies %.2f orb mask filter %.2f\n", f[30] / n, f[31] / n, f[32] / n);
         if (g_cpu_steps.load()) fprintf(stderr, "[sind] phase-A thread CPU per step: flow slices %.1f ms, ORB thread %.1f ms (octree threads not included)\n", g_cpu_us_flow.load() / 1e3 / g_cpu_steps.load(), g_cpu_us_orb.load() / 1e3 / g_cpu_steps.load());
         if (n) fprintf(stderr, "[sind] stream waits: %.2f ms and %.1f calls per frame (occ + tail + batch stream)\n", g_sind_wait_ns.load() / 1e6 / n, (double)g_sind_wait_calls.load() / n);
         if (n) fprintf(stderr, "[sind] tail ms/frame over %ld frames: flow_masks %.2f kmeans %.2f labels %.2f cal_occluded %.2f seg_merge %.2f fusion %.2f\n", n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n);
@@ -326,12 +327,16 @@ static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, in
     int r = sb->depth_ahead ? p->tails[s]->flow_stage(sb->U.p + np * k, sb->V.p + np * k, sb->dout[k], dy.data(), lb.data(), sb->occ[k].gridFlow)
                             : p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k]);
     if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return; }
+    double* tf = p->tails[s]->t_fine; double t0 = now_ms();
     dilate15_codes(dy.data(), W, H, dil.data());
+    { const double t1 = now_ms(); tf[30] += t1 - t0; t0 = t1; }
     if (o.dyna) std::memcpy(o.dyna + np * k, dy.data(), np);
     if (o.label) std::memcpy(o.label + np * k, lb.data(), np);
     if (o.mask) std::memcpy(o.mask + np * k, dil.data(), np);
+    { const double t1 = now_ms(); tf[31] += t1 - t0; t0 = t1; }
     std::vector<OrbKeyPoint> kk; std::vector<uint8_t> dd;
     p->orb.finish(sb->orb[k], dil.data(), W, kk, dd);
+    { const double t1 = now_ms(); tf[32] += t1 - t0; t0 = t1; }
     if ((int)kk.size() > o.cap && o.kps) { sb->tail_rc[s] = SIND_E_CAPACITY; sb->tail_err[s] = "keypoint capacity exceeded"; return; }
     if (o.nkp) o.nkp[k] = (int)kk.size();
     if (o.kps) std::memcpy(o.kps + (size_t)k * o.cap, kk.data(), kk.size() * sizeof(sind_keypoint));

@@ -134,25 +134,32 @@ public:
             size_t k = 0; for (; k < runs.size(); k++) if (runs[k] == r) break; if (k == runs.size()) runs.push_back(r); run_of[i] = (int)k; }
         const int nr = ry1 - ry0 + 1; const uint64_t tm = tail_mask();
         std::vector<uint64_t> Hbuf(runs.size() * (size_t)nr * nw, 0), acc(nw), tmp(nw);
-        for (size_t k = 0; k < runs.size(); k++) {
-            const int a = runs[k].first - e.ax, L = runs[k].second - runs[k].first;     // shifts a .. a+L-1
-            for (int y = ry0; y <= ry1; y++) {
-                const uint64_t* s = row(y) + kw0;
-                bool nz = false; for (int q = 0; q < nw; q++) nz |= s[q] != 0;
-                if (!nz) continue;
-                // every run of an elliptical element contains the anchor column (a <= 0 <= a+L-1): build the window as
-                // OR_{t=0..mp} src[x+t]  |  OR_{t=0..mn} src[x-t], each by doubling, so partial windows at the borders survive
-                uint64_t* hrow = &Hbuf[(k * nr + (size_t)(y - ry0)) * nw];
-                for (int dir = 0; dir < 2; dir++) {
-                    const int m = dir == 0 ? a + L - 1 : -a, sgn = dir == 0 ? 1 : -1;
-                    std::copy(s, s + nw, acc.begin());
-                    int p = 1;                                          // acc covers t = 0..p-1
-                    while (p * 2 <= m + 1) { std::copy(acc.begin(), acc.end(), tmp.begin()); or_shift(acc.data(), tmp.data(), nw, sgn * p); p *= 2; }
-                    if (p < m + 1) { std::copy(acc.begin(), acc.end(), tmp.begin()); or_shift(acc.data(), tmp.data(), nw, sgn * (m + 1 - p)); }
+        // every run of an elliptical element contains the anchor column: run k reaches ext[0][k] pixels to the right and ext[1][k] to
+        // the left of it.  Per source row the one-sided windows OR_{t=0..m} src[x +- t] are grown ONCE, from the smallest extent to the
+        // largest (a window of length m + 1 extends by up to m + 1 pixels per shift-and-or), and every run picks its two windows up
+        // on the way, so partial windows at the borders survive and no extent is built twice.
+        std::vector<int> ext[2], ord[2];
+        for (int dir = 0; dir < 2; dir++) {
+            for (size_t k = 0; k < runs.size(); k++) ext[dir].push_back(dir == 0 ? runs[k].second - 1 - e.ax : e.ax - runs[k].first);
+            ord[dir].resize(runs.size()); for (size_t k = 0; k < runs.size(); k++) ord[dir][k] = (int)k;
+            std::sort(ord[dir].begin(), ord[dir].end(), [&](int a, int b) { return ext[dir][a] < ext[dir][b]; });
+        }
+        for (int y = ry0; y <= ry1; y++) {
+            const uint64_t* s = row(y) + kw0;
+            bool nz = false; for (int q = 0; q < nw; q++) nz |= s[q] != 0;
+            if (!nz) continue;
+            for (int dir = 0; dir < 2; dir++) {
+                const int sgn = dir == 0 ? 1 : -1;
+                std::copy(s, s + nw, acc.begin());
+                int m = 0;                                           // acc covers t = 0..m
+                for (int k : ord[dir]) {
+                    const int target = std::max(ext[dir][k], 0);
+                    while (m < target) { const int step = std::min(m + 1, target - m); std::copy(acc.begin(), acc.end(), tmp.begin()); or_shift(acc.data(), tmp.data(), nw, sgn * step); m += step; }
+                    uint64_t* hrow = &Hbuf[((size_t)k * nr + (size_t)(y - ry0)) * nw];
                     for (int q = 0; q < nw; q++) hrow[q] |= acc[q];
                 }
-                if (has_tail) hrow[nw - 1] &= tm;
             }
+            if (has_tail) for (size_t k = 0; k < runs.size(); k++) Hbuf[(k * nr + (size_t)(y - ry0)) * nw + nw - 1] &= tm;
         }
         for (int i = 0; i < e.n; i++) {
             if (run_of[i] < 0) continue;

@@ -1,0 +1,15 @@
+"""Builds examples/rgbd_tum_noros_shim.cpp (the reference's frame loop on the drop-in C++ classes of include/) with plain g++."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build(out_path):
+    lib_dir = os.path.join(ROOT, "sindslam_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libsind_hip.so")):
+        raise RuntimeError("libsind_hip.so is missing: run __graft_entry__.build() first")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "rgbd_tum_noros_shim.cpp"),
+           "-L" + lib_dir, "-lsind_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", out_path]
+    subprocess.check_call(cmd)
+    return out_path

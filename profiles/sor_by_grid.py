@@ -1,5 +1,6 @@
-"""Bins the k_sor_fused launches of a rocprofv3 --kernel-trace CSV by grid size (= pyramid level): count, total and mean duration.
-usage: python3 profiles/sor_by_grid.py <rocprof output dir>"""
+"""Bins the launches of one kernel (default k_sor_fused) of a rocprofv3 --kernel-trace CSV by grid size (= pyramid level): count, total
+and mean duration.
+usage: python3 profiles/sor_by_grid.py <rocprof output dir> [kernel substring]"""
 import csv
 import glob
 import sys
@@ -8,7 +9,7 @@ from collections import defaultdict
 f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
 bins = defaultdict(lambda: [0, 0.0]); tot = 0.0
 for r in csv.DictReader(open(f)):
-    if 'k_sor_fused' not in r['Kernel_Name']:
+    if (sys.argv[2] if len(sys.argv) > 2 else 'k_sor_fused') not in r['Kernel_Name']:
         continue
     g = (int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), int(r['Grid_Size_Y']), int(r['Workgroup_Size_X']))
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3

@@ -57,7 +57,7 @@ private:
 
 struct sind_pipe {
     sind_pipe_config c{}; DynaConfig dc; int S = 0, T = 0, fw = 0, fh = 0;
-    hipStream_t stream = nullptr, orb_stream = nullptr; hipEvent_t ev_gray = nullptr; std::vector<hipStream_t> worker_streams, worker_streams_lo;      // one HIP stream per pool worker, shared by the tasks it runs
+    hipStream_t stream = nullptr, orb_stream = nullptr; hipEvent_t ev_gray = nullptr, ev_depth = nullptr; std::vector<hipStream_t> worker_streams, worker_streams_lo;      // one HIP stream per pool worker, shared by the tasks it runs
     DynaFront front; std::vector<std::unique_ptr<DynaFront>> extra_fronts; std::vector<hipStream_t> extra_streams; hipEvent_t ev_pool = nullptr;      // batch slices 1.. of the dense flow (slice 0 = front)
     OrbEngine orb; std::vector<std::unique_ptr<DynaTail>> tails;
     std::vector<std::unique_ptr<PinnedBuf<uint8_t>>> upload_stage;        // page-locked staging of sind_pipe_process (host-buffer entry point), two 4 MB buffers per uploading worker
@@ -65,7 +65,7 @@ struct sind_pipe {
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
     struct StepBuf {
-        DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; std::vector<uint16_t> depth_h; std::vector<OrbFrameResult> orb; std::vector<OccResult> occ; bool pending = false;
+        DevBuf<float> U, V; DevBuf<uint16_t> depth_dev; PinnedBuf<uint16_t> depth_h;       /* page-locked: the 157 MB device-to-host copy of a step must not block the enqueueing thread */ std::vector<OrbFrameResult> orb; std::vector<OccResult> occ; bool pending = false;
         DevBuf<uint8_t> occ2_dev, depthN_dev;                  // per frame: plane-edge mask and normalised depth for the tails' RAG statistics (filled by the CalOccluded tasks)
         DevBuf<float> grid_dev; PinnedBuf<float> grid_h;       // flow at the 10-px sample grid of every frame (DD:1182-1204), gathered right after the dense flow
         std::atomic<int> occ_next{0};                          // next frame for the CalOccluded runner tasks
@@ -112,7 +112,7 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     p->c = *cfg; p->S = cfg->streams; p->T = cfg->frames_per_step;
     p->dc.W = cfg->width; p->dc.H = cfg->height; p->dc.fx = cfg->fx; p->dc.fy = cfg->fy; p->dc.cx = cfg->cx; p->dc.cy = cfg->cy; p->dc.depthScale = cfg->depth_scale; p->dc.device = cfg->device;
     const bool flow_hi = getenv("SIND_FLOW_PRIORITY") && atoi(getenv("SIND_FLOW_PRIORITY")) != 0;
-    SIND_TRY(make_stream(&p->stream, flow_hi)); SIND_TRY(make_stream(&p->orb_stream, false)); HIP_TRY(hipEventCreateWithFlags(&p->ev_gray, hipEventDisableTiming));
+    SIND_TRY(make_stream(&p->stream, flow_hi)); SIND_TRY(make_stream(&p->orb_stream, false)); HIP_TRY(hipEventCreateWithFlags(&p->ev_gray, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_depth, hipEventDisableTiming));
     const int B = p->S * p->T; const size_t np = (size_t)cfg->width * cfg->height;
     // dense-flow slices: three concurrent streams keep the GPU busy through the launch tails and the small pyramid levels of each other
     // (measured at B = 256: 270 -> 253 ms per step); small batches stay in one piece
@@ -153,7 +153,7 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     p->workers.start(nworkers, cfg->device);
     SIND_TRY(p->gray.alloc(np * B)); SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
     if (cfg->orb_gray_rgb_order) SIND_TRY(p->gray_orb.alloc(np * B));
-    for (int k = 0; k < 2; k++) { SIND_TRY(p->sb[k].U.alloc(np * B)); SIND_TRY(p->sb[k].V.alloc(np * B)); SIND_TRY(p->sb[k].depth_dev.alloc(np * B)); p->sb[k].depth_h.resize(np * B); }
+    for (int k = 0; k < 2; k++) { SIND_TRY(p->sb[k].U.alloc(np * B)); SIND_TRY(p->sb[k].V.alloc(np * B)); SIND_TRY(p->sb[k].depth_dev.alloc(np * B)); SIND_TRY(p->sb[k].depth_h.alloc(np * B)); }
     p->primed.assign(p->S, 0);
     *out = p.release(); return SIND_OK;
 }
@@ -178,6 +178,7 @@ int sind_pipe_destroy(sind_pipe* p) {
     for (size_t w = 0; w < p->worker_streams_lo.size(); w++) if (w >= p->worker_streams.size() || p->worker_streams_lo[w] != p->worker_streams[w]) ss.push_back(p->worker_streams_lo[w]); ss.push_back(p->orb_stream); ss.insert(ss.end(), p->extra_streams.begin(), p->extra_streams.end());
     if (p->ev_pool) (void)hipEventDestroy(p->ev_pool);
     if (p->ev_gray) (void)hipEventDestroy(p->ev_gray);
+    if (p->ev_depth) (void)hipEventDestroy(p->ev_depth);
     delete p;
     for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
     return SIND_OK;
@@ -210,6 +211,11 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     // ORB front (pyramid, FAST, octree, orientation, blur, BRIEF) of all frames: independent of the flow, so it runs on its own HIP
     // stream and host thread underneath the dense flow instead of after it
     HIP_TRY(hipEventRecord(p->ev_gray, p->stream));
+    // private copies of the depth frames: device (tail kernels of this step run while the caller may reuse its buffer) and host.  They go
+    // ahead of the ORB front on its stream (157 MB to the host, ~3 ms): the flow slices need not wait for them, only the CalOccluded tasks do
+    HIP_TRY(hipMemcpyAsync(sb.depth_dev.p, depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToDevice, p->orb_stream));
+    HIP_TRY(hipMemcpyAsync(sb.depth_h.data(), sb.depth_dev.p, np * B * sizeof(uint16_t), hipMemcpyDeviceToHost, p->orb_stream));
+    HIP_TRY(hipEventRecord(p->ev_depth, p->orb_stream));
     int orb_rc = SIND_OK; std::string orb_err;
     std::thread orb_thread([&] {
         (void)pthread_setname_np(pthread_self(), "sind-orb");
@@ -219,10 +225,6 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         if (orb_rc != SIND_OK) orb_err = sind_last_error();
         g_cpu_us_orb += (long long)(thread_cpu_ms() * 1e3); });
     struct OrbJoin { std::thread& t; ~OrbJoin() { if (t.joinable()) t.join(); } } orb_join{orb_thread};
-    // private copies of the depth frames: device (tail kernels of this step run while the caller may reuse its buffer) and host
-    HIP_TRY(hipMemcpyAsync(sb.depth_dev.p, depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToDevice, p->stream));
-    HIP_TRY(hipMemcpyAsync(sb.depth_h.data(), sb.depth_dev.p, np * B * sizeof(uint16_t), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(sind_stream_wait(p->stream));
     // CalOccluded of every frame (state free: depth only) on the streams' own host threads / HIP streams, concurrent with the
     // dense flow below (the host cores would otherwise idle while the GPU runs the flow solver)
     sb.occ.assign(B, OccResult());
@@ -241,12 +243,12 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     // threads than the CPU quota of the box (cgroup cpu.max, 16 cores per GPU) only burn the quota early in a period and stall EVERY
     // thread of the process, the flow's launch threads included, until the period ends
     sb.occ_next.store(0);
-    for (int r = 0; r < std::min(p->occ_workers, B); r++) p->workers.push(sb.occ_group, [p, &sb, B, np](int w) {
+    auto push_occ = [&] { for (int r = 0; r < std::min(p->occ_workers, B); r++) p->workers.push(sb.occ_group, [p, &sb, B, np](int w) {
         for (int k; (k = sb.occ_next.fetch_add(1)) < B;) {
             const int rc = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
             if (rc != SIND_OK) { sb.occ_rc[k] = rc; sb.occ_err[k] = sind_last_error(); }
             if (sb.depth_ahead && sb.gate[k].fetch_add(1) == 1) { sind_pipe::StepBuf* sbp = &sb; p->workers.push(sb.depth_group, [p, sbp, k](int w2) { depth_task(p, sbp, k, w2); }); }
-        } });
+        } }); };
     t[1] = now_ms();
     // dense flow for every (n, n-2) pair, second pass for large-motion pairs, refinement, up-scale
     std::vector<int> cur(B), p1(B), p2(B);
@@ -271,9 +273,13 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
             if (rc[i] == SIND_OK && sind_stream_wait(f.stream) != hipSuccess) rc[i] = SIND_E_HIP;
             if (rc[i] != SIND_OK) er[i] = sind_last_error();
         };
-        for (int i = 1; i < nsl; i++) th.emplace_back([&, i] { (void)pthread_setname_np(pthread_self(), "sind-flow"); (void)hipSetDevice(p->c.device); run(i); g_cpu_us_flow += (long long)(thread_cpu_ms() * 1e3); });
-        { const double c0 = thread_cpu_ms(); run(0); g_cpu_us_flow += (long long)((thread_cpu_ms() - c0) * 1e3); g_cpu_steps++; }
+        for (int i = 0; i < nsl; i++) th.emplace_back([&, i] { (void)pthread_setname_np(pthread_self(), "sind-flow"); (void)hipSetDevice(p->c.device); run(i); g_cpu_us_flow += (long long)(thread_cpu_ms() * 1e3); });
+        g_cpu_steps++;
+        // the slices are on their way: wait for the depth copies and start the CalOccluded tasks from here
+        const hipError_t depth_ok = sind_event_wait(p->ev_depth);
+        if (depth_ok == hipSuccess) push_occ();
         for (auto& t : th) t.join();
+        if (depth_ok != hipSuccess) { (void)hipGetLastError(); sind_set_error("copy of the depth frames failed"); return SIND_E_HIP; }
         for (int i = 0; i < nsl; i++) if (rc[i] != SIND_OK) { sind_set_error("dense flow slice %d: %s", i, er[i].c_str()); return rc[i]; }
         for (int k = 0; k < B; k++) sb.occ[k].gridFlow = sb.grid_h.p + gsz * k;
         p->sor_ms = 0; p->sor_bytes = 0; p->sor_launches = 0; p->sor_slices = nsl;

@@ -391,8 +391,8 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     if (C > 254) { sind_set_error("seg_and_merge: %d pieces exceed the 8-bit label range of the reference", C); return SIND_E_CAPACITY; }
     for (Piece& p : all) p.score = (float)(p.area * 0.0003f - p.cz);
     std::sort(all.begin(), all.end(), [](const Piece& a, const Piece& b) { return a.score > b.score; });
-    std::vector<uint8_t> total(N, (uint8_t)(C + 1));
-    for (int i = 0; i < C; i++) all[i].img.paint_u8(total.data(), W, (uint8_t)i);
+    std::vector<uint8_t> pieceOf(N, (uint8_t)(C + 1));       // index of the piece that owns a pixel (the reference paints the pieces in score order)
+    for (int i = 0; i < C; i++) all[i].img.paint_u8(pieceOf.data(), W, (uint8_t)i);
     // ---- RAG statistics on the GPU: upload the 3*C bit planes, one pass over the frame
     const int wpr = W / 64; const size_t pw = (size_t)H * wpr;
     SIND_TRY(h_planes.alloc((size_t)3 * C * pw)); SIND_TRY(h_rag.alloc((size_t)3 * C * C + C + (size_t)C * 256));
@@ -490,7 +490,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
         for (int q = 0; q <= M; q++) if (sel[q]) lut[q] = (uint8_t)labelindex;
         labelindex++;
     }
-    for (int k = 0; k < N; k++) labelNew[k] = lut[total[k]];
+    for (int k = 0; k < N; k++) labelNew[k] = lut[pieceOf[k]];
     FLAP(9)
     #undef FLAP
     return SIND_OK;

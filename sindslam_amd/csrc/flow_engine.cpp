@@ -60,7 +60,7 @@ int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, 
     // One level is ~36 launches.  A thread that enqueues the whole pyramid runs far ahead of the GPU, fills the queue and then SPINS inside
     // the launch call for the rest of the solve (measured: a slice thread burnt a full core, 215 ms per step); so the thread stays at
     // most `launch_ahead` levels ahead and sleeps on the level events instead.
-    while ((int)level_done.size() < L) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); level_done.push_back(e); }
+    while ((int)level_done.size() < L) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); level_done.push_back(ev); }
     for (int l = L - 1; l >= 0; --l) {
         const int w = levels[l].first, h = levels[l].second;
         if (launch_ahead > 0 && l + launch_ahead < L) HIP_TRY(sind_event_wait(level_done[l + launch_ahead]));

@@ -189,9 +189,9 @@ public:
         int k0, k1; word_extent(y0, y1, k0, k1);
         if (k1 < k0) return out;
         // the erosion is a subset of the source: only the words [k0, k1] of rows [y0, y1] are needed from the dilated complement
-        const BitImg d = inverted().dilated_win(e, std::max(y0 - e.n, 0), std::min(y1 + e.n, h - 1), k0 - 1, k1 + 1);
+        const BitImg dil = inverted().dilated_win(e, std::max(y0 - e.n, 0), std::min(y1 + e.n, h - 1), k0 - 1, k1 + 1);
         const uint64_t tm = tail_mask();
-        for (int y = y0; y <= y1; y++) { const uint64_t* p = d.row(y); uint64_t* o = out.row(y); for (int k = k0; k <= k1; k++) o[k] = ~p[k]; o[wpr - 1] &= tm; }
+        for (int y = y0; y <= y1; y++) { const uint64_t* p = dil.row(y); uint64_t* o = out.row(y); for (int k = k0; k <= k1; k++) o[k] = ~p[k]; o[wpr - 1] &= tm; }
         return out;
     }
     BitImg opened(const EllipseElem& e) const { return eroded(e).dilated(e); }

@@ -191,7 +191,7 @@ struct Fitter {
         const int nPl = (int)planes.size();
         struct PlaneC { double n[3], c[3], thr; };
         std::vector<PlaneC> pc(nPl);
-        for (int k = 0; k < nPl; k++) { const Seg& S = pool[planes[k]]; for (int q = 0; q < 3; q++) { pc[k].n[q] = S.normal[q]; pc[k].c[q] = S.center[q]; } pc[k].thr = 9 * S.mse + 1e-5; }
+        for (int k = 0; k < nPl; k++) { const Seg& sg = pool[planes[k]]; for (int q = 0; q < 3; q++) { pc[k].n[q] = sg.normal[q]; pc[k].c[q] = sg.center[q]; } pc[k].thr = 9 * sg.mse + 1e-5; }
         std::vector<char> linkSeen((size_t)nPl * nPl, 0);
         std::vector<float> distMap((size_t)W * H, std::numeric_limits<float>::max());
         auto visit = [&](int cx, int cy, int pl, const PlaneC& S) {
@@ -244,7 +244,7 @@ struct Fitter {
                 const int pl = m[x], x0 = x; while (x < W && m[x] == pl) x++;
                 if (pl < 0 || plmap[pl] < 0 || plmap[pl] >= nOut) continue;
                 const int o = plmap[pl]; uint64_t* r = masks[o].row(y); const int a = x0, b = x - 1, ka = a >> 6, kb = b >> 6;
-                for (int q = ka; q <= kb; q++) { uint64_t v = ~0ull; if (q == ka) v &= ~0ull << (a & 63); if (q == kb) v &= (b & 63) == 63 ? ~0ull : ((1ull << ((b & 63) + 1)) - 1); r[q] |= v; }
+                for (int q = ka; q <= kb; q++) { uint64_t bits = ~0ull; if (q == ka) bits &= ~0ull << (a & 63); if (q == kb) bits &= (b & 63) == 63 ? ~0ull : ((1ull << ((b & 63) + 1)) - 1); r[q] |= bits; }
                 yLo[o] = std::min(yLo[o], y); yHi[o] = y;
             }
         }

@@ -278,7 +278,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         // the slices are on their way: wait for the depth copies and start the CalOccluded tasks from here
         const hipError_t depth_ok = sind_event_wait(p->ev_depth);
         if (depth_ok == hipSuccess) push_occ();
-        for (auto& t : th) t.join();
+        for (auto& slice_thread : th) slice_thread.join();
         if (depth_ok != hipSuccess) { (void)hipGetLastError(); sind_set_error("copy of the depth frames failed"); return SIND_E_HIP; }
         for (int i = 0; i < nsl; i++) if (rc[i] != SIND_OK) { sind_set_error("dense flow slice %d: %s", i, er[i].c_str()); return rc[i]; }
         for (int k = 0; k < B; k++) sb.occ[k].gridFlow = sb.grid_h.p + gsz * k;

@@ -93,9 +93,9 @@ def cgroup_throttle():
 
 
 def pmc_traffic(pairs_per_step):
-    """HBM bytes per k_sor_fused launch from the committed rocprofv3 PMC passes (profiles/r01/v11_pmc_k_sor_fused.json: separate
+    """HBM bytes per k_sor_fused launch from the committed rocprofv3 PMC passes (profiles/r01/v13_pmc_k_sor_fused.json: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction), scaled to this batch; None if absent."""
-    f = os.path.join(ROOT, "profiles", "r01", "v11_pmc_k_sor_fused.json")
+    f = os.path.join(ROOT, "profiles", "r01", "v13_pmc_k_sor_fused.json")
     if not os.path.exists(f):
         return None
     d = json.load(open(f))
@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=64)
+    ap.add_argument("--streams", type=int, default=128)
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the cpu_baseline leg (one oracle instance and one stream each)")

@@ -35,7 +35,11 @@ inline void find_contours(const BitImg& src, std::vector<Contour>& out, bool ext
         signed char* rowp = &img[(size_t)y * w];
         for (int x = 1; x < w; x++) {
             int p = rowp[x];
-            if (p == prev) continue;
+            if (p == prev) {            // nothing happens inside a run of equal values (background, blob interior): skip it eight pixels at a time
+                const uint64_t pat = (uint64_t)(uint8_t)prev * 0x0101010101010101ull;
+                while (x + 8 < w) { uint64_t v; std::memcpy(&v, rowp + x + 1, 8); if (v != pat) break; x += 8; }
+                continue;
+            }
             bool is_hole = false, start = true;
             if (!(prev == 0 && p == 1)) {
                 if (p != 0 || prev < 1) start = false;

@@ -67,6 +67,20 @@ def test_drawing_matches_oracle_pipeline(H):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("seed,n,outlier_step,noise", [(11, 2501, 5, 0.3), (12, 2902, 3, 1.0), (13, 403, 2, 0.1), (14, 7, 0, 0.0), (15, 2900, 0, 2.5)])
+def test_homography_identical_to_oracle_more_cases(H, seed, n, outlier_step, noise):
+    """pair counts that are not a multiple of the SIMD width, heavy outliers, few points, pure noise"""
+    rng = np.random.default_rng(seed); Hm = np.array([[1.01, -0.02, 3.0], [0.015, 0.99, -2.5], [1e-6, -2e-6, 1.0]])
+    src = rng.uniform(0, 640, (n, 2)).astype(np.float32)
+    p = np.c_[src, np.ones(len(src))] @ Hm.T; dst = (p[:, :2] / p[:, 2:] + rng.normal(0, noise, (len(src), 2))).astype(np.float32)
+    if outlier_step:
+        dst[::outlier_step] += rng.uniform(-40, 40, dst[::outlier_step].shape).astype(np.float32)
+    out = np.zeros(9)
+    ok = H.sindh_find_homography(P(src), P(dst), len(src), P(out))
+    rok, ref = O.find_homography(src, dst)
+    assert bool(ok) == bool(rok) and np.array_equal(out.reshape(3, 3), ref)
+
+
 def test_homography_identical_to_oracle(H):
     rng = np.random.default_rng(3); Hm = np.array([[0.99, 0.01, 4.0], [-0.01, 1.0, 1.5], [2e-6, 1e-6, 1.0]])
     src = rng.uniform(0, 640, (2500, 2)).astype(np.float32)

@@ -19,16 +19,24 @@ inline void find_contours(const BitImg& src, std::vector<Contour>& out, bool ext
     Rect bb = roi ? *roi : src.bbox();
     if (bb.empty()) return;
     bb.x0 = std::max(bb.x0, 0); bb.y0 = std::max(bb.y0, 0); bb.x1 = std::min(bb.x1, src.w - 1); bb.y1 = std::min(bb.y1, src.h - 1);
-    const int bw = bb.x1 - bb.x0 + 1, bh = bb.y1 - bb.y0 + 1, w = bw + 2, h = bh + 2;
+    // byte copy of the box, widened to whole 64-pixel words (8 bits -> 8 bytes per step instead of one store per set pixel) plus a
+    // one-pixel empty frame; pixels of the words that lie outside the box columns are masked off
+    const int kx0 = bb.x0 >> 6, kx1 = bb.x1 >> 6, xa = kx0 << 6;
+    const int bw = (kx1 - kx0 + 1) << 6, bh = bb.y1 - bb.y0 + 1, w = bw + 2, h = bh + 2;
     std::vector<signed char> img((size_t)w * h, 0);
-    for (int y = 0; y < bh; y++) {                                     // expand the set bits of the bounding box rows
-        const uint64_t* r = src.row(bb.y0 + y); signed char* o = &img[(size_t)(y + 1) * w + 1 - bb.x0];
-        for (int k = bb.x0 >> 6; k <= bb.x1 >> 6; k++) { uint64_t m = r[k]; while (m) { const int x = (k << 6) + __builtin_ctzll(m); m &= m - 1; if (x >= bb.x0 && x <= bb.x1) o[x] = 1; } }
+    const uint64_t first = ~0ull << (bb.x0 & 63), last = (bb.x1 & 63) == 63 ? ~0ull : ((1ull << ((bb.x1 & 63) + 1)) - 1);
+    for (int y = 0; y < bh; y++) {
+        const uint64_t* r = src.row(bb.y0 + y); signed char* o = &img[(size_t)(y + 1) * w + 1];
+        for (int k = kx0; k <= kx1; k++) {
+            uint64_t m = r[k]; if (k == kx0) m &= first; if (k == kx1) m &= last;
+            if (!m) continue;
+            for (int q = 0; q < 8; q++) { const uint64_t v = spread8((unsigned)(m >> (8 * q)) & 0xffu) & 0x0101010101010101ull; std::memcpy(o + ((k - kx0) << 6) + 8 * q, &v, 8); }
+        }
     }
     const int d8[8] = {1, -w + 1, -w, -w - 1, -1, w - 1, w, w + 1};
     int deltas[16]; for (int i = 0; i < 16; i++) deltas[i] = d8[i & 7];
     static const int cdx[8] = {1, 1, 0, -1, -1, -1, 0, 1}, cdy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-    const int ox = bb.x0 - 1, oy = bb.y0 - 1;
+    const int ox = xa - 1, oy = bb.y0 - 1;
     int nbd = 2;
     for (int y = 1; y < h - 1; y++) {
         int prev = 0, lnbd_x = 0;

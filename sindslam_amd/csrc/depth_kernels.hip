@@ -407,6 +407,38 @@ __global__ void __launch_bounds__(256) k_rag_stats(const unsigned long long* __r
     }
 }
 
+// Elliptical dilation of bit planes (64 pixels per word), dst(x, y) = OR over the element of src(x + j - ax, y + i - ay) with positions
+// outside the image ignored: the 7x7 dilation of every piece of SegAndMergeV2 (DD:760-ish "imgEachClusterDilate") for the region-adjacency
+// statistics.  One thread per output word; a row of the element is a run of <= 15 shifts over a three-word window.
+__global__ void k_dilate_planes(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, int nplanes, int wpr, int H, MorphElem e,
+                                unsigned long long tail_mask) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, pw = (size_t)wpr * H;
+    if (idx >= pw * nplanes) return;
+    const int c = (int)(idx / pw), rem = (int)(idx - (size_t)c * pw), y = rem / wpr, k = rem - y * wpr;
+    const unsigned long long* sp = src + (size_t)c * pw;
+    unsigned long long acc = 0ull;
+    for (int i = 0; i < e.n; i++) {
+        const int ys = y + i - e.ay;
+        if (ys < 0 || ys >= H || e.j2[i] <= e.j1[i]) continue;
+        const unsigned long long* r = sp + (size_t)ys * wpr;
+        const unsigned long long cur = r[k], prev = k > 0 ? r[k - 1] : 0ull, next = k + 1 < wpr ? r[k + 1] : 0ull;
+        for (int j = e.j1[i]; j < e.j2[i]; j++) {
+            const int t = j - e.ax;                      // dst bit x takes src bit x + t
+            if (t == 0) acc |= cur;
+            else if (t > 0) acc |= (cur >> t) | (next << (64 - t));
+            else acc |= (cur << (-t)) | (prev >> (64 + t));
+        }
+    }
+    if (k == wpr - 1) acc &= tail_mask;
+    dst[idx] = acc;
+}
+int launch_dilate_planes(hipStream_t s, const unsigned long long* src, unsigned long long* dst, int nplanes, int w, int h, int n) {
+    const int wpr = (w + 63) / 64; const size_t total = (size_t)wpr * h * nplanes;
+    const unsigned long long tm = (w & 63) ? ((1ull << (w & 63)) - 1) : ~0ull;
+    hipLaunchKernelGGL(k_dilate_planes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, nplanes, wpr, h, make_ellipse(n), tm);
+    return SIND_OK;
+}
+
 // ---------------------------------------------------------------- launchers
 int launch_depth_half(hipStream_t s, const uint16_t* src, uint16_t* dst, int dw, int dh) { hipLaunchKernelGGL(k_depth_half, dim3(divup(dw, 128), dh), dim3(128), 0, s, src, dst, dw, dh); return SIND_OK; }
 int launch_points(hipStream_t s, const uint16_t* depth, float* px, float* py, float* pz, int w, int h, float scale, float fx, float fy, float cx, float cy, float depthScale) {

@@ -337,11 +337,11 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
 // ---- DD:653-1018: split every depth cluster on edges into pieces, region-adjacency statistics on the GPU, greedy merge on the host
 int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,
                             const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew, const OccResult* pre) {
-    struct Piece { BitImg img, dil, lianjie; bool hasLianjie = false; float area = 0, score = -10, cz = 0; };
+    struct Piece { BitImg img, lianjie; bool hasLianjie = false; float area = 0, score = -10, cz = 0; };
     std::vector<Piece> all;
     double tf = tick_ms();
     #define FLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tf; tf = t_; }
-    const EllipseElem e4(4), e7(7), e9(9), e10(10);
+    const EllipseElem e4(4), e9(9), e10(10);
     const BitImg occDil = occ1.dilated(e10);
     const float depth_weight = 1.5f;
     for (int i = 0; i + 1 < (int)allLabels.size(); i++) {
@@ -360,7 +360,6 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
             Piece p; p.img.create(W, H); draw_filled(p.img, c);
             p.img = p.img.dilated(e9, bb.y0, bb.y1); p.img.and_rows(orig, bb.y0 - 4, bb.y1 + 4);       // the 9x9 element reaches 4 rows up and down
             p.area = (float)p.img.count_rows(bb.y0 - 4, bb.y1 + 4);
-            p.dil = p.img.dilated(e7, bb.y0 - 4, bb.y1 + 4);
             QLAP(14)
             BitImg t1(W, H); draw_thick2(t1, c); t1.andnot_rows(occDil, bb.y0 - 1, bb.y1 + 1); t1.and_rows(labelForSegEdge, bb.y0 - 1, bb.y1 + 1);
             if (t1.count_rows(bb.y0 - 1, bb.y1 + 1) > 20) {
@@ -397,16 +396,18 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     const int wpr = W / 64; const size_t pw = (size_t)H * wpr;
     SIND_TRY(h_planes.alloc((size_t)3 * C * pw)); SIND_TRY(h_rag.alloc((size_t)3 * C * C + C + (size_t)C * 256));
     unsigned long long* planes = h_planes.p; const size_t planes_n = (size_t)3 * C * pw;
+    // plane sets: [0, C) pieces, [C, 2C) their 7x7 dilations (formed on the GPU from the first set), [2C, 3C) connection areas
     for (int i = 0; i < C; i++) if (!all[i].hasLianjie) std::memset(&planes[((size_t)2 * C + i) * pw], 0, pw * 8);
     for (int i = 0; i < C; i++) {
         std::memcpy(&planes[((size_t)0 * C + i) * pw], all[i].img.d.data(), pw * 8);
-        std::memcpy(&planes[((size_t)1 * C + i) * pw], all[i].dil.d.data(), pw * 8);
         if (all[i].hasLianjie) std::memcpy(&planes[((size_t)2 * C + i) * pw], all[i].lianjie.d.data(), pw * 8);
     }
     FLAP(10)
     SIND_TRY(planes_d.alloc(planes_n)); SIND_TRY(rag_d.alloc((size_t)3 * C * C + C + (size_t)C * 256));
     FLAP(11)
-    HIP_TRY(hipMemcpyAsync(planes_d.p, planes, planes_n * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(planes_d.p, planes, (size_t)C * pw * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(planes_d.p + (size_t)2 * C * pw, planes + (size_t)2 * C * pw, (size_t)C * pw * 8, hipMemcpyHostToDevice, stream));
+    SIND_TRY(launch_dilate_planes(stream, planes_d.p, planes_d.p + (size_t)C * pw, C, W, H, 7));
     const uint8_t* occ2_use = pre && pre->occ2_dev ? pre->occ2_dev : occ2_d.p;
     if (!(pre && pre->occ2_dev)) { occ2.to_u8((h_ab.p + N), W, 255); HIP_TRY(hipMemcpyAsync(occ2_d.p, (h_ab.p + N), N, hipMemcpyHostToDevice, stream)); }
     FLAP(7)

@@ -105,4 +105,17 @@ int sind_dyna_debug(sind_dyna* d, float* flow_deep, float* flow_refined, float* 
     return SIND_OK;
 }
 
+// parity-test access to the bit-plane dilation of the RAG stage (k_dilate_planes): planes are [nplanes][height][ceil(width / 64)] words, host memory
+int sind_debug_dilate_planes(const unsigned long long* planes, int nplanes, int width, int height, int n, int device, unsigned long long* out) {
+    if (!planes || !out || nplanes < 1 || width < 1 || height < 1 || n < 1 || n > MORPH_MAX) { sind_set_error("sind_debug_dilate_planes: bad arguments"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    const size_t words = (size_t)nplanes * height * ((width + 63) / 64);
+    DevBuf<unsigned long long> a, b; SIND_TRY(a.alloc(words)); SIND_TRY(b.alloc(words));
+    HIP_TRY(hipMemcpy(a.p, planes, words * 8, hipMemcpyHostToDevice));
+    SIND_TRY(sind::launch_dilate_planes(nullptr, a.p, b.p, nplanes, width, height, n));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, b.p, words * 8, hipMemcpyDeviceToHost));
+    return SIND_OK;
+}
+
 }  // extern "C"

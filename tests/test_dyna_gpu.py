@@ -61,3 +61,25 @@ def test_requires_prime():
                                 out.ctypes.data_as(C.c_void_p), 0)
     assert rc == -4 and b"prime" in lib().sind_last_error()
     lib().sind_dyna_destroy(h)
+
+
+@pytest.mark.parametrize("w,n", [(640, 7), (640, 9), (200, 7), (64, 3), (130, 15)])
+def test_bit_plane_dilation_equals_oracle_morphology(w, n):
+    """k_dilate_planes (the pieces' 7x7 dilation of the region-adjacency stage, on 64-pixel words) against the oracle's cv::dilate,
+    including widths that are not a multiple of 64 (tail word) and blobs touching every border"""
+    import ctypes as C
+    from sindslam_amd._lib import check, lib, ptr
+    rng = np.random.default_rng(w + n); h, planes = 57, 3
+    imgs = np.zeros((planes, h, w), np.uint8)
+    for p in range(planes):
+        imgs[p][rng.random((h, w)) < 0.01] = 255
+        imgs[p, 0, :5] = 255; imgs[p, -1, -3:] = 255; imgs[p, 10:20, 0] = 255; imgs[p, 30:40, -1] = 255
+    wpr = (w + 63) // 64
+    packed = np.zeros((planes, h, wpr * 64), np.uint8); packed[:, :, :w] = imgs > 0
+    words = np.packbits(packed.reshape(planes, h, wpr, 64), axis=-1, bitorder="little").view(np.uint64).reshape(planes, h, wpr).copy()
+    out = np.zeros_like(words)
+    check(lib().sind_debug_dilate_planes(ptr(words), planes, w, h, n, 0, ptr(out)), "sind_debug_dilate_planes")
+    got = np.unpackbits(out.view(np.uint8).reshape(planes, h, wpr * 8), axis=-1, bitorder="little")[:, :, :w]
+    for p in range(planes):
+        assert np.array_equal(got[p] * 255, O.morph(imgs[p], n, "dilate")), (p, w, n)
+    assert not np.unpackbits(out.view(np.uint8).reshape(planes, h, wpr * 8), axis=-1, bitorder="little")[:, :, w:].any()      # tail bits stay clear

@@ -39,3 +39,32 @@ def frame_pairs_per_second(local_pairs: int, local_seconds: float, group=None):
     t = torch.tensor([local_seconds], dtype=torch.float64, device=dev); n = torch.tensor([local_pairs], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group); dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
     return float(n.item() / t.item())
+
+
+def gather_sequence_masks(masks, owned, group=None):
+    """One long sequence sharded by frame (sequence.process_sequence): every rank passes its u8 array [N, H, W] (numpy or torch; only the
+    frames in `owned`, a contiguous ascending range, are meaningful) -> the same array with the owned frames of ALL ranks filled in, on every
+    rank.  The ranks own different numbers of frames, so each contributes a block padded to the largest count (one all_gather of the
+    counts, one of the blocks -- the RCCL gather of the per-frame dynamic masks of the north star)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group); backend = dist.get_backend(group)
+    dev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.as_tensor(masks)
+    first = int(owned[0]) if len(owned) else 0; count = len(owned)
+    if count and list(owned) != list(range(first, first + count)):
+        raise ValueError("gather_sequence_masks: the owned frames of a rank must be one contiguous range")
+    meta = torch.tensor([first, count], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    maxc = max(int(m[1]) for m in metas)
+    block = torch.zeros((max(maxc, 1),) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+    if count:
+        block[:count] = t[first:first + count].to(dev)
+    blocks = gather_masks(block, group=group)
+    out = t.clone()
+    for r in range(world):
+        f, c = int(metas[r][0]), int(metas[r][1])
+        if c:
+            out[f:f + c] = blocks[r][:c].to(out.device)
+    return out.numpy() if isinstance(masks, np.ndarray) else out

@@ -1,34 +1,125 @@
 #!/usr/bin/env python3
 """bench.py -- DynaDetect+ORB frame-pairs/s at 640x480 on MI355X (BASELINE.json metric).
 
-One step = one pass of the batched pipeline over S streams x T frames (S*T frame pairs) of the synthetic TUM-shaped
-RGB-D stream (TUM3 intrinsics, depth factor 5000, FAST 15/5, 1500 features; BASELINE.json configs[1] shape -- the real
-TUM frames are not available offline).  Inputs are resident in HBM before the timed region (at most 12 distinct steps of input are
-generated; a longer run cycles through them, the jump at the wrap is just another large-motion frame pair).  With --gpus N every rank
-runs its own S streams (frames shard by stream, no data-path collective inside the hot path) and the per-frame dynamic
-masks are gathered with one RCCL all_gather per step (north_star); value = all ranks' frame pairs / max-over-ranks time.
+One step = one pass of the batched pipeline over S streams x T frames (S*T frame pairs).  Inputs are resident in HBM before the timed
+region.  Two workloads:
 
-Prints ONE JSON line (see README / DESIGN.md "Measurement").
+  streams   (default at --gpus 1)  S independent TUM-shaped camera streams per GPU (BASELINE.json configs[1] shape: 640x480, TUM3
+            intrinsics, depth factor 5000, FAST 15/5, 1500 features; the real TUM frames are not available offline).
+  sequence  (default at --gpus N > 1; BASELINE.json configs[3]) ONE synthetic RGB-D sequence sharded by frame: the owned frames are cut
+            into N*S contiguous chunks, chunk g = rank*S + s is stream s of rank `rank`; the W warm-up steps of the bench are the chunks'
+            state warm-up frames (sindslam_amd/sequence.py), the K timed steps process the owned frames, and after every step the per-frame
+            dynamic masks of all ranks are gathered with one RCCL all_gather over xGMI and written into the sequence-ordered mask array
+            that every rank holds.  Weak scaling: K*S*T owned frames per GPU, sequence length 2 + N*S*K*T + W*T (4098 frames at
+            --gpus 8 --steps 1).  After the timed region rank 0 re-runs the first chunks in the in-order ("exact") mode and reports the
+            chunk-seam IoU and the exact mode's own rate.
+
+--gpus N without a launcher (WORLD_SIZE unset): this process starts N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set)
+BEFORE anything touches torch or the GPU and only waits for them; under torch.distributed.run the ranks are already there.
+Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# BASELINE.json configs that fit one GPU; `tum3` is the one the metric is quoted on
+CONFIGS = {
+    "tum3": dict(width=640, height=480, intr="TUM3", rgb=1, flow_max_levels=0, streams=128,
+                 workload="TUM fr3/walking_xyz-shaped synthetic RGB-D stream, 640x480, TUM3 intrinsics, FAST 15/5, 1500 features"),
+    "bonn": dict(width=640, height=480, intr="BONN", rgb=1, flow_max_levels=0, streams=128,
+                 workload="Bonn rgbd-dynamic-shaped synthetic RGB-D stream, 640x480, Bonn intrinsics, FAST 20/7, 1500 features"),
+    "d455_720p": dict(width=1280, height=720, intr="D455", rgb=0, flow_max_levels=3, streams=48,
+                      workload="D455-shaped synthetic RGB-D stream, 1280x720, D455 intrinsics x2, depth factor 1000, FAST 20/7, 1500 features, 3-level flow pyramid"),
+}
 
-def make_inputs(S, T, nsteps, seed=12345):
-    """Base synthetic sequence + cheap per-stream variants (flips / gain) so that streams differ."""
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="tum3", help="BASELINE.json config (default: the one the metric is quoted on)")
+    ap.add_argument("--workload", choices=["auto", "streams", "sequence"], default="auto", help="auto: streams at 1 GPU, sequence (frame-sharded, RCCL mask gather) at N > 1")
+    ap.add_argument("--streams", type=int, default=0, help="streams (= sequence chunks) per GPU; 0 = the config's default")
+    ap.add_argument("--frames-per-step", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the first cpu_baseline setting (the reference pins its OpenMP loops to 8)")
+    ap.add_argument("--no-exact-leg", action="store_true", help="sequence workload: skip the in-order re-run of the first chunks (seam IoU, exact-mode rate)")
+    ap.add_argument("--host-input", action="store_true", help="hand over HOST buffers each step (sind_pipe_process, PCIe-inclusive rate; DESIGN.md 6) instead of HBM-resident inputs")
+    ap.add_argument("--thread-cpu", action="store_true", help="print the CPU seconds the live threads used inside the timed region, by thread name (stderr)")
+    ap.add_argument("--pipelined", action="store_true", help="software-pipeline consecutive steps (submit/flush); off by default: measured slower on MI355X")
+    ap.add_argument("--host-threads", type=int, default=0, help="host worker pool size (0 = library default, the GPU box's CPU share)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="ranks only meet, count themselves and exit (launcher test, needs no GPU)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args) -> int:
+    """Parent of a --gpus N run without a launcher: start N rank processes, never touch torch / the GPU here, exit with the first failure."""
+    n = args.gpus
+    port = int(os.environ.get("MASTER_PORT", 29400 + os.getpid() % 2000))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    print(f"[bench launcher] pid {os.getpid()} spawned {n} ranks {[p.pid for p in procs]}; torch imported in the launcher: {'torch' in sys.modules}", file=sys.stderr, flush=True)
+    rc = 0; left = list(procs)
+    while left:
+        for p in list(left):
+            r = p.poll()
+            if r is None:
+                continue
+            left.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in left:           # a dead rank would leave the others in a collective forever: end exactly the processes started here
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------ inputs
+_GEN = {}
+
+
+def _gen_frame(a):
     from sindslam_amd.synth import SyntheticStream
-    F = T * nsteps + 2
-    base_b, base_d = SyntheticStream(seed=seed).frames(0, F)
+    import sindslam_amd.synth as SY
+    w, h, seed, intr, t = a
+    if a[:4] not in _GEN:                    # one generator (textures) per worker process
+        _GEN[a[:4]] = SyntheticStream(w, h, seed, getattr(SY, intr))
+    return _GEN[a[:4]].frame(t)
+
+
+def base_frames(cfg, n, seed):
+    """n consecutive frames of the synthetic generator, produced by a few forked workers (numpy only -- called before torch / HIP exist)"""
+    import multiprocessing as mp
+    import numpy as np
+    jobs = [(cfg["width"], cfg["height"], seed, cfg["intr"], t) for t in range(n)]
+    nw = max(1, min(8, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    if nw > 1:
+        with mp.get_context("fork").Pool(nw) as pool:
+            fr = pool.map(_gen_frame, jobs, chunksize=1)
+    else:
+        fr = [_gen_frame(j) for j in jobs]
+    return np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr])
+
+
+def stream_variants(base_b, base_d, S):
+    """cheap per-stream variants (flips / gain) of one base sequence so that the streams differ"""
+    import numpy as np
+    F = base_b.shape[0]
     bgr = np.empty((S, F) + base_b.shape[1:], np.uint8); depth = np.empty((S, F) + base_d.shape[1:], np.uint16)
     for s in range(S):
         b, d = base_b, base_d
@@ -40,31 +131,71 @@ def make_inputs(S, T, nsteps, seed=12345):
     return bgr, depth
 
 
-def cpu_baseline(n_par, bgr, depth, gpu_dyna, gpu_kps, threads=8, n_timed=10):
-    """Oracle ('port') DynaDetect + dilate + ORB on the host over a bounded sample of the same workload: the first `n_timed` frame
-    pairs of the bench's first `threads` streams, one scalar oracle instance per thread (the reference pins its own loops to
-    omp_set_num_threads(8), DynaDetect.cc:268) -> also the parity figures of the metric ("mask IoU vs CPU ref", ORB keypoints
-    bit-exact) on the first n_par frames of each of those streams, which the GPU pipeline processed in its first step."""
+def pingpong(f, P):
+    """frame f of an arbitrarily long sequence made of P base frames walked forth and back (consecutive frames stay neighbours)"""
+    m = f % (2 * P - 2)
+    return m if m < P else 2 * P - 2 - m
+
+
+# ------------------------------------------------------------------------------------------------------------------ CPU baseline
+def host_cpu_info():
+    """nproc, and the cgroup-v2 CPU quota of this container (cores), if any"""
+    info = {"nproc": os.cpu_count(), "cgroup_cpu_max_cores": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            info["cgroup_cpu_max_cores"] = int(q) / int(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    return info
+
+
+def cpu_baseline(frames_of_stream, intr, cfg, n_par, gpu_dyna, gpu_kps, threads=8, n_streams=8):
+    """Oracle ('port') DynaDetect + dilate + ORB on the host over a bounded sample of the same workload: one scalar oracle
+    instance and one of the bench's streams per thread.  Setting A: `threads` (8, the reference's omp_set_num_threads(8), DynaDetect.cc:268)
+    threads x (5 warm-up + 7 timed) pairs = 56 timed pairs; setting B: all cores of the box's quota x (2 + 4) pairs.  Stage means follow the
+    reference's own stdout timers (DynaDetect.cc:1421,1499,1518,1161,1644 + ORB).  Also the parity figures of the metric ("mask IoU vs
+    CPU ref", ORB keypoints bit-exact) on the first n_par frames of each sampled stream, which the GPU pipeline processed in its first step."""
     from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from sindslam_amd.synth import TUM3
-    threads = max(1, min(threads, bgr.shape[0], os.cpu_count() or 1)); n_timed = min(max(n_par, n_timed), bgr.shape[1] - 2)
     O.lib()                                  # load before the clock starts; ctypes calls release the GIL
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        res = list(ex.map(lambda s: O.baseline_run(bgr[s, :n_timed + 2], depth[s, :n_timed + 2], TUM3, want_outputs=True), range(threads)))
-    wall = time.perf_counter() - t0
-    ious = []; kp_equal = 0; st = np.zeros(3); cpu_s = 0.0
-    for s, (t, stage, dyna, kps) in enumerate(res):
-        st += stage; cpu_s += t
+    info = host_cpu_info()
+    cores_all = int(info["cgroup_cpu_max_cores"] or info.get("sched_affinity") or info["nproc"] or 1)
+
+    def run(nthreads, warm, timed, want):
+        data = [frames_of_stream(s % n_streams, warm + timed + 2) for s in range(nthreads)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(nthreads) as ex:
+            res = list(ex.map(lambda s: O.baseline_run(data[s][0], data[s][1], intr, orb_gray_rgb_order=cfg["rgb"], want_outputs=want, warmup_pairs=warm,
+                                                       flow_max_levels=cfg["flow_max_levels"]), range(nthreads)))
+        wall = time.perf_counter() - t0
+        timed_s = sum(r[0] for r in res); st = np.sum([r[1][3:9] for r in res], axis=0) / (nthreads * timed)
+        rate = nthreads * timed / max(r[0] for r in res)            # pairs of all threads over the slowest thread's timed span
+        return res, dict(value=rate, threads=nthreads, warmup_pairs_per_thread=warm, timed_pairs=nthreads * timed, wall_s=wall, pairs_per_core_second=nthreads * timed / timed_s,
+                         stage_ms_per_pair={k: float(v * 1e3) for k, v in zip(O.STAGES, st)})
+
+    threads = max(1, min(threads, cores_all))
+    resA, a = run(threads, 5, 7, True)
+    b = None
+    if cores_all > threads:
+        _, b = run(cores_all, 2, 4, False)
+    ious = []; kp_equal = 0
+    for s in range(min(threads, n_streams, len(gpu_dyna))):
+        _, _, dyna, kps = resA[s]
         for i in range(n_par):
-            a, r = gpu_dyna[s][i] == 255, dyna[i] == 255; u = np.logical_or(a, r).sum()
-            ious.append(1.0 if u == 0 else float(np.logical_and(a, r).sum() / u))
+            g, r = gpu_dyna[s][i] == 255, dyna[i] == 255; u = np.logical_or(g, r).sum()
+            ious.append(1.0 if u == 0 else float(np.logical_and(g, r).sum() / u))
             kp_equal += int(gpu_kps[s][i].tobytes() == kps[i].tobytes())
-    base = {"value": threads * n_timed / wall, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{threads} streams x {n_timed} frame pairs of the synthetic 640x480 workload, one oracle instance per thread: {wall:.1f} s wall, "
-                      f"{cpu_s:.1f} core-seconds (flow {st[0]:.1f}, tail {st[1]:.1f}, orb {st[2]:.1f}) = {threads * n_timed / cpu_s:.2f} pairs/s per core"}
+    base = {"value": a["value"], "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} threads x (5 warm-up + 7 timed) frame pairs of the bench's first {min(threads, n_streams)} streams, one scalar oracle instance per thread "
+                      f"({a['wall_s']:.1f} s wall); second setting: all {cores_all} cores of the quota x (2 + 4) pairs" + ("" if b else " -- skipped, no more cores than threads"),
+            "host": info, "threads_8": a, "all_cores": b}
     parity = {"mask_iou_mean": float(np.mean(ious)), "mask_iou_min": float(np.min(ious)), "orb_keypoints_bit_exact_frames": kp_equal, "frames": len(ious),
               "reference": "CPU oracle (parity unpinned: the reference ships no golden vectors and cannot be built here)"}
     return base, parity
@@ -92,35 +223,67 @@ def cgroup_throttle():
         return None
 
 
-def pmc_traffic(pairs_per_step):
-    """HBM bytes per k_sor_fused launch from the committed rocprofv3 PMC passes (profiles/r01/v13_pmc_k_sor_fused.json: separate
-    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction), scaled to this batch; None if absent."""
-    f = os.path.join(ROOT, "profiles", "r01", "v13_pmc_k_sor_fused.json")
-    if not os.path.exists(f):
+def pmc_profile():
+    """The committed rocprofv3 PMC passes of the solver kernel for the default config (separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per
+    the gfx950 correction): newest profiles/rNN/*pmc_k_sor*.json, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_k_sor*.json")), key=lambda f: (os.path.basename(os.path.dirname(f)), os.path.getmtime(f)))
+    if not files:
         return None
-    d = json.load(open(f))
-    return d["hbm_bytes_per_launch_per_pair"] * pairs_per_step
+    d = json.load(open(files[-1])); d["file"] = os.path.relpath(files[-1], ROOT)
+    return d
 
 
+# ------------------------------------------------------------------------------------------------------------------ main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=128)
-    ap.add_argument("--frames-per-step", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the cpu_baseline leg (one oracle instance and one stream each)")
-    ap.add_argument("--host-input", action="store_true", help="hand over HOST buffers each step (sind_pipe_process, PCIe-inclusive rate; DESIGN.md 6) instead of HBM-resident inputs")
-    ap.add_argument("--thread-cpu", action="store_true", help="print the CPU seconds the live threads used inside the timed region, by thread name (stderr)")
-    ap.add_argument("--pipelined", action="store_true", help="software-pipeline consecutive steps (submit/flush); off by default: measured slower on MI355X")
-    ap.add_argument("--host-threads", type=int, default=0, help="host worker pool size (0 = library default, the GPU box's CPU share)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rendezvous_only:                 # launcher test: meet, count, leave (no GPU needed)
+        import torch
+        import torch.distributed as dist
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            t = torch.ones(1); dist.all_reduce(t); seen = int(t.item()); dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            print(json.dumps({"ranks_seen": seen, "n_gpus": world, "gpus_arg": args.gpus}))
+        return
+
+    import numpy as np
+    cfg = dict(CONFIGS[args.config]); workload = args.workload if args.workload != "auto" else ("sequence" if world > 1 else "streams")
+    S = args.streams or cfg["streams"]; T, K, Wm = args.frames_per_step, args.steps, args.warmup
+    nsteps = K + Wm
+    import sindslam_amd.synth as SY
+    intr0 = getattr(SY, cfg["intr"]); sc = cfg["width"] / 640.0
+    intr = dict(intr0, fx=intr0["fx"] * sc, fy=intr0["fy"] * sc, cx=intr0["cx"] * sc, cy=intr0["cy"] * sc)
+    # ---- synthetic input on the host, before torch / HIP are loaded (the frame generator forks workers)
+    if workload == "streams":
+        ndata = min(nsteps, 12)             # distinct steps of input kept in host + device memory; longer runs cycle through them (the jump at the wrap is just another large-motion pair)
+        base_b, base_d = base_frames(cfg, T * ndata + 2, 12345 + rank)
+        bgr, depth = stream_variants(base_b, base_d, S)
+
+        def frames_of_stream(s, count):
+            return bgr[s, :count], depth[s, :count]
+    else:
+        if Wm < 1:
+            raise SystemExit("bench.py --workload sequence needs --warmup >= 1: the warm-up steps are the chunks' state warm-up frames")
+        P = 50; ndata = nsteps
+        base_b, base_d = base_frames(cfg, P, 12345)           # every rank builds the same sequence
+        chunk0 = rank * S
+        a_of = lambda g: 2 + g * K * T                        # first processed frame of chunk g; owned frames start W*T later
+        seq_frames = 2 + world * S * K * T + Wm * T
+
+        def frames_of_stream(s, count):
+            idx = [pingpong(a_of(chunk0 + s) - 2 + i, P) for i in range(count)]
+            return base_b[idx], base_d[idx]
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     local = local % torch.cuda.device_count()          # rehearsal on a 1-GPU box: ranks share the card
@@ -128,35 +291,52 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)     # backend "nccl" is RCCL on ROCm
+    comm_dev = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
 
     from sindslam_amd.pipeline import Pipeline
-    from sindslam_amd.synth import TUM3
-    S, T, K, Wm = args.streams, args.frames_per_step, args.steps, args.warmup
-    nsteps = K + Wm
-    ndata = min(nsteps, 12)                 # distinct steps of input kept in host + device memory (393 MB each); longer runs cycle through them
-    bgr, depth = make_inputs(S, T, ndata, seed=12345 + rank)
-    pipe = Pipeline(S, T, 640, 480, TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"], 1500, 1.2, 8, TUM3["ini_th"], TUM3["min_th"],
-                    orb_gray_rgb_order=1, device=local, host_threads=args.host_threads)
-    for s in range(S):
-        pipe.prime(s, bgr[s, 1], bgr[s, 0])
+    H, W = cfg["height"], cfg["width"]
+    pipe = Pipeline(S, T, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],
+                    orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=args.host_threads, flow_max_levels=cfg["flow_max_levels"])
     # inputs resident in HBM before the timed region, laid out [step][S][T]...
-    dev_b = [torch.from_numpy(np.ascontiguousarray(bgr[:, 2 + i * T: 2 + (i + 1) * T])).cuda() for i in range(ndata)]
-    dev_d = [torch.from_numpy(np.ascontiguousarray(depth[:, 2 + i * T: 2 + (i + 1) * T]).view(np.int16)).cuda() for i in range(ndata)]
+    if workload == "streams":
+        for s in range(S):
+            pipe.prime(s, bgr[s, 1], bgr[s, 0])
+        dev_b = [torch.from_numpy(np.ascontiguousarray(bgr[:, 2 + i * T: 2 + (i + 1) * T])).cuda() for i in range(ndata)]
+        dev_d = [torch.from_numpy(np.ascontiguousarray(depth[:, 2 + i * T: 2 + (i + 1) * T]).view(np.int16)).cuda() for i in range(ndata)]
+    else:
+        for s in range(S):
+            a = a_of(chunk0 + s); pipe.prime(s, base_b[pingpong(a - 1, P)], base_b[pingpong(a - 2, P)])
+        bb = torch.from_numpy(base_b).cuda(); bd = torch.from_numpy(base_d.view(np.int16)).cuda()
+        dev_b, dev_d = [], []
+        for i in range(ndata):
+            idx = torch.tensor([[pingpong(a_of(chunk0 + s) + i * T + t, P) for t in range(T)] for s in range(S)], device="cuda")
+            dev_b.append(bb[idx].contiguous()); dev_d.append(bd[idx].contiguous())
+        # the sequence-ordered dynamic masks of ALL ranks' owned frames, on every rank: frame 2 + W*T + ((r*S + s)*K + k)*T + t
+        seq_masks = torch.zeros((world, S, K, T, H, W), dtype=torch.uint8, device="cuda" if comm_dev == "cuda" else "cpu")
     torch.cuda.synchronize()
     from sindslam_amd.parallel import gather_masks
 
     gbuf = {}
 
-    def gather():
-        if world > 1:   # RCCL gather of the per-frame dynamic masks over xGMI (page-locked source, persistent device buffers)
+    def gather(step_index=None):
+        """RCCL all_gather of this step's per-frame dynamic masks over xGMI (page-locked source, persistent device buffers); in the sequence
+        workload the gathered block lands in the sequence-ordered array.  The upload is complete before the next step may rewrite the source."""
+        if world > 1:
             m = pipe.dyna_pinned if pipe.dyna_pinned is not None else torch.from_numpy(pipe.dyna)
-            if args.backend == "nccl":
+            if comm_dev == "cuda":
                 if "dev" not in gbuf:
                     gbuf["dev"] = torch.empty_like(m, device="cuda"); gbuf["out"] = torch.empty((world,) + tuple(m.shape), dtype=m.dtype, device="cuda")
                 gbuf["dev"].copy_(m, non_blocking=True)
-                gather_masks(gbuf["dev"], out=gbuf["out"])
+                out = gather_masks(gbuf["dev"], out=gbuf["out"])
+                torch.cuda.current_stream().synchronize()
             else:
-                gather_masks(m)
+                out = gather_masks(m)
+        elif workload == "sequence":
+            out = torch.from_numpy(pipe.dyna)[None]
+        else:
+            return
+        if workload == "sequence" and step_index is not None and step_index >= Wm:
+            seq_masks[:, :, step_index - Wm].copy_(out)
 
     NPS = min(S, args.cpu_threads) if (world == 1 and not args.no_cpu_baseline) else 0
 
@@ -165,11 +345,10 @@ def main():
 
     host_b = host_d = None
     if args.host_input:
-        host_b = [np.ascontiguousarray(bgr[:, 2 + i * T: 2 + (i + 1) * T]) for i in range(ndata)]
-        host_d = [np.ascontiguousarray(depth[:, 2 + i * T: 2 + (i + 1) * T]) for i in range(ndata)]
+        host_b = [t_.cpu().numpy() for t_ in dev_b]; host_d = [t_.cpu().numpy().view(np.uint16) for t_ in dev_d]
     first_dyna = first_kps = None
     for i in range(Wm):                     # warm-up: synchronous steps
-        pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather()
+        pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather(i)
         if i == 0:                          # the first streams' first T results, for the parity figures below
             first_dyna, first_kps = parity_sample()
     if world > 1:
@@ -178,34 +357,82 @@ def main():
     thr0 = cgroup_throttle()
     t0 = time.perf_counter(); c0 = time.process_time(); th0 = thread_cpu_seconds() if args.thread_cpu else None
     sor_ms = sor_bytes = sor_union = 0.0; sor_launches = 0; sor_slices = 1; stages = np.zeros(6)
-    for i in range(Wm, Wm + K):             # timed: software-pipelined steps (phase A of step i overlaps the tails of step i-1)
+    pending_step = None
+    for i in range(Wm, Wm + K):             # timed steps
         if args.host_input:
-            pipe.process(host_b[i % ndata], host_d[i % ndata]); gather()
+            pipe.process(host_b[i % ndata], host_d[i % ndata]); gather(i)
         elif not args.pipelined:
-            pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather()
-        elif pipe.submit_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()):
-            gather()
+            pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather(i)
+        else:                               # software-pipelined: phase A of step i overlaps the tails of step i-1, whose results arrive now
+            if pipe.submit_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()):
+                gather(pending_step)
+            pending_step = i
         if first_dyna is None and not args.pipelined:     # --warmup 0: take the parity sample from the first timed step (a few MB copied)
             first_dyna, first_kps = parity_sample()
         st = pipe.stats()
         sor_ms += st["sor_ms"]; sor_bytes += st["sor_alg_bytes"]; sor_launches += st["sor_launches"]; sor_union += st["sor_union_ms"]; sor_slices = st["sor_slices"]
         stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"], st["upload_ms"]])
     if args.pipelined and pipe.flush():      # drain the last step inside the timed region
-        gather()
+        gather(pending_step)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     th1 = thread_cpu_seconds() if args.thread_cpu else None
     thr1 = cgroup_throttle()
     dt = time.perf_counter() - t0; cpu_busy = (time.process_time() - c0) / dt      # host cores this rank kept busy (all threads)
+    ranks_seen = 1
     if world > 1:
-        tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        tt = torch.tensor([dt], device=comm_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        rs = torch.ones(1, device=comm_dev); dist.all_reduce(rs); ranks_seen = int(rs.item())
     pairs = S * T * K * world
     if args.thread_cpu and rank == 0:       # short-lived threads (flow slices, ORB, octree) that ended before the second sample are not listed
         for name in sorted(th1, key=lambda n: -(th1[n] - th0.get(n, 0.0))):
             print(f"[thread-cpu] {name:16s} {(th1[name] - th0.get(name, 0.0)) / K * 1e3:9.1f} core-ms per step", file=sys.stderr)
         live = sum(th1[n] - th0.get(n, 0.0) for n in th1)
         print(f"[thread-cpu] {'(exited threads)':16s} {(cpu_busy * dt - live) / K * 1e3:9.1f} core-ms per step   total {cpu_busy * dt / K * 1e3:.1f}", file=sys.stderr)
+
+    # ---- sequence workload, rank 0: the first chunks again in the in-order mode -> chunk-seam IoU and the exact mode's own rate
+    seq_info = None
+    if workload == "sequence":
+        seq_info = {"frames": seq_frames, "owned_frames": world * S * K * T, "chunks": world * S, "chunk_frames": K * T, "chunk_warmup_frames": Wm * T,
+                    "mask_gather": ("RCCL all_gather per step, %.1f MB per rank" % (S * T * H * W / 1e6)) if world > 1 else "single rank (no collective)",
+                    "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
+        if rank == 0 and not args.no_exact_leg:
+            KT, WT = K * T, Wm * T
+            E = max(min(WT + 3 * KT, 160), min(KT + WT + 8, WT + 2 * KT))       # frames [2, 2 + E): chunk 0 and (part of) the chunks after it
+            E = min(E, WT + world * S * KT)
+            Te = 32 if E >= 64 else 16
+            ex = Pipeline(1, Te, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],
+                          orb_gray_rgb_order=cfg["rgb"], device=local, flow_max_levels=cfg["flow_max_levels"])
+            ex.prime(0, base_b[pingpong(1, P)], base_b[pingpong(0, P)]); ex.set_depth_ahead(True)
+            nst = (E + Te - 1) // Te; E = nst * Te
+            eb = [bb[torch.tensor([pingpong(2 + k * Te + t, P) for t in range(Te)], device="cuda")].contiguous() for k in range(nst)]
+            ed = [bd[torch.tensor([pingpong(2 + k * Te + t, P) for t in range(Te)], device="cuda")].contiguous() for k in range(nst)]
+            torch.cuda.synchronize(); exact = np.zeros((E, H, W), np.uint8); te0 = time.perf_counter(); prev = None
+            for k in range(nst):
+                if ex.submit_dev(eb[k].data_ptr(), ed[k].data_ptr()):
+                    exact[prev * Te:(prev + 1) * Te] = ex.dyna[0]
+                prev = k
+            if ex.flush():
+                exact[prev * Te:(prev + 1) * Te] = ex.dyna[0]
+            te = time.perf_counter() - te0; ex.close()
+            sm = seq_masks.reshape(world * S, K * T, H, W)
+            ious = []; seam = []
+            for f in range(2 + WT, 2 + E):                   # owned frame f belongs to chunk g at offset o
+                g, o = divmod(f - 2 - WT, KT)
+                if g < 1 or g >= world * S:
+                    continue                                  # chunk 0 starts like the sequential run: identical by construction
+                a_ = sm[g, o].cpu().numpy() == 255; b_ = exact[f - 2] == 255; u = np.logical_or(a_, b_).sum()
+                v = 1.0 if u == 0 else float(np.logical_and(a_, b_).sum() / u); ious.append(v)
+                if o == 0: seam.append(v)
+            seq_info.update({"seam_iou_mean": float(np.mean(ious)) if ious else None, "seam_iou_min": float(np.min(ious)) if ious else None,
+                             "seam_iou_first_frames": seam, "seam_frames_compared": len(ious),
+                             "seam_note": "chunked (throughput) mode vs the in-order run on the same GPU code, frames of the chunks after the first; the chunked mode rebuilds the tail "
+                                          "state in the warm-up frames and returns valid but not identical masks -- parity (IoU >= 0.99 vs the oracle) holds for the in-order mode",
+                             "exact_mode": {"frames": E, "frames_per_step": Te, "fps": E / te,
+                                            "bound": "1 / per-frame latency of the slower tail chain (depth chain: k-means warm labels; flow chain: weights, previous high mask); "
+                                                     "host + launch latency bound, does not grow with the number of GPUs"}})
+
     if rank == 0:
         # The batch runs as `sor_slices` slices on concurrent HIP streams, so solver launches overlap on the GPU.  achieved = algorithmic
         # bytes of all launches / time with at least one solver launch in flight (union of the HIP-event intervals of all slices on a
@@ -213,23 +440,42 @@ def main():
         # (a launch that shares the GPU with the other slices) are reported next to it.
         achieved = sor_bytes / (sor_union * 1e-3) / 1e9 if sor_union > 0 else 0.0      # GB/s
         per_launch = sor_bytes / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
+        pmc = pmc_profile() if args.config == "tum3" else None
+        pairs_per_launch = S * T / max(sor_slices, 1)
+        traffic = pmc["hbm_bytes_per_launch_per_pair"] * pairs_per_launch if pmc else None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                "traffic_source": (pmc["file"] + " (committed rocprofv3 --pmc passes of this command, per pair x pairs per launch; not re-measured in this run)") if pmc else None,
+                "kernel": "k_sor_fused", "launches": sor_launches, "avg_launch_us": (sor_ms * 1e3 / sor_launches) if sor_launches else None,
+                "alg_bytes_per_launch": (sor_bytes / sor_launches) if sor_launches else None,
+                "concurrent_launches": sor_slices, "achieved_per_launch": per_launch, "solver_busy_ms_per_step": sor_union / K}
+        if pmc and sor_launches and sor_union > 0:
+            # real HBM bytes of all launches over the time the solver was busy, against the 8 TB/s peak: the kernel keeps the system in registers
+            # for several iterations, so this is far below `frac` (which prices the ALGORITHMIC bytes) -- the honest HBM utilisation
+            roof["hbm_frac_measured"] = traffic * sor_launches / (sor_union * 1e-3) / 8e12
+        # VALU floor: pixel updates (algorithmic bytes / 44 B) x VALU lane-operations per update (ISA count of the inner loop) x halo redundancy of the tiling,
+        # over the FP32 vector peak of 78.6e12 lane-operations/s (157.3 TFLOP/s / 2 flops per FMA lane; MI355X_MICROARCH.md)
+        valu_ops_per_update = (pmc or {}).get("valu_ops_per_pixel_update", 44); halo = (pmc or {}).get("halo_redundancy", 2.1)
+        if sor_union > 0:
+            roof["valu_frac"] = (sor_bytes / 44.0) * valu_ops_per_update * halo / 78.6e12 / (sor_union * 1e-3)
         out = {
             "metric": "DynaDetect+ORB frame-pairs/sec at 640x480; mask IoU vs CPU ref", "value": pairs / dt, "unit": "frame-pairs/s",
-            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "TUM fr3/walking_xyz-shaped synthetic RGB-D stream, 640x480, TUM3 intrinsics, FAST 15/5, 1500 features",
-                       "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world, "parallelism": f"stream-sharded x{world}", "pipelined": bool(args.pipelined),
+            "config": {"workload": cfg["workload"] + ("; ONE sequence of %d frames, frame-sharded in %d chunks, per-step RCCL gather of the dynamic masks" % (seq_frames, world * S) if workload == "sequence" else ""),
+                       "name": args.config, "mode": workload, "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world,
+                       "parallelism": ("frame-sharded x%d" if workload == "sequence" else "stream-sharded x%d") % world, "pipelined": bool(args.pipelined),
+                       "flow_pyramid_levels": cfg["flow_max_levels"] or "all (49 at 640x480)",
                        "inputs": "host buffers, H2D inside the timed region" if args.host_input else "resident in HBM"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": pmc_traffic(S * T / max(sor_slices, 1)),
-                         "kernel": "k_sor_fused", "launches": sor_launches, "avg_launch_us": (sor_ms * 1e3 / sor_launches) if sor_launches else None,
-                         "alg_bytes_per_launch": (sor_bytes / sor_launches) if sor_launches else None,
-                         "concurrent_launches": sor_slices, "achieved_per_launch": per_launch, "solver_busy_ms_per_step": sor_union / K},
+            "ranks_seen": ranks_seen,
+            "roofline": roof,
             "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "host_upload": stages[5] / K, "total": stages[4] / K},
             "host_cores_busy": cpu_busy,
             "cpu_quota": None if not (thr0 and thr1) else {"periods": thr1[0] - thr0[0], "throttled_periods": thr1[1] - thr0[1], "throttled_ms": (thr1[2] - thr0[2]) / 1e3},
         }
+        if seq_info:
+            out["sequence"] = seq_info
         if not args.no_cpu_baseline and world == 1 and first_dyna is not None:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(min(T, 4), bgr, depth, first_dyna, first_kps, threads=NPS)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(frames_of_stream, intr, cfg, min(T, 4), first_dyna, first_kps, threads=args.cpu_threads, n_streams=NPS)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -47,6 +47,9 @@ int sind_flow_varref_f32(sind_flow* f, const float* i0, const float* i1, int w, 
 int sind_flow_deepflow_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v);   /* device pointers, async */
 int sind_flow_refine_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int B, float* u, float* v);
 int sind_flow_sync(sind_flow* f);
+/* build-side option (BASELINE.json config 5, "3-level flow pyramid"; no reference counterpart -- OpenCV 4.2's DeepFlow never advances its
+ * maxLayers counter): n > 0 keeps only the finest n levels of the 0.95 pyramid, the flow starts from zero at the coarsest of them; 0 = all */
+int sind_flow_set_max_levels(sind_flow* f, int n);
 /* solver variant (process-wide): mode 1 = fused register-resident SOR, 1x8 strips, IEEE division (default), 2 = fused, 1x4 strips +
  * reciprocal (Markstein) division, 0 = one launch per colour (cross-check); fuse = iterations per launch on tiled levels (default 5);
  * tile_w = 64 (default) or 128 (mode 1 only) */
@@ -93,6 +96,7 @@ int sind_orb_debug_selected(sind_orb* o, int frame, sind_keypoint* kps, int cap,
 typedef struct sind_dyna sind_dyna;
 int sind_dyna_create(int width, int height, float fx, float fy, float cx, float cy, float depth_scale, int device, sind_dyna** out);
 int sind_dyna_destroy(sind_dyna* d);
+int sind_dyna_set_flow_max_levels(sind_dyna* d, int n);      /* see sind_flow_set_max_levels */
 int sind_dyna_prime(sind_dyna* d, const uint8_t* bgr_last, const uint8_t* bgr_lastlast, int stride);
 int sind_dyna_detect(sind_dyna* d, const uint8_t* bgr, int bgr_stride, const uint16_t* depth, int depth_stride,
                      uint8_t* dyna_out, uint8_t* label_out, int n_img);
@@ -125,7 +129,8 @@ typedef struct sind_pipe_config {
     int nfeatures; float scale_factor; int nlevels, ini_th_fast, min_th_fast;
     int orb_gray_rgb_order;      /* 1: ORB gray uses RGB2GRAY on the BGR buffer (Camera.RGB: 1, src/Tracking.cc:246-251), 0: BGR2GRAY */
     int streams, frames_per_step, device;
-    int host_threads;            /* 0 = one per stream */
+    int host_threads;            /* 0 = library default (2 x the CPU share of the process) */
+    int flow_max_levels;         /* 0 = the reference's full DeepFlow pyramid; n > 0: finest n levels only (see sind_flow_set_max_levels) */
 } sind_pipe_config;
 int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out);
 int sind_pipe_destroy(sind_pipe* p);
@@ -143,8 +148,18 @@ int sind_pipe_flush(sind_pipe* p, uint8_t* dyna, uint8_t* label, uint8_t* mask_d
                     int* have_output);
 /* Schedule of the synchronous step (sind_pipe_process / _process_dev): on != 0 runs the flow-independent half of every tail (depth
  * k-means, SegAndMerge; reference DynaDetect.cc:1410-1551) underneath the dense flow instead of after it.  Results are identical;
- * default off (environment SIND_DEPTH_AHEAD=1 turns it on at create), see DESIGN.md 3.1 item 7 for the measurement. */
+ * default off (environment SIND_DEPTH_AHEAD=1 turns it on at create), see DESIGN.md 3.1 item 7 for the measurement.  It also applies to
+ * sind_pipe_submit_dev: the depth chain of step i+1 then runs next to the flow chain of step i -- the schedule of the in-order
+ * ("exact") single-sequence mode (streams = 1), whose rate is 1 / max(depth-chain, flow-chain latency per frame). */
 int sind_pipe_set_depth_ahead(sind_pipe* p, int on);
+/* Inter-frame state of one stream (reference DynaDetect.h:172-178: imgDynaLast, imgLabelLast, imgMaskHighErrorLast, plus the k-means
+ * warm labels of DynaDetect.cc:374-395; rolled at DynaDetect.cc:1660-1664) as an opaque blob of sind_pipe_state_bytes() bytes.  Lets one
+ * long sequence continue on another handle or rank exactly where this one stopped (phase A sharded, phase B strictly in
+ * frame order).  get: nothing may be pending.  set: after sind_pipe_prime (which resets the state); allowed while a step submitted
+ * WITHOUT depth-ahead waits for its tails -- submit (phase A), receive the predecessor's state, set, flush. */
+size_t sind_pipe_state_bytes(sind_pipe* p);
+int sind_pipe_get_state(sind_pipe* p, int stream, uint8_t* buf, size_t n);
+int sind_pipe_set_state(sind_pipe* p, int stream, const uint8_t* buf, size_t n);
 /* per-stage wall times of the last step in milliseconds: {front_gray, dense_flow, orb_front, host_upload (sind_pipe_process only, else 0), tails, total},
  * plus HIP-event statistics of the flow solver: sor_launches, sor_ms (sum of event-bracketed SOR launch groups),
  * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */

@@ -41,6 +41,7 @@ void orc_varref(const float* i0, const float* i1, int w, int h, float* wu, float
         for (int k = 0; k < 17; k++) if (inter[k]) put(*a[k], inter[k]); }
 }
 void orc_deepflow(const uint8_t* i0, const uint8_t* i1, int w, int h, float* flow /* w*h*2 */) { ImgF f; deepflow_calc(wrap8(i0, w, h), wrap8(i1, w, h), f); put(f, flow); }
+void orc_deepflow_levels_capped(const uint8_t* i0, const uint8_t* i1, int w, int h, int max_levels, float* flow) { ImgF f; DeepFlowParams P; P.maxLevels = max_levels; deepflow_calc(wrap8(i0, w, h), wrap8(i1, w, h), f, P); put(f, flow); }
 
 int orc_find_homography(const float* src, const float* dst, int n, double* H) {
     std::vector<Pt2f> s(n), d(n); for (int i = 0; i < n; i++) { s[i] = {src[2*i], src[2*i+1]}; d[i] = {dst[2*i], dst[2*i+1]}; }
@@ -68,6 +69,7 @@ void* orc_dyna_create(const uint8_t* bgr_last, const uint8_t* bgr_lastlast, int 
     return new DynaDetect(wrap8(bgr_last, w, h, 3), wrap8(bgr_lastlast, w, h, 3), fx, fy, cx, cy, depthScale);
 }
 void orc_dyna_destroy(void* p) { delete (DynaDetect*)p; }
+void orc_dyna_set_flow_max_levels(void* p, int n) { ((DynaDetect*)p)->flow_max_levels = n; }
 void orc_dyna_detect(void* p, const uint8_t* bgr, const uint16_t* depth, uint8_t* dyna_out, uint8_t* label_out) {
     DynaDetect* d = (DynaDetect*)p; Img8 dy, lb;
     d->DetectDynaArea(wrap8(bgr, d->width, d->height, 3), wrap16(depth, d->width, d->height), dy, lb);
@@ -176,15 +178,18 @@ static int put_kps(const std::vector<KeyPoint>& v, OrcKp* out, int cap);
 // ---------------------------------------------------------------- CPU baseline: frames through DynaDetect + dilate + ORB, seconds out
 // bgr: n frames (w*h*3 each), depth: n frames.  Frames 0,1 prime the detector; pairs = n-2.  Gray for ORB = BGR2GRAY (Camera.RGB: 0).
 double orc_baseline_run(const uint8_t* bgr, const uint16_t* depth, int n, int w, int h, float fx, float fy, float cx, float cy, float depthScale,
-                        int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, double* stage_seconds /*flow, tail, orb*/,
+                        int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, double* stage_seconds /*flow, tail, orb, then the reference's breakdown: kmeans, depth-edge, seg-merge, flow+refine+masks, fusion, orb (9 values)*/,
                         int orb_gray_rgb_order, uint8_t* dyna_out /* (n-2) x h x w or NULL */, int* nkp_out /* n-2 or NULL */,
-                        OrcKp* kps_out /* (n-2) x kp_cap or NULL */, int kp_cap) {
+                        OrcKp* kps_out /* (n-2) x kp_cap or NULL */, int kp_cap, int skip_first /* untimed warm-up pairs */, int flow_max_levels) {
     const size_t fb = (size_t)w * h * 3, fd = (size_t)w * h;
     DynaDetect dd(wrap8(bgr + fb, w, h, 3), wrap8(bgr, w, h, 3), fx, fy, cx, cy, depthScale);
+    dd.flow_max_levels = flow_max_levels;
     ORBextractor orb(nfeatures, scaleFactor, nlevels, iniTh, minTh);
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now(), tf = 0, tt = 0, to = 0;
+    if (skip_first < 0) skip_first = 0;
     for (int i = 2; i < n; i++) {
+        if (i - 2 == skip_first) { t0 = now(); tf = tt = to = 0; for (double& q : dd.t_stage) q = 0; }       // warm-up pairs end here
         Img8 img = wrap8(bgr + fb * i, w, h, 3); Img16 dp = wrap16(depth + fd * i, w, h);
         Img8 dy, lb, dil, gray; std::vector<KeyPoint> k; std::vector<uint8_t> d;
         double a = now();
@@ -201,7 +206,10 @@ double orc_baseline_run(const uint8_t* bgr, const uint16_t* depth, int n, int w,
         if (kps_out) put_kps(k, kps_out + (size_t)(i - 2) * kp_cap, kp_cap);
         tf += b - a; tt += c - b; to += e - c;
     }
-    if (stage_seconds) { stage_seconds[0] = tf; stage_seconds[1] = tt; stage_seconds[2] = to; }
+    if (stage_seconds) { stage_seconds[0] = tf; stage_seconds[1] = tt; stage_seconds[2] = to;
+        for (int k = 0; k < 5; k++) stage_seconds[3 + k] = dd.t_stage[k];
+        stage_seconds[3 + 3] += tf;                       /* the dense flow was computed outside DetectDynaArea (skip_flow) */
+        stage_seconds[8] = to; }
     return now() - t0;
 }
 

@@ -7,6 +7,7 @@
 //   C-14 applyNMS sorts end-points by an uninitialised float -> here the scan order is kept (stable);
 //   a-19 octree ties on node addresses                         -> creation order (see orb.hpp).
 #pragma once
+#include <chrono>
 #include "cvx_core.hpp"
 #include "cvx_shape.hpp"
 #include "homography.hpp"
@@ -47,7 +48,13 @@ public:
     StructElem element3, element4, element5, element7, element9, element10;
     peac::PlaneFitter pf;
     DynaIntermediates dbg;
+    int flow_max_levels = 0;  // build-side option of BASELINE.json config 5 ("3-level flow pyramid"); 0 = the reference's full pyramid
     bool skip_flow = false;   // test hook: reuse dbg.flowFull supplied by the caller instead of computing it
+    // wall seconds per stage in the reference's own breakdown (its stdout timers: "K-means timecost" DD:1421, "Calculate DepthEdge" DD:1499,
+    // "SegAndMergeV2 timecost" DD:1518, "DenseFlow + Refine" DD:1161 -- here incl. the mask half of the flow thread --, "Dynamic detection
+    // timecost" DD:1644 = fusion): {k-means, depth-edge, seg-and-merge, flow+refine, fusion}
+    double t_stage[5] = {0, 0, 0, 0, 0};
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     // reference DynaDetect.h:98-126
     DynaDetect(const Img8& imgLast, const Img8& imgLastLast, float fx_, float fy_, float cx_, float cy_, float depthScale_)
@@ -69,7 +76,8 @@ public:
         resize_linear_u8(imgGrayLast, dbg.grayLastMin, fw, fh);
         resize_linear_u8(imgGrayLastLast, dbg.grayLastLastMin, fw, fh);
         ImgF flow;
-        deepflow_calc(dbg.grayMin, dbg.grayLastLastMin, flow);
+        DeepFlowParams dfp; dfp.maxLevels = flow_max_levels;
+        deepflow_calc(dbg.grayMin, dbg.grayLastLastMin, flow, dfp);
         for (auto& v : flow.d) v *= -1.0f;
         bool largeMotion = false;
         {   // DD:1081-1114
@@ -85,7 +93,7 @@ public:
             if (endFlow2 > endFlow) largeMotion = true;
             dbg.endFlow = endFlow; dbg.endFlow2 = endFlow2;
         }
-        if (largeMotion) { deepflow_calc(dbg.grayMin, dbg.grayLastMin, flow); for (auto& v : flow.d) v *= -1.0f; }
+        if (largeMotion) { deepflow_calc(dbg.grayMin, dbg.grayLastMin, flow, dfp); for (auto& v : flow.d) v *= -1.0f; }
         dbg.largeMotion = largeMotion; dbg.flowDeep = flow;
         {   // DD:1133-1143 VariationalRefinement::create()->calc on the u8 images, defaults
             const Img8& other = largeMotion ? dbg.grayLastMin : dbg.grayLastLastMin;
@@ -427,8 +435,11 @@ public:
         dbg.gray = imgGray; dbg.grayLast = imgGrayLast; dbg.grayLastLast = imgGrayLastLast;
         imgDyna.fill(0);
         Img8 maskLow, maskHigh;
+        double ts = now_s();
+        #define ORC_LAP(i) { const double t_ = now_s(); t_stage[i] += t_ - ts; ts = t_; }
         if (!skip_flow) ComputeDenseFlow();
         FlowToMasks(maskLow, maskHigh);          // the reference runs this in a side thread; it only reads *Last state
+        ORC_LAP(3)
         // k-means
         ImgI labelI; std::vector<float> points, centers;
         SegByKmeans(labelI, points, centers);
@@ -449,12 +460,15 @@ public:
             if (count0 <= 5 && ratioArea < 0.6f) { for (size_t k = 0; k < each.d.size(); k++) labelForSegEdge.d[k] |= each.d[k]; ++count0; }
         }
         dilate(labelForSegEdge, labelForSegEdge, element7);
+        ORC_LAP(0)
         Img8 occ1(width, height, 1, 0), occ2(width, height, 1, 0);
         CalOccluded(totalArea, occ1, occ2);
+        ORC_LAP(1)
         dbg.labelForSegEdge = labelForSegEdge; dbg.totalArea = totalArea; dbg.occluded1 = occ1; dbg.occluded2 = occ2;
         Img8 label3(width, height, 1, 0);
         if (!allLabels.empty()) SegAndMergeV2(allLabels, occ1, occ2, labelForSegEdge, points, label3);
         imgLabel = label3;
+        ORC_LAP(2)
         int maxNum = 0; for (uint8_t v : label3.d) maxNum = std::max<int>(maxNum, v);
         // fusion (DD:1553-1636)
         for (size_t k = 0; k < maskLow.d.size(); k++) { uint8_t v = imgMaskHighErrorLast.d[k] | maskLow.d[k]; maskLow.d[k] = (v ? 128 : 0) & totalArea.d[k]; }
@@ -480,6 +494,8 @@ public:
         dilate(imgDyna, imgDyna, element9);
         for (size_t k = 0; k < imgDyna.d.size(); k++) if (!imgDyna.d[k] && totalArea.d[k]) imgDyna.d[k] = 125;   // DD:1633-1634
         imgDynaOut = imgDyna; imgLabelOut = imgLabel;
+        ORC_LAP(4)
+        #undef ORC_LAP
         dbg.dyna = imgDyna; dbg.label = imgLabel;
         imgDynaLast = imgDyna; imgRGBLastLast = imgRGBLast; imgRGBLast = imgRGB; imgMaskHighErrorLast = maskHigh; imgLabelLast = imgLabel;
     }

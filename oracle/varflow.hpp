@@ -176,6 +176,7 @@ struct DeepFlowParams {
     int fixedPointIterations = 5, sorIterations = 25;
     float alpha = 1.0f, delta = 0.5f, gamma = 5.0f, omega = 1.6f;
     int maxLayers = 200;
+    int maxLevels = 0;      // build-side option (BASELINE.json config 5, "3-level flow pyramid"): keep only the finest maxLevels levels; 0 = OpenCV behaviour
 };
 
 // OpticalFlowDeepFlow::buildPyramid sizes: (int)(prev*0.95f + 0.5f) until a side <= minSize.
@@ -186,6 +187,7 @@ inline std::vector<std::pair<int, int>> deepflow_level_sizes(int w, int h, const
         if (nh <= P.minSize || nw <= P.minSize) break;
         s.push_back({nw, nh});
     }
+    if (P.maxLevels > 0 && (int)s.size() > P.maxLevels) s.resize(P.maxLevels);
     return s;
 }
 

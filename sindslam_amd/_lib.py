@@ -33,6 +33,7 @@ def lib() -> C.CDLL:
             pass
         _lib = C.CDLL(SO_PATH)
         _lib.sind_last_error.restype = C.c_char_p
+        _lib.sind_pipe_state_bytes.restype = C.c_size_t
     return _lib
 
 

@@ -17,7 +17,7 @@ int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float
     HIP_TRY(hipSetDevice(device));
     sind_dyna* d = new sind_dyna();
     d->cfg.W = w; d->cfg.H = h; d->cfg.fx = fx; d->cfg.fy = fy; d->cfg.cx = cx; d->cfg.cy = cy; d->cfg.depthScale = ds; d->cfg.device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { delete d; sind_set_error("sind_dyna_create: hipStreamCreate failed"); return SIND_E_HIP; }
     int r = d->front.init(d->cfg, 1, d->stream);
     if (r == SIND_OK) r = d->tail.init(d->cfg, d->stream);
     const size_t np = (size_t)w * h;
@@ -29,10 +29,11 @@ int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float
     if (r == SIND_OK) r = d->V.alloc(np);
     if (r == SIND_OK) r = d->dil_a.alloc(np);
     if (r == SIND_OK) r = d->dil_b.alloc(np);
-    if (r != SIND_OK) { delete d; return r; }
+    if (r != SIND_OK) { hipStream_t st = d->stream; delete d; (void)hipStreamDestroy(st); return r; }
     d->tail.keep_debug = true;
     *out = d; return SIND_OK;
 }
+int sind_dyna_set_flow_max_levels(sind_dyna* d, int n) { if (!d || n < 0) return SIND_E_ARG; d->front.flow.max_levels = n; return SIND_OK; }
 int sind_dyna_destroy(sind_dyna* d) {
     if (!d) return SIND_OK;
     (void)hipSetDevice(d->cfg.device);

@@ -10,6 +10,7 @@ struct sind_flow {
 
 extern "C" {
 
+int sind_flow_set_max_levels(sind_flow* f, int n) { if (!f || n < 0) return SIND_E_ARG; f->eng.max_levels = n; return SIND_OK; }
 int sind_device_count(int* count) { if (!count) return SIND_E_ARG; HIP_TRY(hipGetDeviceCount(count)); return SIND_OK; }
 
 int sind_flow_create(int fw, int fh, int max_batch, int device, sind_flow** out) {

@@ -25,7 +25,7 @@ int sind_orb_create(int nfeatures, float sf, int nlevels, int ini, int mn, int d
     if (!out || nfeatures < 1 || nlevels < 1 || nlevels > 16 || sf <= 1.0f) { sind_set_error("sind_orb_create: bad arguments"); return SIND_E_ARG; }
     HIP_TRY(hipSetDevice(device));
     sind_orb* o = new sind_orb(); o->device = device; o->nfeatures = nfeatures; o->sf = sf; o->nlevels = nlevels; o->ini = ini; o->mn = mn;
-    HIP_TRY(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess) { delete o; sind_set_error("sind_orb_create: hipStreamCreate failed"); return SIND_E_HIP; }
     *out = o; return SIND_OK;
 }
 int sind_orb_destroy(sind_orb* o) {

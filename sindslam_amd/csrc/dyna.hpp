@@ -51,8 +51,9 @@ public:
     ~DynaTail() { for (auto& g : kmGraph) if (g) (void)hipGraphExecDestroy(g); }
     // depth_host: H x W u16 (host); depth_dev: same on the device; U/V: device full-resolution flow of this frame.
     // dyna_out / label_out: host H x W u8 (0 invalid / 125 static / 255 dynamic ; 0 invalid, 1..n clusters).
+    // depth_half: the tail object that carries the depth half's state and workspaces (nullptr = this one)
     int process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out,
-                const OccResult* precomputed = nullptr);
+                const OccResult* precomputed = nullptr, DynaTail* depth_half = nullptr);
     // process() = depth_stage() + flow_stage().  The two halves keep separate state (the k-means warm labels belong to the depth half,
     // the sample weights / previous masks to the flow half), so the depth half of the next frames may run ahead of the flow half.
     int depth_stage(const uint16_t* depth_host, const uint16_t* depth_dev, const OccResult* precomputed, DepthStageOut& out);
@@ -61,6 +62,13 @@ public:
     // of the step is still on the GPU and the host cores are idle
     int compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out);
     void reset();
+    // Inter-frame state (reference DynaDetect.h:172-178, rolled at DynaDetect.cc:1660-1664) as one flat blob, so that a sequence can
+    // continue on another handle / rank exactly where this one stopped ("phase B strictly in frame order"):
+    //   [dynaLast N][labelLast N][highLast N (0/255)][lastCnt 256 x i32][lastDyn 256 x i32]   flow half (sample weights, previous high mask)
+    //   [kmLabelLast N][kmLabelLastAny i32]                                                  depth half (k-means warm labels)
+    size_t state_bytes() const { return (size_t)4 * N + 2 * 256 * sizeof(int) + sizeof(int); }
+    void save_state(uint8_t* buf, bool flow_half = true, bool depth_half = true) const;
+    void load_state(const uint8_t* buf, bool flow_half = true, bool depth_half = true);
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; long n_frames = 0;
     double t_fine[40] = {0};       // cal_occluded: gpu+d2h, pack, endpoints, peac, contour filter, close | seg_merge: pieces, planes+h2d, rag gpu, merge    // flow masks, k-means, label prep, CalOccluded, SegAndMerge, fusion (ms, SIND_TAIL_TIMING=1)
 private:

@@ -124,6 +124,21 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
 }
 void DynaTail::reset() { dynaLast.assign(N, 0); labelLast.assign(N, 0); kmLabelLast.assign(N, 0); highLast.create(W, H); kmLabelLastAny = false; std::memset(lastCnt, 0, sizeof(lastCnt)); std::memset(lastDyn, 0, sizeof(lastDyn)); }
 
+void DynaTail::save_state(uint8_t* buf, bool flow_half, bool depth_half) const {
+    uint8_t* q = buf;
+    if (flow_half) { std::memcpy(q, dynaLast.data(), N); std::memcpy(q + N, labelLast.data(), N); highLast.to_u8(q + 2 * (size_t)N, W, 255);
+                     std::memcpy(q + 3 * (size_t)N, lastCnt, sizeof(lastCnt)); std::memcpy(q + 3 * (size_t)N + sizeof(lastCnt), lastDyn, sizeof(lastDyn)); }
+    q += 3 * (size_t)N + sizeof(lastCnt) + sizeof(lastDyn);
+    if (depth_half) { std::memcpy(q, kmLabelLast.data(), N); const int any = kmLabelLastAny ? 1 : 0; std::memcpy(q + N, &any, sizeof(int)); }
+}
+void DynaTail::load_state(const uint8_t* buf, bool flow_half, bool depth_half) {
+    const uint8_t* q = buf;
+    if (flow_half) { std::memcpy(dynaLast.data(), q, N); std::memcpy(labelLast.data(), q + N, N); highLast = BitImg::from_u8(q + 2 * (size_t)N, W, H, W);
+                     std::memcpy(lastCnt, q + 3 * (size_t)N, sizeof(lastCnt)); std::memcpy(lastDyn, q + 3 * (size_t)N + sizeof(lastCnt), sizeof(lastDyn)); }
+    q += 3 * (size_t)N + sizeof(lastCnt) + sizeof(lastDyn);
+    if (depth_half) { std::memcpy(kmLabelLast.data(), q, N); int any = 0; std::memcpy(&any, q + N, sizeof(int)); kmLabelLastAny = any != 0; }
+}
+
 // ---- DD:1163-1367: sample weights -> PROSAC pairs -> homography -> residual -> Otsu / Triangle thresholds -> masks
 int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& high, const float* gridFlowPre) {
     const int numCluster = KM_K;
@@ -508,14 +523,14 @@ int DynaTail::compute_occluded(const uint16_t* depth_host, const uint16_t* depth
 }
 
 int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out,
-                      const OccResult* pre) {
+                      const OccResult* pre, DynaTail* depth_half) {
     // same stage order as the reference (flow masks, clustering, fusion); the order also matters for throughput: a pool of tails that
     // all start with the 50-launch k-means chain was measured 20 ms per step slower than one that starts with the host-side pair sorting
     HIP_TRY(hipSetDevice(cfg.device));
     BitImg maskLow, maskHigh; n_frames++;
     { const double t0 = tick_ms(); SIND_TRY(flow_masks(U, V, maskLow, maskHigh, pre ? pre->gridFlow : nullptr)); t_stage[0] += tick_ms() - t0; }
     DepthStageOut d;
-    SIND_TRY(depth_stage(depth_host, depth_dev, pre, d));
+    SIND_TRY((depth_half ? depth_half : this)->depth_stage(depth_host, depth_dev, pre, d));
     return fuse(maskLow, maskHigh, d, dyna_out, label_out);
 }
 

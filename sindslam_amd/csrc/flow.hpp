@@ -62,6 +62,8 @@ public:
     int varref_f32(const float* I0, const float* I1, int w, int h, int B, float* u, float* v, const VarParams& V);
     FlowPlanes planes{};
     SorTimer sor_timer;
+    int max_levels = 0;                          // > 0: use only the finest max_levels pyramid levels, zero flow at the coarsest of them (DeepFlow's maxLayers knob made
+                                                 // effective -- OpenCV 4.2 never increments its layer counter; BASELINE.json config 5 "3-level flow pyramid"); 0 = all levels
     int launch_ahead = 3;                        // pyramid levels the launching thread may be ahead of the GPU (0 = unbounded)
     ~FlowEngine() { for (hipEvent_t e : level_done) (void)hipEventDestroy(e); }
 private:

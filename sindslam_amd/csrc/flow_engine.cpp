@@ -43,7 +43,7 @@ int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, 
     // getGaussianKernel(3, 0.6): exp(-x^2/(2 sigma^2)) normalised, cast to float
     const double sigma = 0.6f; const double e = std::exp(-0.5 * 1.0 * 1.0 / (sigma * sigma)), sum = (e + 1.0) + e;
     const float k0 = (float)(1.0 / sum), k1 = (float)(e / sum);
-    const int L = (int)levels.size();
+    const int L = max_levels > 0 ? std::min(max_levels, (int)levels.size()) : (int)levels.size();
     SIND_TRY(launch_u8_to_f32_blur3(stream, g0, level_ptr(pyr0, 0, B), fw, fh, B, k0, k1, true));
     SIND_TRY(launch_u8_to_f32_blur3(stream, g1, level_ptr(pyr1, 0, B), fw, fh, B, k0, k1, true));
     for (int l = 1; l < L; l++) {

@@ -8,6 +8,7 @@
 // imgwarp.cpp remap); the parity tests compare these kernels with the CPU oracle bit for bit.
 //
 // Roofline: all kernels here are HBM/L2-bound stencil passes (no MFMA: nothing is a contraction).
+#include <mutex>
 #include "common.hpp"
 #include "flow.hpp"
 
@@ -603,8 +604,10 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         }
         *nlaunch += 2LL * total; return SIND_OK;
     }
-    static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_sor_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+    // the flow slices call this concurrently from their own threads: set the (idempotent) attribute exactly once
+    static std::once_flag attr_once; static hipError_t attr_rc = hipSuccess;
+    std::call_once(attr_once, [] { attr_rc = hipFuncSetAttribute((const void*)k_sor_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    HIP_TRY(attr_rc);
     auto sor_lds_bytes = [](int EW, int nt) { const int NR = 2 * ((nt / 2) / (EW / SOR_PX)); return (size_t)6 * (NR + 2) * (EW / 8 + 2) * sizeof(float4); };
     auto threads_for = [](int EW, int EH) { const int halfn = (EW / SOR_PX) * ((EH + 1) / 2); return 2 * ((halfn + 63) / 64 * 64); };
     const int EWw = (w + SOR_PX - 1) / SOR_PX * SOR_PX;
@@ -616,8 +619,9 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         *nlaunch += 1; return SIND_OK;
     }
     if (g_sor_mode == 2) {                             // 1x4 strips + reciprocal division (k_sor_fused4), 64 x 64 tiles, 1024 threads
-        static bool attr4 = false;
-        if (!attr4) { HIP_TRY(hipFuncSetAttribute((const void*)k_sor_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr4 = true; }
+        static std::once_flag attr4_once; static hipError_t attr4_rc = hipSuccess;
+        std::call_once(attr4_once, [] { attr4_rc = hipFuncSetAttribute((const void*)k_sor_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
+        HIP_TRY(attr4_rc);
         const int EW = 64, EH = 64, nt = 1024;
         const size_t shm = (size_t)4 * (EH + 2) * (EW / 4 + 2) * sizeof(float2);
         for (int done = 0; done < total;) {

@@ -60,6 +60,9 @@ struct sind_pipe {
     hipStream_t stream = nullptr, orb_stream = nullptr; hipEvent_t ev_gray = nullptr, ev_depth = nullptr; std::vector<hipStream_t> worker_streams, worker_streams_lo;      // one HIP stream per pool worker, shared by the tasks it runs
     DynaFront front; std::vector<std::unique_ptr<DynaFront>> extra_fronts; std::vector<hipStream_t> extra_streams; hipEvent_t ev_pool = nullptr;      // batch slices 1.. of the dense flow (slice 0 = front)
     OrbEngine orb; std::vector<std::unique_ptr<DynaTail>> tails;
+    // Depth halves (k-means warm labels + their workspaces) as objects of their own, present once depth-ahead has been switched on: the
+    // depth chain of step i+1 (phase A) may then run while the flow chain of step i (phase B) is still going on the same stream of frames.
+    std::vector<std::unique_ptr<DynaTail>> dtails;
     std::vector<std::unique_ptr<PinnedBuf<uint8_t>>> upload_stage;        // page-locked staging of sind_pipe_process (host-buffer entry point), two 4 MB buffers per uploading worker
     std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
@@ -105,10 +108,9 @@ static int make_stream(hipStream_t* out, bool high_priority) {
 
 extern "C" {
 
-int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
-    if (!cfg || !out || cfg->streams < 1 || cfg->frames_per_step < 1 || cfg->width < 64 || cfg->height < 64) { sind_set_error("sind_pipe_create: bad configuration"); return SIND_E_ARG; }
-    HIP_TRY(hipSetDevice(cfg->device));
-    std::unique_ptr<sind_pipe> p(new sind_pipe());
+int sind_pipe_destroy(sind_pipe* p);
+static int ensure_dtails(sind_pipe* p);
+static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     p->c = *cfg; p->S = cfg->streams; p->T = cfg->frames_per_step;
     p->dc.W = cfg->width; p->dc.H = cfg->height; p->dc.fx = cfg->fx; p->dc.fy = cfg->fy; p->dc.cx = cfg->cx; p->dc.cy = cfg->cy; p->dc.depthScale = cfg->depth_scale; p->dc.device = cfg->device;
     const bool flow_hi = getenv("SIND_FLOW_PRIORITY") && atoi(getenv("SIND_FLOW_PRIORITY")) != 0;
@@ -123,6 +125,7 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
         hipStream_t st = nullptr; SIND_TRY(make_stream(&st, flow_hi)); p->extra_streams.push_back(st);
         p->extra_fronts.emplace_back(new DynaFront()); SIND_TRY(p->extra_fronts.back()->init(p->dc, Bs, st));
     }
+    p->front.flow.max_levels = std::max(0, cfg->flow_max_levels); for (auto& f : p->extra_fronts) f->flow.max_levels = p->front.flow.max_levels;
     p->fw = p->front.fw; p->fh = p->front.fh;
     SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->orb_stream));
     // CPU share of this process: the container's quota (cgroup v2 cpu.max, 16 cores per GPU on the MI355X boxes), else the machine's cores
@@ -150,12 +153,22 @@ int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
     p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads
     if (const char* e = getenv("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
     p->depth_ahead = getenv("SIND_DEPTH_AHEAD") && atoi(getenv("SIND_DEPTH_AHEAD")) != 0;
+    if (p->depth_ahead) SIND_TRY(ensure_dtails(p));
     p->workers.start(nworkers, cfg->device);
-    SIND_TRY(p->gray.alloc(np * B)); SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
+    SIND_TRY(p->gray.alloc(np * std::max(B, 2)));          // sind_pipe_prime converts the two priming frames through this scratch, also when S * T == 1
+    SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
     if (cfg->orb_gray_rgb_order) SIND_TRY(p->gray_orb.alloc(np * B));
     for (int k = 0; k < 2; k++) { SIND_TRY(p->sb[k].U.alloc(np * B)); SIND_TRY(p->sb[k].V.alloc(np * B)); SIND_TRY(p->sb[k].depth_dev.alloc(np * B)); SIND_TRY(p->sb[k].depth_h.alloc(np * B)); }
     p->primed.assign(p->S, 0);
-    *out = p.release(); return SIND_OK;
+    return SIND_OK;
+}
+int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out) {
+    if (!cfg || !out || cfg->streams < 1 || cfg->frames_per_step < 1 || cfg->width < 64 || cfg->height < 64) { sind_set_error("sind_pipe_create: bad configuration"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(cfg->device));
+    sind_pipe* p = new sind_pipe();
+    const int rc = pipe_build(p, cfg);
+    if (rc != SIND_OK) { const std::string keep = sind_last_error(); sind_pipe_destroy(p); sind_set_error("%s", keep.c_str()); return rc; }      // streams, events and workers created so far go with it
+    *out = p; return SIND_OK;
 }
 int sind_pipe_destroy(sind_pipe* p) {
     if (!p) return SIND_OK;
@@ -192,8 +205,20 @@ int sind_pipe_prime(sind_pipe* p, int s, const uint8_t* last, const uint8_t* las
     HIP_TRY(hipMemcpyAsync(p->bgr_d.p + np * 3, last, np * 3, hipMemcpyHostToDevice, p->stream));
     SIND_TRY(p->front.gray_and_min(p->bgr_d.p, 2, p->gray.p, p->pool.p + fb * (size_t)s * (p->T + 2)));   // slots 0 (n-2), 1 (n-1)
     HIP_TRY(sind_stream_wait(p->stream));
-    p->tails[s]->reset(); p->primed[s] = 1;
+    p->tails[s]->reset(); if (!p->dtails.empty()) p->dtails[s]->reset(); p->primed[s] = 1;
     return SIND_OK;
+}
+
+// depth half of stream s: its own object when depth-ahead is (or was) on, else the stream's tail
+static DynaTail* depth_half(sind_pipe* p, int s) { return !p->dtails.empty() ? p->dtails[s].get() : p->tails[s].get(); }
+static int ensure_dtails(sind_pipe* p) {
+    if (!p->dtails.empty()) return SIND_OK;
+    std::vector<std::unique_ptr<DynaTail>> d(p->S); std::vector<uint8_t> st;
+    for (int s = 0; s < p->S; s++) {
+        d[s].reset(new DynaTail()); SIND_TRY(d[s]->init(p->dc, p->worker_streams[s % p->worker_streams.size()]));
+        st.resize(p->tails[s]->state_bytes()); p->tails[s]->save_state(st.data(), false, true); d[s]->load_state(st.data(), false, true);      // the warm labels move over
+    }
+    p->dtails.swap(d); return SIND_OK;
 }
 
 // ---- phase A of one step (state free, batched over S*T frames, shared HIP stream): fills a StepBuf
@@ -319,8 +344,8 @@ struct PipeOut { uint8_t *dyna, *label, *mask; sind_keypoint* kps; int cap; int*
 // (the k-means warm labels are the previous frame's merged labels).  It opens the gate of the stream's next frame when it is done.
 static void depth_task(sind_pipe* p, sind_pipe::StepBuf* sb, int k, int worker) {
     const int T = p->T, s = k / T, t = k % T; const size_t np = (size_t)p->c.width * p->c.height;
-    p->tails[s]->stream = p->worker_streams_lo[worker];
-    const int r = p->tails[s]->depth_stage(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, &sb->occ[k], sb->dout[k]);
+    DynaTail* dt = depth_half(p, s); dt->stream = p->worker_streams_lo[worker];
+    const int r = dt->depth_stage(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, &sb->occ[k], sb->dout[k]);
     if (r != SIND_OK) { sb->depth_rc[k] = r; sb->depth_err[k] = sind_last_error(); }
     if (t + 1 < T && sb->gate[k + 1].fetch_add(1) == 1) p->workers.push(sb->depth_group, [p, sb, k](int w) { depth_task(p, sb, k + 1, w); });
 }
@@ -331,7 +356,8 @@ static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, in
     dy.resize(np); lb.resize(np); dil.resize(np);
     const int k = s * T + t;
     int r = sb->depth_ahead ? p->tails[s]->flow_stage(sb->U.p + np * k, sb->V.p + np * k, sb->dout[k], dy.data(), lb.data(), sb->occ[k].gridFlow)
-                            : p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k]);
+                            : p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k],
+                                                   p->dtails.empty() ? nullptr : (p->dtails[s]->stream = p->worker_streams[worker], p->dtails[s].get()));
     if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return; }
     double* tf = p->tails[s]->t_fine; double t0 = now_ms();
     dilate15_codes(dy.data(), W, H, dil.data());
@@ -343,7 +369,7 @@ static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, in
     std::vector<OrbKeyPoint> kk; std::vector<uint8_t> dd;
     p->orb.finish(sb->orb[k], dil.data(), W, kk, dd);
     { const double t1 = now_ms(); tf[32] += t1 - t0; t0 = t1; }
-    if ((int)kk.size() > o.cap && o.kps) { sb->tail_rc[s] = SIND_E_CAPACITY; sb->tail_err[s] = "keypoint capacity exceeded"; return; }
+    if ((int)kk.size() > o.cap && (o.kps || o.desc)) { sb->tail_rc[s] = SIND_E_CAPACITY; sb->tail_err[s] = "keypoint capacity exceeded"; return; }
     if (o.nkp) o.nkp[k] = (int)kk.size();
     if (o.kps) std::memcpy(o.kps + (size_t)k * o.cap, kk.data(), kk.size() * sizeof(sind_keypoint));
     if (o.desc) std::memcpy(o.desc + (size_t)k * o.cap * 32, dd.data(), dd.size());
@@ -396,12 +422,16 @@ int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* d
     const double tb0 = now_ms(); double tb1 = tb0;
     if (has_prev) phase_b_start(p, p->sb[prev], o);            // queued ahead of this step's CalOccluded tasks
     double t[4]; const double t0 = now_ms();
-    const int ra = phase_a(p, p->sb[p->cur], bgr_dev, depth_dev, t);
+    const int ra = phase_a(p, p->sb[p->cur], bgr_dev, depth_dev, t, p->depth_ahead);      // with depth-ahead the depth chain of this step runs next to the flow chain of the previous one
     int rb = SIND_OK;
     if (has_prev) { rb = phase_b_finish(p, p->sb[prev]); tb1 = now_ms(); }
     const double t4 = now_ms();
-    if (rb != SIND_OK) return rb;
-    SIND_TRY(ra);
+    if (rb != SIND_OK || ra != SIND_OK) {          // a failed step leaves nothing pending: the next call starts from a clean two-buffer state
+        std::string keep = sind_last_error(); if (rb != SIND_OK && ra != SIND_OK) keep = "tails of the previous step failed, and so did phase A of this one: " + keep;
+        p->sb[0].pending = p->sb[1].pending = false; p->cur = 0;
+        sind_set_error("%s", keep.c_str());
+        return rb != SIND_OK ? rb : ra;
+    }
     p->stage_ms[0] = t[1] - t[0]; p->stage_ms[1] = t[2] - t[1]; p->stage_ms[2] = t[3] - t[2]; p->stage_ms[3] = 0; p->stage_ms[4] = tb1 - tb0; p->stage_ms[5] = t4 - t0;
     p->cur ^= 1;
     return SIND_OK;
@@ -457,7 +487,27 @@ int sind_pipe_process(sind_pipe* p, const uint8_t* bgr, const uint16_t* depth, u
 int sind_pipe_set_depth_ahead(sind_pipe* p, int on) {
     if (!p) return SIND_E_ARG;
     if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_set_depth_ahead: a submitted step is still pending"); return SIND_E_STATE; }
+    HIP_TRY(hipSetDevice(p->c.device));
+    if (on) SIND_TRY(ensure_dtails(p));
     p->depth_ahead = on != 0; return SIND_OK;
+}
+
+// ---- inter-frame state of one stream as a flat blob (DynaTail::save_state): lets a sequence continue on another handle / rank
+size_t sind_pipe_state_bytes(sind_pipe* p) { return p && !p->tails.empty() ? p->tails[0]->state_bytes() : 0; }
+int sind_pipe_get_state(sind_pipe* p, int s, uint8_t* buf, size_t n) {
+    if (!p || s < 0 || s >= p->S || !buf || n < sind_pipe_state_bytes(p)) { sind_set_error("sind_pipe_get_state: bad arguments"); return SIND_E_ARG; }
+    if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_get_state: a submitted step is still pending, call sind_pipe_flush first"); return SIND_E_STATE; }
+    p->tails[s]->save_state(buf, true, false); depth_half(p, s)->save_state(buf, false, true);
+    return SIND_OK;
+}
+int sind_pipe_set_state(sind_pipe* p, int s, const uint8_t* buf, size_t n) {
+    if (!p || s < 0 || s >= p->S || !buf || n < sind_pipe_state_bytes(p)) { sind_set_error("sind_pipe_set_state: bad arguments"); return SIND_E_ARG; }
+    if (!p->primed[s]) { sind_set_error("sind_pipe_set_state: prime the stream first (priming resets its state)"); return SIND_E_STATE; }
+    // A submitted step whose tails have not run yet is fine (that is the hand-over point between ranks: phase A done, state arrives, flush),
+    // unless its depth chain already ran ahead on the old warm labels
+    for (int k = 0; k < 2; k++) if (p->sb[k].pending && p->sb[k].depth_ahead) { sind_set_error("sind_pipe_set_state: the depth chain of the pending step already ran (depth-ahead); set the state before submitting"); return SIND_E_STATE; }
+    p->tails[s]->load_state(buf, true, false); depth_half(p, s)->load_state(buf, false, true);
+    return SIND_OK;
 }
 
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices) {

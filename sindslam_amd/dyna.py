@@ -21,6 +21,10 @@ class DynaDetect:
         self._h = h
         check(lib().sind_dyna_prime(self._h, ptr(np.ascontiguousarray(imgLast)), ptr(np.ascontiguousarray(imgLastLast)), self.w * 3), "sind_dyna_prime")
 
+    def set_flow_max_levels(self, n: int):
+        """build-side option of BASELINE.json config 5 ("3-level flow pyramid"): finest n levels of the DeepFlow pyramid only; 0 = all"""
+        check(lib().sind_dyna_set_flow_max_levels(self._h, int(n)), "sind_dyna_set_flow_max_levels")
+
     def close(self):
         if getattr(self, "_h", None):
             lib().sind_dyna_destroy(self._h); self._h = None

@@ -21,6 +21,10 @@ class FlowStage:
         check(lib().sind_flow_create(fw, fh, max_batch, device, C.byref(h)), "sind_flow_create")
         self._h = h
 
+    def set_max_levels(self, n: int):
+        """finest n levels of the 0.95 pyramid only (BASELINE.json config 5, "3-level flow pyramid"); 0 = the full pyramid of OpenCV's DeepFlow"""
+        check(lib().sind_flow_set_max_levels(self._h, int(n)), "sind_flow_set_max_levels")
+
     def close(self):
         if getattr(self, "_h", None):
             lib().sind_flow_destroy(self._h); self._h = None

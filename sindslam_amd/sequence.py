@@ -6,8 +6,16 @@ So a sequence of N frames is cut into contiguous CHUNKS, one per pipeline stream
 independent stream that starts `warmup` frames before its first owned frame, so that its tail state has settled when the owned frames
 begin; the outputs of the warm-up frames are dropped.  Chunk 0 starts at frame 1 primed with frame 0 twice, exactly like the reference
 loop (Examples/RGB-D/rgbd_tum_noros.cc:103-107, 131-139), so its frames equal a sequential run bit for bit; later chunks deviate from a sequential run only through the state they rebuilt
-in `warmup` frames (tests/test_sequence_gpu.py reports the mask IoU at the seams).  With several ranks, rank r owns chunks
-[r * streams, (r + 1) * streams) and the per-frame masks are gathered with one all_gather per step (parallel.gather_masks).
+in `warmup` frames -- the state steers the masks, a rebuilt state gives VALID BUT NOT IDENTICAL masks (per-frame IoU against the
+sequential run down to 0.3-0.8 at some seams, see tests/test_sequence_gpu.py and DESIGN.md 4).  With several ranks, rank r owns chunks
+[r * streams, (r + 1) * streams); process_sequence performs NO collective -- the caller assembles the per-frame masks of all ranks with
+parallel.gather_sequence_masks (one all_gather of padded blocks).
+
+Where the masks must EQUAL one sequential run (the parity mode, "exact"), use process_sequence_exact: the state-free phase A is still
+batched (and sharded over ranks by contiguous frame ranges), the stateful tails run strictly in frame order -- one chain per half
+(depth half: k-means warm labels; flow half: sample weights, previous high mask), the depth chain of step i+1 next to the flow
+chain of step i -- and the state blob is handed from rank r to rank r+1 (point-to-point send / recv).  Its rate is bounded by
+1 / (per-frame chain latency), not by the GPU, and does not grow with the number of ranks.
 """
 from __future__ import annotations
 
@@ -82,4 +90,103 @@ def process_sequence(bgr: np.ndarray, depth: np.ndarray, intr: dict, streams: in
     finally:
         pipe.close()
     out["owned"].sort()
+    return out
+
+
+def split_frames(n_frames: int, world: int) -> list[tuple[int, int]]:
+    """Contiguous frame ranges [first, last) over frames [1, n_frames) for the ranks of the exact mode (the first ranks take one more)."""
+    owned = n_frames - 1
+    base, extra = divmod(owned, world)
+    out, first = [], 1
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((first, first + n)); first += n
+    return out
+
+
+def process_sequence_exact(bgr: np.ndarray, depth: np.ndarray, intr: dict, frames_per_step: int = 64, nfeatures: int = 1500, scale_factor: float = 1.2,
+                           nlevels: int = 8, orb_gray_rgb_order: int = 1, device: int = 0, rank: int = 0, world: int = 1, group=None,
+                           want_keypoints: bool = True, first_step: int | None = None, timing: dict | None = None):
+    """In-order ("exact") run of one sequence: results equal the sequential reference loop frame for frame (rgbd_tum_noros.cc:110-170,
+    state roll DynaDetect.cc:1660-1664).  Rank r owns the contiguous range split_frames(n, world)[r]; phase A of its steps is batched on
+    its GPU, its tails run in frame order once the state of rank r-1 has arrived (send / recv of the state blob), and the final state goes
+    to rank r+1.  Same return value as process_sequence.  first_step: length of a rank's first step, the only one whose tails do not overlap
+    with a phase A (rank > 0; default frames_per_step // 4)."""
+    import torch
+    from .pipeline import Pipeline
+    n, h, w, _ = bgr.shape
+    f0, f1 = split_frames(n, world)[rank]
+    out = dict(dyna=np.zeros((n, h, w), np.uint8), label=np.zeros((n, h, w), np.uint8), mask=np.zeros((n, h, w), np.uint8), owned=list(range(f0, f1)),
+               keypoints=[None] * n, descriptors=[None] * n)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+    dev = torch.device("cuda", device)
+    comm_dev = dev if (world > 1 and dist.get_backend(group) == "nccl") else torch.device("cpu")
+
+    def recv_state(nbytes):
+        t = torch.empty(nbytes, dtype=torch.uint8, device=comm_dev); dist.recv(t, src=rank - 1, group=group); return t.cpu().numpy()
+
+    def send_state(blob):
+        dist.send(torch.from_numpy(blob).to(comm_dev), dst=rank + 1, group=group)
+
+    # step plan: [first_step (ranks > 0)] + full steps of T + one remainder step; each distinct length gets its own pipeline handle
+    T = max(1, frames_per_step); L = f1 - f0; plan = []
+    fs = min(L, first_step if first_step is not None else max(1, T // 4)) if rank > 0 else 0
+    if fs: plan.append(fs)
+    plan += [T] * ((L - fs) // T)
+    if (L - fs) % T: plan.append((L - fs) % T)
+    state = None; pipes = {}; t_wait = 0.0
+    import time
+
+    def pipe_for(t_len, first_frame):
+        """handle with T = t_len, primed with the two frames before first_frame, carrying `state`"""
+        if t_len not in pipes:
+            pipes[t_len] = Pipeline(1, t_len, w, h, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], nfeatures, scale_factor, nlevels,
+                                    intr["ini_th"], intr["min_th"], orb_gray_rgb_order=orb_gray_rgb_order, device=device)
+        p = pipes[t_len]
+        p.prime(0, bgr[first_frame - 1], bgr[max(first_frame - 2, 0)])
+        return p
+
+    def collect(p, first_frame, t_len):
+        for t in range(t_len):
+            f = first_frame + t
+            out["dyna"][f] = p.dyna[0, t]; out["label"][f] = p.label[0, t]; out["mask"][f] = p.mask[0, t]
+            if want_keypoints:
+                k, d = p.keypoints(0, t); out["keypoints"][f] = k.copy(); out["descriptors"][f] = d.copy()
+
+    def upload(first_frame, t_len):
+        b = torch.from_numpy(np.ascontiguousarray(bgr[first_frame:first_frame + t_len])).to(dev)
+        d = torch.from_numpy(np.ascontiguousarray(depth[first_frame:first_frame + t_len]).view(np.int16)).to(dev)
+        torch.cuda.synchronize(dev); return b, d
+
+    try:
+        f = f0; i = 0
+        while i < len(plan):
+            t_len = plan[i]; run = 1
+            while i + run < len(plan) and plan[i + run] == t_len: run += 1            # consecutive steps of one length share a handle and pipeline
+            p = pipe_for(t_len, f)
+            if rank > 0 and i == 0:
+                # phase A of the first step before the predecessor's state is there (no depth-ahead: both chains wait for the state)
+                p.set_depth_ahead(False)
+                b, d = upload(f, t_len); p.submit_dev(b.data_ptr(), d.data_ptr())
+                tw = time.perf_counter(); state = recv_state(p.get_state_bytes()); t_wait += time.perf_counter() - tw
+                p.set_state(0, state); p.flush(); collect(p, f, t_len); state = p.get_state(0); f += t_len; i += 1
+                continue
+            if state is not None: p.set_state(0, state)
+            p.set_depth_ahead(True)
+            prev = None
+            for k in range(run):
+                b, d = upload(f + k * t_len, t_len)
+                if p.submit_dev(b.data_ptr(), d.data_ptr()): collect(p, prev, t_len)
+                prev = f + k * t_len
+            if p.flush(): collect(p, prev, t_len)
+            state = p.get_state(0); f += run * t_len; i += run
+        if world > 1 and rank + 1 < world:
+            if state is None:               # a rank without frames forwards what it received
+                nb = Pipeline.state_bytes_for(w, h); state = recv_state(nb) if rank > 0 else np.zeros(nb, np.uint8)
+            send_state(state)
+    finally:
+        for p in pipes.values(): p.close()
+    if timing is not None: timing["state_wait_s"] = t_wait
     return out

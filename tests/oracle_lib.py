@@ -106,8 +106,10 @@ def varref(i0, i1, wu, wv, fp_iters=5, sor_iters=5, alpha=20.0, delta=5.0, gamma
     return (wu, wv, inter) if want_inter else (wu, wv)
 
 
-def deepflow(i0, i1):
+def deepflow(i0, i1, max_levels=0):
     h, w = i0.shape; out = np.empty((h, w, 2), np.float32)
+    if max_levels > 0:
+        lib().orc_deepflow_levels_capped(_p(np.ascontiguousarray(i0)), _p(np.ascontiguousarray(i1)), w, h, int(max_levels), _p(out)); return out
     lib().orc_deepflow(_p(np.ascontiguousarray(i0)), _p(np.ascontiguousarray(i1)), w, h, _p(out)); return out
 
 
@@ -148,6 +150,9 @@ class DynaDetect:
     def __del__(self):
         if getattr(self, "p", None):
             lib().orc_dyna_destroy(self.p); self.p = None
+
+    def set_flow_max_levels(self, n):
+        lib().orc_dyna_set_flow_max_levels(self.p, int(n))
 
     def detect(self, bgr, depth):
         dyna = np.empty((self.h, self.w), np.uint8); label = np.empty((self.h, self.w), np.uint8)
@@ -213,15 +218,19 @@ class ORBextractor:
         lib().orc_orb_tables(self.p, *[_p(t[k]) for k in ["scale", "inv_scale", "sigma2", "inv_sigma2", "per_level", "umax"]]); return t
 
 
-def baseline_run(bgr, depth, intr, nfeatures=1500, scale=1.2, nlevels=8, orb_gray_rgb_order=1, want_outputs=False, kp_cap=4096):
-    """frames 0,1 prime the detector; returns (seconds, stage seconds[, dyna masks (n-2,h,w), keypoints per pair])"""
-    n, h, w, _ = bgr.shape; st = np.zeros(3)
+STAGES = ["kmeans", "depth_edge", "seg_and_merge", "flow_refine_masks", "fusion", "orb"]
+
+
+def baseline_run(bgr, depth, intr, nfeatures=1500, scale=1.2, nlevels=8, orb_gray_rgb_order=1, want_outputs=False, kp_cap=4096, warmup_pairs=0, flow_max_levels=0):
+    """frames 0,1 prime the detector; the first `warmup_pairs` pairs are not timed.  Returns (seconds, stage seconds[, dyna masks (n-2,h,w),
+    keypoints per pair]); stage seconds = [flow, tail, orb] + the reference's own breakdown (STAGES: DynaDetect.cc:1421,1499,1518,1161,1644 + ORB)"""
+    n, h, w, _ = bgr.shape; st = np.zeros(9)
     dyna = np.zeros((n - 2, h, w), np.uint8) if want_outputs else None
     nkp = np.zeros(n - 2, np.int32) if want_outputs else None
     kps = np.zeros((n - 2, kp_cap), KP_DTYPE) if want_outputs else None
     t = lib().orc_baseline_run(_p(np.ascontiguousarray(bgr)), _p(np.ascontiguousarray(depth)), n, w, h, C.c_float(intr["fx"]), C.c_float(intr["fy"]),
                                C.c_float(intr["cx"]), C.c_float(intr["cy"]), C.c_float(intr["depth_factor"]), nfeatures, C.c_float(scale), nlevels,
-                               intr["ini_th"], intr["min_th"], _p(st), int(orb_gray_rgb_order), _p(dyna), _p(nkp), _p(kps), kp_cap)
+                               intr["ini_th"], intr["min_th"], _p(st), int(orb_gray_rgb_order), _p(dyna), _p(nkp), _p(kps), kp_cap, int(warmup_pairs), int(flow_max_levels))
     if want_outputs:
         return t, st, dyna, [kps[i, :nkp[i]] for i in range(n - 2)]
     return t, st

@@ -92,3 +92,56 @@ def test_depth_ahead_schedule_equals_default(frames):
             n = ref.nkp[k]; assert ref.kps[k, :n].tobytes() == pip.kps[k, :n].tobytes() and np.array_equal(ref.desc[k, :n], pip.desc[k, :n])
         assert (ref.label > 0).any()
     ref.close(); pip.close()
+
+
+def test_single_frame_steps_and_the_state_blob(frames):
+    """S = 1, T = 1 (the smallest batch: the priming scratch must hold two frames) against the single-stream DynaDetect class, and a second
+    handle that continues the stream from the first one's state blob (sind_pipe_get_state / set_state) instead of its own history"""
+    from sindslam_amd.dyna import DynaDetect
+    from sindslam_amd.pipeline import Pipeline
+    bgr, depth = frames
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    dd = DynaDetect(bgr[1], bgr[0], *K)
+    a = Pipeline(1, 1, 640, 480, *K, 1500, 1.2, 8, 15, 5); a.prime(0, bgr[1], bgr[0])
+    for f in (2, 3):
+        rd, rl = dd.DetectDynaArea(bgr[f], depth[f], f)
+        a.process(bgr[None, None, f], depth[None, None, f])
+        assert np.array_equal(a.dyna[0, 0], rd) and np.array_equal(a.label[0, 0], rl), f
+    blob = a.get_state(0)
+    assert blob.size == Pipeline.state_bytes_for(640, 480) == a.get_state_bytes()
+    b = Pipeline(1, 2, 640, 480, *K, 1500, 1.2, 8, 15, 5); b.prime(0, bgr[3], bgr[2]); b.set_state(0, blob)
+    b.process(bgr[None, 4:6], depth[None, 4:6])
+    for t, f in enumerate((4, 5)):
+        rd, rl = dd.DetectDynaArea(bgr[f], depth[f], f)
+        assert np.array_equal(b.dyna[0, t], rd) and np.array_equal(b.label[0, t], rl), f
+    # without the blob the same frames give another (valid) answer: the state matters
+    c = Pipeline(1, 2, 640, 480, *K, 1500, 1.2, 8, 15, 5); c.prime(0, bgr[3], bgr[2]); c.process(bgr[None, 4:6], depth[None, 4:6])
+    assert not np.array_equal(c.label, b.label)
+    dd.close(); a.close(); b.close(); c.close()
+
+
+def test_pipelined_depth_ahead_equals_sync(frames):
+    """the schedule of the in-order sequence mode: submit / flush with depth-ahead (depth chain of step i+1 next to the flow chain of step i,
+    on separate tail objects) returns the synchronous results"""
+    import torch
+    from sindslam_amd.pipeline import Pipeline
+    bgr, depth = frames
+    S, T = 1, 2
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    ref = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5); pip = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5)
+    ref.prime(0, bgr[1], bgr[0]); pip.prime(0, bgr[1], bgr[0]); pip.set_depth_ahead(True)
+    expect = []
+    for step in range(2):
+        lo = 2 + step * T
+        ref.process(bgr[None, lo:lo + T], depth[None, lo:lo + T]); expect.append((ref.dyna.copy(), ref.label.copy(), ref.mask.copy()))
+    dev = [(torch.from_numpy(np.ascontiguousarray(bgr[None, 2 + i * T: 4 + i * T])).cuda(), torch.from_numpy(np.ascontiguousarray(depth[None, 2 + i * T: 4 + i * T]).view(np.int16)).cuda()) for i in range(2)]
+    got = []
+    assert pip.submit_dev(dev[0][0].data_ptr(), dev[0][1].data_ptr()) is False
+    assert pip.submit_dev(dev[1][0].data_ptr(), dev[1][1].data_ptr()) is True
+    got.append((pip.dyna.copy(), pip.label.copy(), pip.mask.copy()))
+    assert pip.flush() is True
+    got.append((pip.dyna.copy(), pip.label.copy(), pip.mask.copy()))
+    for e, g in zip(expect, got):
+        for x, y in zip(e, g):
+            assert np.array_equal(x, y)
+    ref.close(); pip.close()

@@ -109,6 +109,10 @@ int sind_dyna_debug(sind_dyna* d, float* flow_deep, float* flow_refined, float* 
                     uint8_t* mask_low, uint8_t* mask_high, uint8_t* kmeans_label, float* centers36, uint8_t* occ1, uint8_t* occ2,
                     uint8_t* total_area, uint8_t* grad_edge, uint8_t* plane_contours, int* info3);
 
+/* parity-test access to the k-means centre sums: out = the FP32 value of  acc = 0; for (i) acc += x[i]  (round to nearest even, exactly cv::kmeans'
+ * centre accumulation, kmeans.cpp) computed by the wave-parallel window arithmetic of k_km_seqsum (csrc/depth_kernels.hip) */
+int sind_debug_seqsum(const float* x, int n, int device, float* out);
+
 /* parity-test access to the bit-plane dilation used by the region-adjacency stage (7x7 ellipse on 64-pixel words, cv::dilate semantics):
  * planes / out are host arrays [nplanes][height][ceil(width / 64)] of 64-bit words, bit i of word k = pixel 64 k + i. */
 int sind_debug_dilate_planes(const unsigned long long* planes, int nplanes, int width, int height, int n, int device, unsigned long long* out);

@@ -33,6 +33,13 @@ int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float
     d->tail.keep_debug = true;
     *out = d; return SIND_OK;
 }
+int sind_debug_seqsum(const float* x, int n, int device, float* out) {
+    if (!x || !out || n < 0) return SIND_E_ARG;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<float> xd; DevBuf<int> scratch; SIND_TRY(xd.alloc((size_t)std::max(n, 1))); SIND_TRY(scratch.alloc(2 * KM_K + 64 + sizeof(sind::KmState) / 4 + 4));
+    HIP_TRY(hipMemcpy(xd.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return sind::debug_seqsum(nullptr, xd.p, n, scratch.p, out);
+}
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n) { if (!d || n < 0) return SIND_E_ARG; d->front.flow.max_levels = n; return SIND_OK; }
 int sind_dyna_destroy(sind_dyna* d) {
     if (!d) return SIND_OK;

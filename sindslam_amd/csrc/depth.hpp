@@ -19,8 +19,10 @@ int launch_points(hipStream_t s, const uint16_t* depth, float* px, float* py, fl
 int launch_labels_grid(hipStream_t s, int* labels, int w, int h);
 int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw, int sh, int dw, int dh);
 int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh);
-int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, double* partial, KmState* st,
+// segcnt: (KM_MAX_BLOCKS * 4 + 1) * KM_K ints (per wave-segment cluster counts + the totals row) + 64 floats (the pass's 36 sequential sums); comp: 3 * n floats (per-cluster runs of every coordinate)
+int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, int* segcnt, float* comp, KmState* st,
                         int maxCount, double eps2);
+int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev, float* out_host);
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n);
 int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h);
 int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out);

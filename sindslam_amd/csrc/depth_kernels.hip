@@ -5,6 +5,7 @@
 //   PEAC initial 16x16 block statistics (PEAC/AHCPlaneSeg.hpp:180-262)
 //   SegAndMergeV2 region-adjacency statistics (:784-893, cal_hist :1685-1739) from per-pixel membership words
 // Integer stages are bit-exact; FP32 expressions are written in the reference's operation order (-ffp-contract=off).
+#include <mutex>
 #include "common.hpp"
 #include "depth.hpp"
 
@@ -61,9 +62,15 @@ __global__ void k_labels_resize(const T* __restrict__ src, int* __restrict__ dst
 }
 
 // ---------------------------------------------------------------- k-means (cv::kmeans, KMEANS_USE_INITIAL_LABELS), device resident
-// Centre sums: per-workgroup partials in FP64 with a fixed-order final sum (deterministic; OpenCV sums sequentially in FP32, so
-// centres agree to ~1e-7 relative and labels on all but <=1e-3 of the pixels).  One KmState per pyramid level; k_km_update runs
-// the centre step (sums -> centres, empty-cluster repair, shift test, last-iteration decision) with cv::kmeans' operations.
+// Centre sums are EXACTLY cv::kmeans': one FP32 accumulator per centre coordinate, samples added in index order (kmeans.cpp "compute centers").
+// FP32 addition is not associative and DynaDetect amplifies a centre that is off by one ulp (a handful of border pixels change cluster,
+// SegAndMerge merges differently, the next frame's warm labels start another local optimum: measured IoU 0.38 against the oracle twenty
+// frames later with the former FP64 tree sums), so the order is reproduced instead of approximated:
+//   k_km_count / k_km_assign_count   per wave-segment (a contiguous index range) counts of every cluster      -- parallel
+//   k_km_compact                     ordered scatter of the coordinates into per-cluster runs (stable partition) -- parallel
+//   k_km_update                      36 lanes of one wave add their run front to back (the only serial part: 4 cycles per sample of the
+//                                    largest cluster), then the centre step with cv::kmeans' operations: empty-cluster repair, scale,
+//                                    shift test, last-iteration decision.  One KmState per pyramid level.
 __device__ void km_try_finalize(KmState* st) {
     // look for an empty cluster; if there is one, request a farthest-point search and return
     for (int k = 0; k < KM_K; k++) {
@@ -85,39 +92,285 @@ __device__ void km_try_finalize(KmState* st) {
     st->phase = 1;                                        // centres of this iteration are final
     if (st->iter == (st->maxCount > 2 ? st->maxCount : 2) || max_center_shift <= st->eps2) st->done = 1;
 }
-// Wave-level sum of the 48 per-lane accumulators (12 clusters x {x, y, z, count}) as a reduce-scatter: in every step a lane hands half
-// of its values to its partner and keeps the other half, so 51 shuffles replace 48 x 6; after the xor-4 step three values are left per
-// lane, finished by two plain exchange steps.  Lane l (l % 4 == 0) ends up with the sums of accumulators j + 3*b2 + 6*b3 + 12*b4 + 24*b5
-// (b = bits of l), which it writes to acc[...][wave].  Fixed order, hence deterministic.
-__device__ __forceinline__ void km_wave_reduce_store(double (&s)[KM_K][4], double (*acc)[4][4], int lane, int wv) {
-    double v[48];
-    #pragma unroll
-    for (int k = 0; k < KM_K; k++) { v[4 * k] = s[k][0]; v[4 * k + 1] = s[k][1]; v[4 * k + 2] = s[k][2]; v[4 * k + 3] = s[k][3]; }
-    #define KM_STEP(HALF, MASK)                                                                               \
-        _Pragma("unroll")                                                                                     \
-        for (int j = 0; j < (HALF); j++) {                                                                    \
-            const bool up = (lane & (MASK)) != 0;                                                             \
-            const double send = up ? v[j] : v[j + (HALF)], keep = up ? v[j + (HALF)] : v[j];                  \
-            v[j] = keep + __shfl_xor(send, (MASK));                                                           \
-        }
-    KM_STEP(24, 32) KM_STEP(12, 16) KM_STEP(6, 8) KM_STEP(3, 4)
-    #undef KM_STEP
-    #pragma unroll
-    for (int j = 0; j < 3; j++) { v[j] += __shfl_xor(v[j], 2); v[j] += __shfl_xor(v[j], 1); }
-    if ((lane & 3) == 0) {
-        const int base = ((lane >> 2) & 1) * 3 + ((lane >> 3) & 1) * 6 + ((lane >> 4) & 1) * 12 + ((lane >> 5) & 1) * 24;
+// Segment geometry shared by the count / compact kernels: the points are cut into nseg contiguous segments of seg_len (a multiple of 64),
+// one per wave; segment s = blockIdx.x * 4 + wave.
+#define KM_WAVES 4
+__device__ __forceinline__ void km_count_store(const int (&c)[KM_K], int* __restrict__ segcnt, int seg, int lane) {
+    if (lane < KM_K) { int v = 0;
         #pragma unroll
-        for (int j = 0; j < 3; j++) { const int a = base + j; acc[a >> 2][a & 3][wv] = v[j]; }
+        for (int k = 0; k < KM_K; k++) if (lane == k) v = c[k];
+        segcnt[seg * KM_K + lane] = v; }
+}
+// first centre pass of a level: counts of the given labels
+__global__ void __launch_bounds__(64 * KM_WAVES) k_km_count(const int* __restrict__ labels, int n, int seg_len, int* __restrict__ segcnt, const KmState* __restrict__ st) {
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, seg = blockIdx.x * KM_WAVES + (threadIdx.x >> 6);
+    const int lo = seg * seg_len, hi = min(n, lo + seg_len);
+    int c[KM_K];
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++) c[k] = 0;
+    for (int i = lo + lane; i - lane < hi; i += 64) {                     // wave-uniform trip count (the ballots below need every lane)
+        const int l = i < hi ? labels[i] : -1;
+        #pragma unroll
+        for (int k = 0; k < KM_K; k++) c[k] += __popcll(__ballot(l == k));
+    }
+    km_count_store(c, segcnt, seg, lane);
+}
+// re-assignment to the nearest centre (cv::kmeans' KMeansDistanceComputer: float accumulation, first minimum wins) + the counts of the new labels
+__global__ void __launch_bounds__(64 * KM_WAVES) k_km_assign_count(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                                   int* __restrict__ labels, int n, int seg_len, int* __restrict__ segcnt, const KmState* __restrict__ st) {
+    if (st->done || st->phase != 1) return;
+    __shared__ float ctr[KM_K][3];
+    const int tid = threadIdx.x, lane = tid & 63, seg = blockIdx.x * KM_WAVES + (tid >> 6);
+    if (tid < KM_K * 3) ctr[tid / 3][tid % 3] = st->ctr[tid / 3][tid % 3];
+    __syncthreads();
+    const int lo = seg * seg_len, hi = min(n, lo + seg_len);
+    int c[KM_K];
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++) c[k] = 0;
+    for (int i = lo + lane; i - lane < hi; i += 64) {
+        int best = -1;
+        if (i < hi) {
+            const float xf = px[i], yf = py[i], zf = pz[i];
+            float md = 3.402823466e+38f; best = 0;
+            #pragma unroll
+            for (int k = 0; k < KM_K; k++) {
+                float t = xf - ctr[k][0]; float dist = 0.f; dist += t * t;
+                t = yf - ctr[k][1]; dist += t * t;
+                t = zf - ctr[k][2]; dist += t * t;
+                if (md > dist) { md = dist; best = k; }
+            }
+            labels[i] = best;
+        }
+        #pragma unroll
+        for (int k = 0; k < KM_K; k++) c[k] += __popcll(__ballot(best == k));
+    }
+    km_count_store(c, segcnt, seg, lane);
+}
+// Stable partition by label: cluster k's samples, in index order, become the run comp[j][start_k .. start_k + n_k) of every coordinate
+// plane j (start_k = samples of the clusters before k).  A wave derives its write positions from the count table alone.
+__global__ void __launch_bounds__(64 * KM_WAVES) k_km_compact(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                              const int* __restrict__ labels, int n, int seg_len, int nseg, const int* __restrict__ segcnt,
+                                                              float* __restrict__ comp, int* __restrict__ tot_out, const KmState* __restrict__ st) {
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, seg = blockIdx.x * KM_WAVES + (threadIdx.x >> 6);
+    // per cluster: samples in the segments before this one (before) and in all segments (total); lanes stride over the table rows
+    int before[KM_K], total[KM_K];
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++) { before[k] = 0; total[k] = 0; }
+    for (int q = lane; q < nseg; q += 64) {
+        #pragma unroll
+        for (int k = 0; k < KM_K; k++) { const int v = segcnt[q * KM_K + k]; total[k] += v; if (q < seg) before[k] += v; }
+    }
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++) for (int o = 32; o > 0; o >>= 1) { before[k] += __shfl_xor(before[k], o); total[k] += __shfl_xor(total[k], o); }
+    int pos[KM_K]; int run = 0;
+    #pragma unroll
+    for (int k = 0; k < KM_K; k++) { pos[k] = run + before[k]; run += total[k]; }
+    if (seg == 0 && lane < KM_K) { int v = 0;              // cluster sizes for k_km_seqsum / k_km_update, behind the table's last row
+        #pragma unroll
+        for (int k = 0; k < KM_K; k++) if (lane == k) v = total[k];
+        tot_out[lane] = v; }
+    float* cx = comp; float* cy = comp + n; float* cz = comp + 2 * (size_t)n;
+    const int lo = seg * seg_len, hi = min(n, lo + seg_len);
+    for (int i = lo + lane; i - lane < hi; i += 64) {
+        const bool in = i < hi; const int l = in ? labels[i] : -1;
+        const float x = in ? px[i] : 0.f, y = in ? py[i] : 0.f, z = in ? pz[i] : 0.f;
+        #pragma unroll
+        for (int k = 0; k < KM_K; k++) {
+            const unsigned long long m = __ballot(l == k);
+            if (l == k) { const int d = pos[k] + __popcll(m & ((1ull << lane) - 1ull)); cx[d] = x; cy[d] = y; cz[d] = z; }
+            pos[k] += __popcll(m);
+        }
     }
 }
-// Centre step of one k-means iteration in ONE workgroup: reduce the per-block partial sums, repair every empty cluster
-// (block-wide farthest-point search over the biggest cluster, as cv::kmeans does, repeated until no cluster is empty), scale,
-// shift test, stop decision.  No host round trip and no provisioning limit.
-__global__ void __launch_bounds__(1024) k_km_update(const double* __restrict__ partial, int nblocks, KmState* __restrict__ gst,
+// ---- the sequential FP32 sums  acc = 0; for (i) acc = acc + x[i]  (round to nearest even), bit for bit, by one wave per run.
+// A dependent FP32 add costs ~8 cycles, a run has up to ~10^5 samples and a frame needs 16 passes: adding one sample at a time was measured
+// at 0.3-0.5 ms per pass.  The additions are therefore done a WINDOW (256 samples) at a time in exact integer arithmetic:
+//   while the accumulator stays inside one binade [2^e, 2^(e+1)) it is an integer S in [2^23, 2^24) times u = 2^(e-23), and
+//   RN(S u + x) = (S + rint(x / u)) u  unless  x / u is an exact tie (the even-mantissa rule then depends on S) or the result leaves the binade.
+// A window step scales its samples by 1 / u (exact), rounds them, prefix-sums the integers over the wave and looks for the FIRST sample that
+// breaks a premise (tie, |x / u| >= 2^22, result outside (2^23, 2^24), or exactly 2^23 reached from above, where the spacing halves).
+// Everything before that sample is the sequential result by induction; the sample itself is added by the hardware FP32 add, which re-bases
+// the binade, and the next window starts behind it.  Premises fail ~20-30 times per run (once per binade the sum grows through), so a run
+// costs ~n / 256 steps of ~0.2 us instead of n dependent adds.  acc == 0 (leading zero coordinates of the invalid points) is handled by
+// skipping to the first non-zero sample.  Samples are staged through an LDS ring by the other three waves of the workgroup (a window start is
+// arbitrary after a re-base, and one wave cannot hide the memory latency of its own stream).
+#define KM_EPL 8
+#define KM_WIN (64 * KM_EPL)      /* 512 samples per window step */
+#define KM_CH 2048                /* samples per LDS chunk (a multiple of KM_WIN, at least 2 * KM_WIN + KM_SER_MAX) */
+#define KM_RING (4 * KM_CH)       /* four chunk slots: two being read (a window or a serial stretch may straddle), one being written, one spare */
+#define KM_SER_MAX 256            /* longest stretch of plain one-by-one adds after a broken premise */
+// ring position of sample i: one pad word per eight samples, so that lane l's samples pos + 8 l + q (q fixed) sit 9 words apart -- an odd stride,
+// 32 consecutive lanes hit 32 different banks (the plain layout puts them 8 apart: a 16-way conflict on every window read)
+#define KM_RING_WORDS (KM_RING + KM_RING / 8)
+__device__ __forceinline__ int km_at(int i) { const int j = i & (KM_RING - 1); return j + (j >> 3); }
+// The step state (accumulator, position, stretch length) is wave-uniform: pinning it to scalar registers turns the step's control flow into
+// scalar branches.  Lane reads with a uniform index are v_readlane (a generic __shfl is a ds_bpermute round trip of ~100 cycles, and a step is
+// one long dependency chain).
+__device__ __forceinline__ int km_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float km_unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ int km_rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float km_rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+// sample / integer `slot` of lane `lane` (both uniform): eight lane reads and a scalar select -- never a dynamically indexed register array,
+// which the compiler would spill to scratch memory
+__device__ __forceinline__ float km_pick(const float (&v)[KM_EPL], int lane, int slot) { float o = km_rlf(v[0], lane);
+    #pragma unroll
+    for (int i = 1; i < KM_EPL; i++) { const float t = km_rlf(v[i], lane); o = slot == i ? t : o; }
+    return o; }
+__device__ __forceinline__ int km_picki(const int (&v)[KM_EPL], int lane, int slot) { int o = km_rl(v[0], lane);
+    #pragma unroll
+    for (int i = 1; i < KM_EPL; i++) { const int t = km_rl(v[i], lane); o = slot == i ? t : o; }
+    return o; }
+// inclusive prefix sum over the 64 lanes: DPP row shifts inside the four rows of 16, then the row totals through readlane
+__device__ __forceinline__ int km_wave_scan(int v, int lane) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1 (lanes without a source receive 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    const int r0 = km_rl(v, 15), r1 = km_rl(v, 31), r2 = km_rl(v, 47);
+    return v + (lane >= 48 ? r0 + r1 + r2 : lane >= 32 ? r0 + r1 : lane >= 16 ? r0 : 0);
+}
+// lane l's KM_EPL consecutive samples of the window starting at pos (the ring is zero behind the run's end)
+__device__ __forceinline__ void km_window(const float* __restrict__ ring, int lane, int pos, float (&x)[KM_EPL]) {
+    const int g0 = pos + KM_EPL * lane;
+    #pragma unroll
+    for (int q = 0; q < KM_EPL; q++) x[q] = ring[km_at(g0 + q)];
+}
+// One window step of the wave on the samples x = [pos, pos + KM_WIN); acc, pos are uniform.  Returns the next position; `broke` tells
+// whether a premise failed (the failing sample has then been added by the hardware add).  The arithmetic runs on magnitudes: the samples are
+// scaled by sign(acc) / u, so the running integer stays positive and every premise is a plain range test.
+__device__ __forceinline__ int km_seq_step(const float (&x)[KM_EPL], int lane, float& acc, int pos, bool& broke) {
+    broke = false;
+    const unsigned ab = __float_as_uint(acc);
+    if ((ab << 1) == 0u) {                                 // acc == 0: zeros leave it there, the first non-zero sample becomes the accumulator
+        int loc = KM_EPL;
+        #pragma unroll
+        for (int q = KM_EPL - 1; q >= 0; q--) loc = x[q] != 0.f ? q : loc;
+        const unsigned long long m = __ballot(loc < KM_EPL);
+        if (!m) return pos + KM_WIN;
+        const int fl = __ffsll((long long)m) - 1, floc = km_rl(loc, fl);
+        acc = km_unif(0.f + km_pick(x, fl, floc));
+        return pos + KM_EPL * fl + floc + 1;
+    }
+    const int ef = (int)((ab >> 23) & 0xffu);
+    if (ef < 127 - 80 || ef > 127 + 100) { acc = km_unif(acc + km_rlf(x[0], 0)); broke = true; return pos + 1; }       // far-out exponents (and denormal / inf / nan): plain add
+    const unsigned sb = ab & 0x80000000u;                  // sign of the accumulator, folded into the scale factors
+    const float scale = __uint_as_float(((unsigned)(127 + 23 + 127 - ef) << 23) | sb), unit = __uint_as_float(((unsigned)(ef - 23) << 23) | sb);
+    const int S_in = (int)(acc * scale);                   // exact: |acc| / u, an integer in [2^23, 2^24)
+    int r[KM_EPL]; bool bad[KM_EPL], down[KM_EPL];
+    #pragma unroll
+    for (int q = 0; q < KM_EPL; q++) {
+        const float xs = x[q] * scale, rf = rintf(xs);     // power-of-two scaling: exact (or a harmless underflow towards 0)
+        bad[q] = !(fabsf(xs) < 4194304.f) || fabsf(xs - rf) == 0.5f;
+        r[q] = bad[q] ? 0 : (int)rf; down[q] = xs < 0.f;
+    }
+    int c[KM_EPL]; c[0] = r[0];
+    #pragma unroll
+    for (int q = 1; q < KM_EPL; q++) c[q] = c[q - 1] + r[q];
+    const int base = S_in + km_wave_scan(c[KM_EPL - 1], lane) - c[KM_EPL - 1];
+    int Sq[KM_EPL]; int loc = KM_EPL;
+    #pragma unroll
+    for (int q = KM_EPL - 1; q >= 0; q--) {
+        Sq[q] = base + c[q];
+        // valid results lie in (2^23, 2^24); exactly 2^23 only when reached without moving down (below it the spacing halves)
+        const bool fail = bad[q] || (unsigned)(Sq[q] - 8388608) >= 8388608u || (Sq[q] == 8388608 && down[q]);
+        loc = fail ? q : loc;
+    }
+    const unsigned long long fm = __ballot(loc < KM_EPL);
+    if (!fm) { acc = km_unif((float)km_rl(Sq[KM_EPL - 1], 63) * unit); return pos + KM_WIN; }      // clean window
+    const int fl = __ffsll((long long)fm) - 1, f = km_uni(KM_EPL * fl + km_rl(loc, fl));
+    int Sprev = S_in;
+    if (f > 0) Sprev = km_picki(Sq, (f - 1) / KM_EPL, (f - 1) & (KM_EPL - 1));
+    const float before = (float)Sprev * unit;              // exact
+    acc = km_unif(before + km_pick(x, f / KM_EPL, f & (KM_EPL - 1)));
+    broke = true;
+    return pos + f + 1;
+}
+// plain sequential adds of the samples [pos, pos + cnt), cnt a multiple of 64: the mode for stretches in which the sum keeps changing binade
+// (e.g. a cluster astride the optical axis: every image row drags its x-sum down and up through zero).  One conflict-free LDS read hands 64
+// samples to the lanes; they reach the accumulator through v_readlane with constant lane numbers, so a sample costs its dependent add and
+// one scalar-register read.
+__device__ __forceinline__ void km_seq_serial(const float* __restrict__ ring, int lane, float& acc, int pos, int cnt) {
+    float a = acc;
+    float v = ring[km_at(pos + lane)];
+    for (int i = 0; i < cnt; i += 64) {
+        const float vn = ring[km_at(pos + i + 64 + lane)];      // the next 64 are on their way while these are added
+        #pragma unroll
+        for (int q = 0; q < 64; q++) a = a + km_rlf(v, q);
+        v = vn;
+    }
+    acc = km_unif(a);
+}
+// chunk ch of the run (zero-filled behind its end): global -> registers, registers -> ring slot
+#define KM_NR ((KM_CH / 4 + 191) / 192)          /* float4 pieces per thread of the three loader waves (the four-wave prologue needs fewer) */
+__device__ __forceinline__ void km_chunk_fetch(const float* __restrict__ p, int nk, int ch, int tid, int nthreads, float4 (&R)[KM_NR]) {
+    struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+    #pragma unroll
+    for (int u = 0; u < KM_NR; u++) {
+        const int v4 = tid + u * nthreads; float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v4 < KM_CH / 4) { const int g = ch * KM_CH + 4 * v4;
+            if (g + 4 <= nk) { const F4u a = *reinterpret_cast<const F4u*>(p + g); v = make_float4(a.x, a.y, a.z, a.w); }
+            else { if (g < nk) v.x = p[g]; if (g + 1 < nk) v.y = p[g + 1]; if (g + 2 < nk) v.z = p[g + 2]; } }
+        R[u] = v;
+    }
+}
+__device__ __forceinline__ void km_chunk_store(float* __restrict__ ring, int ch, int tid, int nthreads, const float4 (&R)[KM_NR]) {
+    #pragma unroll
+    for (int u = 0; u < KM_NR; u++) {
+        const int v4 = tid + u * nthreads;
+        if (v4 < KM_CH / 4) { const int o = km_at(ch * KM_CH + 4 * v4);      // four samples of one group of eight: contiguous words
+            ring[o] = R[u].x; ring[o + 1] = R[u].y; ring[o + 2] = R[u].z; ring[o + 3] = R[u].w; }
+    }
+}
+// grid = 36 runs (cluster k = blockIdx.x / 3, coordinate j = blockIdx.x % 3), 256 threads: wave 0 sums, waves 1..3 keep the ring ahead of it
+// (chunk ch + 2 goes into the ring while chunk ch is summed, chunk ch + 3 is already on its way in registers)
+__global__ void __launch_bounds__(256) k_km_seqsum(const int* __restrict__ segcnt, int nseg, const float* __restrict__ comp, int n, float* __restrict__ seqsums,
+                                                   const KmState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ float ring[KM_RING_WORDS];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, k = blockIdx.x / 3, j = blockIdx.x % 3;
+    const int* tot = segcnt + nseg * KM_K;                 // cluster sizes, left behind the count table by k_km_compact
+    int start = 0; for (int q = 0; q < k; q++) start += tot[q];
+    const int nk = tot[k]; const float* p = comp + (size_t)j * n + start;
+    const int nch = (nk + KM_CH - 1) / KM_CH;              // chunks 0 .. nch are staged: the one behind the run's end is all zero (windows and stretches read past the end)
+    float4 R[KM_NR];
+    { float4 R1[KM_NR];                                    // chunks 0 and 1 by all four waves, both fetches in flight together
+      km_chunk_fetch(p, nk, 0, t, 256, R); km_chunk_fetch(p, nk, 1, t, 256, R1);
+      km_chunk_store(ring, 0, t, 256, R); km_chunk_store(ring, 1, t, 256, R1); }
+    if (wv > 0) km_chunk_fetch(p, nk, 2, t - 64, 192, R);
+    __syncthreads();
+    float acc = 0.f; int pos = 0, ser = 0;
+    for (int ch = 0; ch < nch; ch++) {
+        if (wv == 0) {
+            const int lim = min(nk, (ch + 1) * KM_CH);
+            float x[KM_EPL]; km_window(ring, lane, pos, x);
+            while (pos < lim) {
+                float xn[KM_EPL]; km_window(ring, lane, pos + KM_WIN, xn);            // the next window, read while this one is worked on (stays inside chunk ch + 1)
+                bool broke; const int from = pos;
+                pos = km_uni(km_seq_step(x, lane, acc, pos, broke));
+                if (broke) {                               // plain adds for a while; the stretch doubles as long as windows keep breaking
+                    ser = km_uni(ser ? min(2 * ser, KM_SER_MAX) : 64);
+                    km_seq_serial(ring, lane, acc, pos, ser); pos += ser;
+                    km_window(ring, lane, pos, x);
+                } else if (pos == from + KM_WIN) {
+                    ser = 0;
+                    #pragma unroll
+                    for (int q = 0; q < KM_EPL; q++) x[q] = xn[q];
+                } else km_window(ring, lane, pos, x);          // zero accumulator: the window ended at the first non-zero sample
+            }
+        } else { if (ch + 2 <= nch) km_chunk_store(ring, ch + 2, t - 64, 192, R); if (ch + 3 <= nch) km_chunk_fetch(p, nk, ch + 3, t - 64, 192, R); }
+        __syncthreads();
+    }
+    if (t == 0) seqsums[blockIdx.x] = acc;
+}
+// Centre step of one k-means iteration in ONE workgroup: take the 36 sequential sums of k_km_seqsum, then repair every empty cluster (block-wide farthest-point search over the biggest cluster, as cv::kmeans
+// does, repeated until no cluster is empty), scale, shift test, stop decision.  No host round trip and no provisioning limit.
+__global__ void __launch_bounds__(1024) k_km_update(const int* __restrict__ segcnt, int nseg, const float* __restrict__ seqsums, KmState* __restrict__ gst,
                                                     const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                     int* __restrict__ labels, int n) {
-    __shared__ double sums[KM_K * 4];
-    __shared__ double stage[KM_MAX_BLOCKS * KM_K * 4];
+    __shared__ float sums[KM_K * 3];
+    __shared__ int tot[KM_K + 1];
     __shared__ unsigned long long wbest[16];
     __shared__ int s_fix;
     __shared__ KmState S;                                  // the state lives in LDS while the centre step runs: the serial part below touches it
@@ -126,14 +379,14 @@ __global__ void __launch_bounds__(1024) k_km_update(const double* __restrict__ p
     if (gst->done) return;
     const int t = threadIdx.x;
     for (int i = t; i < (int)(sizeof(KmState) / 4); i += blockDim.x) reinterpret_cast<unsigned*>(&S)[i] = reinterpret_cast<const unsigned*>(gst)[i];
-    for (int i = t; i < nblocks * KM_K * 4; i += blockDim.x) stage[i] = partial[i];     // parallel fetch, then a fixed-order (deterministic) sum
+    if (t < KM_K) tot[t] = segcnt[nseg * KM_K + t];
     __syncthreads();
     KmState* st = &S;
-    if (t < KM_K * 4) { double v = 0; for (int b = 0; b < nblocks; b++) v += stage[b * KM_K * 4 + t]; sums[t] = v; }
+    if (t < KM_K * 3) sums[t] = seqsums[t];
     __syncthreads();
     if (t == 0) {
         st->phase = 0;
-        for (int k = 0; k < KM_K; k++) { for (int j = 0; j < 3; j++) { st->old[k][j] = st->ctr[k][j]; st->ctr[k][j] = (float)sums[k * 4 + j]; } st->cnt[k] = (int)sums[k * 4 + 3]; }
+        for (int k = 0; k < KM_K; k++) { for (int j = 0; j < 3; j++) { st->old[k][j] = st->ctr[k][j]; st->ctr[k][j] = sums[k * 3 + j]; } st->cnt[k] = tot[k]; }
         km_try_finalize(st);
         s_fix = st->fix_k;
     }
@@ -174,55 +427,6 @@ __global__ void __launch_bounds__(1024) k_km_update(const double* __restrict__ p
         __syncthreads();
     }
     for (int i = t; i < (int)(sizeof(KmState) / 4); i += blockDim.x) reinterpret_cast<unsigned*>(gst)[i] = reinterpret_cast<const unsigned*>(&S)[i];
-}
-__global__ void __launch_bounds__(256) k_km_partial_dev(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                        const int* __restrict__ labels, int n, double* __restrict__ partial, const KmState* __restrict__ st) {
-    if (st->done) return;
-    __shared__ double acc[KM_K][4][4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double s[KM_K][4];
-    #pragma unroll
-    for (int k = 0; k < KM_K; k++) { s[k][0] = s[k][1] = s[k][2] = s[k][3] = 0.0; }
-    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
-        const int l = labels[i]; const double x = px[i], y = py[i], z = pz[i];
-        #pragma unroll
-        for (int k = 0; k < KM_K; k++) if (l == k) { s[k][0] += x; s[k][1] += y; s[k][2] += z; s[k][3] += 1.0; }
-    }
-    km_wave_reduce_store(s, acc, lane, wv);
-    __syncthreads();
-    if (tid < KM_K * 4) { const int k = tid >> 2, c = tid & 3; partial[((size_t)blockIdx.x * KM_K + k) * 4 + c] = ((acc[k][c][0] + acc[k][c][1]) + acc[k][c][2]) + acc[k][c][3]; }
-}
-// re-assignment to the nearest centre fused with the centre sums of the next iteration (cv::kmeans' assignment step followed by the sums of
-// k_km_partial_dev: one pass over the points and one launch instead of two)
-__global__ void __launch_bounds__(256) k_km_assign_partial(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                           int* __restrict__ labels, int n, double* __restrict__ partial, const KmState* __restrict__ st) {
-    if (st->done || st->phase != 1) return;
-    __shared__ double acc[KM_K][4][4];
-    __shared__ float ctr[KM_K][3];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < KM_K * 3) ctr[tid / 3][tid % 3] = st->ctr[tid / 3][tid % 3];
-    __syncthreads();
-    double s[KM_K][4];
-    #pragma unroll
-    for (int k = 0; k < KM_K; k++) { s[k][0] = s[k][1] = s[k][2] = s[k][3] = 0.0; }
-    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
-        const float xf = px[i], yf = py[i], zf = pz[i];
-        int best = 0; float md = 3.402823466e+38f;
-        #pragma unroll
-        for (int k = 0; k < KM_K; k++) {
-            float t = xf - ctr[k][0]; float dist = 0.f; dist += t * t;
-            t = yf - ctr[k][1]; dist += t * t;
-            t = zf - ctr[k][2]; dist += t * t;
-            if (md > dist) { md = dist; best = k; }
-        }
-        labels[i] = best;
-        const double x = xf, y = yf, z = zf;
-        #pragma unroll
-        for (int k = 0; k < KM_K; k++) if (best == k) { s[k][0] += x; s[k][1] += y; s[k][2] += z; s[k][3] += 1.0; }
-    }
-    km_wave_reduce_store(s, acc, lane, wv);
-    __syncthreads();
-    if (tid < KM_K * 4) { const int k = tid >> 2, c = tid & 3; partial[((size_t)blockIdx.x * KM_K + k) * 4 + c] = ((acc[k][c][0] + acc[k][c][1]) + acc[k][c][2]) + acc[k][c][3]; }
 }
 __global__ void k_km_reset(KmState* st, int maxCount, double eps2) {
     if (threadIdx.x == 0) { st->iter = 0; st->done = 0; st->phase = 0; st->overflow = 0; st->fix_k = -1; st->max_k = 0; st->far = 0ull; st->maxCount = maxCount; st->eps2 = eps2;
@@ -449,16 +653,31 @@ int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw,
     hipLaunchKernelGGL(k_labels_resize<uint8_t>, dim3(divup(dw, 128), dh), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh)); return SIND_OK; }
 int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh) {
     hipLaunchKernelGGL(k_labels_resize<int>, dim3(divup(dw, 128), dh), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh)); return SIND_OK; }
-int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, double* partial, KmState* st,
+int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, int* segcnt, float* comp, KmState* st,
                         int maxCount, double eps2) {
-    const int nb = std::min(divup(n, 256), KM_MAX_BLOCKS), iters = std::max(maxCount, 2);
+    // nseg wave-segments of seg_len (multiple of 64) contiguous points; at most KM_MAX_BLOCKS * KM_WAVES rows in the count table;
+    // the 36 sequential sums of a pass live behind the count table
+    const int nb = std::min(divup(n, 1024), KM_MAX_BLOCKS), nseg = nb * 4, seg_len = divup(divup(n, nseg), 64) * 64, iters = std::max(maxCount, 2);
+    float* seqsums = reinterpret_cast<float*>(segcnt + (KM_MAX_BLOCKS * 4 + 1) * KM_K);
     hipLaunchKernelGGL(k_km_reset, dim3(1), dim3(64), 0, s, st, maxCount, eps2);
-    hipLaunchKernelGGL(k_km_partial_dev, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, partial, st);
-    hipLaunchKernelGGL(k_km_update, dim3(1), dim3(1024), 0, s, partial, nb, st, px, py, pz, labels, n);
-    for (int it = 1; it < iters; it++) {           // every later kernel is a no-op once the centre step has set st->done
-        hipLaunchKernelGGL(k_km_assign_partial, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, partial, st);
-        hipLaunchKernelGGL(k_km_update, dim3(1), dim3(1024), 0, s, partial, nb, st, px, py, pz, labels, n);
+    hipLaunchKernelGGL(k_km_count, dim3(nb), dim3(256), 0, s, labels, n, seg_len, segcnt, st);
+    for (int it = 0; it < iters; it++) {           // every kernel is a no-op once the centre step has set st->done
+        if (it > 0) hipLaunchKernelGGL(k_km_assign_count, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, seg_len, segcnt, st);
+        hipLaunchKernelGGL(k_km_compact, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, seg_len, nseg, segcnt, comp, segcnt + nseg * KM_K, st);
+        hipLaunchKernelGGL(k_km_seqsum, dim3(KM_K * 3), dim3(256), 0, s, segcnt, nseg, comp, n, seqsums, st);
+        hipLaunchKernelGGL(k_km_update, dim3(1), dim3(1024), 0, s, segcnt, nseg, seqsums, st, px, py, pz, labels, n);
     }
+    return SIND_OK;
+}
+// parity-test access: the sequential FP32 sum of n host floats through k_km_seqsum's window arithmetic (one run)
+int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev /* KM_K ints + 36 floats + a KmState */, float* out_host) {
+    int* segcnt = scratch_dev; float* sums = reinterpret_cast<float*>(scratch_dev + 2 * KM_K); KmState* st = reinterpret_cast<KmState*>(scratch_dev + 2 * KM_K + 64);
+    int h[2 * KM_K] = {n}; h[KM_K] = n;                     // one table row + the totals row: everything is cluster 0, run 0 = coordinate plane 0
+    HIP_TRY(hipMemcpyAsync(segcnt, h, sizeof(h), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(st, 0, sizeof(KmState), s));
+    hipLaunchKernelGGL(k_km_seqsum, dim3(1), dim3(256), 0, s, segcnt, 1, x_dev, n, sums, st);
+    HIP_TRY(hipMemcpyAsync(out_host, sums, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return SIND_OK;
 }
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n) { hipLaunchKernelGGL(k_labels_to_u8, dim3(divup(n, 256)), dim3(256), 0, s, labels, out, n); return SIND_OK; }

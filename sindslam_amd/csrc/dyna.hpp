@@ -78,7 +78,7 @@ private:
     std::vector<uint8_t> kmLabelLast; bool kmLabelLastAny = false;   // imgLabelLast as seen by the depth half (k-means warm labels, DD:374-395)
     // device workspaces
     DevBuf<uint16_t> dpyr[4], filt; DevBuf<float> px, py, pz; DevBuf<int> lab[4]; DevBuf<uint8_t> lab8, labPrev8, edge, edgeTmp, total, depthN, occ2_d, magu8, low_d;
-    DevBuf<double> kpart; DevBuf<unsigned long long> planes_d; DevBuf<unsigned> umax_d; DevBuf<int> hist_d, rag_d; DevBuf<float> mag, grid_d;
+    DevBuf<int> kpart; DevBuf<float> kcomp; DevBuf<unsigned long long> planes_d; DevBuf<unsigned> umax_d; DevBuf<int> hist_d, rag_d; DevBuf<float> mag, grid_d;
     DevBuf<PeacBlockStats> blocks_d;
     // page-locked staging of everything that crosses PCIe in a tail
     PinnedBuf<float> h_grid; PinnedBuf<int> h_hist, h_rag; PinnedBuf<uint8_t> h_ab, h_lab8; PinnedBuf<KmState> h_kstate; PinnedBuf<PeacBlockStats> h_blocks;

@@ -105,7 +105,8 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     SIND_TRY(filt.alloc(N)); SIND_TRY(px.alloc(N)); SIND_TRY(py.alloc(N)); SIND_TRY(pz.alloc(N)); SIND_TRY(lab8.alloc(N)); SIND_TRY(labPrev8.alloc(N));
     SIND_TRY(edge.alloc(N)); SIND_TRY(edgeTmp.alloc(N)); SIND_TRY(total.alloc(N)); SIND_TRY(depthN.alloc(N)); SIND_TRY(occ2_d.alloc(N));
     SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc((size_t)2 * N)); SIND_TRY(mag.alloc(N));       // low_d: low mask, then high mask (one D2H)
-    SIND_TRY(kpart.alloc((size_t)KM_MAX_BLOCKS * KM_K * 4)); SIND_TRY(umax_d.alloc(2));
+    SIND_TRY(kpart.alloc((size_t)(KM_MAX_BLOCKS * 4 + 1) * KM_K + 64));       // count table, totals row, the 36 sums
+    SIND_TRY(kcomp.alloc((size_t)3 * N)); SIND_TRY(umax_d.alloc(2));
     SIND_TRY(h_grid.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(h_hist.alloc(257)); SIND_TRY(h_ab.alloc((size_t)2 * N)); SIND_TRY(h_lab8.alloc(N));
     SIND_TRY(h_kstate.alloc(4)); SIND_TRY(h_blocks.alloc((size_t)(W / 16) * (H / 16)));
     { // RAG workspaces for up to 64 pieces up front: a later (re)allocation synchronises the whole device, i.e. waits for the
@@ -117,7 +118,7 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     SIND_TRY(grid_d.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
     // every kernel operand of the tail must exist before the first launch (a missing workspace would be a wild device write)
     const void* ws[] = {dpyr[1].p, dpyr[2].p, dpyr[3].p, lab[0].p, lab[1].p, lab[2].p, lab[3].p, filt.p, px.p, py.p, pz.p, lab8.p, labPrev8.p, edge.p, edgeTmp.p, total.p,
-                        depthN.p, occ2_d.p, magu8.p, low_d.p, mag.p, kpart.p, umax_d.p, h_grid.p, h_hist.p, h_ab.p, h_lab8.p, h_kstate.p, h_blocks.p, h_planes.p, planes_d.p,
+                        depthN.p, occ2_d.p, magu8.p, low_d.p, mag.p, kpart.p, kcomp.p, umax_d.p, h_grid.p, h_hist.p, h_ab.p, h_lab8.p, h_kstate.p, h_blocks.p, h_planes.p, planes_d.p,
                         h_rag.p, rag_d.p, kstate.p, depth_fix.p, hist_d.p, grid_d.p, blocks_d.p};
     for (const void* q : ws) if (!q) { sind_set_error("DynaTail::init: a workspace was not allocated"); return SIND_E_STATE; }
     return SIND_OK;
@@ -258,7 +259,7 @@ int DynaTail::kmeans_enqueue(const uint16_t* depth0, bool prevLabels) {
         SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale));
         if (level == 3) { if (!prevLabels) SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp)); else SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp)); }
         else SIND_TRY(launch_labels_resize_i32(stream, lab[level + 1].p, lab[level].p, wp / 2, hp / 2, wp, hp));
-        SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, kstate.p + level, 4, 0.07 * 0.07));
+        SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, kcomp.p, kstate.p + level, 4, 0.07 * 0.07));
     }
     SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N));
     return SIND_OK;

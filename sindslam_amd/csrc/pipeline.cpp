@@ -174,9 +174,9 @@ int sind_pipe_destroy(sind_pipe* p) {
     if (!p) return SIND_OK;
     if (getenv("SIND_TAIL_TIMING")) {
         double t[6] = {0}; long n = 0;
-        for (auto& tl : p->tails) { for (int i = 0; i < 6; i++) t[i] += tl->t_stage[i]; n += tl->n_frames; }
-        double f[40] = {0}; for (auto& tl : p->tails) for (int i = 0; i < 40; i++) f[i] += tl->t_fine[i];
-        for (auto& tl : p->occ_tails) for (int i = 0; i < 40; i++) f[i] += tl->t_fine[i];
+        for (auto& tl : p->tails) if (tl) { for (int i = 0; i < 6; i++) t[i] += tl->t_stage[i]; n += tl->n_frames; }       // (a handle whose creation failed half-way has empty slots)
+        double f[40] = {0}; for (auto& tl : p->tails) if (tl) for (int i = 0; i < 40; i++) f[i] += tl->t_fine[i];
+        for (auto& tl : p->occ_tails) if (tl) for (int i = 0; i < 40; i++) f[i] += tl->t_fine[i];
         if (n) fprintf(stderr, "[sind] cal_occluded: gpu+d2h %.2f pack %.2f endpoints %.2f peac %.2f contour-filter %.2f close %.2f | seg_merge: pieces %.2f sort+paint+pack %.2f alloc %.2f h2d-enqueue %.2f rag %.2f merge %.2f\n", f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5] / n, f[6] / n, f[10] / n, f[11] / n, f[7] / n, f[8] / n, f[9] / n);
         if (n) fprintf(stderr, "[sind] pieces: open %.2f contours %.2f masks %.2f lianjie %.2f centre %.2f | flow_masks host: weights %.2f sort+wait %.2f homography %.2f pack %.2f | fusion: low %.2f clusters %.2f fill %.2f out+state %.2f\n",
                        f[12] / n, f[13] / n, f[14] / n, f[15] / n, f[16] / n, f[20] / n, f[21] / n, f[22] / n, f[23] / n, f[25] / n, f[26] / n, f[27] / n, f[28] / n);

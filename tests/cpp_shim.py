@@ -13,3 +13,14 @@ def build(out_path):
            "-L" + lib_dir, "-lsind_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", out_path]
     subprocess.check_call(cmd)
     return out_path
+
+
+def build_boundary(out_path):
+    """tests/cpp/boundary_callsites.cpp: the reference's call sites on cv:: types, -DSIND_WITH_OPENCV, against the test-only <opencv2/core.hpp>"""
+    lib_dir = os.path.join(ROOT, "sindslam_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libsind_hip.so")):
+        raise RuntimeError("libsind_hip.so is missing: run __graft_entry__.build() first")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-DSIND_WITH_OPENCV", "-I" + os.path.join(ROOT, "tests", "opencv_mock"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "boundary_callsites.cpp"), "-L" + lib_dir, "-lsind_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", out_path]
+    subprocess.check_call(cmd)
+    return out_path

@@ -45,6 +45,10 @@ void orc_deepflow_levels_capped(const uint8_t* i0, const uint8_t* i1, int w, int
 
 int orc_find_homography(const float* src, const float* dst, int n, double* H) {
     std::vector<Pt2f> s(n), d(n); for (int i = 0; i < n; i++) { s[i] = {src[2*i], src[2*i+1]}; d[i] = {dst[2*i], dst[2*i+1]}; }
+    return find_homography_rho_scheme(s, d, H) ? 1 : 0;
+}
+int orc_find_homography_prosac_ls(const float* src, const float* dst, int n, double* H) {          // round 1's estimator (sensitivity comparison only)
+    std::vector<Pt2f> s(n), d(n); for (int i = 0; i < n; i++) { s[i] = {src[2*i], src[2*i+1]}; d[i] = {dst[2*i], dst[2*i+1]}; }
     return find_homography_prosac(s, d, H) ? 1 : 0;
 }
 
@@ -69,6 +73,13 @@ void* orc_dyna_create(const uint8_t* bgr_last, const uint8_t* bgr_lastlast, int 
     return new DynaDetect(wrap8(bgr_last, w, h, 3), wrap8(bgr_lastlast, w, h, 3), fx, fy, cx, cy, depthScale);
 }
 void orc_dyna_destroy(void* p) { delete (DynaDetect*)p; }
+void orc_dyna_set_h_estimator(void* p, int which, uint64_t seed) { ((DynaDetect*)p)->h_estimator = which; ((DynaDetect*)p)->h_seed = seed; }
+// a second detector that continues from the same inter-frame state (the five *Last images of DynaDetect.h:172-178)
+void* orc_dyna_fork(void* p) {
+    DynaDetect* a = (DynaDetect*)p; DynaDetect* b = new DynaDetect(a->imgRGBLast, a->imgRGBLastLast, a->fx, a->fy, a->cx, a->cy, a->depthScale);
+    b->imgDynaLast = a->imgDynaLast; b->imgLabelLast = a->imgLabelLast; b->imgMaskHighErrorLast = a->imgMaskHighErrorLast; b->flow_max_levels = a->flow_max_levels;
+    return b;
+}
 void orc_dyna_set_flow_max_levels(void* p, int n) { ((DynaDetect*)p)->flow_max_levels = n; }
 void orc_dyna_detect(void* p, const uint8_t* bgr, const uint16_t* depth, uint8_t* dyna_out, uint8_t* label_out) {
     DynaDetect* d = (DynaDetect*)p; Img8 dy, lb;

@@ -49,6 +49,10 @@ public:
     peac::PlaneFitter pf;
     DynaIntermediates dbg;
     int flow_max_levels = 0;  // build-side option of BASELINE.json config 5 ("3-level flow pyramid"); 0 = the reference's full pyramid
+    // a-8 (cv::findHomography(..., RHO), DD:1235): 0 = RHO's published scheme (PROSAC + SPRT + LM, homography.hpp; the product implements the same
+    // scheme), 2 = round 1's lighter PROSAC + least-squares estimator, kept for the sensitivity comparison of tests/test_a8_sensitivity_cpu.py;
+    // h_seed != 0 replaces the estimator's fixed PRNG seed (another draw order)
+    int h_estimator = 0; uint64_t h_seed = 0;
     bool skip_flow = false;   // test hook: reuse dbg.flowFull supplied by the caller instead of computing it
     // wall seconds per stage in the reference's own breakdown (its stdout timers: "K-means timecost" DD:1421, "Calculate DepthEdge" DD:1499,
     // "SegAndMergeV2 timecost" DD:1518, "DenseFlow + Refine" DD:1161 -- here incl. the mask half of the flow thread --, "Dynamic detection
@@ -137,7 +141,8 @@ public:
         }
         dbg.nPairs = (int)in.size();
         double H[9];
-        find_homography_prosac(in, inLast, H);
+        if (h_estimator == 2) { if (h_seed) find_homography_prosac(in, inLast, H, 3.0, 0.995, 2000, h_seed); else find_homography_prosac(in, inLast, H); }
+        else find_homography_rho_scheme(in, inLast, H, 3.0f, 0.995, 2000, h_seed ? h_seed : ~0ull);
         std::copy(H, H + 9, dbg.H);
         ImgF mag(width, height); float maxErr = 0;
         for (int row = 0; row < height; ++row) for (int col = 0; col < width; ++col) {   // DD:1252-1271

@@ -130,13 +130,13 @@ inline bool refine_h(const Pt2f* s, const Pt2f* d, const std::vector<int>& in, d
 
 // src -> dst homography; points sorted by decreasing quality.  Returns false (H = 0) on failure.
 inline bool find_homography_prosac(const std::vector<Pt2f>& src, const std::vector<Pt2f>& dst, double H[9],
-                                   double thresh = 3.0, double confidence = 0.995, int maxIters = 2000) {
+                                   double thresh = 3.0, double confidence = 0.995, int maxIters = 2000, uint64_t seed = 0x9E3779B97F4A7C15ull) {
     using namespace hdetail;
     const int N = (int)src.size();
     std::fill(H, H + 9, 0.0);
     if (N < 4) return false;
     const double t2 = thresh * thresh;
-    RNG rng(0x9E3779B97F4A7C15ull);
+    RNG rng(seed);                 // other seeds: tests/test_a8_sensitivity_cpu.py (how much does the mask depend on the draw order?)
     // PROSAC growth function
     double Tn = maxIters;
     for (int i = 0; i < 4; i++) Tn *= (double)(4 - i) / (double)(N - i);
@@ -177,6 +177,123 @@ inline bool find_homography_prosac(const std::vector<Pt2f>& src, const std::vect
         if (cnt >= best_cnt) std::copy(Hr, Hr + 9, bestH);
     }
     std::copy(bestH, bestH + 9, H);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// SECOND, INDEPENDENT estimator: the published scheme behind cv::RHO (Bazargani, Bilaniuk & Laganiere, "A fast and robust homography scheme
+// for real-time planar target detection", 2015; OpenCV calib3d/src/rho.cpp), restated from the paper and from memory of rho.cpp's structure --
+// PROSAC sampling over the quality-sorted correspondences, a float32 minimal solver, the orientation test on the sample, SPRT evaluation
+// (Matas & Chum's optimal randomized RANSAC: likelihood ratio with early rejection, t_M = 25, m_S = 1, eps_0 = 0.1, delta_0 = 0.01),
+// the confidence bound on the iteration count, Levenberg-Marquardt on the inliers in float32 with a damped Cholesky solve.  It shares no code
+// with find_homography_prosac above (nor with the product's sindslam_amd/csrc/host/homography.cpp).  It is NOT bit-compatible with OpenCV
+// (its PRNG seeding, the N* non-randomness test and several constants are not reproducible offline); its purpose is the question the parity
+// tests cannot answer by comparing the substitute with itself: how far does the dynamic mask move when the homography comes from a
+// different, RHO-like estimator on the same correspondences?  (tests/test_a8_sensitivity_cpu.py)
+namespace rho_scheme {
+struct Xs128 { uint64_t s[2];
+    explicit Xs128(uint64_t seed) { s[0] = seed ^ 0x2545F4914F6CDD1Dull; s[1] = ~seed + 0x9E3779B97F4A7C15ull; for (int i = 0; i < 20; i++) next(); }
+    uint64_t next() { uint64_t x = s[0]; const uint64_t y = s[1]; s[0] = y; x ^= x << 23; s[1] = x ^ y ^ (x >> 17) ^ (y >> 26); return s[1] + y; }
+    unsigned below(unsigned n) { return (unsigned)((double)(next() >> 11) * (1.0 / 9007199254740992.0) * n); } };
+inline bool solve4(const Pt2f* s, const Pt2f* d, const unsigned id[4], float H[9]) {      // 8 x 9 augmented system, float32 Gauss-Jordan with row pivoting
+    float M[8][9];
+    for (int i = 0; i < 4; i++) { const float X = s[id[i]].x, Y = s[id[i]].y, u = d[id[i]].x, v = d[id[i]].y;
+        const float r0[9] = {X, Y, 1, 0, 0, 0, -u * X, -u * Y, u}, r1[9] = {0, 0, 0, X, Y, 1, -v * X, -v * Y, v};
+        for (int k = 0; k < 9; k++) { M[2 * i][k] = r0[k]; M[2 * i + 1][k] = r1[k]; } }
+    for (int c = 0; c < 8; c++) {
+        int p = c; for (int r = c + 1; r < 8; r++) if (std::fabs(M[r][c]) > std::fabs(M[p][c])) p = r;
+        if (std::fabs(M[p][c]) < 1e-9f) return false;
+        if (p != c) for (int k = 0; k < 9; k++) std::swap(M[p][k], M[c][k]);
+        const float inv = 1.0f / M[c][c];
+        for (int k = c; k < 9; k++) M[c][k] *= inv;
+        for (int r = 0; r < 8; r++) if (r != c) { const float f = M[r][c]; if (f != 0.f) for (int k = c; k < 9; k++) M[r][k] -= f * M[c][k]; }
+    }
+    for (int i = 0; i < 8; i++) { H[i] = M[i][8]; if (!(H[i] == H[i])) return false; }
+    H[8] = 1.f; return true;
+}
+inline float orient(const Pt2f& a, const Pt2f& b, const Pt2f& c) { return (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x); }
+inline bool sample_ok(const Pt2f* s, const Pt2f* d, const unsigned id[4]) {           // no three points collinear, orientation of every triple preserved
+    static const int T[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+    for (auto& t : T) { const float a = orient(s[id[t[0]]], s[id[t[1]]], s[id[t[2]]]), b = orient(d[id[t[0]]], d[id[t[1]]], d[id[t[2]]]);
+        if (std::fabs(a) < 1e-3f || std::fabs(b) < 1e-3f || (a > 0) != (b > 0)) return false; }
+    return true;
+}
+inline float err2(const float H[9], const Pt2f& s, const Pt2f& d) {
+    const float w = H[6] * s.x + H[7] * s.y + H[8]; if (std::fabs(w) < 1e-12f) return 1e30f;
+    const float iw = 1.0f / w, ex = (H[0] * s.x + H[1] * s.y + H[2]) * iw - d.x, ey = (H[3] * s.x + H[4] * s.y + H[5]) * iw - d.y;
+    return ex * ex + ey * ey;
+}
+struct Sprt { double eps, delta, A, lamAccept, lamReject;
+    void design(double e, double dl) { eps = e; delta = dl; const double tM = 25, mS = 1;
+        const double C = (1 - delta) * std::log((1 - delta) / (1 - eps)) + delta * std::log(delta / eps), K = tM * C / mS + 1;
+        double a = K; for (int i = 0; i < 10; i++) a = K + std::log(a);
+        A = a; lamAccept = delta / eps; lamReject = (1 - delta) / (1 - eps); } };
+inline bool chol8(float A[8][8], float b[8], float x[8]) {                            // A = L L^T in place (lower), then the two triangular solves
+    for (int j = 0; j < 8; j++) { float sum = A[j][j]; for (int k = 0; k < j; k++) sum -= A[j][k] * A[j][k];
+        if (!(sum > 0.f)) return false; A[j][j] = std::sqrt(sum);
+        for (int i = j + 1; i < 8; i++) { float t = A[i][j]; for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k]; A[i][j] = t / A[j][j]; } }
+    float y[8];
+    for (int i = 0; i < 8; i++) { float t = b[i]; for (int k = 0; k < i; k++) t -= A[i][k] * y[k]; y[i] = t / A[i][i]; }
+    for (int i = 7; i >= 0; i--) { float t = y[i]; for (int k = i + 1; k < 8; k++) t -= A[k][i] * x[k]; x[i] = t / A[i][i]; }
+    return true;
+}
+inline float lm_cost(const Pt2f* s, const Pt2f* d, const std::vector<unsigned>& in, const float H[9], float JtJ[8][8], float Jtr[8]) {
+    float cost = 0.f;
+    if (JtJ) { for (int a = 0; a < 8; a++) { Jtr[a] = 0.f; for (int b = 0; b < 8; b++) JtJ[a][b] = 0.f; } }
+    for (unsigned i : in) { const float X = s[i].x, Y = s[i].y, w = H[6] * X + H[7] * Y + 1.0f; if (std::fabs(w) < 1e-12f) continue;
+        const float iw = 1.0f / w, px = (H[0] * X + H[1] * Y + H[2]) * iw, py = (H[3] * X + H[4] * Y + H[5]) * iw, rx = d[i].x - px, ry = d[i].y - py;
+        cost += rx * rx + ry * ry;
+        if (JtJ) { const float jx[8] = {X * iw, Y * iw, iw, 0, 0, 0, -X * px * iw, -Y * px * iw}, jy[8] = {0, 0, 0, X * iw, Y * iw, iw, -X * py * iw, -Y * py * iw};
+            for (int a = 0; a < 8; a++) { Jtr[a] += jx[a] * rx + jy[a] * ry; for (int b = 0; b <= a; b++) JtJ[a][b] += jx[a] * jx[b] + jy[a] * jy[b]; } } }
+    return cost;
+}
+}  // namespace rho_scheme
+
+inline bool find_homography_rho_scheme(const std::vector<Pt2f>& src, const std::vector<Pt2f>& dst, double Hout[9],
+                                       float maxD = 3.0f, double cfd = 0.995, unsigned maxI = 2000, uint64_t seed = ~0ull) {
+    using namespace rho_scheme;
+    const unsigned N = (unsigned)src.size(); std::fill(Hout, Hout + 9, 0.0);
+    if (N < 4) return false;
+    const Pt2f* s = src.data(); const Pt2f* d = dst.data(); const float maxD2 = maxD * maxD;
+    Xs128 rng(seed); Sprt sprt; sprt.design(0.1, 0.01);
+    // SPRT tests the points in a fixed random order (Matas & Chum): in index order a run of bad leading correspondences -- the PROSAC ranking is
+    // only a prior -- would reject every model, the right one included, after a dozen points
+    std::vector<unsigned> order(N); for (unsigned i = 0; i < N; i++) order[i] = i;
+    for (unsigned i = N - 1; i > 0; i--) std::swap(order[i], order[rng.below(i + 1)]);
+    // PROSAC (Chum & Matas 2005): the n best correspondences are sampled until T'_n hypotheses were drawn, then n grows
+    double Tn = maxI; for (int i = 0; i < 4; i++) Tn *= (double)(4 - i) / (double)(N - i);
+    unsigned n = 4, TnPrime = 1, bestInl = 0, limit = maxI; float best[9] = {0};
+    for (unsigned it = 1; it <= limit; it++) {
+        if (it > TnPrime && n < N) { const double Tn1 = Tn * (n + 1) / (double)(n + 1 - 4); TnPrime += (unsigned)std::ceil(Tn1 - Tn); Tn = Tn1; n++; }
+        unsigned id[4]; const bool prosac = n < N;
+        const unsigned pool = prosac ? n - 1 : N, need = prosac ? 3 : 4;
+        for (unsigned k = 0; k < need; k++) { bool dup; do { id[k] = rng.below(pool); dup = false; for (unsigned q = 0; q < k; q++) dup |= id[q] == id[k]; } while (dup); }
+        if (prosac) id[3] = n - 1;
+        if (!sample_ok(s, d, id)) continue;
+        float Hc[9]; if (!solve4(s, d, id, Hc)) continue;
+        // SPRT: multiply the likelihood ratio point by point; a bad model is rejected after a few points
+        double lambda = 1.0; unsigned inl = 0, tested = 0; bool rejected = false;
+        for (unsigned q = 0; q < N; q++) { const unsigned i = order[q]; const bool in = err2(Hc, s[i], d[i]) <= maxD2; inl += in; tested++;
+            lambda *= in ? sprt.lamAccept : sprt.lamReject;
+            if (lambda > sprt.A) { rejected = true; break; } }
+        if (rejected) { const double dl = (double)inl / tested; if (dl > 0 && std::fabs(dl - sprt.delta) / sprt.delta > 0.05 && dl < sprt.eps) sprt.design(sprt.eps, dl); continue; }
+        if (inl > bestInl) { bestInl = inl; std::copy(Hc, Hc + 9, best);
+            const double e = (double)inl / N; if (e > sprt.eps) sprt.design(e, sprt.delta);
+            const double p4 = e * e * e * e; limit = p4 > 1 - 1e-12 ? it : (unsigned)std::min<double>(maxI, std::ceil(std::log(1 - cfd) / std::log(1 - p4))); }
+    }
+    if (bestInl < 4) return false;
+    std::vector<unsigned> in; for (unsigned i = 0; i < N; i++) if (err2(best, s[i], d[i]) <= maxD2) in.push_back(i);
+    // Levenberg-Marquardt on the inliers (8 parameters, h33 = 1), damped Cholesky, float32
+    float H[9]; std::copy(best, best + 9, H); float lam = 0.01f, JtJ[8][8], Jtr[8]; float cost = lm_cost(s, d, in, H, JtJ, Jtr);
+    for (int it = 0; it < 10; it++) {
+        float A[8][8], b[8], dx[8];
+        for (int a = 0; a < 8; a++) { b[a] = Jtr[a]; for (int c = 0; c <= a; c++) A[a][c] = JtJ[a][c]; A[a][a] += lam * JtJ[a][a] + 1e-12f; }
+        if (!chol8(A, b, dx)) { lam *= 10.f; continue; }
+        float Hn[9]; for (int a = 0; a < 8; a++) Hn[a] = H[a] + dx[a]; Hn[8] = 1.f;
+        const float c2 = lm_cost(s, d, in, Hn, nullptr, nullptr);
+        if (c2 < cost) { std::copy(Hn, Hn + 9, H); lam *= 0.1f; cost = lm_cost(s, d, in, H, JtJ, Jtr); } else lam *= 10.f;
+    }
+    for (int i = 0; i < 9; i++) Hout[i] = H[i];
     return true;
 }
 

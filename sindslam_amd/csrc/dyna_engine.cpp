@@ -178,7 +178,7 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     }
     double Hm[9];
     tq = tick_ms();
-    find_homography_prosac(in, inLast, Hm);
+    find_homography_rho(in, inLast, Hm);
     QLAP(22)
     SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, (unsigned*)(hist_d.p + 256), hist_d.p, magu8.p, W, H));
     HIP_TRY(hipMemcpyAsync(h_hist.p, hist_d.p, 257 * sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -9,7 +9,7 @@
 namespace sind {
 
 struct Pt2f { float x, y; };
-bool find_homography_prosac(const std::vector<Pt2f>& src, const std::vector<Pt2f>& dst, double H[9]);
+bool find_homography_rho(const std::vector<Pt2f>& src, const std::vector<Pt2f>& dst, double H[9]);
 
 // PEAC plane-contour extraction (reference include/PEAC/*, called from DynaDetect.cc:592-593).
 // blocks: per 16x16 window statistics computed on the GPU (k_peac_block_stats); depth: host copy of the raw depth.

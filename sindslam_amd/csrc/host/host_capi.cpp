@@ -46,7 +46,7 @@ void sindh_draw(const uint8_t* src, int w, int h, int filled, uint8_t* out) {   
 }
 int sindh_find_homography(const float* src, const float* dst, int n, double* H) {
     std::vector<Pt2f> s(n), d(n); for (int i = 0; i < n; i++) { s[i] = {src[2 * i], src[2 * i + 1]}; d[i] = {dst[2 * i], dst[2 * i + 1]}; }
-    return find_homography_prosac(s, d, H) ? 1 : 0;
+    return find_homography_rho(s, d, H) ? 1 : 0;
 }
 // block statistics in the same sequential order as k_peac_block_stats (test-only stand-in for the kernel)
 void sindh_peac(const uint16_t* depth, int w, int h, float fx, float fy, float cx, float cy, float depthScale, uint8_t* out) {

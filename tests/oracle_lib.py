@@ -30,6 +30,7 @@ def lib():
     _lib.orc_fast_atan2.restype = C.c_float
     _lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
     _lib.orc_dyna_create.restype = C.c_void_p
+    _lib.orc_dyna_fork.restype = C.c_void_p
     _lib.orc_orb_create.restype = C.c_void_p
     _lib.orc_baseline_run.restype = C.c_double
     return _lib
@@ -118,6 +119,12 @@ def find_homography(src, dst):
     ok = lib().orc_find_homography(_p(src), _p(dst), len(src), _p(H)); return ok, H.reshape(3, 3)
 
 
+def find_homography_prosac_ls(src, dst):
+    """round 1's lighter estimator (PROSAC + least squares + Gauss-Newton), kept in the oracle for the a-8 sensitivity comparison"""
+    src = np.ascontiguousarray(src, np.float32); dst = np.ascontiguousarray(dst, np.float32); H = np.zeros(9, np.float64)
+    ok = lib().orc_find_homography_prosac_ls(_p(src), _p(dst), len(src), _p(H)); return ok, H.reshape(3, 3)
+
+
 def morph(src, n, op):
     h, w = src.shape; out = np.empty_like(src)
     lib().orc_morph(_p(np.ascontiguousarray(src)), w, h, n, {"dilate": 0, "erode": 1, "open": 2, "close": 3}[op], _p(out)); return out
@@ -150,6 +157,14 @@ class DynaDetect:
     def __del__(self):
         if getattr(self, "p", None):
             lib().orc_dyna_destroy(self.p); self.p = None
+
+    def fork(self):
+        """another detector continuing from this one's inter-frame state"""
+        o = DynaDetect.__new__(DynaDetect); o.h, o.w = self.h, self.w; o.p = C.c_void_p(lib().orc_dyna_fork(self.p)); return o
+
+    def set_h_estimator(self, which=0, seed=0):
+        """0: RHO's published scheme (seed 0 = its fixed seed), 2: round 1's PROSAC + least-squares estimator"""
+        lib().orc_dyna_set_h_estimator(self.p, int(which), C.c_uint64(seed))
 
     def set_flow_max_levels(self, n):
         lib().orc_dyna_set_flow_max_levels(self.p, int(n))

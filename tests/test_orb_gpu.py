@@ -62,8 +62,8 @@ def test_mask_filter_and_fallback(orb, grays):
 
 def test_batch_and_other_params(grays):
     from sindslam_amd.orb import ORBextractor
-    o = ORBextractor(1000, 1.2, 8, 20, 7)           # Bonn / D455 settings (reference Bonn.yaml, D455.yaml)
-    ref = O.ORBextractor(1000, 1.2, 8, 20, 7)
+    o = ORBextractor(1500, 1.2, 8, 20, 7)           # Bonn / D455 settings (reference Bonn.yaml:41,53,54, D455.yaml:41,53,54)
+    ref = O.ORBextractor(1500, 1.2, 8, 20, 7)
     ks, ds = o.extract_batch(np.stack(grays))
     for g, k, d in zip(grays, ks, ds):
         rk, rd = ref.extract(g)

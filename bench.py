@@ -395,7 +395,7 @@ def main():
     seq_info = None
     if workload == "sequence":
         seq_info = {"frames": seq_frames, "owned_frames": world * S * K * T, "chunks": world * S, "chunk_frames": K * T, "chunk_warmup_frames": Wm * T,
-                    "mask_gather": ("RCCL all_gather per step, %.1f MB per rank" % (S * T * H * W / 1e6)) if world > 1 else "single rank (no collective)",
+                    "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if world > 1 else "single rank (no collective)",
                     "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
         if rank == 0 and not args.no_exact_leg:
             KT, WT = K * T, Wm * T
@@ -461,7 +461,7 @@ def main():
             "metric": "DynaDetect+ORB frame-pairs/sec at 640x480; mask IoU vs CPU ref", "value": pairs / dt, "unit": "frame-pairs/s",
             "n_gpus": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["workload"] + ("; ONE sequence of %d frames, frame-sharded in %d chunks, per-step RCCL gather of the dynamic masks" % (seq_frames, world * S) if workload == "sequence" else ""),
+            "config": {"workload": cfg["workload"] + ("; ONE sequence of %d frames, frame-sharded in %d chunks, per-step %s gather of the dynamic masks" % (seq_frames, world * S, "RCCL" if args.backend == "nccl" else args.backend) if workload == "sequence" else ""),
                        "name": args.config, "mode": workload, "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world,
                        "parallelism": ("frame-sharded x%d" if workload == "sequence" else "stream-sharded x%d") % world, "pipelined": bool(args.pipelined),
                        "flow_pyramid_levels": cfg["flow_max_levels"] or "all (49 at 640x480)",

@@ -52,6 +52,15 @@ int orc_find_homography_prosac_ls(const float* src, const float* dst, int n, dou
     return find_homography_prosac(s, d, H) ? 1 : 0;
 }
 
+// property-test access to the k-means and flood-fill restatements
+void orc_kmeans(const float* data, int N, int dims, int K, int* labels /* in: initial, out: final */, int maxCount, double eps, float* centers /* K x dims */) {
+    std::vector<float> c; kmeans_initial_labels(data, N, dims, K, labels, maxCount, eps, c); std::copy(c.begin(), c.end(), centers);
+}
+int orc_flood_fill_mask_only(const uint8_t* image, int w, int h, uint8_t* mask /* (h+2) x (w+2), in/out */, int sx, int sy, int new_val, int diff) {
+    Img8 img = wrap8(image, w, h), m = wrap8(mask, w + 2, h + 2);
+    const int area = flood_fill_mask_only(img, m, Pt{sx, sy}, (uint8_t)new_val, diff); put(m, mask); return area;
+}
+
 // morphology / contours for unit tests
 void orc_morph(const uint8_t* src, int w, int h, int n, int op /*0 dilate 1 erode 2 open 3 close*/, uint8_t* out) {
     Img8 s = wrap8(src, w, h), d; StructElem e = ellipse_elem(n);

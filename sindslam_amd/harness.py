@@ -113,20 +113,35 @@ def write_png(path: str, img: np.ndarray):
 
 
 # ------------------------------------------------------------------ the frame loop
+class GpuBackend:
+    """the two drop-in classes on the MI355X (the default, and the only backend this package ships: there is no CPU fallback)"""
+    def __init__(self, device: int = 0):
+        self.device = device
+
+    def make_detector(self, img_last, img_lastlast, fx, fy, cx, cy, depth_scale):
+        from .dyna import DynaDetect
+        return DynaDetect(img_last, img_lastlast, fx, fy, cx, cy, depth_scale, device=self.device)
+
+    def make_extractor(self, nfeatures, scale_factor, nlevels, ini_th, min_th):
+        from .orb import ORBextractor
+        return ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=self.device)
+
+
 def run_sequence(settings_path: str, sequence_dir: str, association_path: str, out_dir: str | None = None, max_frames: int | None = None,
-                 device: int = 0, verbose: bool = True):
-    """-> list of per-frame dicts {timestamp, dyna, label, mask, keypoints, descriptors}; writes masks as PNG when out_dir is given"""
-    from .dyna import DynaDetect
-    from .orb import ORBextractor
+                 device: int = 0, verbose: bool = True, backend=None):
+    """-> list of per-frame dicts {timestamp, dyna, label, mask, keypoints, descriptors}; writes masks as PNG when out_dir is given.
+    backend: factory of the two classes (make_detector / make_extractor, see GpuBackend); the tests inject one built on their CPU checker to run
+    the loop without a GPU (BASELINE.json configs[0], "20 frames, CPU path via rgbd_tum_noros (plumbing, no GPU)")."""
+    backend = backend or GpuBackend(device)
     S = read_settings(settings_path)
     ts, rgbs, deps = load_associations(association_path)
     if len(rgbs) != len(deps):
         raise ValueError("Different number of images for rgb and depth.")
     n = len(rgbs) if max_frames is None else min(len(rgbs), max_frames)
     first = read_png(os.path.join(sequence_dir, rgbs[0]))
-    dd = DynaDetect(first, first.copy(), S["Camera.fx"], S["Camera.fy"], S["Camera.cx"], S["Camera.cy"], S["DepthMapFactor"], device=device)
-    orb = ORBextractor(int(S["ORBextractor.nFeatures"]), float(S["ORBextractor.scaleFactor"]), int(S["ORBextractor.nLevels"]),
-                       int(S["ORBextractor.iniThFAST"]), int(S["ORBextractor.minThFAST"]), device=device)
+    dd = backend.make_detector(first, first.copy(), S["Camera.fx"], S["Camera.fy"], S["Camera.cx"], S["Camera.cy"], S["DepthMapFactor"])
+    orb = backend.make_extractor(int(S["ORBextractor.nFeatures"]), float(S["ORBextractor.scaleFactor"]), int(S["ORBextractor.nLevels"]),
+                                 int(S["ORBextractor.iniThFAST"]), int(S["ORBextractor.minThFAST"]))
     rgb_order = int(S.get("Camera.RGB", 0)) == 1
     h, w = first.shape[:2]
     results = []; t_dyn = []
@@ -153,7 +168,9 @@ def run_sequence(settings_path: str, sequence_dir: str, association_path: str, o
         print("-------\n")
         print(f"Images in the sequence: {n}")
         print(f"mean dynamic detecting time: {sum(t_dyn) / max(len(t_dyn), 1):.6f}")
-    dd.close(); orb.close()
+    for o in (dd, orb):
+        if hasattr(o, "close"):
+            o.close()
     return results
 
 

@@ -68,3 +68,56 @@ def test_png_round_trip_and_all_filters(tmp_path):
     (tmp_path / "bad.png").write_bytes(b"not a png")
     with pytest.raises(ValueError):
         Hn.read_png(str(tmp_path / "bad.png"))
+
+
+class _OracleBackend:
+    """the harness' two classes built on the CPU checker (test infrastructure; the product has no CPU path)"""
+    def make_detector(self, img_last, img_lastlast, fx, fy, cx, cy, depth_scale):
+        import oracle_lib as O
+
+        class D:
+            def __init__(s):
+                s.o = O.DynaDetect(img_last, img_lastlast, fx, fy, cx, cy, depth_scale)
+
+            def DetectDynaArea(s, bgr, depth, ni):
+                return s.o.detect(bgr, depth)
+
+            def dilate15(s, dyna):
+                return O.dilate15(dyna)
+        return D()
+
+    def make_extractor(self, nfeatures, scale_factor, nlevels, ini_th, min_th):
+        import oracle_lib as O
+        e = O.ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        return lambda gray, mask: e.extract(gray, mask)
+
+
+@pytest.mark.timeout(600)
+def test_config1_twenty_frames_cpu_plumbing(tmp_path):
+    """BASELINE.json configs[0] / SURVEY 8d-1: the first 20 frames of the synthetic TUM-shaped stream as a TUM folder (PNG files, association
+    list, TUM3.yaml) through the rgbd_tum_noros-shaped loop with the CPU restatement -- parser, PNG codec, settings, frame 0 passed through,
+    DetectDynaArea from frame 1 on, dilation, RGB-order gray, ORB, mask PNGs out -- and the same numbers when the detector is driven directly."""
+    import oracle_lib as O
+    from sindslam_amd.synth import SyntheticStream, TUM3
+    n = 20
+    bgr, depth = SyntheticStream(seed=12345).frames(0, n)
+    os.makedirs(tmp_path / "rgb"); os.makedirs(tmp_path / "depth")
+    lines = []
+    for i in range(n):
+        Hn.write_png(str(tmp_path / "rgb" / f"{i:04d}.png"), bgr[i]); Hn.write_png(str(tmp_path / "depth" / f"{i:04d}.png"), depth[i])
+        lines.append(f"{1305031102.0 + i / 30:.6f} rgb/{i:04d}.png {1305031102.0 + i / 30:.6f} depth/{i:04d}.png")
+    (tmp_path / "assoc.txt").write_text("\n".join(lines) + "\n")
+    (tmp_path / "TUM3.yaml").write_text("%YAML:1.0\nCamera.fx: 535.4\nCamera.fy: 539.2\nCamera.cx: 320.1\nCamera.cy: 247.6\nCamera.RGB: 1\nDepthMapFactor: 5000.0\n"
+                                        "ORBextractor.nFeatures: 1500\nORBextractor.scaleFactor: 1.2\nORBextractor.nLevels: 8\nORBextractor.iniThFAST: 15\nORBextractor.minThFAST: 5\n")
+    res = Hn.run_sequence(str(tmp_path / "TUM3.yaml"), str(tmp_path), str(tmp_path / "assoc.txt"), out_dir=str(tmp_path / "out"), verbose=False, backend=_OracleBackend())
+    assert len(res) == n and not res[0]["dyna"].any() and len(res[0]["keypoints"]) > 250          # frame 0: all-zero mask, plain ORB
+    ref = O.DynaDetect(bgr[0], bgr[0].copy(), TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"]); orb = O.ORBextractor(1500, 1.2, 8, 15, 5)
+    some = False
+    for i in range(1, n):
+        rd, rl = ref.detect(bgr[i], depth[i])
+        assert np.array_equal(res[i]["dyna"], rd) and np.array_equal(res[i]["label"], rl) and np.array_equal(res[i]["mask"], O.dilate15(rd)), i
+        rk, rdesc = orb.extract(O.bgr2gray(bgr[i], swap_rb=True), res[i]["mask"])
+        assert res[i]["keypoints"].tobytes() == rk.tobytes() and np.array_equal(res[i]["descriptors"], rdesc), i
+        assert np.array_equal(Hn.read_png(str(tmp_path / "out" / f"dynaMask_{i:05d}.png")), res[i]["mask"])
+        some |= bool((rd == 255).any())
+    assert some and set(np.unique(res[5]["dyna"])) <= {0, 125, 255}

@@ -14,16 +14,20 @@ struct MorphElem { int n, ax, ay; int j1[MORPH_MAX], j2[MORPH_MAX]; };
 struct PeacBlockStats { double sx, sy, sz, sxx, syy, szz, sxy, syz, sxz; int N, valid; };
 
 MorphElem make_ellipse(int n);
-int launch_depth_half(hipStream_t s, const uint16_t* src, uint16_t* dst, int dw, int dh);
-int launch_points(hipStream_t s, const uint16_t* depth, float* px, float* py, float* pz, int w, int h, float scale, float fx, float fy, float cx, float cy, float depthScale);
-int launch_labels_grid(hipStream_t s, int* labels, int w, int h);
-int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw, int sh, int dw, int dh);
-int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh);
+// k-means chain: every launcher takes a batch of B frames (default one) with per-frame plane strides in elements
+int launch_depth_half(hipStream_t s, const uint16_t* src, uint16_t* dst, int dw, int dh, int B = 1, size_t src_stride = 0, size_t dst_stride = 0);
+int launch_points(hipStream_t s, const uint16_t* depth, float* px, float* py, float* pz, int w, int h, float scale, float fx, float fy, float cx, float cy, float depthScale,
+                  int B = 1, size_t depth_stride = 0, size_t pt_stride = 0);
+// use_prev (device, one int per frame, or nullptr): the grid labels go to the frames with use_prev == 0, the resized previous labels to the others
+int launch_labels_grid(hipStream_t s, int* labels, int w, int h, int B = 1, size_t stride = 0, const int* use_prev = nullptr);
+int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw, int sh, int dw, int dh, int B = 1, size_t src_stride = 0, size_t dst_stride = 0, const int* use_prev = nullptr);
+int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh, int B = 1, size_t src_stride = 0, size_t dst_stride = 0);
 // segcnt: (KM_MAX_BLOCKS * 4 + 1) * KM_K ints (per wave-segment cluster counts + the totals row) + 64 floats (the pass's 36 sequential sums); comp: 3 * n floats (per-cluster runs of every coordinate)
+#define KM_SEG_WORDS ((KM_MAX_BLOCKS * 4 + 1) * KM_K + 64)
 int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, int* segcnt, float* comp, KmState* st,
-                        int maxCount, double eps2);
+                        int maxCount, double eps2, int B = 1, size_t pt_stride = 0, size_t lab_stride = 0, size_t seg_stride = 0, size_t comp_stride = 0, size_t st_stride = 0);
 int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev, float* out_host);
-int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n);
+int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n, int B = 1, size_t lab_stride = 0, size_t out_stride = 0);
 int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h);
 int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out);
 int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, uint8_t* edge, uint8_t* total_area, int w, int h, float depthScale);

@@ -12,8 +12,11 @@
 namespace sind {
 
 // ---------------------------------------------------------------- cv::resize(INTER_LINEAR) with exact 2x -> INTER_AREA fast path, CV_16U
-__global__ void k_depth_half(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int dw, int dh) {
+// Every kernel of the k-means chain takes a batch of frames: blockIdx.z (2-D grids) or blockIdx.y (1-D grids) is the frame, *_stride the
+// distance between two frames' planes in elements (the pipeline runs the chain for all streams' frame t at once; one frame = batch of 1).
+__global__ void k_depth_half(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int dw, int dh, size_t src_stride, size_t dst_stride) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    src += blockIdx.z * src_stride; dst += blockIdx.z * dst_stride;
     if (x >= dw) return;
     const int sw = dw * 2;
     const int s = src[(2 * y) * sw + 2 * x] + src[(2 * y) * sw + 2 * x + 1] + src[(2 * y + 1) * sw + 2 * x] + src[(2 * y + 1) * sw + 2 * x + 1];
@@ -22,8 +25,9 @@ __global__ void k_depth_half(const uint16_t* __restrict__ src, uint16_t* __restr
 
 // ---------------------------------------------------------------- back-projection (DD:347-369), SoA points
 __global__ void k_points(const uint16_t* __restrict__ depth, float* __restrict__ px, float* __restrict__ py, float* __restrict__ pz,
-                         int w, int h, float scale, float fx, float fy, float cx, float cy, float depthScale, float depth_weight) {
+                         int w, int h, float scale, float fx, float fy, float cx, float cy, float depthScale, float depth_weight, size_t depth_stride, size_t pt_stride) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    depth += blockIdx.z * depth_stride; px += blockIdx.z * pt_stride; py += blockIdx.z * pt_stride; pz += blockIdx.z * pt_stride;
     if (col >= w) return;
     const int i = row * w + col;
     const uint16_t d = (uint16_t)(depth[i] * scale);
@@ -35,16 +39,18 @@ __global__ void k_points(const uint16_t* __restrict__ depth, float* __restrict__
 }
 
 // ---------------------------------------------------------------- initial labels
-__global__ void k_labels_grid(int* __restrict__ labels, int w, int h, float batch_rows, float batch_cols, int ncol) {
+__global__ void k_labels_grid(int* __restrict__ labels, int w, int h, float batch_rows, float batch_cols, int ncol, size_t stride, const int* __restrict__ use_prev) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= w) return;
-    labels[i * w + j] = (int)floorf(i / batch_rows) * ncol + (int)floorf(j / batch_cols);
+    if (j >= w || (use_prev && use_prev[blockIdx.z])) return;             // frames with labels from their previous frame are filled by k_labels_resize
+    labels[blockIdx.z * stride + i * w + j] = (int)floorf(i / batch_rows) * ncol + (int)floorf(j / batch_cols);
 }
 // bilinear resize of a label image converted to float, then cvRound (DD:390-394, 402-406)
 template <class T>
-__global__ void k_labels_resize(const T* __restrict__ src, int* __restrict__ dst, int sw, int sh, int dw, int dh, double scale_x, double scale_y) {
+__global__ void k_labels_resize(const T* __restrict__ src, int* __restrict__ dst, int sw, int sh, int dw, int dh, double scale_x, double scale_y,
+                                size_t src_stride, size_t dst_stride, const int* __restrict__ use_prev) {
     const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
-    if (dx >= dw) return;
+    src += blockIdx.z * src_stride; dst += blockIdx.z * dst_stride;
+    if (dx >= dw || (use_prev && !use_prev[blockIdx.z])) return;          // first frame of a stream: the 3 x 4 grid labels (k_labels_grid)
     float fx = (float)((dx + 0.5) * scale_x - 0.5);
     int sx = d_cvFloorf(fx); fx -= sx;
     const bool two = sx + 1 < sw;
@@ -102,7 +108,10 @@ __device__ __forceinline__ void km_count_store(const int (&c)[KM_K], int* __rest
         segcnt[seg * KM_K + lane] = v; }
 }
 // first centre pass of a level: counts of the given labels
-__global__ void __launch_bounds__(64 * KM_WAVES) k_km_count(const int* __restrict__ labels, int n, int seg_len, int* __restrict__ segcnt, const KmState* __restrict__ st) {
+// per-frame strides of the k-means buffers (elements): points / labels planes, count table, compacted runs, state records
+struct KmStride { size_t pt, lab, seg, comp, st; };
+__global__ void __launch_bounds__(64 * KM_WAVES) k_km_count(const int* __restrict__ labels, int n, int seg_len, int* __restrict__ segcnt, const KmState* __restrict__ st, KmStride ks) {
+    labels += blockIdx.y * ks.lab; segcnt += blockIdx.y * ks.seg; st += blockIdx.y * ks.st;
     if (st->done) return;
     const int lane = threadIdx.x & 63, seg = blockIdx.x * KM_WAVES + (threadIdx.x >> 6);
     const int lo = seg * seg_len, hi = min(n, lo + seg_len);
@@ -118,7 +127,8 @@ __global__ void __launch_bounds__(64 * KM_WAVES) k_km_count(const int* __restric
 }
 // re-assignment to the nearest centre (cv::kmeans' KMeansDistanceComputer: float accumulation, first minimum wins) + the counts of the new labels
 __global__ void __launch_bounds__(64 * KM_WAVES) k_km_assign_count(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                                   int* __restrict__ labels, int n, int seg_len, int* __restrict__ segcnt, const KmState* __restrict__ st) {
+                                                                   int* __restrict__ labels, int n, int seg_len, int* __restrict__ segcnt, const KmState* __restrict__ st, KmStride ks) {
+    px += blockIdx.y * ks.pt; py += blockIdx.y * ks.pt; pz += blockIdx.y * ks.pt; labels += blockIdx.y * ks.lab; segcnt += blockIdx.y * ks.seg; st += blockIdx.y * ks.st;
     if (st->done || st->phase != 1) return;
     __shared__ float ctr[KM_K][3];
     const int tid = threadIdx.x, lane = tid & 63, seg = blockIdx.x * KM_WAVES + (tid >> 6);
@@ -151,7 +161,9 @@ __global__ void __launch_bounds__(64 * KM_WAVES) k_km_assign_count(const float* 
 // plane j (start_k = samples of the clusters before k).  A wave derives its write positions from the count table alone.
 __global__ void __launch_bounds__(64 * KM_WAVES) k_km_compact(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                               const int* __restrict__ labels, int n, int seg_len, int nseg, const int* __restrict__ segcnt,
-                                                              float* __restrict__ comp, int* __restrict__ tot_out, const KmState* __restrict__ st) {
+                                                              float* __restrict__ comp, int* __restrict__ tot_out, const KmState* __restrict__ st, KmStride ks) {
+    px += blockIdx.y * ks.pt; py += blockIdx.y * ks.pt; pz += blockIdx.y * ks.pt; labels += blockIdx.y * ks.lab; segcnt += blockIdx.y * ks.seg; comp += blockIdx.y * ks.comp;
+    tot_out += blockIdx.y * ks.seg; st += blockIdx.y * ks.st;
     if (st->done) return;
     const int lane = threadIdx.x & 63, seg = blockIdx.x * KM_WAVES + (threadIdx.x >> 6);
     // per cluster: samples in the segments before this one (before) and in all segments (total); lanes stride over the table rows
@@ -326,7 +338,8 @@ __device__ __forceinline__ void km_chunk_store(float* __restrict__ ring, int ch,
 // grid = 36 runs (cluster k = blockIdx.x / 3, coordinate j = blockIdx.x % 3), 256 threads: wave 0 sums, waves 1..3 keep the ring ahead of it
 // (chunk ch + 2 goes into the ring while chunk ch is summed, chunk ch + 3 is already on its way in registers)
 __global__ void __launch_bounds__(256) k_km_seqsum(const int* __restrict__ segcnt, int nseg, const float* __restrict__ comp, int n, float* __restrict__ seqsums,
-                                                   const KmState* __restrict__ st) {
+                                                   const KmState* __restrict__ st, KmStride ks) {
+    segcnt += blockIdx.y * ks.seg; comp += blockIdx.y * ks.comp; seqsums += blockIdx.y * ks.seg; st += blockIdx.y * ks.st;
     if (st->done) return;
     __shared__ float ring[KM_RING_WORDS];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, k = blockIdx.x / 3, j = blockIdx.x % 3;
@@ -368,7 +381,9 @@ __global__ void __launch_bounds__(256) k_km_seqsum(const int* __restrict__ segcn
 // does, repeated until no cluster is empty), scale, shift test, stop decision.  No host round trip and no provisioning limit.
 __global__ void __launch_bounds__(1024) k_km_update(const int* __restrict__ segcnt, int nseg, const float* __restrict__ seqsums, KmState* __restrict__ gst,
                                                     const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                    int* __restrict__ labels, int n) {
+                                                    int* __restrict__ labels, int n, KmStride ks) {
+    segcnt += blockIdx.y * ks.seg; seqsums += blockIdx.y * ks.seg; gst += blockIdx.y * ks.st; px += blockIdx.y * ks.pt; py += blockIdx.y * ks.pt; pz += blockIdx.y * ks.pt;
+    labels += blockIdx.y * ks.lab;
     __shared__ float sums[KM_K * 3];
     __shared__ int tot[KM_K + 1];
     __shared__ unsigned long long wbest[16];
@@ -428,13 +443,15 @@ __global__ void __launch_bounds__(1024) k_km_update(const int* __restrict__ segc
     }
     for (int i = t; i < (int)(sizeof(KmState) / 4); i += blockDim.x) reinterpret_cast<unsigned*>(gst)[i] = reinterpret_cast<const unsigned*>(&S)[i];
 }
-__global__ void k_km_reset(KmState* st, int maxCount, double eps2) {
+__global__ void k_km_reset(KmState* st, int maxCount, double eps2, size_t st_stride) {
+    st += blockIdx.y * st_stride;
     if (threadIdx.x == 0) { st->iter = 0; st->done = 0; st->phase = 0; st->overflow = 0; st->fix_k = -1; st->max_k = 0; st->far = 0ull; st->maxCount = maxCount; st->eps2 = eps2;
         for (int k = 0; k < KM_K; k++) { st->cnt[k] = 0; for (int j = 0; j < 3; j++) { st->ctr[k][j] = 0.f; st->old[k][j] = 0.f; } } }
 }
 
-__global__ void k_labels_to_u8(const int* __restrict__ labels, uint8_t* __restrict__ out, int n) {
+__global__ void k_labels_to_u8(const int* __restrict__ labels, uint8_t* __restrict__ out, int n, size_t lab_stride, size_t out_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    labels += blockIdx.y * lab_stride; out += blockIdx.y * out_stride;
     if (i < n) { const int v = labels[i]; out[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 }
 
@@ -644,43 +661,47 @@ int launch_dilate_planes(hipStream_t s, const unsigned long long* src, unsigned 
 }
 
 // ---------------------------------------------------------------- launchers
-int launch_depth_half(hipStream_t s, const uint16_t* src, uint16_t* dst, int dw, int dh) { hipLaunchKernelGGL(k_depth_half, dim3(divup(dw, 128), dh), dim3(128), 0, s, src, dst, dw, dh); return SIND_OK; }
-int launch_points(hipStream_t s, const uint16_t* depth, float* px, float* py, float* pz, int w, int h, float scale, float fx, float fy, float cx, float cy, float depthScale) {
-    hipLaunchKernelGGL(k_points, dim3(divup(w, 128), h), dim3(128), 0, s, depth, px, py, pz, w, h, scale, fx, fy, cx, cy, depthScale, 1.5f); return SIND_OK; }
-int launch_labels_grid(hipStream_t s, int* labels, int w, int h) {
-    hipLaunchKernelGGL(k_labels_grid, dim3(divup(w, 128), h), dim3(128), 0, s, labels, w, h, (float)h / 3, (float)w / 4, 4); return SIND_OK; }
-int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw, int sh, int dw, int dh) {
-    hipLaunchKernelGGL(k_labels_resize<uint8_t>, dim3(divup(dw, 128), dh), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh)); return SIND_OK; }
-int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh) {
-    hipLaunchKernelGGL(k_labels_resize<int>, dim3(divup(dw, 128), dh), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh)); return SIND_OK; }
+int launch_depth_half(hipStream_t s, const uint16_t* src, uint16_t* dst, int dw, int dh, int B, size_t src_stride, size_t dst_stride) {
+    hipLaunchKernelGGL(k_depth_half, dim3(divup(dw, 128), dh, B), dim3(128), 0, s, src, dst, dw, dh, src_stride, dst_stride); return SIND_OK; }
+int launch_points(hipStream_t s, const uint16_t* depth, float* px, float* py, float* pz, int w, int h, float scale, float fx, float fy, float cx, float cy, float depthScale,
+                  int B, size_t depth_stride, size_t pt_stride) {
+    hipLaunchKernelGGL(k_points, dim3(divup(w, 128), h, B), dim3(128), 0, s, depth, px, py, pz, w, h, scale, fx, fy, cx, cy, depthScale, 1.5f, depth_stride, pt_stride); return SIND_OK; }
+int launch_labels_grid(hipStream_t s, int* labels, int w, int h, int B, size_t stride, const int* use_prev) {
+    hipLaunchKernelGGL(k_labels_grid, dim3(divup(w, 128), h, B), dim3(128), 0, s, labels, w, h, (float)h / 3, (float)w / 4, 4, stride, use_prev); return SIND_OK; }
+int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw, int sh, int dw, int dh, int B, size_t src_stride, size_t dst_stride, const int* use_prev) {
+    hipLaunchKernelGGL(k_labels_resize<uint8_t>, dim3(divup(dw, 128), dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh), src_stride, dst_stride, use_prev); return SIND_OK; }
+int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh, int B, size_t src_stride, size_t dst_stride) {
+    hipLaunchKernelGGL(k_labels_resize<int>, dim3(divup(dw, 128), dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh), src_stride, dst_stride, (const int*)nullptr); return SIND_OK; }
 int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, int* segcnt, float* comp, KmState* st,
-                        int maxCount, double eps2) {
-    // nseg wave-segments of seg_len (multiple of 64) contiguous points; at most KM_MAX_BLOCKS * KM_WAVES rows in the count table;
-    // the 36 sequential sums of a pass live behind the count table
+                        int maxCount, double eps2, int B, size_t pt_stride, size_t lab_stride, size_t seg_stride, size_t comp_stride, size_t st_stride) {
+    // nseg wave-segments of seg_len (multiple of 64) contiguous points; at most KM_MAX_BLOCKS * KM_WAVES rows in the count table, then the totals row
+    // and the 36 sequential sums of the pass
     const int nb = std::min(divup(n, 1024), KM_MAX_BLOCKS), nseg = nb * 4, seg_len = divup(divup(n, nseg), 64) * 64, iters = std::max(maxCount, 2);
     float* seqsums = reinterpret_cast<float*>(segcnt + (KM_MAX_BLOCKS * 4 + 1) * KM_K);
-    hipLaunchKernelGGL(k_km_reset, dim3(1), dim3(64), 0, s, st, maxCount, eps2);
-    hipLaunchKernelGGL(k_km_count, dim3(nb), dim3(256), 0, s, labels, n, seg_len, segcnt, st);
-    for (int it = 0; it < iters; it++) {           // every kernel is a no-op once the centre step has set st->done
-        if (it > 0) hipLaunchKernelGGL(k_km_assign_count, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, seg_len, segcnt, st);
-        hipLaunchKernelGGL(k_km_compact, dim3(nb), dim3(256), 0, s, px, py, pz, labels, n, seg_len, nseg, segcnt, comp, segcnt + nseg * KM_K, st);
-        hipLaunchKernelGGL(k_km_seqsum, dim3(KM_K * 3), dim3(256), 0, s, segcnt, nseg, comp, n, seqsums, st);
-        hipLaunchKernelGGL(k_km_update, dim3(1), dim3(1024), 0, s, segcnt, nseg, seqsums, st, px, py, pz, labels, n);
+    const KmStride ks{pt_stride, lab_stride, seg_stride, comp_stride, st_stride};
+    hipLaunchKernelGGL(k_km_reset, dim3(1, B), dim3(64), 0, s, st, maxCount, eps2, st_stride);
+    hipLaunchKernelGGL(k_km_count, dim3(nb, B), dim3(256), 0, s, labels, n, seg_len, segcnt, st, ks);
+    for (int it = 0; it < iters; it++) {           // every kernel is a no-op for a frame whose centre step has set st->done
+        if (it > 0) hipLaunchKernelGGL(k_km_assign_count, dim3(nb, B), dim3(256), 0, s, px, py, pz, labels, n, seg_len, segcnt, st, ks);
+        hipLaunchKernelGGL(k_km_compact, dim3(nb, B), dim3(256), 0, s, px, py, pz, labels, n, seg_len, nseg, segcnt, comp, segcnt + nseg * KM_K, st, ks);
+        hipLaunchKernelGGL(k_km_seqsum, dim3(KM_K * 3, B), dim3(256), 0, s, segcnt, nseg, comp, n, seqsums, st, ks);
+        hipLaunchKernelGGL(k_km_update, dim3(1, B), dim3(1024), 0, s, segcnt, nseg, seqsums, st, px, py, pz, labels, n, ks);
     }
     return SIND_OK;
 }
 // parity-test access: the sequential FP32 sum of n host floats through k_km_seqsum's window arithmetic (one run)
-int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev /* KM_K ints + 36 floats + a KmState */, float* out_host) {
+int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev /* 2 * KM_K ints + 64 floats + a KmState */, float* out_host) {
     int* segcnt = scratch_dev; float* sums = reinterpret_cast<float*>(scratch_dev + 2 * KM_K); KmState* st = reinterpret_cast<KmState*>(scratch_dev + 2 * KM_K + 64);
     int h[2 * KM_K] = {n}; h[KM_K] = n;                     // one table row + the totals row: everything is cluster 0, run 0 = coordinate plane 0
     HIP_TRY(hipMemcpyAsync(segcnt, h, sizeof(h), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(st, 0, sizeof(KmState), s));
-    hipLaunchKernelGGL(k_km_seqsum, dim3(1), dim3(256), 0, s, segcnt, 1, x_dev, n, sums, st);
+    hipLaunchKernelGGL(k_km_seqsum, dim3(1), dim3(256), 0, s, segcnt, 1, x_dev, n, sums, st, KmStride{0, 0, 0, 0, 0});
     HIP_TRY(hipMemcpyAsync(out_host, sums, sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SIND_OK;
 }
-int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n) { hipLaunchKernelGGL(k_labels_to_u8, dim3(divup(n, 256)), dim3(256), 0, s, labels, out, n); return SIND_OK; }
+int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n, int B, size_t lab_stride, size_t out_stride) {
+    hipLaunchKernelGGL(k_labels_to_u8, dim3(divup(n, 256), B), dim3(256), 0, s, labels, out, n, lab_stride, out_stride); return SIND_OK; }
 int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h) { hipLaunchKernelGGL(k_median5_u16, dim3(divup(w, 64), h), dim3(64), 0, s, src, dst, w, h); return SIND_OK; }
 int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out) {
     HIP_TRY(hipMemsetAsync(out, 0, sizeof(unsigned), s));

@@ -44,6 +44,25 @@ struct OccResult { BitImg totalArea, occ1, occ2; bool ready = false; const float
 // half (flow masks, fusion) needs from it.  The pipeline computes it for all frames of a step while the dense flow is on the GPU.
 struct DepthStageOut { std::vector<uint8_t> label3; int maxNum = 0; BitImg totalArea; bool ready = false; };
 
+// ---- cv::kmeans of SegByKmeans (DD:315-420) for one frame of EVERY stream at once: the streams are independent, their per-frame chains of ~70
+// small kernels are not worth a launch each (measured: 55 k launches per 512-pair step, the tails phase bound by their summed durations at a
+// concurrency of ~2) -- one batched chain with blockIdx = (work, frame) does the same arithmetic with 1 / B of the launches.
+struct KmFrameResult { const uint8_t* label8; float centers[KM_K][3]; int counts[KM_K]; };
+class KMeansBatch {
+public:
+    int init(const DynaConfig& c, int maxB, hipStream_t s);
+    // frame b: device depth at depth_base + b * depth_stride; prev[b] = the stream's previous merged labels (host u8 [H*W]) or nullptr for the
+    // 3 x 4 grid start.  Blocks until the results are on the host; they stay valid until the next call.
+    int run(const uint16_t* depth_base, size_t depth_stride, int B, const uint8_t* const* prev);
+    const KmFrameResult& result(int b) const { return res[b]; }
+    hipStream_t stream = nullptr;
+private:
+    DynaConfig cfg; int W = 0, H = 0, N = 0, maxB = 0;
+    DevBuf<uint16_t> dpyr[4]; DevBuf<float> px, py, pz, comp; DevBuf<int> lab[4], seg, use_prev_d; DevBuf<uint8_t> labPrev8, lab8; DevBuf<KmState> kstate;
+    PinnedBuf<uint8_t> h_prev, h_lab8; PinnedBuf<KmState> h_state; PinnedBuf<int> h_use_prev;
+    std::vector<KmFrameResult> res;
+};
+
 class DynaTail {
 public:
     DynaConfig cfg; hipStream_t stream = nullptr; DynaDebug dbg; bool keep_debug = false;
@@ -53,10 +72,13 @@ public:
     // dyna_out / label_out: host H x W u8 (0 invalid / 125 static / 255 dynamic ; 0 invalid, 1..n clusters).
     // depth_half: the tail object that carries the depth half's state and workspaces (nullptr = this one)
     int process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out,
-                const OccResult* precomputed = nullptr, DynaTail* depth_half = nullptr);
+                const OccResult* precomputed = nullptr, DynaTail* depth_half = nullptr, const KmFrameResult* km = nullptr);
+    // the k-means warm labels of the next frame (nullptr before the first frame of a stream): what KMeansBatch::run wants as prev[b]
+    const uint8_t* prev_km_labels() const { return kmLabelLastAny ? kmLabelLast.data() : nullptr; }
     // process() = depth_stage() + flow_stage().  The two halves keep separate state (the k-means warm labels belong to the depth half,
     // the sample weights / previous masks to the flow half), so the depth half of the next frames may run ahead of the flow half.
-    int depth_stage(const uint16_t* depth_host, const uint16_t* depth_dev, const OccResult* precomputed, DepthStageOut& out);
+    // km: this frame's k-means result when it was computed by the batched chain (else the stage runs its own)
+    int depth_stage(const uint16_t* depth_host, const uint16_t* depth_dev, const OccResult* precomputed, DepthStageOut& out, const KmFrameResult* km = nullptr);
     int flow_stage(const float* U, const float* V, const DepthStageOut& d, uint8_t* dyna_out, uint8_t* label_out, const float* gridFlowPre = nullptr);
     // CalOccluded (DD:429-642) depends on the depth frame only: the pipeline runs it on this tail's stream while the dense flow
     // of the step is still on the GPU and the host cores are idle

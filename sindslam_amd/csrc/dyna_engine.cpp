@@ -296,6 +296,45 @@ int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, fl
     return SIND_OK;
 }
 
+// ---- the same chain for one frame of every stream (see dyna.hpp)
+int KMeansBatch::init(const DynaConfig& c, int maxB_, hipStream_t s) {
+    cfg = c; W = c.W; H = c.H; N = W * H; maxB = maxB_; stream = s;
+    const size_t B = (size_t)maxB;
+    for (int l = 1; l < 4; l++) SIND_TRY(dpyr[l].alloc(((size_t)N >> (2 * l)) * B));
+    for (int l = 0; l < 4; l++) SIND_TRY(lab[l].alloc(((size_t)N >> (2 * l)) * B));
+    SIND_TRY(px.alloc((size_t)N * B)); SIND_TRY(py.alloc((size_t)N * B)); SIND_TRY(pz.alloc((size_t)N * B)); SIND_TRY(comp.alloc((size_t)3 * N * B));
+    SIND_TRY(seg.alloc((size_t)KM_SEG_WORDS * B)); SIND_TRY(use_prev_d.alloc(B)); SIND_TRY(labPrev8.alloc((size_t)N * B)); SIND_TRY(lab8.alloc((size_t)N * B)); SIND_TRY(kstate.alloc(4 * B));
+    SIND_TRY(h_prev.alloc((size_t)N * B)); SIND_TRY(h_lab8.alloc((size_t)N * B)); SIND_TRY(h_state.alloc(4 * B)); SIND_TRY(h_use_prev.alloc(B));
+    res.resize(maxB);
+    return SIND_OK;
+}
+int KMeansBatch::run(const uint16_t* depth_base, size_t depth_stride, int B, const uint8_t* const* prev) {
+    if (B < 1 || B > maxB) { sind_set_error("KMeansBatch::run: batch %d outside [1,%d]", B, maxB); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(cfg.device));
+    bool any_prev = false;
+    for (int b = 0; b < B; b++) { h_use_prev.p[b] = prev[b] ? 1 : 0; if (prev[b]) { std::memcpy(h_prev.p + (size_t)N * b, prev[b], N); any_prev = true; } }
+    HIP_TRY(hipMemcpyAsync(use_prev_d.p, h_use_prev.p, B * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (any_prev) HIP_TRY(hipMemcpyAsync(labPrev8.p, h_prev.p, (size_t)N * B, hipMemcpyHostToDevice, stream));
+    const float scales[4] = {1.0f, 0.5f, 0.25f, 0.125f};
+    const uint16_t* dl[4] = {depth_base, dpyr[1].p, dpyr[2].p, dpyr[3].p};
+    const size_t ds[4] = {depth_stride, (size_t)N >> 2, (size_t)N >> 4, (size_t)N >> 6};
+    for (int l = 1; l < 4; l++) SIND_TRY(launch_depth_half(stream, dl[l - 1], dpyr[l].p, W >> l, H >> l, B, ds[l - 1], ds[l]));
+    for (int level = 3; level >= 0; level--) {
+        const int hp = (int)(H * scales[level]), wp = (int)(W * scales[level]), n = hp * wp; const size_t ls = (size_t)N >> (2 * level);
+        SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale, B, ds[level], N));
+        if (level == 3) { SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp, B, ls, use_prev_d.p)); SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp, B, N, ls, use_prev_d.p)); }
+        else SIND_TRY(launch_labels_resize_i32(stream, lab[level + 1].p, lab[level].p, wp / 2, hp / 2, wp, hp, B, (size_t)N >> (2 * (level + 1)), ls));
+        SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, seg.p, comp.p, kstate.p + level, 4, 0.07 * 0.07, B, N, ls, KM_SEG_WORDS, (size_t)3 * N, 4));
+    }
+    SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N, B, N, N));
+    HIP_TRY(hipMemcpyAsync(h_state.p, kstate.p, (size_t)4 * B * sizeof(KmState), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_lab8.p, lab8.p, (size_t)N * B, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(sind_stream_wait(stream));
+    for (int b = 0; b < B; b++) { const KmState& st = h_state.p[4 * b];
+        res[b].label8 = h_lab8.p + (size_t)N * b; std::memcpy(res[b].centers, st.ctr, sizeof(st.ctr)); std::memcpy(res[b].counts, st.cnt, sizeof(st.cnt)); }
+    return SIND_OK;
+}
+
 // ---- DD:429-642: depth-gradient edges (GPU), end points, PEAC plane contours, plane-edge filtering (host)
 int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2) {
     double tf = tick_ms();
@@ -524,24 +563,25 @@ int DynaTail::compute_occluded(const uint16_t* depth_host, const uint16_t* depth
 }
 
 int DynaTail::process(const uint16_t* depth_host, const uint16_t* depth_dev, const float* U, const float* V, uint8_t* dyna_out, uint8_t* label_out,
-                      const OccResult* pre, DynaTail* depth_half) {
+                      const OccResult* pre, DynaTail* depth_half, const KmFrameResult* km) {
     // same stage order as the reference (flow masks, clustering, fusion); the order also matters for throughput: a pool of tails that
     // all start with the 50-launch k-means chain was measured 20 ms per step slower than one that starts with the host-side pair sorting
     HIP_TRY(hipSetDevice(cfg.device));
     BitImg maskLow, maskHigh; n_frames++;
     { const double t0 = tick_ms(); SIND_TRY(flow_masks(U, V, maskLow, maskHigh, pre ? pre->gridFlow : nullptr)); t_stage[0] += tick_ms() - t0; }
     DepthStageOut d;
-    SIND_TRY((depth_half ? depth_half : this)->depth_stage(depth_host, depth_dev, pre, d));
+    SIND_TRY((depth_half ? depth_half : this)->depth_stage(depth_host, depth_dev, pre, d, km));
     return fuse(maskLow, maskHigh, d, dyna_out, label_out);
 }
 
 // flow-independent half: k-means (DD:1410-1414), cluster order (DD:1428-1491), CalOccluded (DD:1493), SegAndMerge (DD:1495-1551)
-int DynaTail::depth_stage(const uint16_t* depth_host, const uint16_t* depth_dev, const OccResult* pre, DepthStageOut& out) {
+int DynaTail::depth_stage(const uint16_t* depth_host, const uint16_t* depth_dev, const OccResult* pre, DepthStageOut& out, const KmFrameResult* km) {
     HIP_TRY(hipSetDevice(cfg.device));
     double tk = tick_ms();
     #define LAP(i) { const double t_ = tick_ms(); t_stage[i] += t_ - tk; tk = t_; }
     std::vector<uint8_t> label8; float centers[KM_K][3]; int counts[KM_K];
-    SIND_TRY(kmeans(depth_dev, label8, centers, counts));
+    if (km) { label8.assign(km->label8, km->label8 + N); std::memcpy(centers, km->centers, sizeof(centers)); std::memcpy(counts, km->counts, sizeof(counts)); }
+    else SIND_TRY(kmeans(depth_dev, label8, centers, counts));
     if (keep_debug) { dbg.kmeansLabel = label8; std::memcpy(dbg.centers, centers, sizeof(centers)); }
     LAP(1)
     // nearest clusters first (DD:1428-1491)

@@ -63,6 +63,9 @@ struct sind_pipe {
     // Depth halves (k-means warm labels + their workspaces) as objects of their own, present once depth-ahead has been switched on: the
     // depth chain of step i+1 (phase A) may then run while the flow chain of step i (phase B) is still going on the same stream of frames.
     std::vector<std::unique_ptr<DynaTail>> dtails;
+    // k-means of one frame of every stream as ONE batched kernel chain (phase B then runs frame t of all streams as a round: batched k-means,
+    // then the S tails of that frame on the pool); used when there are several streams and the depth half is not run ahead
+    KMeansBatch kmb; hipStream_t km_stream = nullptr; bool batch_km = false; std::thread round_thread;
     std::vector<std::unique_ptr<PinnedBuf<uint8_t>>> upload_stage;        // page-locked staging of sind_pipe_process (host-buffer entry point), two 4 MB buffers per uploading worker
     std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
@@ -154,6 +157,8 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     if (const char* e = getenv("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
     p->depth_ahead = getenv("SIND_DEPTH_AHEAD") && atoi(getenv("SIND_DEPTH_AHEAD")) != 0;
     if (p->depth_ahead) SIND_TRY(ensure_dtails(p));
+    p->batch_km = p->S >= 2 && !(getenv("SIND_KM_BATCH") && atoi(getenv("SIND_KM_BATCH")) == 0);
+    if (p->batch_km) { SIND_TRY(make_stream(&p->km_stream, true)); SIND_TRY(p->kmb.init(p->dc, p->S, p->km_stream)); }
     p->workers.start(nworkers, cfg->device);
     SIND_TRY(p->gray.alloc(np * std::max(B, 2)));          // sind_pipe_prime converts the two priming frames through this scratch, also when S * T == 1
     SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
@@ -187,7 +192,8 @@ int sind_pipe_destroy(sind_pipe* p) {
     }
     (void)hipSetDevice(p->c.device);
     (void)hipDeviceSynchronize();
-    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream);
+    if (p->round_thread.joinable()) p->round_thread.join();
+    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream); ss.push_back(p->km_stream);
     for (size_t w = 0; w < p->worker_streams_lo.size(); w++) if (w >= p->worker_streams.size() || p->worker_streams_lo[w] != p->worker_streams[w]) ss.push_back(p->worker_streams_lo[w]); ss.push_back(p->orb_stream); ss.insert(ss.end(), p->extra_streams.begin(), p->extra_streams.end());
     if (p->ev_pool) (void)hipEventDestroy(p->ev_pool);
     if (p->ev_gray) (void)hipEventDestroy(p->ev_gray);
@@ -349,7 +355,7 @@ static void depth_task(sind_pipe* p, sind_pipe::StepBuf* sb, int k, int worker) 
     if (r != SIND_OK) { sb->depth_rc[k] = r; sb->depth_err[k] = sind_last_error(); }
     if (t + 1 < T && sb->gate[k + 1].fetch_add(1) == 1) p->workers.push(sb->depth_group, [p, sb, k](int w) { depth_task(p, sb, k + 1, w); });
 }
-static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker) {
+static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker, const KmFrameResult* km = nullptr, bool chain = true) {
     p->tails[s]->stream = p->worker_streams[worker];
     const int T = p->T, W = p->c.width, H = p->c.height; const size_t np = (size_t)W * H;
     static thread_local std::vector<uint8_t> dy, lb, dil;
@@ -357,7 +363,7 @@ static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, in
     const int k = s * T + t;
     int r = sb->depth_ahead ? p->tails[s]->flow_stage(sb->U.p + np * k, sb->V.p + np * k, sb->dout[k], dy.data(), lb.data(), sb->occ[k].gridFlow)
                             : p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k],
-                                                   p->dtails.empty() ? nullptr : (p->dtails[s]->stream = p->worker_streams[worker], p->dtails[s].get()));
+                                                   p->dtails.empty() ? nullptr : (p->dtails[s]->stream = p->worker_streams[worker], p->dtails[s].get()), km);
     if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return; }
     double* tf = p->tails[s]->t_fine; double t0 = now_ms();
     dilate15_codes(dy.data(), W, H, dil.data());
@@ -373,15 +379,30 @@ static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, in
     if (o.nkp) o.nkp[k] = (int)kk.size();
     if (o.kps) std::memcpy(o.kps + (size_t)k * o.cap, kk.data(), kk.size() * sizeof(sind_keypoint));
     if (o.desc) std::memcpy(o.desc + (size_t)k * o.cap * 32, dd.data(), dd.size());
-    if (t + 1 < T) p->workers.push(sb->tail_group, [p, sb, o, s, t](int w) { tail_task(p, sb, o, s, t + 1, w); });
+    if (chain && t + 1 < T) p->workers.push(sb->tail_group, [p, sb, o, s, t](int w) { tail_task(p, sb, o, s, t + 1, w); });
 }
 static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
     const int S = p->S;
     sb.tail_rc.assign(S, SIND_OK); sb.tail_err.assign(S, std::string());
     sind_pipe::StepBuf* sbp = &sb;
+    if (p->batch_km && !sb.depth_ahead) {
+        // rounds: frame t of every stream -- the batched k-means chain on its own stream, then the S tails of that frame on the pool
+        p->round_thread = std::thread([p, sbp, o, S] {
+            (void)pthread_setname_np(pthread_self(), "sind-rounds"); (void)hipSetDevice(p->c.device);
+            const size_t np = (size_t)p->c.width * p->c.height; std::vector<const uint8_t*> prev(S);
+            for (int t = 0; t < p->T; t++) {
+                for (int s = 0; s < S; s++) prev[s] = depth_half(p, s)->prev_km_labels();
+                const int rc = p->kmb.run(sbp->depth_dev.p + np * t, np * p->T, S, prev.data());
+                if (rc != SIND_OK) { const std::string e = sind_last_error(); for (int s = 0; s < S; s++) if (sbp->tail_rc[s] == SIND_OK) { sbp->tail_rc[s] = rc; sbp->tail_err[s] = "batched k-means: " + e; } return; }
+                for (int s = 0; s < S; s++) if (sbp->tail_rc[s] == SIND_OK) p->workers.push(sbp->tail_group, [p, sbp, o, s, t](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb.result(s), false); });
+                WorkerPool::wait(sbp->tail_group);
+            } });
+        return;
+    }
     for (int s = 0; s < S; s++) p->workers.push(sb.tail_group, [p, sbp, o, s](int w) { tail_task(p, sbp, o, s, 0, w); });
 }
 static int phase_b_finish(sind_pipe* p, sind_pipe::StepBuf& sb) {
+    if (p->round_thread.joinable()) p->round_thread.join();
     WorkerPool::wait(sb.tail_group);
     sb.pending = false;
     for (int s = 0; s < p->S; s++) if (sb.tail_rc[s] != SIND_OK) { sind_set_error("stream %d: %s", s, sb.tail_err[s].c_str()); return sb.tail_rc[s]; }

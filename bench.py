@@ -55,7 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-exact-leg", action="store_true", help="sequence workload: skip the in-order re-run of the first chunks (seam IoU, exact-mode rate)")
     ap.add_argument("--host-input", action="store_true", help="hand over HOST buffers each step (sind_pipe_process, PCIe-inclusive rate; DESIGN.md 6) instead of HBM-resident inputs")
     ap.add_argument("--thread-cpu", action="store_true", help="print the CPU seconds the live threads used inside the timed region, by thread name (stderr)")
-    ap.add_argument("--pipelined", action="store_true", help="software-pipeline consecutive steps (submit/flush); off by default: measured slower on MI355X")
+    ap.add_argument("--sync", action="store_true", help="synchronous steps (phase A, then the tails) instead of the default software pipeline in which phase A of step i+1 "
+                                                     "overlaps the tails of step i (sind_pipe_submit_dev / flush; all K steps are drained inside the timed region)")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker pool size (0 = library default, the GPU box's CPU share)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
     ap.add_argument("--rendezvous-only", action="store_true", help="ranks only meet, count themselves and exit (launcher test, needs no GPU)")
@@ -237,6 +238,7 @@ def pmc_profile():
 # ------------------------------------------------------------------------------------------------------------------ main
 def main():
     args = parse_args()
+    args.pipelined = not args.sync and not args.host_input
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 

@@ -65,7 +65,7 @@ struct sind_pipe {
     std::vector<std::unique_ptr<DynaTail>> dtails;
     // k-means of one frame of every stream as ONE batched kernel chain (phase B then runs frame t of all streams as a round: batched k-means,
     // then the S tails of that frame on the pool); used when there are several streams and the depth half is not run ahead
-    KMeansBatch kmb; hipStream_t km_stream = nullptr; bool batch_km = false; std::thread round_thread;
+    KMeansBatch kmb; hipStream_t km_stream = nullptr; bool batch_km = false; std::thread round_thread; double km_round_ms = 0; long km_rounds = 0;
     std::vector<std::unique_ptr<PinnedBuf<uint8_t>>> upload_stage;        // page-locked staging of sind_pipe_process (host-buffer entry point), two 4 MB buffers per uploading worker
     std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
@@ -185,6 +185,7 @@ int sind_pipe_destroy(sind_pipe* p) {
         if (n) fprintf(stderr, "[sind] cal_occluded: gpu+d2h %.2f pack %.2f endpoints %.2f peac %.2f contour-filter %.2f close %.2f | seg_merge: pieces %.2f sort+paint+pack %.2f alloc %.2f h2d-enqueue %.2f rag %.2f merge %.2f\n", f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5] / n, f[6] / n, f[10] / n, f[11] / n, f[7] / n, f[8] / n, f[9] / n);
         if (n) fprintf(stderr, "[sind] pieces: open %.2f contours %.2f masks %.2f lianjie %.2f centre %.2f | flow_masks host: weights %.2f sort+wait %.2f homography %.2f pack %.2f | fusion: low %.2f clusters %.2f fill %.2f out+state %.2f\n",
                        f[12] / n, f[13] / n, f[14] / n, f[15] / n, f[16] / n, f[20] / n, f[21] / n, f[22] / n, f[23] / n, f[25] / n, f[26] / n, f[27] / n, f[28] / n);
+        if (p->km_rounds) fprintf(stderr, "[sind] batched k-means: %.2f ms per round of %d frames (%ld rounds)\n", p->km_round_ms / p->km_rounds, p->S, p->km_rounds);
         if (n) fprintf(stderr, "[sind] after the tail: dilate15 %.2f output copies %.2f orb mask filter %.2f\n", f[30] / n, f[31] / n, f[32] / n);
         if (g_cpu_steps.load()) fprintf(stderr, "[sind] phase-A thread CPU per step: flow slices %.1f ms, ORB thread %.1f ms (octree threads not included)\n", g_cpu_us_flow.load() / 1e3 / g_cpu_steps.load(), g_cpu_us_orb.load() / 1e3 / g_cpu_steps.load());
         if (n) fprintf(stderr, "[sind] stream waits: %.2f ms and %.1f calls per frame (occ + tail + batch stream)\n", g_sind_wait_ns.load() / 1e6 / n, (double)g_sind_wait_calls.load() / n);
@@ -392,7 +393,9 @@ static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o
             const size_t np = (size_t)p->c.width * p->c.height; std::vector<const uint8_t*> prev(S);
             for (int t = 0; t < p->T; t++) {
                 for (int s = 0; s < S; s++) prev[s] = depth_half(p, s)->prev_km_labels();
+                const double tk = now_ms();
                 const int rc = p->kmb.run(sbp->depth_dev.p + np * t, np * p->T, S, prev.data());
+                p->km_round_ms += now_ms() - tk; p->km_rounds++;
                 if (rc != SIND_OK) { const std::string e = sind_last_error(); for (int s = 0; s < S; s++) if (sbp->tail_rc[s] == SIND_OK) { sbp->tail_rc[s] = rc; sbp->tail_err[s] = "batched k-means: " + e; } return; }
                 for (int s = 0; s < S; s++) if (sbp->tail_rc[s] == SIND_OK) p->workers.push(sbp->tail_group, [p, sbp, o, s, t](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb.result(s), false); });
                 WorkerPool::wait(sbp->tail_group);

@@ -110,9 +110,16 @@ __device__ __forceinline__ void km_count_store(const int (&c)[KM_K], int* __rest
 // first centre pass of a level: counts of the given labels
 // per-frame strides of the k-means buffers (elements): points / labels planes, count table, compacted runs, state records
 struct KmStride { size_t pt, lab, seg, comp, st; };
-__global__ void __launch_bounds__(64 * KM_WAVES) k_km_count(const int* __restrict__ labels, int n, int seg_len, int* __restrict__ segcnt, const KmState* __restrict__ st, KmStride ks) {
+// first centre pass of a level: counts of the given labels; its first thread also resets the level's state record and the pass ticket (no kernel of the
+// level has run yet, so nobody reads them concurrently)
+__global__ void __launch_bounds__(64 * KM_WAVES) k_km_count(const int* __restrict__ labels, int n, int seg_len, int* __restrict__ segcnt, KmState* __restrict__ st, KmStride ks,
+                                                            int maxCount, double eps2, int ticket_word) {
     labels += blockIdx.y * ks.lab; segcnt += blockIdx.y * ks.seg; st += blockIdx.y * ks.st;
-    if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->iter = 0; st->done = 0; st->phase = 0; st->overflow = 0; st->fix_k = -1; st->max_k = 0; st->far = 0ull; st->maxCount = maxCount; st->eps2 = eps2;
+        for (int k = 0; k < KM_K; k++) { st->cnt[k] = 0; for (int j = 0; j < 3; j++) { st->ctr[k][j] = 0.f; st->old[k][j] = 0.f; } }
+        segcnt[ticket_word] = 0;
+    }
     const int lane = threadIdx.x & 63, seg = blockIdx.x * KM_WAVES + (threadIdx.x >> 6);
     const int lo = seg * seg_len, hi = min(n, lo + seg_len);
     int c[KM_K];
@@ -212,6 +219,7 @@ __global__ void __launch_bounds__(64 * KM_WAVES) k_km_compact(const float* __res
 #define KM_WIN (64 * KM_EPL)      /* 512 samples per window step */
 #define KM_CH 2048                /* samples per LDS chunk (a multiple of KM_WIN, at least 2 * KM_WIN + KM_SER_MAX) */
 #define KM_RING (4 * KM_CH)       /* four chunk slots: two being read (a window or a serial stretch may straddle), one being written, one spare */
+#define KM_TICKET 40               /* word behind the 36 sums that counts the finished runs of a pass */
 #define KM_SER_MAX 256            /* longest stretch of plain one-by-one adds after a broken premise */
 // ring position of sample i: one pad word per eight samples, so that lane l's samples pos + 8 l + q (q fixed) sit 9 words apart -- an odd stride,
 // 32 consecutive lanes hit 32 different banks (the plain layout puts them 8 apart: a 16-way conflict on every window read)
@@ -335,55 +343,11 @@ __device__ __forceinline__ void km_chunk_store(float* __restrict__ ring, int ch,
             ring[o] = R[u].x; ring[o + 1] = R[u].y; ring[o + 2] = R[u].z; ring[o + 3] = R[u].w; }
     }
 }
-// grid = 36 runs (cluster k = blockIdx.x / 3, coordinate j = blockIdx.x % 3), 256 threads: wave 0 sums, waves 1..3 keep the ring ahead of it
-// (chunk ch + 2 goes into the ring while chunk ch is summed, chunk ch + 3 is already on its way in registers)
-__global__ void __launch_bounds__(256) k_km_seqsum(const int* __restrict__ segcnt, int nseg, const float* __restrict__ comp, int n, float* __restrict__ seqsums,
-                                                   const KmState* __restrict__ st, KmStride ks) {
-    segcnt += blockIdx.y * ks.seg; comp += blockIdx.y * ks.comp; seqsums += blockIdx.y * ks.seg; st += blockIdx.y * ks.st;
-    if (st->done) return;
-    __shared__ float ring[KM_RING_WORDS];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, k = blockIdx.x / 3, j = blockIdx.x % 3;
-    const int* tot = segcnt + nseg * KM_K;                 // cluster sizes, left behind the count table by k_km_compact
-    int start = 0; for (int q = 0; q < k; q++) start += tot[q];
-    const int nk = tot[k]; const float* p = comp + (size_t)j * n + start;
-    const int nch = (nk + KM_CH - 1) / KM_CH;              // chunks 0 .. nch are staged: the one behind the run's end is all zero (windows and stretches read past the end)
-    float4 R[KM_NR];
-    { float4 R1[KM_NR];                                    // chunks 0 and 1 by all four waves, both fetches in flight together
-      km_chunk_fetch(p, nk, 0, t, 256, R); km_chunk_fetch(p, nk, 1, t, 256, R1);
-      km_chunk_store(ring, 0, t, 256, R); km_chunk_store(ring, 1, t, 256, R1); }
-    if (wv > 0) km_chunk_fetch(p, nk, 2, t - 64, 192, R);
-    __syncthreads();
-    float acc = 0.f; int pos = 0, ser = 0;
-    for (int ch = 0; ch < nch; ch++) {
-        if (wv == 0) {
-            const int lim = min(nk, (ch + 1) * KM_CH);
-            float x[KM_EPL]; km_window(ring, lane, pos, x);
-            while (pos < lim) {
-                float xn[KM_EPL]; km_window(ring, lane, pos + KM_WIN, xn);            // the next window, read while this one is worked on (stays inside chunk ch + 1)
-                bool broke; const int from = pos;
-                pos = km_uni(km_seq_step(x, lane, acc, pos, broke));
-                if (broke) {                               // plain adds for a while; the stretch doubles as long as windows keep breaking
-                    ser = km_uni(ser ? min(2 * ser, KM_SER_MAX) : 64);
-                    km_seq_serial(ring, lane, acc, pos, ser); pos += ser;
-                    km_window(ring, lane, pos, x);
-                } else if (pos == from + KM_WIN) {
-                    ser = 0;
-                    #pragma unroll
-                    for (int q = 0; q < KM_EPL; q++) x[q] = xn[q];
-                } else km_window(ring, lane, pos, x);          // zero accumulator: the window ended at the first non-zero sample
-            }
-        } else { if (ch + 2 <= nch) km_chunk_store(ring, ch + 2, t - 64, 192, R); if (ch + 3 <= nch) km_chunk_fetch(p, nk, ch + 3, t - 64, 192, R); }
-        __syncthreads();
-    }
-    if (t == 0) seqsums[blockIdx.x] = acc;
-}
-// Centre step of one k-means iteration in ONE workgroup: take the 36 sequential sums of k_km_seqsum, then repair every empty cluster (block-wide farthest-point search over the biggest cluster, as cv::kmeans
+// Centre step of one k-means iteration in ONE workgroup: take the 36 sequential sums, then repair every empty cluster (block-wide farthest-point search over the biggest cluster, as cv::kmeans
 // does, repeated until no cluster is empty), scale, shift test, stop decision.  No host round trip and no provisioning limit.
-__global__ void __launch_bounds__(1024) k_km_update(const int* __restrict__ segcnt, int nseg, const float* __restrict__ seqsums, KmState* __restrict__ gst,
-                                                    const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                    int* __restrict__ labels, int n, KmStride ks) {
-    segcnt += blockIdx.y * ks.seg; seqsums += blockIdx.y * ks.seg; gst += blockIdx.y * ks.st; px += blockIdx.y * ks.pt; py += blockIdx.y * ks.pt; pz += blockIdx.y * ks.pt;
-    labels += blockIdx.y * ks.lab;
+// Runs in the workgroup of k_km_seqsum that finishes LAST for its frame (all pointers already belong to that frame), any block size.
+__device__ void km_centre_step(const int* __restrict__ segcnt, int nseg, const float* __restrict__ seqsums, KmState* __restrict__ gst,
+                               const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int* __restrict__ labels, int n) {
     __shared__ float sums[KM_K * 3];
     __shared__ int tot[KM_K + 1];
     __shared__ unsigned long long wbest[16];
@@ -391,7 +355,6 @@ __global__ void __launch_bounds__(1024) k_km_update(const int* __restrict__ segc
     __shared__ KmState S;                                  // the state lives in LDS while the centre step runs: the serial part below touches it
                                                            // ~100 times, and every touch of the global copy would be a dependent ~1 us round trip
     static_assert(sizeof(KmState) % 4 == 0, "KmState is copied word by word");
-    if (gst->done) return;
     const int t = threadIdx.x;
     for (int i = t; i < (int)(sizeof(KmState) / 4); i += blockDim.x) reinterpret_cast<unsigned*>(&S)[i] = reinterpret_cast<const unsigned*>(gst)[i];
     if (t < KM_K) tot[t] = segcnt[nseg * KM_K + t];
@@ -443,12 +406,63 @@ __global__ void __launch_bounds__(1024) k_km_update(const int* __restrict__ segc
     }
     for (int i = t; i < (int)(sizeof(KmState) / 4); i += blockDim.x) reinterpret_cast<unsigned*>(gst)[i] = reinterpret_cast<const unsigned*>(&S)[i];
 }
-__global__ void k_km_reset(KmState* st, int maxCount, double eps2, size_t st_stride) {
-    st += blockIdx.y * st_stride;
-    if (threadIdx.x == 0) { st->iter = 0; st->done = 0; st->phase = 0; st->overflow = 0; st->fix_k = -1; st->max_k = 0; st->far = 0ull; st->maxCount = maxCount; st->eps2 = eps2;
-        for (int k = 0; k < KM_K; k++) { st->cnt[k] = 0; for (int j = 0; j < 3; j++) { st->ctr[k][j] = 0.f; st->old[k][j] = 0.f; } } }
+// grid = 36 runs (cluster k = blockIdx.x / 3, coordinate j = blockIdx.x % 3), 256 threads: wave 0 sums, waves 1..3 keep the ring ahead of it
+// (chunk ch + 2 goes into the ring while chunk ch is summed, chunk ch + 3 is already on its way in registers)
+// The workgroup that finishes last for its frame (ticket counter behind the sums, agent-scope fences around it) runs the centre step right away:
+// one launch per pass less, and no second kernel whose only job is to wait for this one.
+__global__ void __launch_bounds__(256) k_km_seqsum(const int* __restrict__ segcnt, int nseg, const float* __restrict__ comp, int n, float* __restrict__ seqsums,
+                                                   KmState* __restrict__ st, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                   int* __restrict__ labels, KmStride ks) {
+    segcnt += blockIdx.y * ks.seg; comp += blockIdx.y * ks.comp; seqsums += blockIdx.y * ks.seg; st += blockIdx.y * ks.st;
+    if (st->done) return;
+    __shared__ float ring[KM_RING_WORDS];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, k = blockIdx.x / 3, j = blockIdx.x % 3;
+    const int* tot = segcnt + nseg * KM_K;                 // cluster sizes, left behind the count table by k_km_compact
+    int start = 0; for (int q = 0; q < k; q++) start += tot[q];
+    const int nk = tot[k]; const float* p = comp + (size_t)j * n + start;
+    const int nch = (nk + KM_CH - 1) / KM_CH;              // chunks 0 .. nch are staged: the one behind the run's end is all zero (windows and stretches read past the end)
+    float4 R[KM_NR];
+    { float4 R1[KM_NR];                                    // chunks 0 and 1 by all four waves, both fetches in flight together
+      km_chunk_fetch(p, nk, 0, t, 256, R); km_chunk_fetch(p, nk, 1, t, 256, R1);
+      km_chunk_store(ring, 0, t, 256, R); km_chunk_store(ring, 1, t, 256, R1); }
+    if (wv > 0) km_chunk_fetch(p, nk, 2, t - 64, 192, R);
+    __syncthreads();
+    float acc = 0.f; int pos = 0, ser = 0;
+    for (int ch = 0; ch < nch; ch++) {
+        if (wv == 0) {
+            const int lim = min(nk, (ch + 1) * KM_CH);
+            float x[KM_EPL]; km_window(ring, lane, pos, x);
+            while (pos < lim) {
+                float xn[KM_EPL]; km_window(ring, lane, pos + KM_WIN, xn);            // the next window, read while this one is worked on (stays inside chunk ch + 1)
+                bool broke; const int from = pos;
+                pos = km_uni(km_seq_step(x, lane, acc, pos, broke));
+                if (broke) {                               // plain adds for a while; the stretch doubles as long as windows keep breaking
+                    ser = km_uni(ser ? min(2 * ser, KM_SER_MAX) : 64);
+                    km_seq_serial(ring, lane, acc, pos, ser); pos += ser;
+                    km_window(ring, lane, pos, x);
+                } else if (pos == from + KM_WIN) {
+                    ser = 0;
+                    #pragma unroll
+                    for (int q = 0; q < KM_EPL; q++) x[q] = xn[q];
+                } else km_window(ring, lane, pos, x);          // zero accumulator: the window ended at the first non-zero sample
+            }
+        } else { if (ch + 2 <= nch) km_chunk_store(ring, ch + 2, t - 64, 192, R); if (ch + 3 <= nch) km_chunk_fetch(p, nk, ch + 3, t - 64, 192, R); }
+        __syncthreads();
+    }
+    __shared__ int s_last;
+    if (t == 0) {
+        seqsums[blockIdx.x] = acc;
+        __threadfence();                                   // release: the sum is visible device-wide before the ticket is taken
+        int* ticket = reinterpret_cast<int*>(seqsums) + KM_TICKET;
+        const int got = atomicAdd(ticket, 1);
+        s_last = got == (int)gridDim.x - 1;
+        if (s_last) *ticket = 0;                           // next pass starts from zero again (nobody else touches it any more)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                       // acquire: the other 35 sums (written by other CUs) are read from memory, not from a stale L1 line
+    if (px) km_centre_step(segcnt, nseg, seqsums, st, px + blockIdx.y * ks.pt, py + blockIdx.y * ks.pt, pz + blockIdx.y * ks.pt, labels + blockIdx.y * ks.lab, n);
 }
-
 __global__ void k_labels_to_u8(const int* __restrict__ labels, uint8_t* __restrict__ out, int n, size_t lab_stride, size_t out_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     labels += blockIdx.y * lab_stride; out += blockIdx.y * out_stride;
@@ -679,13 +693,12 @@ int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const f
     const int nb = std::min(divup(n, 1024), KM_MAX_BLOCKS), nseg = nb * 4, seg_len = divup(divup(n, nseg), 64) * 64, iters = std::max(maxCount, 2);
     float* seqsums = reinterpret_cast<float*>(segcnt + (KM_MAX_BLOCKS * 4 + 1) * KM_K);
     const KmStride ks{pt_stride, lab_stride, seg_stride, comp_stride, st_stride};
-    hipLaunchKernelGGL(k_km_reset, dim3(1, B), dim3(64), 0, s, st, maxCount, eps2, st_stride);
-    hipLaunchKernelGGL(k_km_count, dim3(nb, B), dim3(256), 0, s, labels, n, seg_len, segcnt, st, ks);
+    const int ticket_word = (KM_MAX_BLOCKS * 4 + 1) * KM_K + KM_TICKET;
+    hipLaunchKernelGGL(k_km_count, dim3(nb, B), dim3(256), 0, s, labels, n, seg_len, segcnt, st, ks, maxCount, eps2, ticket_word);
     for (int it = 0; it < iters; it++) {           // every kernel is a no-op for a frame whose centre step has set st->done
         if (it > 0) hipLaunchKernelGGL(k_km_assign_count, dim3(nb, B), dim3(256), 0, s, px, py, pz, labels, n, seg_len, segcnt, st, ks);
         hipLaunchKernelGGL(k_km_compact, dim3(nb, B), dim3(256), 0, s, px, py, pz, labels, n, seg_len, nseg, segcnt, comp, segcnt + nseg * KM_K, st, ks);
-        hipLaunchKernelGGL(k_km_seqsum, dim3(KM_K * 3, B), dim3(256), 0, s, segcnt, nseg, comp, n, seqsums, st, ks);
-        hipLaunchKernelGGL(k_km_update, dim3(1, B), dim3(1024), 0, s, segcnt, nseg, seqsums, st, px, py, pz, labels, n, ks);
+        hipLaunchKernelGGL(k_km_seqsum, dim3(KM_K * 3, B), dim3(256), 0, s, segcnt, nseg, comp, n, seqsums, st, px, py, pz, labels, ks);
     }
     return SIND_OK;
 }
@@ -693,9 +706,10 @@ int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const f
 int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev /* 2 * KM_K ints + 64 floats + a KmState */, float* out_host) {
     int* segcnt = scratch_dev; float* sums = reinterpret_cast<float*>(scratch_dev + 2 * KM_K); KmState* st = reinterpret_cast<KmState*>(scratch_dev + 2 * KM_K + 64);
     int h[2 * KM_K] = {n}; h[KM_K] = n;                     // one table row + the totals row: everything is cluster 0, run 0 = coordinate plane 0
+    HIP_TRY(hipMemsetAsync(scratch_dev, 0, (2 * KM_K + 64) * sizeof(int), s));
     HIP_TRY(hipMemcpyAsync(segcnt, h, sizeof(h), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(st, 0, sizeof(KmState), s));
-    hipLaunchKernelGGL(k_km_seqsum, dim3(1), dim3(256), 0, s, segcnt, 1, x_dev, n, sums, st, KmStride{0, 0, 0, 0, 0});
+    hipLaunchKernelGGL(k_km_seqsum, dim3(1), dim3(256), 0, s, segcnt, 1, x_dev, n, sums, st, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (int*)nullptr, KmStride{0, 0, 0, 0, 0});
     HIP_TRY(hipMemcpyAsync(out_host, sums, sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SIND_OK;

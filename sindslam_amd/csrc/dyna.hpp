@@ -66,6 +66,7 @@ private:
 class DynaTail {
 public:
     DynaConfig cfg; hipStream_t stream = nullptr; DynaDebug dbg; bool keep_debug = false;
+    int piece_threads = 1;        // host threads for the per-cluster piece extraction of SegAndMerge (> 1 only when host cores idle: a single stream in the in-order mode)
     int init(const DynaConfig& c, hipStream_t s);
     ~DynaTail() { for (auto& g : kmGraph) if (g) (void)hipGraphExecDestroy(g); }
     // depth_host: H x W u16 (host); depth_dev: same on the device; U/V: device full-resolution flow of this frame.

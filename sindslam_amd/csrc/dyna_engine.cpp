@@ -8,6 +8,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include "dyna.hpp"
 #include <chrono>
 #include "host/rng.hpp"
@@ -399,12 +401,13 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     const EllipseElem e4(4), e9(9), e10(10);
     const BitImg occDil = occ1.dilated(e10);
     const float depth_weight = 1.5f;
-    for (int i = 0; i + 1 < (int)allLabels.size(); i++) {
+    // pieces of one depth cluster (DD:668-760); the clusters are independent, the result keeps the cluster order
+    auto pieces_of = [&](int i, std::vector<Piece>& out, bool timed) {
         const BitImg& orig = allLabels[i];
         double tq = tick_ms();
-        #define QLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; }
+        #define QLAP(i) { if (timed) { const double t_ = tick_ms(); t_fine[i] += t_ - tq; tq = t_; } }
         BitImg each = orig; each.andnot(occ1);
-        { const Rect eb = each.bbox(); if (eb.empty()) continue; each = each.opened_rows(e4, eb.y0, eb.y1); }
+        { const Rect eb = each.bbox(); if (eb.empty()) return; each = each.opened_rows(e4, eb.y0, eb.y1); }
         QLAP(12)
         std::vector<Contour> contours; find_contours(each, contours, true);
         QLAP(13)
@@ -434,9 +437,19 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
                     f3 += pzv; } } }
               p.cz = f3 / p.area; }
             QLAP(16)
-            all.push_back(std::move(p));
+            out.push_back(std::move(p));
         }
-    }
+        #undef QLAP
+    };
+    const int nCl = std::max(0, (int)allLabels.size() - 1);
+    if (piece_threads > 1 && nCl > 1) {        // a stream alone on the GPU (in-order sequence mode) leaves host cores idle: the clusters go to a few helper threads
+        std::vector<std::vector<Piece>> per(nCl); std::atomic<int> next{0}; std::vector<std::thread> team;
+        auto work = [&] { for (int i; (i = next.fetch_add(1)) < nCl;) pieces_of(i, per[i], false); };
+        for (int t = 1; t < std::min(piece_threads, nCl); t++) team.emplace_back(work);
+        work();
+        for (auto& t : team) t.join();
+        for (auto& v : per) for (Piece& q : v) all.push_back(std::move(q));
+    } else for (int i = 0; i < nCl; i++) pieces_of(i, all, true);
     FLAP(6)
     const int C = (int)all.size();
     dbg.nClusters = C;

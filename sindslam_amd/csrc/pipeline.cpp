@@ -152,7 +152,8 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
         else SIND_TRY(make_stream(&p->worker_streams_lo[w], false));
         p->occ_tails[w].reset(new DynaTail()); SIND_TRY(p->occ_tails[w]->init(p->dc, p->worker_streams_lo[w]));
     }
-    for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers])); }
+    for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers]));
+        if (p->S == 1) p->tails[s]->piece_threads = std::max(1, std::min(4, cpu_share / 3)); }       // one stream: the tails are two serial chains, host cores idle
     p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads
     if (const char* e = getenv("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
     p->depth_ahead = getenv("SIND_DEPTH_AHEAD") && atoi(getenv("SIND_DEPTH_AHEAD")) != 0;
@@ -180,7 +181,9 @@ int sind_pipe_destroy(sind_pipe* p) {
     if (getenv("SIND_TAIL_TIMING")) {
         double t[6] = {0}; long n = 0;
         for (auto& tl : p->tails) if (tl) { for (int i = 0; i < 6; i++) t[i] += tl->t_stage[i]; n += tl->n_frames; }       // (a handle whose creation failed half-way has empty slots)
+        for (auto& tl : p->dtails) if (tl) for (int i = 0; i < 6; i++) t[i] += tl->t_stage[i];              // depth halves running ahead (their frames are counted by the flow halves)
         double f[40] = {0}; for (auto& tl : p->tails) if (tl) for (int i = 0; i < 40; i++) f[i] += tl->t_fine[i];
+        for (auto& tl : p->dtails) if (tl) for (int i = 0; i < 40; i++) f[i] += tl->t_fine[i];
         for (auto& tl : p->occ_tails) if (tl) for (int i = 0; i < 40; i++) f[i] += tl->t_fine[i];
         if (n) fprintf(stderr, "[sind] cal_occluded: gpu+d2h %.2f pack %.2f endpoints %.2f peac %.2f contour-filter %.2f close %.2f | seg_merge: pieces %.2f sort+paint+pack %.2f alloc %.2f h2d-enqueue %.2f rag %.2f merge %.2f\n", f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5] / n, f[6] / n, f[10] / n, f[11] / n, f[7] / n, f[8] / n, f[9] / n);
         if (n) fprintf(stderr, "[sind] pieces: open %.2f contours %.2f masks %.2f lianjie %.2f centre %.2f | flow_masks host: weights %.2f sort+wait %.2f homography %.2f pack %.2f | fusion: low %.2f clusters %.2f fill %.2f out+state %.2f\n",
@@ -224,6 +227,7 @@ static int ensure_dtails(sind_pipe* p) {
     for (int s = 0; s < p->S; s++) {
         d[s].reset(new DynaTail()); SIND_TRY(d[s]->init(p->dc, p->worker_streams[s % p->worker_streams.size()]));
         st.resize(p->tails[s]->state_bytes()); p->tails[s]->save_state(st.data(), false, true); d[s]->load_state(st.data(), false, true);      // the warm labels move over
+        d[s]->piece_threads = p->tails[s]->piece_threads;
     }
     p->dtails.swap(d); return SIND_OK;
 }

@@ -36,7 +36,7 @@ int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float
 int sind_debug_seqsum(const float* x, int n, int device, float* out) {
     if (!x || !out || n < 0) return SIND_E_ARG;
     HIP_TRY(hipSetDevice(device));
-    DevBuf<float> xd; DevBuf<int> scratch; SIND_TRY(xd.alloc((size_t)std::max(n, 1))); SIND_TRY(scratch.alloc(2 * KM_K + 64 + sizeof(sind::KmState) / 4 + 4));
+    DevBuf<float> xd; DevBuf<int> scratch; SIND_TRY(xd.alloc((size_t)std::max(n, 1) + 8)); SIND_TRY(scratch.alloc(2 * KM_K + 64 + sizeof(sind::KmState) / 4 + 4));
     HIP_TRY(hipMemcpy(xd.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     return sind::debug_seqsum(nullptr, xd.p, n, scratch.p, out);
 }

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(64 * KM_WAVES) k_km_compact(const float* __res
 #define KM_CH 2048                /* samples per LDS chunk (a multiple of KM_WIN, at least 2 * KM_WIN + KM_SER_MAX) */
 #define KM_RING (4 * KM_CH)       /* four chunk slots: two being read (a window or a serial stretch may straddle), one being written, one spare */
 #define KM_TICKET 40               /* word behind the 36 sums that counts the finished runs of a pass */
-#define KM_SER_MAX 256            /* longest stretch of plain one-by-one adds after a broken premise */
+#define KM_SER_MAX 512            /* longest stretch of plain one-by-one adds after a broken premise */
 // ring position of sample i: one pad word per eight samples, so that lane l's samples pos + 8 l + q (q fixed) sit 9 words apart -- an odd stride,
 // 32 consecutive lanes hit 32 different banks (the plain layout puts them 8 apart: a 16-way conflict on every window read)
 #define KM_RING_WORDS (KM_RING + KM_RING / 8)

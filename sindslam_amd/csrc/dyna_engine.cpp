@@ -108,7 +108,7 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     SIND_TRY(edge.alloc(N)); SIND_TRY(edgeTmp.alloc(N)); SIND_TRY(total.alloc(N)); SIND_TRY(depthN.alloc(N)); SIND_TRY(occ2_d.alloc(N));
     SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc((size_t)2 * N)); SIND_TRY(mag.alloc(N));       // low_d: low mask, then high mask (one D2H)
     SIND_TRY(kpart.alloc((size_t)(KM_MAX_BLOCKS * 4 + 1) * KM_K + 64));       // count table, totals row, the 36 sums
-    SIND_TRY(kcomp.alloc((size_t)3 * N)); SIND_TRY(umax_d.alloc(2));
+    SIND_TRY(kcomp.alloc((size_t)3 * N + 8)); /* + 8: k_km_seqsum's window loads may touch up to 7 floats behind the last run */ SIND_TRY(umax_d.alloc(2));
     SIND_TRY(h_grid.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(h_hist.alloc(257)); SIND_TRY(h_ab.alloc((size_t)2 * N)); SIND_TRY(h_lab8.alloc(N));
     SIND_TRY(h_kstate.alloc(4)); SIND_TRY(h_blocks.alloc((size_t)(W / 16) * (H / 16)));
     { // RAG workspaces for up to 64 pieces up front: a later (re)allocation synchronises the whole device, i.e. waits for the
@@ -304,7 +304,7 @@ int KMeansBatch::init(const DynaConfig& c, int maxB_, hipStream_t s) {
     const size_t B = (size_t)maxB;
     for (int l = 1; l < 4; l++) SIND_TRY(dpyr[l].alloc(((size_t)N >> (2 * l)) * B));
     for (int l = 0; l < 4; l++) SIND_TRY(lab[l].alloc(((size_t)N >> (2 * l)) * B));
-    SIND_TRY(px.alloc((size_t)N * B)); SIND_TRY(py.alloc((size_t)N * B)); SIND_TRY(pz.alloc((size_t)N * B)); SIND_TRY(comp.alloc((size_t)3 * N * B));
+    SIND_TRY(px.alloc((size_t)N * B)); SIND_TRY(py.alloc((size_t)N * B)); SIND_TRY(pz.alloc((size_t)N * B)); SIND_TRY(comp.alloc((size_t)3 * N * B + 8));
     SIND_TRY(seg.alloc((size_t)KM_SEG_WORDS * B)); SIND_TRY(use_prev_d.alloc(B)); SIND_TRY(labPrev8.alloc((size_t)N * B)); SIND_TRY(lab8.alloc((size_t)N * B)); SIND_TRY(kstate.alloc(4 * B));
     SIND_TRY(h_prev.alloc((size_t)N * B)); SIND_TRY(h_lab8.alloc((size_t)N * B)); SIND_TRY(h_state.alloc(4 * B)); SIND_TRY(h_use_prev.alloc(B));
     res.resize(maxB);

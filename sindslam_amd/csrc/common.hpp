@@ -36,6 +36,24 @@ void sind_set_error(const char* fmt, ...);
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 
+// CPU tokens: the GPU boxes bound a process to a CPU quota (cgroup cpu.max, 16 cores per GPU on this pool); more runnable threads than that burn the
+// quota early in a 100 ms period and the kernel then stalls EVERY thread of the process -- the flow's launch threads included -- until the period ends
+// (bench.py reports it as cpu_quota.throttled_periods).  Pool tasks therefore hold a token while they compute and hand it back while they wait for
+// the GPU (sind_stream_wait / sind_event_wait do that themselves), so that at most `capacity` of them are runnable at any time.
+#include <condition_variable>
+#include <mutex>
+struct SindHostGate {
+    std::mutex m; std::condition_variable cv; int free_tokens = 1 << 20;
+    void set_capacity(int n) { std::lock_guard<std::mutex> lk(m); free_tokens = n; cv.notify_all(); }
+    void acquire() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return free_tokens > 0; }); free_tokens--; }
+    void release() { { std::lock_guard<std::mutex> lk(m); free_tokens++; } cv.notify_one(); }
+};
+extern SindHostGate g_sind_gate; extern thread_local bool t_sind_has_token;
+struct SindTokenPause {        // scope in which a token holder does not need its token (a wait for the GPU)
+    bool had; SindTokenPause() : had(t_sind_has_token) { if (had) { t_sind_has_token = false; g_sind_gate.release(); } }
+    ~SindTokenPause() { if (had) { g_sind_gate.acquire(); t_sind_has_token = true; } }
+};
+
 // Host wait for a stream that does not burn a core.  hipStreamSynchronize spins (measured on MI355X: CPU time == wall time), and a
 // GPU box bounds the CPU share of a process (16 cores per GPU on this pool): a spinning waiter takes that share away from the host
 // stages of the other streams.  Short waits stay hot (a few queries), long ones sleep between queries.
@@ -44,7 +62,7 @@ static inline hipError_t sind_stream_wait(hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipErrorNotReady;
     for (int i = 0; i < 8 && e == hipErrorNotReady; i++) e = hipStreamQuery(s);
-    while (e == hipErrorNotReady) { std::this_thread::sleep_for(std::chrono::microseconds(20)); e = hipStreamQuery(s); }
+    if (e == hipErrorNotReady) { SindTokenPause pause; while (e == hipErrorNotReady) { std::this_thread::sleep_for(std::chrono::microseconds(20)); e = hipStreamQuery(s); } }
     g_sind_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
     g_sind_wait_calls.fetch_add(1, std::memory_order_relaxed);
     return e;
@@ -53,7 +71,7 @@ static inline hipError_t sind_stream_wait(hipStream_t s) {
 // Same for an event: used to bound how far a launching thread runs ahead of the GPU (a HIP launch into a full queue spins)
 static inline hipError_t sind_event_wait(hipEvent_t ev) {
     hipError_t e = hipEventQuery(ev);
-    while (e == hipErrorNotReady) { std::this_thread::sleep_for(std::chrono::microseconds(50)); e = hipEventQuery(ev); }
+    if (e == hipErrorNotReady) { SindTokenPause pause; while (e == hipErrorNotReady) { std::this_thread::sleep_for(std::chrono::microseconds(50)); e = hipEventQuery(ev); } }
     return e;
 }
 

@@ -39,7 +39,9 @@ public:
             for (;;) {
                 std::pair<std::function<void(int)>, TaskGroup*> job;
                 { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return stop || !q.empty(); }); if (q.empty()) return; job = std::move(q.front()); q.pop_front(); }
+                g_sind_gate.acquire(); t_sind_has_token = true;          // a CPU token while the task computes (handed back inside every wait for the GPU)
                 job.first(i);
+                t_sind_has_token = false; g_sind_gate.release();
                 { std::lock_guard<std::mutex> lk(job.second->m); if (--job.second->left == 0) job.second->cv.notify_all(); }
             } });
     }
@@ -82,6 +84,9 @@ struct sind_pipe {
         TaskGroup occ_group, tail_group; std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
     } sb[2];
     int cur = 0; int occ_workers = 24;
+    // CPU tokens (common.hpp) for the software-pipelined steps, where CalOccluded runners and tails compete for the quota (measured: throttled periods 7 -> 2
+    // of 22, +1 %); synchronous steps run ungated -- there the hand-over of tokens at every GPU wait costs more than the throttling (tails 145 -> 173 ms)
+    int cpu_tokens = 15;
     // Optional schedule of the synchronous step: run the depth half of the tails (k-means, SegAndMerge) underneath the dense flow.
     // Parity-tested, off by default: the tails phase shrinks from ~75 to ~23 ms, but the solver loses as much to the ~13 k extra small
     // launches it then shares the GPU with (dense flow 232 -> 287 ms at high stream priority; at normal priority the chains starve).
@@ -154,6 +159,7 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     }
     for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers]));
         if (p->S == 1) p->tails[s]->piece_threads = std::max(1, std::min(4, cpu_share / 3)); }       // one stream: the tails are two serial chains, host cores idle
+    p->cpu_tokens = getenv("SIND_CPU_TOKENS") ? std::max(1, atoi(getenv("SIND_CPU_TOKENS"))) : std::max(2, cpu_share - 1);       // one core stays with the flow launch threads, the ORB thread and the round driver (they mostly sleep)
     p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads
     if (const char* e = getenv("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
     p->depth_ahead = getenv("SIND_DEPTH_AHEAD") && atoi(getenv("SIND_DEPTH_AHEAD")) != 0;
@@ -429,6 +435,7 @@ int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* 
                           sind_keypoint* kps, int cap, int* nkp, uint8_t* desc) {
     SIND_TRY(check_inputs(p, bgr_dev, depth_dev));
     if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_process: a submitted step is still pending, call sind_pipe_flush first"); return SIND_E_STATE; }
+    g_sind_gate.set_capacity(1 << 20);                 // no pool task is running between two calls: safe to re-base the token count
     double t[4]; const double t0 = now_ms();
     SIND_TRY(phase_a(p, p->sb[0], bgr_dev, depth_dev, t, p->depth_ahead));
     const PipeOut o{dyna, label, mask_dil, kps, cap, nkp, desc};
@@ -443,6 +450,7 @@ int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* 
 int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* depth_dev, uint8_t* dyna, uint8_t* label, uint8_t* mask_dil,
                          sind_keypoint* kps, int cap, int* nkp, uint8_t* desc, int* have_output) {
     SIND_TRY(check_inputs(p, bgr_dev, depth_dev));
+    g_sind_gate.set_capacity(p->cpu_tokens);
     const int prev = p->cur ^ 1;
     const bool has_prev = p->sb[prev].pending;
     if (have_output) *have_output = has_prev ? 1 : 0;

@@ -401,7 +401,7 @@ def main():
                     "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
         if rank == 0 and not args.no_exact_leg:
             KT, WT = K * T, Wm * T
-            E = max(min(WT + 3 * KT, 160), min(KT + WT + 8, WT + 2 * KT))       # frames [2, 2 + E): chunk 0 and (part of) the chunks after it
+            E = max(min(WT + 20 * KT, 320), min(KT + WT + 8, WT + 2 * KT))      # frames [2, 2 + E): chunk 0 and (part of) the chunks after it; long enough for a steady-state rate
             E = min(E, WT + world * S * KT)
             Te = 32 if E >= 64 else 16
             ex = Pipeline(1, Te, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],

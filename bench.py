@@ -59,6 +59,7 @@ def parse_args(argv=None):
                                                      "overlaps the tails of step i (sind_pipe_submit_dev / flush; all K steps are drained inside the timed region)")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker pool size (0 = library default, the GPU box's CPU share)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
+    ap.add_argument("--collective-at-1", action="store_true", help="with one rank, still create the process group and run the per-step mask gather (RCCL calls at world size 1)")
     ap.add_argument("--rendezvous-only", action="store_true", help="ranks only meet, count themselves and exit (launcher test, needs no GPU)")
     return ap.parse_args(argv)
 
@@ -290,10 +291,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     local = local % torch.cuda.device_count()          # rehearsal on a 1-GPU box: ranks share the card
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # a process group exists for several ranks, and for ONE rank when --collective-at-1 asks for it (the RCCL gather path on a single card: same calls,
+    # same buffers, world size 1 -- what can be rehearsed of the multi-GPU path on a one-GPU box)
+    pg = world > 1 or args.collective_at_1
+    if pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
         dist.init_process_group(args.backend, rank=rank, world_size=world)     # backend "nccl" is RCCL on ROCm
-    comm_dev = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
+    comm_dev = "cuda" if (pg and args.backend == "nccl") else "cpu"
 
     from sindslam_amd.pipeline import Pipeline
     H, W = cfg["height"], cfg["width"]
@@ -323,7 +327,7 @@ def main():
     def gather(step_index=None):
         """RCCL all_gather of this step's per-frame dynamic masks over xGMI (page-locked source, persistent device buffers); in the sequence
         workload the gathered block lands in the sequence-ordered array.  The upload is complete before the next step may rewrite the source."""
-        if world > 1:
+        if pg:
             m = pipe.dyna_pinned if pipe.dyna_pinned is not None else torch.from_numpy(pipe.dyna)
             if comm_dev == "cuda":
                 if "dev" not in gbuf:
@@ -353,7 +357,7 @@ def main():
         pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather(i)
         if i == 0:                          # the first streams' first T results, for the parity figures below
             first_dyna, first_kps = parity_sample()
-    if world > 1:
+    if pg:
         dist.barrier()
     torch.cuda.synchronize()
     thr0 = cgroup_throttle()
@@ -377,13 +381,13 @@ def main():
     if args.pipelined and pipe.flush():      # drain the last step inside the timed region
         gather(pending_step)
     torch.cuda.synchronize()
-    if world > 1:
+    if pg:
         dist.barrier()
     th1 = thread_cpu_seconds() if args.thread_cpu else None
     thr1 = cgroup_throttle()
     dt = time.perf_counter() - t0; cpu_busy = (time.process_time() - c0) / dt      # host cores this rank kept busy (all threads)
     ranks_seen = 1
-    if world > 1:
+    if pg:
         tt = torch.tensor([dt], device=comm_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
         rs = torch.ones(1, device=comm_dev); dist.all_reduce(rs); ranks_seen = int(rs.item())
     pairs = S * T * K * world
@@ -397,7 +401,7 @@ def main():
     seq_info = None
     if workload == "sequence":
         seq_info = {"frames": seq_frames, "owned_frames": world * S * K * T, "chunks": world * S, "chunk_frames": K * T, "chunk_warmup_frames": Wm * T,
-                    "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if world > 1 else "single rank (no collective)",
+                    "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if pg else "single rank (no collective)",
                     "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
         if rank == 0 and not args.no_exact_leg:
             KT, WT = K * T, Wm * T
@@ -419,16 +423,18 @@ def main():
                 exact[prev * Te:(prev + 1) * Te] = ex.dyna[0]
             te = time.perf_counter() - te0; ex.close()
             sm = seq_masks.reshape(world * S, K * T, H, W)
-            ious = []; seam = []
+            ious = []; seam = []; inter_sum = union_sum = 0
             for f in range(2 + WT, 2 + E):                   # owned frame f belongs to chunk g at offset o
                 g, o = divmod(f - 2 - WT, KT)
                 if g < 1 or g >= world * S:
                     continue                                  # chunk 0 starts like the sequential run: identical by construction
                 a_ = sm[g, o].cpu().numpy() == 255; b_ = exact[f - 2] == 255; u = np.logical_or(a_, b_).sum()
-                v = 1.0 if u == 0 else float(np.logical_and(a_, b_).sum() / u); ious.append(v)
+                it_ = np.logical_and(a_, b_).sum(); inter_sum += int(it_); union_sum += int(u)
+                v = 1.0 if u == 0 else float(it_ / u); ious.append(v)
                 if o == 0: seam.append(v)
             seq_info.update({"seam_iou_mean": float(np.mean(ious)) if ious else None, "seam_iou_min": float(np.min(ious)) if ious else None,
-                             "seam_iou_first_frames": seam, "seam_frames_compared": len(ious),
+                             "seam_iou_pooled": (inter_sum / union_sum) if union_sum else None, "seam_iou_below_0.99": int(sum(v < 0.99 for v in ious)),
+                             "seam_iou_first_frames": seam[:8], "seam_frames_compared": len(ious),
                              "seam_note": "chunked (throughput) mode vs the in-order run on the same GPU code, frames of the chunks after the first; the chunked mode rebuilds the tail "
                                           "state in the warm-up frames and returns valid but not identical masks -- parity (IoU >= 0.99 vs the oracle) holds for the in-order mode",
                              "exact_mode": {"frames": E, "frames_per_step": Te, "fps": E / te,
@@ -482,7 +488,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     pipe.close()
-    if world > 1:
+    if pg:
         dist.destroy_process_group()
 
 

@@ -273,8 +273,10 @@ def main():
         def frames_of_stream(s, count):
             return bgr[s, :count], depth[s, :count]
     else:
-        if Wm < 1:
-            raise SystemExit("bench.py --workload sequence needs --warmup >= 1: the warm-up steps are the chunks' state warm-up frames")
+        # the warm-up steps are the chunks' state warm-up frames: a chunk re-synchronises with the sequential run within ~16-24 frames
+        # (profiles/r02/seam_iou_by_warmup.txt: 4 or 8 frames leave IoU 0.05-0.9 at some seams, 16 frames >= 0.98; bench: 20 frames -> mean 0.9995,
+        # 4 of 220 frames below 0.99), so at least 24 run untimed
+        Wm = max(Wm, -(-24 // T)); nsteps = K + Wm
         P = 50; ndata = nsteps
         base_b, base_d = base_frames(cfg, P, 12345)           # every rank builds the same sequence
         chunk0 = rank * S
@@ -401,6 +403,7 @@ def main():
     seq_info = None
     if workload == "sequence":
         seq_info = {"frames": seq_frames, "owned_frames": world * S * K * T, "chunks": world * S, "chunk_frames": K * T, "chunk_warmup_frames": Wm * T,
+                    "chunk_overhead": "every chunk after the first processes %d warm-up frames for %d owned ones (+%.0f %% work; they run in the bench's untimed warm-up steps)" % (Wm * T, K * T, 100.0 * Wm / K),
                     "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if pg else "single rank (no collective)",
                     "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
         if rank == 0 and not args.no_exact_leg:

@@ -5,12 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from sindslam_amd.sequence import plan_chunks, process_sequence
 from sindslam_amd.synth import SyntheticStream, TUM3
 from sindslam_amd.dyna import DynaDetect
-n, S, T = 34, 4, 2
+n, S, T = 66, 4, 2
 bgr, depth = SyntheticStream(seed=4242).frames(0, n)
 dd = DynaDetect(bgr[0], bgr[0].copy(), TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
 ref = [None] + [dd.DetectDynaArea(bgr[f], depth[f], f)[0] for f in range(1, n)]
 dd.close()
-for W in (0, 2, 4, 8):
+for W in (0, 4, 8, 16):
     got = process_sequence(bgr, depth, TUM3, streams=S, frames_per_step=T, warmup=W, want_keypoints=False)
     ious = []
     for f in range(1, n):

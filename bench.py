@@ -104,10 +104,18 @@ def _gen_frame(a):
     return _GEN[a[:4]].frame(t)
 
 
-def base_frames(cfg, n, seed):
-    """n consecutive frames of the synthetic generator, produced by a few forked workers (numpy only -- called before torch / HIP exist)"""
+def base_frames(cfg, n, seed, nseeds=1):
+    """n consecutive frames of the synthetic generator (for nseeds > 1: of nseeds different scenes, stacked on a leading axis), produced by a few
+    forked workers (numpy only -- called before torch / HIP exist)"""
     import multiprocessing as mp
     import numpy as np
+    if nseeds > 1:
+        jobs = [(cfg["width"], cfg["height"], seed + 1000 * k, cfg["intr"], t) for k in range(nseeds) for t in range(n)]
+        nw = max(1, min(8, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+        with mp.get_context("fork").Pool(nw) as pool:
+            fr = pool.map(_gen_frame, jobs, chunksize=1)
+        b = np.stack([f[0] for f in fr]); d = np.stack([f[1] for f in fr])
+        return b.reshape((nseeds, n) + b.shape[1:]), d.reshape((nseeds, n) + d.shape[1:])
     jobs = [(cfg["width"], cfg["height"], seed, cfg["intr"], t) for t in range(n)]
     nw = max(1, min(8, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     if nw > 1:
@@ -119,17 +127,20 @@ def base_frames(cfg, n, seed):
 
 
 def stream_variants(base_b, base_d, S):
-    """cheap per-stream variants (flips / gain) of one base sequence so that the streams differ"""
+    """per-stream inputs: stream s shows scene s % (number of scenes) (base_b / base_d may carry a leading scene axis), mirrored / dimmed by the
+    higher bits of s, so that the streams differ (3 scenes x 4 flips x 4 gains = 48 distinct streams)"""
     import numpy as np
-    F = base_b.shape[0]
-    bgr = np.empty((S, F) + base_b.shape[1:], np.uint8); depth = np.empty((S, F) + base_d.shape[1:], np.uint16)
-    for s in range(S):
-        b, d = base_b, base_d
+    scenes = base_b.shape[0] if base_b.ndim == 5 else 1
+    if base_b.ndim == 4: base_b, base_d = base_b[None], base_d[None]
+    F = base_b.shape[1]
+    bgr = np.empty((S, F) + base_b.shape[2:], np.uint8); depth = np.empty((S, F) + base_d.shape[2:], np.uint16)
+    for s0 in range(S):
+        b, d = base_b[s0 % scenes], base_d[s0 % scenes]; s = s0 // scenes
         if s & 1: b, d = b[:, :, ::-1], d[:, :, ::-1]
         if s & 2: b, d = b[:, ::-1], d[:, ::-1]
         g = 1.0 - 0.04 * ((s >> 2) % 4)
-        bgr[s] = np.clip(b.astype(np.float32) * g, 0, 255).astype(np.uint8) if g != 1.0 else b
-        depth[s] = d
+        bgr[s0] = np.clip(b.astype(np.float32) * g, 0, 255).astype(np.uint8) if g != 1.0 else b
+        depth[s0] = d
     return bgr, depth
 
 
@@ -267,7 +278,7 @@ def main():
     # ---- synthetic input on the host, before torch / HIP are loaded (the frame generator forks workers)
     if workload == "streams":
         ndata = min(nsteps, 12)             # distinct steps of input kept in host + device memory; longer runs cycle through them (the jump at the wrap is just another large-motion pair)
-        base_b, base_d = base_frames(cfg, T * ndata + 2, 12345 + rank)
+        base_b, base_d = base_frames(cfg, T * ndata + 2, 12345 + rank, nseeds=3)      # three scenes; the first eight streams (the parity sample) cover all of them
         bgr, depth = stream_variants(base_b, base_d, S)
 
         def frames_of_stream(s, count):

@@ -6,8 +6,9 @@ So a sequence of N frames is cut into contiguous CHUNKS, one per pipeline stream
 independent stream that starts `warmup` frames before its first owned frame, so that its tail state has settled when the owned frames
 begin; the outputs of the warm-up frames are dropped.  Chunk 0 starts at frame 1 primed with frame 0 twice, exactly like the reference
 loop (Examples/RGB-D/rgbd_tum_noros.cc:103-107, 131-139), so its frames equal a sequential run bit for bit; later chunks deviate from a sequential run only through the state they rebuilt
-in `warmup` frames -- the state steers the masks, a rebuilt state gives VALID BUT NOT IDENTICAL masks (per-frame IoU against the
-sequential run down to 0.3-0.8 at some seams, see tests/test_sequence_gpu.py and DESIGN.md 4).  With several ranks, rank r owns chunks
+in `warmup` frames -- the state steers the masks, and a rebuilt state re-synchronises with the sequential run only after ~16-24 frames
+(measured: warm-up 4 or 8 leaves per-frame IoU of 0.05-0.9 over whole chunks, 16 frames >= 0.98, 20 frames mean 0.9995), hence the
+default of 24; the masks of later chunks are valid but not guaranteed identical.  With several ranks, rank r owns chunks
 [r * streams, (r + 1) * streams); process_sequence performs NO collective -- the caller assembles the per-frame masks of all ranks with
 parallel.gather_sequence_masks (one all_gather of padded blocks).
 
@@ -35,7 +36,7 @@ class Chunk:
         return self.last - self.start
 
 
-def plan_chunks(n_frames: int, n_chunks: int, warmup: int = 5) -> list[Chunk]:
+def plan_chunks(n_frames: int, n_chunks: int, warmup: int = 24) -> list[Chunk]:
     """Contiguous chunks over frames [1, n_frames): the first (owned % n_chunks) chunks take one frame more; every chunk after the
     first starts `warmup` frames early (never before frame 1).  Chunks may be empty when there are more chunks than frames."""
     if n_frames < 2 or n_chunks < 1 or warmup < 0:
@@ -50,7 +51,7 @@ def plan_chunks(n_frames: int, n_chunks: int, warmup: int = 5) -> list[Chunk]:
     return chunks
 
 
-def process_sequence(bgr: np.ndarray, depth: np.ndarray, intr: dict, streams: int = 8, frames_per_step: int = 4, warmup: int = 5,
+def process_sequence(bgr: np.ndarray, depth: np.ndarray, intr: dict, streams: int = 8, frames_per_step: int = 4, warmup: int = 24,
                      nfeatures: int = 1500, scale_factor: float = 1.2, nlevels: int = 8, orb_gray_rgb_order: int = 1, device: int = 0,
                      rank: int = 0, world: int = 1, want_keypoints: bool = True):
     """bgr u8 [N, H, W, 3], depth u16 [N, H, W] (host) -> dict with dyna / label / mask u8 [N, H, W] (frame 0 stays zero, like the

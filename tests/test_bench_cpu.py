@@ -58,3 +58,7 @@ def test_pingpong_sequence_and_frame_generator():
     assert np.array_equal(b, rb) and np.array_equal(d, rd)
     vb, vd = bench.stream_variants(b, d, 5)
     assert np.array_equal(vb[0], b) and np.array_equal(vb[1], b[:, :, ::-1]) and np.array_equal(vd[2], d[:, ::-1]) and vb[4].mean() < b.mean()
+    b3, d3 = bench.base_frames(cfg, 2, 12345, nseeds=3)                   # three scenes
+    assert b3.shape == (3, 2, 480, 640, 3) and np.array_equal(b3[0], b[:2]) and not np.array_equal(b3[1], b3[0])
+    v3, _ = bench.stream_variants(b3, d3, 7)
+    assert np.array_equal(v3[1], b3[1]) and np.array_equal(v3[3], b3[0][:, :, ::-1]) and np.array_equal(v3[5], b3[2][:, :, ::-1])

@@ -20,4 +20,7 @@ timeout -k 10 300 python3 bench.py --sync --no-cpu-baseline > $O/bench_sync.json
 timeout -k 10 300 python3 bench.py --config bonn > $O/bench_bonn.json 2> $O/bench_bonn.err || exit 1
 timeout -k 10 400 python3 bench.py --config d455_720p > $O/bench_d455_720p.json 2> $O/bench_d455_720p.err || exit 1
 timeout -k 10 300 python3 bench.py --workload sequence --no-cpu-baseline > $O/bench_sequence_1gpu.json 2> $O/bench_sequence_1gpu.err || exit 1
+timeout -k 10 600 python3 bench.py --workload sequence --steps 20 --warmup 5 --no-cpu-baseline --collective-at-1 > $O/bench_sequence_driver_args.json 2> $O/bench_sequence_driver_args.err || exit 1
+timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_default_driver_args.json 2> $O/bench_default_driver_args.err || exit 1
+SIND_TAIL_TIMING=1 timeout -k 10 300 python3 profiles/tools/exact_mode_timing.py 641 32 > $O/exact_mode_timing.txt 2>&1 || exit 1
 echo collected

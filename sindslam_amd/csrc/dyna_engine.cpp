@@ -39,6 +39,7 @@ int DynaFront::gray_and_min(const uint8_t* bgr, int n, uint8_t* gray, uint8_t* g
 
 int DynaFront::gather(const uint8_t* pool, const int* idx, int B, uint8_t* out) {
     const size_t fb = (size_t)fw * fh;
+    if (fb % 16 == 0) return launch_gather_frames(stream, pool, idx, B, out, fb);
     for (int b = 0; b < B; b++) HIP_TRY(hipMemcpyAsync(out + fb * b, pool + fb * idx[b], fb, hipMemcpyDeviceToDevice, stream));
     return SIND_OK;
 }

@@ -32,6 +32,7 @@ struct SorTimer {
     ~SorTimer() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
 
+int launch_gather_frames(hipStream_t s, const uint8_t* pool, const int* idx_host, int B, uint8_t* out, size_t frame_bytes);
 int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w, int h, int B, float k0, float k1, bool blur);
 int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img);

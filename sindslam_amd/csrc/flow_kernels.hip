@@ -61,10 +61,12 @@ __global__ void k_resize_f32(const float* __restrict__ src, float* __restrict__ 
 // VariationalRefinementImpl::prepareBuffers, part 1: warp I1 by the level's initial flow (cv::remap, INTER_LINEAR,
 // BORDER_REPLICATE, coordinates quantised to 1/32 px), averaged image and temporal difference.
 __global__ void k_warp_avg_iz(const float* __restrict__ I0, const float* __restrict__ I1, const float* __restrict__ Wu,
-                              const float* __restrict__ Wv, float* __restrict__ avg, float* __restrict__ Iz, int w, int h) {
+                              const float* __restrict__ Wv, float* __restrict__ avg, float* __restrict__ Iz, float* __restrict__ dWu,
+                              float* __restrict__ dWv, int w, int h) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x >= w) return;
     const size_t base = (size_t)b * w * h; const int i = y * w + x;
+    dWu[base + i] = 0.f; dWv[base + i] = 0.f;               // the level's flow increment starts at zero (two fills less per level)
     const float* S = I1 + base;
     const float mx = x + Wu[base + i], my = y + Wv[base + i];
     int sx = d_cvRound(mx * 32.f), sy = d_cvRound(my * 32.f);
@@ -84,13 +86,18 @@ __global__ void k_warp_avg_iz(const float* __restrict__ I0, const float* __restr
 // ---------------------------------------------------------------------------------------------------------
 // One fixed-point iteration set-up: ComputeDataTerm + ComputeSmoothnessTerm{Hor,Vert}Pass gathered per pixel.
 // The four smoothness contributions are added in the order OpenCV's red/black passes produce for the pixel's colour.
+// A thread walks KC_ROWS consecutive rows of its column: the smoothness weight of a pixel is also its right neighbour's "left" weight and its lower
+// neighbour's "upper" weight, so the left one comes from the neighbouring lane (wave shuffle; the first lane of a wave computes it) and the upper one
+// from the thread's previous row (the first row of a block computes it) -- 1.3 instead of 3 weight evaluations (two loads rows, a square root and a
+// division each) per pixel, same values bit for bit.
+#define KC_ROWS 4
 __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
                        const float* __restrict__ gWv,
                        const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
                        float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z, y0 = blockIdx.y * KC_ROWS;
     if (x >= w) return;
-    const size_t base = (size_t)b * w * h; const int i = y * w + x;
+    const size_t base = (size_t)b * w * h;
     const float zeta2 = P.zeta * P.zeta, eps2 = P.epsilon * P.epsilon, gamma2 = P.gamma / 2, delta2 = P.delta / 2, alpha2 = P.alpha / 2;
     // The seven Sobel(ksize = 1, BORDER_REPLICATE) derivative images of prepareBuffers are formed here from the warped average and
     // the temporal difference (the float operations k_derivs used to store, evaluated at the same replicated positions): two planes
@@ -100,30 +107,6 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
     auto cy = [&](int v) { return min(max(v, 0), h - 1); };
     auto dX = [&](const float* Pp, int yy, int xx) { return Pp[yy * w + cx(xx + 1)] - Pp[yy * w + cx(xx - 1)]; };
     auto dY = [&](const float* Pp, int yy, int xx) { return Pp[cy(yy + 1) * w + xx] - Pp[cy(yy - 1) * w + xx]; };
-    const float Ix = dX(A, y, x), Iy = dY(A, y, x), Iz = Z[i], Ixz = dX(Z, y, x), Iyz = dY(Z, y, x);
-    const float Ixx = dX(A, y, cx(x + 1)) - dX(A, y, cx(x - 1));
-    const float Ixy = dX(A, cy(y + 1), x) - dX(A, cy(y - 1), x);
-    const float Iyy = dY(A, cy(y + 1), x) - dY(A, cy(y - 1), x);
-    const float dU = gdWu[base + i], dV = gdWv[base + i];
-    float derivNorm = Ix * Ix + Iy * Iy + zeta2;
-    const float Ik1z = Iz + Ix * dU + Iy * dV;
-    float weight = (delta2 / sqrtf(Ik1z * Ik1z / derivNorm + eps2)) / derivNorm;
-    float a11 = weight * (Ix * Ix) + zeta2;
-    float a12 = weight * (Ix * Iy);
-    float a22 = weight * (Iy * Iy) + zeta2;
-    float b1 = -weight * (Iz * Ix);
-    float b2 = -weight * (Iz * Iy);
-    derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
-    const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
-    const float Ik1zx = Ixz + Ixx * dU + Ixy * dV;
-    const float Ik1zy = Iyz + Ixy * dU + Iyy * dV;
-    weight = gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
-    a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
-    a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
-    a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
-    b1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
-    b2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
-
     // tempW = W + dW is formed on the fly (OpenCV keeps it in a buffer that it refreshes after every fixed-point iteration with this
     // very addition): two planes less to read here and no k_add_flow pass between the iterations.  Before the first iteration
     // dW = 0, and W + 0 differs from W only in the sign of a zero, which the squared differences below cannot see.
@@ -136,21 +119,57 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
         const float uy = (WU[iy] + DU[iy]) - c_u, vy = (WV[iy] + DV[iy]) - c_v;
         return alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
     };
-    const float wp = wgt_at(y, x);
-    const float wu_c = WU[i], wv_c = WV[i];
-    const bool red = ((x + y) & 1) == 0;
-    // the four link updates (no-ops at the image border)
-    #define OWN_H() if (x < w - 1) { b1 += wp * (WU[i + 1] - wu_c); a11 += wp; b2 += wp * (WV[i + 1] - wv_c); a22 += wp; }
-    #define LEFT_H() if (x > 0) { const float wl = wgt_at(y, x - 1); b1 -= wl * (wu_c - WU[i - 1]); a11 += wl; b2 -= wl * (wv_c - WV[i - 1]); a22 += wl; }
-    #define OWN_V() if (y < h - 1) { b1 += wp * (WU[i + w] - wu_c); a11 += wp; b2 += wp * (WV[i + w] - wv_c); a22 += wp; }
-    #define UP_V() if (y > 0) { const float wq = wgt_at(y - 1, x); b1 -= wq * (wu_c - WU[i - w]); a11 += wq; b2 -= wq * (wv_c - WV[i - w]); a22 += wq; }
-    if (red) { OWN_H() LEFT_H() OWN_V() UP_V() }
-    else     { LEFT_H() OWN_H() UP_V() OWN_V() }
-    #undef OWN_H
-    #undef LEFT_H
-    #undef OWN_V
-    #undef UP_V
-    A11[base + i] = a11; A12[base + i] = a12; A22[base + i] = a22; B1[base + i] = b1; B2[base + i] = b2; Wgt[base + i] = wp;
+    const bool wave_first = (threadIdx.x & 63) == 0;
+    float w_up = 0.f;                                       // weight of (y - 1, x): computed for the block's first row, carried down afterwards
+    #pragma unroll
+    for (int r = 0; r < KC_ROWS; r++) {
+        const int y = y0 + r;
+        if (y >= h) break;                                  // uniform over the block
+        const int i = y * w + x;
+        const float Ix = dX(A, y, x), Iy = dY(A, y, x), Iz = Z[i], Ixz = dX(Z, y, x), Iyz = dY(Z, y, x);
+        const float Ixx = dX(A, y, cx(x + 1)) - dX(A, y, cx(x - 1));
+        const float Ixy = dX(A, cy(y + 1), x) - dX(A, cy(y - 1), x);
+        const float Iyy = dY(A, cy(y + 1), x) - dY(A, cy(y - 1), x);
+        const float dU = gdWu[base + i], dV = gdWv[base + i];
+        float derivNorm = Ix * Ix + Iy * Iy + zeta2;
+        const float Ik1z = Iz + Ix * dU + Iy * dV;
+        float weight = (delta2 / sqrtf(Ik1z * Ik1z / derivNorm + eps2)) / derivNorm;
+        float a11 = weight * (Ix * Ix) + zeta2;
+        float a12 = weight * (Ix * Iy);
+        float a22 = weight * (Iy * Iy) + zeta2;
+        float b1 = -weight * (Iz * Ix);
+        float b2 = -weight * (Iz * Iy);
+        derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
+        const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
+        const float Ik1zx = Ixz + Ixx * dU + Ixy * dV;
+        const float Ik1zy = Iyz + Ixy * dU + Iyy * dV;
+        weight = gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
+        a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
+        a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
+        a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
+        b1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
+        b2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+
+        const float wp = wgt_at(y, x);
+        const float w_from_lane = __shfl_up(wp, 1);          // the left neighbour's own weight (same row, lane - 1)
+        const float wl = (x > 0) ? (wave_first ? wgt_at(y, x - 1) : w_from_lane) : 0.f;
+        const float wq = (y > 0) ? (r == 0 ? wgt_at(y - 1, x) : w_up) : 0.f;
+        const float wu_c = WU[i], wv_c = WV[i];
+        const bool red = ((x + y) & 1) == 0;
+        // the four link updates (no-ops at the image border)
+        #define OWN_H() if (x < w - 1) { b1 += wp * (WU[i + 1] - wu_c); a11 += wp; b2 += wp * (WV[i + 1] - wv_c); a22 += wp; }
+        #define LEFT_H() if (x > 0) { b1 -= wl * (wu_c - WU[i - 1]); a11 += wl; b2 -= wl * (wv_c - WV[i - 1]); a22 += wl; }
+        #define OWN_V() if (y < h - 1) { b1 += wp * (WU[i + w] - wu_c); a11 += wp; b2 += wp * (WV[i + w] - wv_c); a22 += wp; }
+        #define UP_V() if (y > 0) { b1 -= wq * (wu_c - WU[i - w]); a11 += wq; b2 -= wq * (wv_c - WV[i - w]); a22 += wq; }
+        if (red) { OWN_H() LEFT_H() OWN_V() UP_V() }
+        else     { LEFT_H() OWN_H() UP_V() OWN_V() }
+        #undef OWN_H
+        #undef LEFT_H
+        #undef OWN_V
+        #undef UP_V
+        A11[base + i] = a11; A12[base + i] = a12; A22[base + i] = a22; B1[base + i] = b1; B2[base + i] = b2; Wgt[base + i] = wp;
+        w_up = wp;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -564,10 +583,30 @@ __global__ void k_resize_u8(const uint8_t* __restrict__ src, uint8_t* __restrict
     dst[(size_t)b * d_img + (size_t)dy * d_stride + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
 }
 
+// frames of the gray history pool picked by index into a dense batch: out[b] = pool[idx[b]] (16 bytes per thread; the indices travel as
+// kernel arguments, up to 256 per launch) -- one launch instead of one device-to-device copy per frame (3 000 copies per 512-pair step)
+struct GatherIdx { int v[256]; };
+__global__ void k_gather_frames(const uint8_t* __restrict__ pool, GatherIdx idx, uint8_t* __restrict__ out, size_t fb) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i >= fb) return;
+    const uint8_t* s = pool + (size_t)idx.v[blockIdx.y] * fb + i; uint8_t* d = out + (size_t)blockIdx.y * fb + i;
+    if (i + 16 <= fb) *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+    else for (size_t k = 0; i + k < fb; k++) d[k] = s[k];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host-side launchers
 static inline dim3 grid2d(int w, int h, int B, int bx = 128) { return dim3(divup(w, bx), h, B); }
 
+int launch_gather_frames(hipStream_t s, const uint8_t* pool, const int* idx_host, int B, uint8_t* out, size_t fb) {
+    if (fb % 16 != 0) { sind_set_error("launch_gather_frames: frame size %zu is not a multiple of 16 bytes", fb); return SIND_E_ARG; }
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int nb = std::min(256, B - b0); GatherIdx a;
+        for (int i = 0; i < nb; i++) a.v[i] = idx_host[b0 + i];
+        hipLaunchKernelGGL(k_gather_frames, dim3((unsigned)((fb / 16 + 255) / 256), nb), dim3(256), 0, s, pool, a, out + (size_t)b0 * fb, fb);
+    }
+    return SIND_OK;
+}
 int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w, int h, int B, float k0, float k1, bool blur) {
     hipLaunchKernelGGL(k_u8_to_f32_blur3, grid2d(w, h, B), dim3(128), 0, s, src, dst, w, h, k0, k1, blur ? 1 : 0);
     return SIND_OK;
@@ -651,11 +690,9 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
 int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer) {
     const size_t n = (size_t)w * h * B;
     const dim3 g = grid2d(w, h, B), blk(128);
-    hipLaunchKernelGGL(k_warp_avg_iz, g, blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, w, h);
-    HIP_TRY(hipMemsetAsync(P.dWu, 0, n * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(P.dWv, 0, n * sizeof(float), s));
+    hipLaunchKernelGGL(k_warp_avg_iz, g, blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, P.dWu, P.dWv, w, h);
     for (int it = 0; it < V.fixedPointIterations; it++) {
-        hipLaunchKernelGGL(k_coef, g, blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
+        hipLaunchKernelGGL(k_coef, dim3(divup(w, 128), divup(h, KC_ROWS), B), blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
                            P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt);
         if (timer) timer->begin(s);
         long long nlaunch = 0;

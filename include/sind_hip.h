@@ -50,10 +50,14 @@ int sind_flow_sync(sind_flow* f);
 /* build-side option (BASELINE.json config 5, "3-level flow pyramid"; no reference counterpart -- OpenCV 4.2's DeepFlow never advances its
  * maxLayers counter): n > 0 keeps only the finest n levels of the 0.95 pyramid, the flow starts from zero at the coarsest of them; 0 = all */
 int sind_flow_set_max_levels(sind_flow* f, int n);
-/* solver variant (process-wide): mode 1 = fused register-resident SOR, 1x8 strips, IEEE division (default), 2 = fused, 1x4 strips +
- * reciprocal (Markstein) division, 0 = one launch per colour (cross-check); fuse = iterations per launch on tiled levels (default 5);
- * tile_w = 64 (default) or 128 (mode 1 only) */
+/* solver variant (process-wide; every variant returns the same bits).  Fused register-resident SOR with 1x8 pixel strips: mode 4 = divisions
+ * through a reciprocal formed on the fly (hardware estimate + one Newton step, then Markstein's correction; default: 5 iterations per launch on
+ * 64 x 64 tiles), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in registers (three waves per SIMD; instances for
+ * tiles of 256, 384 and 768 threads); 2 = fused, 1x4 strips + reciprocal division; 0 = one launch per colour (cross-check).  fuse = iterations
+ * per launch on tiled levels; tile_w x tile_h = extended tile (tile_w * tile_h / 8 threads).  sind_flow_set_sor keeps the round-1 signature
+ * (tile height 48 for mode 3, 64 otherwise). */
 int sind_flow_set_sor(int mode, int fuse, int tile_w);
+int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h);
 /* HIP-event timing of everything enqueued on the handle's stream between begin and end (bench.py roofline leg) */
 int sind_flow_timer_begin(sind_flow* f);
 int sind_flow_timer_end(sind_flow* f, float* milliseconds);
@@ -112,6 +116,10 @@ int sind_dyna_debug(sind_dyna* d, float* flow_deep, float* flow_refined, float* 
 /* parity-test access to the k-means centre sums: out = the FP32 value of  acc = 0; for (i) acc += x[i]  (round to nearest even, exactly cv::kmeans'
  * centre accumulation, kmeans.cpp) computed by the wave-parallel window arithmetic of k_km_seqsum (csrc/depth_kernels.hip) */
 int sind_debug_seqsum(const float* x, int n, int device, float* out);
+/* exhaustive check of the solver's division: for every float significand and the binary exponents exp_lo..exp_hi, out[0] = reciprocals (hardware
+ * estimate + one Newton step) that differ from the correctly rounded 1 / a, out[1] = quotients through that reciprocal (Markstein) that differ
+ * from the IEEE division (16 numerators per divisor), out[2] = smallest failing significand (all ones if none) */
+int sind_debug_rcp_scan(int device, int exp_lo, int exp_hi, unsigned long long out[3]);
 
 /* parity-test access to the bit-plane dilation used by the region-adjacency stage (7x7 ellipse on 64-pixel words, cv::dilate semantics):
  * planes / out are host arrays [nplanes][height][ceil(width / 64)] of 64-bit words, bit i of word k = pixel 64 k + i. */

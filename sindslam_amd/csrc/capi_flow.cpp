@@ -94,9 +94,28 @@ int sind_flow_refine_dev(sind_flow* f, const uint8_t* i0, const uint8_t* i1, int
     HIP_TRY(hipSetDevice(f->device));
     return f->eng.refine(i0, i1, B, u, v);
 }
+int sind_debug_rcp_scan(int device, int exp_lo, int exp_hi, unsigned long long out[3]) {
+    if (!out || exp_lo < -100 || exp_hi > 100 || exp_lo > exp_hi) { sind_set_error("sind_debug_rcp_scan: bad arguments"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<unsigned long long> d; SIND_TRY(d.alloc(3));
+    const unsigned long long init[3] = {0, 0, ~0ull};
+    HIP_TRY(hipMemcpy(d.p, init, sizeof(init), hipMemcpyHostToDevice));
+    SIND_TRY(sind::debug_rcp_scan(nullptr, exp_lo, exp_hi, d.p));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d.p, sizeof(init), hipMemcpyDeviceToHost));
+    return SIND_OK;
+}
+int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h) {
+    const int nt = tile_w * tile_h / 8;
+    if (mode < 0 || mode > 4 || fuse < 1 || fuse > 12 || tile_w < 16 || tile_w % 8 || tile_h < 8 || tile_h % 2 || nt % 128 || nt > 1024 || 4 * fuse >= tile_w || 4 * fuse >= tile_h ||
+        (mode == 3 && nt != 256 && nt != 384 && nt != 768)) {
+        sind_set_error("sind_flow_set_sor_tiled: bad arguments (mode %d, fuse %d, tile %d x %d)", mode, fuse, tile_w, tile_h); return SIND_E_ARG;
+    }
+    sind::g_sor_mode = mode; sind::g_sor_fuse = fuse; sind::g_sor_tile_w = tile_w; sind::g_sor_tile_h = tile_h; return SIND_OK;
+}
 int sind_flow_set_sor(int mode, int fuse, int tile_w) {
-    if (mode < 0 || mode > 2 || fuse < 1 || fuse > 12 || (tile_w != 64 && tile_w != 128)) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }
-    sind::g_sor_mode = mode; sind::g_sor_fuse = fuse; sind::g_sor_tile_w = tile_w; return SIND_OK;
+    if (tile_w != 64 && tile_w != 128) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }
+    return sind_flow_set_sor_tiled(mode, fuse, tile_w, mode == 3 ? (tile_w == 64 ? 48 : 48) : 64);
 }
 int sind_flow_sync(sind_flow* f) { if (!f) return SIND_E_ARG; HIP_TRY(hipStreamSynchronize(f->stream)); return SIND_OK; }
 int sind_flow_timer_begin(sind_flow* f) { if (!f) return SIND_E_ARG; HIP_TRY(hipEventRecord(f->ev0, f->stream)); return SIND_OK; }

@@ -16,6 +16,7 @@ struct FlowPlanes {
     float *A11, *A12, *A22, *b1, *b2, *wgt;                   // linear system + smoothness weights
     float *Wu, *Wv, *dWu, *dWv, *tWu, *tWv;                    // level flow, increment, W + dW
     float *dWu2, *dWv2;                                       // ping-pong partner of the increment (tiled fused SOR)
+    float *r11, *r22;                                         // RN(1 / A11), RN(1 / A22): the tiled solver divides through them (Markstein)
 };
 
 // HIP-event brackets around the SOR launch groups of the flow solver (bench.py's roofline leg): events are recorded on the
@@ -37,7 +38,8 @@ int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w,
 int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img);
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb);
-extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd;
+extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd, g_sor_tile_h;
+int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev);
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch);
 int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr);
 int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, unsigned* maxbits, int* hist, uint8_t* out_u8, int n, int B);

@@ -20,19 +20,20 @@ static std::vector<std::pair<int, int>> deepflow_sizes(int w, int h) {
 
 int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     fw = fw_; fh = fh_; maxB = maxB_; stream = s;
-    if (const char* e = getenv("SIND_SOR_MODE")) g_sor_mode = atoi(e);       // 0: per-colour launches, 1: fused 1x8 strips (default), 2: fused 1x4 strips + reciprocal division
-    if (const char* e = getenv("SIND_SOR_TILEW")) g_sor_tile_w = atoi(e) == 64 ? 64 : 128;
+    if (const char* e = getenv("SIND_SOR_MODE")) g_sor_mode = atoi(e);       // see g_sor_mode (flow_kernels.hip); the tile / fuse variables are for A/B timing
+    if (const char* e = getenv("SIND_SOR_TILEW")) g_sor_tile_w = atoi(e);
     if (const char* e = getenv("SIND_SOR_FUSE")) g_sor_fuse = std::max(1, std::min(atoi(e), 12));
     if (const char* e = getenv("SIND_SOR_XCD")) g_sor_xcd = atoi(e) != 0;
+    if (const char* e = getenv("SIND_SOR_TILEH")) g_sor_tile_h = atoi(e);
     if (const char* e = getenv("SIND_LAUNCH_AHEAD")) launch_ahead = std::max(0, atoi(e));       // 0: unbounded
     levels = deepflow_sizes(fw, fh);
     level_off.clear(); pyr_pixels = 0;
     for (auto& l : levels) { level_off.push_back(pyr_pixels); pyr_pixels += (size_t)l.first * l.second; }
     const size_t n0 = (size_t)fw * fh * maxB;
-    static_assert(sizeof(FlowPlanes) == 16 * sizeof(float*), "FlowPlanes is filled as an array of 16 plane pointers");
-    SIND_TRY(plane_store.alloc(n0 * 16));
+    static_assert(sizeof(FlowPlanes) == 18 * sizeof(float*), "FlowPlanes is filled as an array of 18 plane pointers");
+    SIND_TRY(plane_store.alloc(n0 * 18));
     float** f = reinterpret_cast<float**>(&planes);
-    for (int i = 0; i < 16; i++) f[i] = plane_store.p + n0 * i;
+    for (int i = 0; i < 18; i++) f[i] = plane_store.p + n0 * i;
     SIND_TRY(pyr0.alloc(pyr_pixels * maxB));
     SIND_TRY(pyr1.alloc(pyr_pixels * maxB));
     return SIND_OK;

@@ -94,7 +94,8 @@ __global__ void k_warp_avg_iz(const float* __restrict__ I0, const float* __restr
 __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
                        const float* __restrict__ gWv,
                        const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
-                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt) {
+                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11,
+                       float* __restrict__ R22) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z, y0 = blockIdx.y * KC_ROWS;
     if (x >= w) return;
     const size_t base = (size_t)b * w * h;
@@ -168,6 +169,7 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
         #undef OWN_V
         #undef UP_V
         A11[base + i] = a11; A12[base + i] = a12; A22[base + i] = a22; B1[base + i] = b1; B2[base + i] = b2; Wgt[base + i] = wp;
+        if (R11) { R11[base + i] = 1.f / a11; R22[base + i] = 1.f / a22; }     // solver mode 3 only: correctly rounded (Markstein's division needs exactly RN(1 / a))
         w_up = wp;
     }
 }
@@ -213,22 +215,69 @@ __global__ void k_sor_color(int w, int h, float omega, int color, const float* _
 // Arithmetic per pixel is identical to k_sor_color / OpenCV RedBlackSOR_ParBody, so results stay bit-exact.
 #define SOR_PX 8
 #define SOR_NT 1024
+// Row stride of the LDS planes in float4: strips + a guard on each side, padded to 4 (mod 8).  A wave's ds_read_b128 is served in four 16-lane groups
+// that each touch four half rows (16 banks) of four different rows two apart; with a stride of 4 (mod 8) float4 the four pieces fall into the four
+// different quarters of the 64 banks (stride 10, the unpadded 64-pixel tile, put two of them on the same quarter: 40 % of the LDS cycles were conflicts).
+__host__ __device__ constexpr int sor_row_stride(int EW) { return (EW / 8 + 2) + ((4 - (EW / 8 + 2)) % 8 + 8) % 8; }
 struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };     // 4-byte aligned 16-byte load (gfx950 allows unaligned dwordx4)
 __device__ __forceinline__ void ld8(const float* __restrict__ p, float (&d)[SOR_PX]) {
     const F4u a = *reinterpret_cast<const F4u*>(p), c = *reinterpret_cast<const F4u*>(p + 4);
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = c.x; d[5] = c.y; d[6] = c.z; d[7] = c.w;
 }
-__global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo_x, int halo, int ntx, int iters, int xcd_remap, float omega,
-                                                      const float* __restrict__ gA11, const float* __restrict__ gA12, const float* __restrict__ gA22,
-                                                      const float* __restrict__ gB1, const float* __restrict__ gB2, const float* __restrict__ gW,
-                                                      const float* __restrict__ gUin, const float* __restrict__ gVin, float* __restrict__ gUout,
-                                                      float* __restrict__ gVout) {
+__device__ __forceinline__ float sor_div(float n, float a, float r) { const float q0 = n * r; const float e = fmaf(-a, q0, n); return fmaf(e, r, q0); }
+// RN(1 / a) without the IEEE division sequence: hardware reciprocal (<= 1 ulp) + one Newton step in FMA arithmetic.  sind_debug_rcp_scan checks it
+// against the correctly rounded division for EVERY float significand (the step is invariant under scaling by powers of two while nothing is denormal).
+// (volatile asm: the compiler must not hoist the loop-invariant reciprocals out of the solver loop, where they would cost 16 registers and spill;
+// s_nop: the transcendental unit's result needs one wait state before a VALU read, which the hazard pass cannot see through inline asm)
+__device__ __forceinline__ float sor_rcp(float a) {
+    float y0; asm volatile("v_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(y0) : "v"(a));
+    const float e = fmaf(-a, y0, 1.f); return fmaf(e, y0, y0);
+}
+__global__ void k_debug_rcp_scan(int exp_lo, int exp_hi, unsigned long long* __restrict__ out) {
+    const unsigned m = blockIdx.x * blockDim.x + threadIdx.x;           // all 2^23 significands
+    if (m >= (1u << 23)) return;
+    unsigned long long bad_r = 0, bad_q = 0; unsigned rng = m * 2654435761u + 12345u;
+    for (int e = exp_lo; e <= exp_hi; e++) {
+        const float a = __uint_as_float(((unsigned)(127 + e) << 23) | m);
+        const float y = sor_rcp(a), ref = 1.f / a;
+        if (__float_as_uint(y) != __float_as_uint(ref)) bad_r++;
+        for (int k = 0; k < 8; k++) {                                   // quotients through the reciprocal (Markstein) against the IEEE division
+            rng = rng * 1664525u + 1013904223u;
+            const float n = __uint_as_float((rng & 0x807fffffu) | ((unsigned)(127 + e - 16 + (int)((rng >> 23) & 31)) << 23));
+            const float q = sor_div(n, a, y), qr = n / a;
+            if (__float_as_uint(q) != __float_as_uint(qr)) bad_q++;
+            const float q2 = sor_div(n, -a, -y), qr2 = n / -a;
+            if (__float_as_uint(q2) != __float_as_uint(qr2)) bad_q++;
+        }
+    }
+    if (bad_r) atomicAdd(&out[0], bad_r);
+    if (bad_q) atomicAdd(&out[1], bad_q);
+    if (bad_r) atomicMin(&out[2], (unsigned long long)m);
+}
+int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev) {
+    hipLaunchKernelGGL(k_debug_rcp_scan, dim3((1u << 23) / 256), dim3(256), 0, s, exp_lo, exp_hi, out_dev);
+    HIP_TRY(hipGetLastError()); return SIND_OK;
+}
+// RCP: the two IEEE divisions of a pixel update (ten VALU instructions each, one of them quarter rate) become Markstein's three-operation
+// sequence on the reciprocals of A11 / A22, formed once per launch and held in registers (see sor_div / k_sor_fused4 below); a pixel outside the
+// image gets the reciprocal 0, which makes its update return exactly 0 and removes the per-pixel validity select from the loop.
+// The ten persistent values per pixel (80 registers per strip) do not fit the 128-register budget of four waves per SIMD, so the RCP instance runs
+// three waves per SIMD (<= 168 registers): MAXT threads per workgroup, WPE waves per SIMD.
+// CEW x CNR: extended tile known at compile time (0 = run-time sizes, the one-workgroup levels): every LDS address then is one base register plus an
+// immediate offset instead of a dozen address registers held across the loop.
+template <int DIV, int MAXT, int WPE, int CEW, int CNR>        // DIV: 0 = IEEE division, 1 = reciprocal planes in registers (RCP), 2 = reciprocal formed on the fly (sor_rcp)
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, MAXT), amdgpu_waves_per_eu(WPE, WPE)))
+k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo_x, int halo, int ntx, int iters, int xcd_remap, float omega,
+            const float* __restrict__ gA11, const float* __restrict__ gA12, const float* __restrict__ gA22, const float* __restrict__ gB1,
+            const float* __restrict__ gB2, const float* __restrict__ gW, const float* __restrict__ gR11, const float* __restrict__ gR22,
+            const float* __restrict__ gUin, const float* __restrict__ gVin, float* __restrict__ gUout, float* __restrict__ gVout) {
+    constexpr bool RCP = DIV == 1;
     extern __shared__ float4 lds4[];             // float4-indexed so that every strip access is one ds_read/write_b128
     float* lds = reinterpret_cast<float*>(lds4);
-    const int SW = EW / SOR_PX;                  // strips per row
-    const int RS4 = EW / 8 + 2;                  // LDS row stride in float4 (one guard float4 on each side)
-    const int half = blockDim.x >> 1;
-    const int NR = 2 * (half / SW);              // rows covered by the thread block (>= EH; surplus rows stay zero)
+    const int SW = (CEW ? CEW : EW) / SOR_PX;    // strips per row
+    const int RS4 = sor_row_stride(CEW ? CEW : EW);      // LDS row stride in float4 (one guard float4 on each side + bank padding)
+    const int half = CEW ? CEW * CNR / (2 * SOR_PX) : (int)(blockDim.x >> 1);
+    const int NR = CEW ? CNR : 2 * (half / SW);  // rows covered by the thread block (>= EH; surplus rows stay zero)
     const int PL4 = (NR + 2) * RS4;              // one plane (guard row above and below)
     const int tid = threadIdx.x;
     const int idx = tid < half ? tid : tid - half;
@@ -250,15 +299,21 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
     for (int i = tid; i < 6 * PL4; i += blockDim.x) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);      // also zeroes the guard ring (planes 4, 5: smoothness weights)
     float a11[SOR_PX], a12[SOR_PX], a22[SOR_PX], b1[SOR_PX], b2[SOR_PX], wp[SOR_PX], du[SOR_PX], dv[SOR_PX];
     float wtop[SOR_PX];                          // weights of the image row above the tile, loaded by the tile's first row only
+    float r11[RCP ? SOR_PX : 1], r22[RCP ? SOR_PX : 1];
     float wl0 = 0.f;
-    unsigned valid = 0;
+    unsigned valid = 0;      // a pixel outside the image keeps the reciprocal 0 (RCP): its update returns exactly 0, with no select in the loop
     const bool row_ok = ly < EH && gy >= 0 && gy < h;
     #pragma unroll
     for (int i = 0; i < SOR_PX; i++) { a11[i] = 1.f; a12[i] = 0.f; a22[i] = 1.f; b1[i] = 0.f; b2[i] = 0.f; wp[i] = 0.f; wtop[i] = 0.f; du[i] = 0.f; dv[i] = 0.f; }
+    if constexpr (RCP) {
+        #pragma unroll
+        for (int i = 0; i < SOR_PX; i++) { r11[i] = 0.f; r22[i] = 0.f; }
+    }
     if (row_ok && gx0 >= 0 && gx0 + SOR_PX <= w) {        // whole strip inside the image: 16-byte loads
         const size_t g = base + (size_t)gy * w + gx0;
         valid = 0xffu;
         ld8(gA11 + g, a11); ld8(gA12 + g, a12); ld8(gA22 + g, a22); ld8(gB1 + g, b1); ld8(gB2 + g, b2); ld8(gW + g, wp); ld8(gUin + g, du); ld8(gVin + g, dv);
+        if constexpr (RCP) { ld8(gR11 + g, r11); ld8(gR22 + g, r22); }
         if (ly == 0 && gy > 0) ld8(gW + g - w, wtop);
     } else if (row_ok) {
         #pragma unroll
@@ -270,6 +325,7 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
                 a11[i] = gA11[g]; a12[i] = gA12[g]; a22[i] = gA22[g]; b1[i] = gB1[g]; b2[i] = gB2[g]; wp[i] = gW[g];
                 if (ly == 0 && gy > 0) wtop[i] = gW[g - w];
                 du[i] = gUin[g]; dv[i] = gVin[g];
+                if constexpr (RCP) { r11[i] = gR11[g]; r22[i] = gR22[g]; }
             }
         }
     }
@@ -319,10 +375,21 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
                 const float sigmaU = wl * ul + wp[i] * ur + wu[k] * uu[k] + wp[i] * ud[k];                                        \
                 const float sigmaV = wl * vl + wp[i] * vr + wu[k] * vu[k] + wp[i] * vd[k];                                        \
                 float nu = du[i], nv = dv[i];                                                                                     \
-                nu += omega * ((sigmaU + b1[i] - nv * a12[i]) / a11[i] - nu);                                                     \
-                nv += omega * ((sigmaV + b2[i] - nu * a12[i]) / a22[i] - nv);                                                     \
-                const bool ok = (valid >> i) & 1u;                                                                                \
-                du[i] = ok ? nu : 0.f; dv[i] = ok ? nv : 0.f;                                                                     \
+                if constexpr (RCP) {                                                                                              \
+                    nu += omega * (sor_div(sigmaU + b1[i] - nv * a12[i], a11[i], r11[i]) - nu);                                   \
+                    nv += omega * (sor_div(sigmaV + b2[i] - nu * a12[i], a22[i], r22[i]) - nv);                                   \
+                    du[i] = nu; dv[i] = nv;                                                                                       \
+                } else if constexpr (DIV == 2) {                                                                                  \
+                    nu += omega * (sor_div(sigmaU + b1[i] - nv * a12[i], a11[i], sor_rcp(a11[i])) - nu);                          \
+                    nv += omega * (sor_div(sigmaV + b2[i] - nu * a12[i], a22[i], sor_rcp(a22[i])) - nv);                          \
+                    const bool ok = (valid >> i) & 1u;                                                                            \
+                    du[i] = ok ? nu : 0.f; dv[i] = ok ? nv : 0.f;                                                                 \
+                } else {                                                                                                          \
+                    nu += omega * ((sigmaU + b1[i] - nv * a12[i]) / a11[i] - nu);                                                 \
+                    nv += omega * ((sigmaV + b2[i] - nu * a12[i]) / a22[i] - nv);                                                 \
+                    const bool ok = (valid >> i) & 1u;                                                                            \
+                    du[i] = ok ? nu : 0.f; dv[i] = ok ? nv : 0.f;                                                                 \
+                }                                                                                                                 \
             }                                                                                                                     \
             lds4[((Q) * 2 + 0) * PL4 + ro4] = make_float4(du[START], du[(START) + 2], du[(START) + 4], du[(START) + 6]);         \
             lds4[((Q) * 2 + 1) * PL4 + ro4] = make_float4(dv[START], dv[(START) + 2], dv[(START) + 4], dv[(START) + 6]);         \
@@ -356,7 +423,6 @@ __global__ void __launch_bounds__(SOR_NT) k_sor_fused(int w, int h, int EW, int 
 // underflow: the system is O(1)).  Same LDS scheme as above with float2 instead of float4 (two pixels per colour and strip).
 // tests/test_flow_gpu.py::test_sor_variants_agree_bitwise holds this kernel to the per-colour reference kernel bit for bit.
 #define SOR4_PX 4
-__device__ __forceinline__ float sor_div(float n, float a, float r) { const float q0 = n * r; const float e = fmaf(-a, q0, n); return fmaf(e, r, q0); }
 __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int EH, int IW, int IH, int halo_x, int halo, int ntx, int iters, int xcd_remap, float omega,
                                                      const float* __restrict__ gA11, const float* __restrict__ gA12, const float* __restrict__ gA22,
                                                      const float* __restrict__ gB1, const float* __restrict__ gB2, const float* __restrict__ gW,
@@ -629,11 +695,13 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 // `total` red-black SOR iterations on the level's system.  Small levels: the whole image is one tile and all iterations run
 // in one launch; larger levels: 64 x 64 tiles, SOR_FUSE iterations per launch with a 2*SOR_FUSE halo, ping-pong between the
 // two increment buffers (a tile reads its halo from neighbours that another workgroup of the same launch rewrites).
-int g_sor_mode = 1;          // 1 = fused, 1x8 strips, IEEE division (default, fastest); 2 = fused, 1x4 strips + reciprocal division on the tiled levels;
-                             // 0 = one launch per colour (kept for A/B timing and as a cross-check)
+int g_sor_mode = 4;          // fused register-resident SOR with 1x8 strips: 4 = divisions through a reciprocal formed on the fly (hardware estimate + Newton step,
+                             // then Markstein's correction; default, fastest), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in
+                             // registers (three waves per SIMD); 2 = fused, 1x4 strips + reciprocal division; 0 = one launch per colour (A/B timing, cross-check)
 int g_sor_fuse = 5;
 int g_sor_xcd = 1;           // XCD-aware tile order of the fused kernel (0 = plain blockIdx order, for A/B timing)
-int g_sor_tile_w = 64;       // 128 x 64 tiles (1024 threads) or 64 x 64 (512 threads)
+int g_sor_tile_w = 64;       // extended tile (multiple of 8 wide, even height, tile_w * tile_h / 8 threads)
+int g_sor_tile_h = 64;
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch) {
     if (g_sor_mode == 0) {
         const dim3 gs(divup(divup(w, 2), 64), h, B), bs(64);
@@ -645,16 +713,22 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     }
     // the flow slices call this concurrently from their own threads: set the (idempotent) attribute exactly once
     static std::once_flag attr_once; static hipError_t attr_rc = hipSuccess;
-    std::call_once(attr_once, [] { attr_rc = hipFuncSetAttribute((const void*)k_sor_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    std::call_once(attr_once, [] {
+        const void* fs[] = {(const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>,
+                            (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_fused<1, 384, 3, 0, 0>, (const void*)k_sor_fused<1, 768, 3, 0, 0>,
+                            (const void*)k_sor_fused<1, 256, 3, 0, 0>};
+        for (const void* f : fs) if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    });
     HIP_TRY(attr_rc);
-    auto sor_lds_bytes = [](int EW, int nt) { const int NR = 2 * ((nt / 2) / (EW / SOR_PX)); return (size_t)6 * (NR + 2) * (EW / 8 + 2) * sizeof(float4); };
+    auto sor_lds_bytes = [](int EW, int nt) { const int NR = 2 * ((nt / 2) / (EW / SOR_PX)); return (size_t)6 * (NR + 2) * sor_row_stride(EW) * sizeof(float4); };
     auto threads_for = [](int EW, int EH) { const int halfn = (EW / SOR_PX) * ((EH + 1) / 2); return 2 * ((halfn + 63) / 64 * 64); };
     const int EWw = (w + SOR_PX - 1) / SOR_PX * SOR_PX;
     if (threads_for(EWw, h) <= SOR_NT) {               // whole image in one workgroup: every iteration in one launch, in place
         const int EW = EWw, EH = h, nt = threads_for(EW, EH);
         const size_t shm = sor_lds_bytes(EW, nt);
-        hipLaunchKernelGGL(k_sor_fused, dim3(1, B), dim3(nt), shm, s, w, h, EW, EH, EW, EH, 0, 0, 1, total, 0, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt,
-                           P.dWu, P.dWv, P.dWu, P.dWv);
+        if (shm > 150 * 1024) { sind_set_error("sor_iterations: a %d x %d level needs %zu bytes of LDS", w, h, shm); return SIND_E_ARG; }
+        hipLaunchKernelGGL((k_sor_fused<0, 1024, 4, 0, 0>), dim3(1, B), dim3(nt), shm, s, w, h, EW, EH, EW, EH, 0, 0, 1, total, 0, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt,
+                           P.r11, P.r22, P.dWu, P.dWv, P.dWu, P.dWv);
         *nlaunch += 1; return SIND_OK;
     }
     if (g_sor_mode == 2) {                             // 1x4 strips + reciprocal division (k_sor_fused4), 64 x 64 tiles, 1024 threads
@@ -673,13 +747,21 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         }
         return SIND_OK;
     }
-    const int EW = g_sor_tile_w, EH = 64, nt = threads_for(EW, EH);
+    // tiled levels.  Reciprocal instance (default): EW x EH tiles of EW * EH / 8 threads at three waves per SIMD; IEEE-division instance: four waves per SIMD
+    const int EW = g_sor_tile_w, EH = g_sor_tile_h, nt = threads_for(EW, EH);
+    const bool rcp = g_sor_mode == 3;
+    if (rcp && nt != 256 && nt != 384 && nt != 768) { sind_set_error("sor_iterations: %d x %d tiles (%d threads) have no reciprocal-solver instance", EW, EH, nt); return SIND_E_ARG; }
+    if (nt > SOR_NT || 2 * 2 * g_sor_fuse >= std::min(EW, EH)) { sind_set_error("sor_iterations: tile %d x %d / %d fused iterations not supported", EW, EH, g_sor_fuse); return SIND_E_ARG; }
     const size_t shm = sor_lds_bytes(EW, nt);
+    if (shm > 150 * 1024) { sind_set_error("sor_iterations: %d x %d tiles need %zu bytes of LDS", EW, EH, shm); return SIND_E_ARG; }
     for (int done = 0; done < total;) {
         const int k = std::min(g_sor_fuse, total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
         const int ntx = divup(w, IW), nty = divup(h, IH);
-        hipLaunchKernelGGL(k_sor_fused, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
-                           P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
+        const bool t64 = EW == 64 && EH == 64 && nt == 512;           // the default tile has instances with compile-time sizes
+        auto kern = g_sor_mode == 4 ? (t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>) : !rcp ? (t64 ? k_sor_fused<0, 512, 4, 64, 64> : k_sor_fused<0, 1024, 4, 0, 0>)
+                    : nt == 384 ? k_sor_fused<1, 384, 3, 0, 0> : nt == 768 ? k_sor_fused<1, 768, 3, 0, 0> : k_sor_fused<1, 256, 3, 0, 0>;
+        hipLaunchKernelGGL(kern, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
+                           P.wgt, P.r11, P.r22, P.dWu, P.dWv, P.dWu2, P.dWv2);
         std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);
         done += k; *nlaunch += 1;
     }
@@ -693,7 +775,7 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     hipLaunchKernelGGL(k_warp_avg_iz, g, blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, P.dWu, P.dWv, w, h);
     for (int it = 0; it < V.fixedPointIterations; it++) {
         hipLaunchKernelGGL(k_coef, dim3(divup(w, 128), divup(h, KC_ROWS), B), blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
-                           P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt);
+                           P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr);
         if (timer) timer->begin(s);
         long long nlaunch = 0;
         SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch));

@@ -8,10 +8,13 @@ import numpy as np
 from ._lib import check, lib, ptr
 
 
-def set_sor_variant(mode: int = 1, fuse: int = 5, tile_w: int = 64):
-    """process-wide solver variant: mode 1 = fused register-resident SOR, 1x8 strips, IEEE division (default), 2 = fused with 1x4
-    strips and reciprocal (Markstein) division, 0 = one launch per colour (cross-check)"""
-    check(lib().sind_flow_set_sor(mode, fuse, tile_w), "sind_flow_set_sor")
+def set_sor_variant(mode: int = 4, fuse: int = 5, tile_w: int = 64, tile_h: int | None = None):
+    """process-wide solver variant (all return the same bits).  Fused register-resident SOR with 1x8 strips: mode 4 = divisions through a reciprocal
+    formed on the fly (default), 1 = IEEE division, 3 = reciprocal planes held in registers (three waves per SIMD; 256/384/768-thread tiles);
+    2 = fused with 1x4 strips and reciprocal division; 0 = one launch per colour (cross-check).  tile_h defaults to 48 (mode 3) / 64."""
+    if tile_h is None:
+        tile_h = 48 if mode == 3 else 64
+    check(lib().sind_flow_set_sor_tiled(mode, fuse, tile_w, tile_h), "sind_flow_set_sor_tiled")
 
 
 class FlowStage:

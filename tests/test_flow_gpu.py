@@ -77,9 +77,21 @@ def test_sor_variants_agree_bitwise(fs, frames):
     g0, g1 = _small_pair(frames, 384, 288)
     i0 = np.stack([g0, g1]); i1 = np.stack([g1, g0])
     try:
-        set_sor_variant(0, 5, 64); ru, rv = fs.deepflow(i0, i1)
-        for mode, fuse, tw in [(2, 5, 64), (2, 3, 64), (2, 7, 64), (2, 1, 64), (1, 5, 64), (1, 3, 64), (1, 7, 64), (1, 5, 128), (1, 1, 64)]:
-            set_sor_variant(mode, fuse, tw); u, v = fs.deepflow(i0, i1)
-            assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32)), (mode, fuse, tw)
+        set_sor_variant(0, 5, 64, 64); ru, rv = fs.deepflow(i0, i1)
+        for mode, fuse, tw, th in [(2, 5, 64, 64), (2, 3, 64, 64), (2, 7, 64, 64), (2, 1, 64, 64), (1, 5, 64, 64), (1, 3, 64, 64), (1, 7, 64, 64), (1, 5, 128, 64),
+                                   (1, 1, 64, 64), (4, 5, 64, 64), (4, 3, 64, 64), (4, 5, 128, 64), (3, 3, 64, 48), (3, 5, 64, 48), (3, 1, 64, 48), (3, 2, 64, 32), (3, 4, 96, 64), (3, 5, 128, 48), (3, 3, 48, 64)]:
+            set_sor_variant(mode, fuse, tw, th); u, v = fs.deepflow(i0, i1)
+            assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32)), (mode, fuse, tw, th)
     finally:
-        set_sor_variant(1, 5, 64)
+        set_sor_variant()
+
+
+def test_division_through_the_reciprocal_is_exact():
+    """the solver's division (hardware reciprocal + one Newton step, then Markstein's correction) against the IEEE division: every one of the 2^23
+    float significands, binary exponents -20..20 (the step is scale invariant; the system's diagonal lies in [0.01, 1e4]), 16 numerators per divisor,
+    quotients from 2^-16 to 2^16 -- no reciprocal and no quotient differs"""
+    import ctypes as C
+    from sindslam_amd._lib import check, lib
+    out = (C.c_ulonglong * 3)()
+    check(lib().sind_debug_rcp_scan(0, -20, 20, out), "sind_debug_rcp_scan")
+    assert out[0] == 0 and out[1] == 0, (out[0], out[1], hex(out[2]))

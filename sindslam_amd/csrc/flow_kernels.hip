@@ -296,7 +296,6 @@ k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo_x, int halo, 
     const size_t base = (size_t)b * w * h;
     const int off = (ex0 + ey0) & 1;             // local parity of the globally "red" pixels
 
-    for (int i = tid; i < 6 * PL4; i += blockDim.x) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);      // also zeroes the guard ring (planes 4, 5: smoothness weights)
     float a11[SOR_PX], a12[SOR_PX], a22[SOR_PX], b1[SOR_PX], b2[SOR_PX], wp[SOR_PX], du[SOR_PX], dv[SOR_PX];
     float wtop[SOR_PX];                          // weights of the image row above the tile, loaded by the tile's first row only
     float r11[RCP ? SOR_PX : 1], r22[RCP ? SOR_PX : 1];
@@ -327,6 +326,18 @@ k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo_x, int halo, 
                 du[i] = gUin[g]; dv[i] = gVin[g];
                 if constexpr (RCP) { r11[i] = gR11[g]; r22[i] = gR22[g]; }
             }
+        }
+    }
+    // zero the guard ring of the six planes (top and bottom row, the cells left and right of the strips; every other cell is written below by the
+    // thread that owns it) while the loads above are in flight
+    {
+        const int GC = RS4 - SW, G = 2 * RS4 + NR * GC;          // guard cells per row / per plane
+        for (int i = tid; i < 6 * G; i += blockDim.x) {
+            const int pl = i / G, c = i - pl * G;
+            int cell;
+            if (c < 2 * RS4) cell = c < RS4 ? c : (NR + 1) * RS4 + (c - RS4);
+            else { const int r = (c - 2 * RS4) / GC, g = (c - 2 * RS4) - r * GC; cell = (r + 1) * RS4 + (g == 0 ? 0 : SW + g); }
+            lds4[pl * PL4 + cell] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();

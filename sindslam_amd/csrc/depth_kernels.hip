@@ -536,31 +536,51 @@ __global__ void k_morph(const uint8_t* __restrict__ src, uint8_t* __restrict__ d
     dst[y * w + x] = (uint8_t)m;
 }
 
-// ---------------------------------------------------------------- PEAC initial block statistics: ONE thread per 16x16 block so that the FP64
-// sums are accumulated in the reference's row-major order (bit-exact with a sequential CPU loop; 1200 blocks -> negligible time).
-__global__ void k_peac_block_stats(const uint16_t* __restrict__ depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy,
-                                   float depthScale, double depthAlpha, double depthChangeTol, PeacBlockStats* __restrict__ out) {
-    const int Nw = w / bw, Nh = h / bh;
-    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= Nw * Nh) return;
+// ---------------------------------------------------------------- PEAC initial block statistics (16 x 16 blocks): one wave per block.
+// The lanes form the block's points and its validity in parallel (a block with a missing point or a depth jump to the right / lower neighbour is
+// dropped as a whole, so the order of that test is free); the nine FP64 moments are then accumulated by nine lanes, each adding its 256 terms in the
+// reference's row-major order (bit-exact with a sequential CPU loop).  One thread per block took 0.3 ms of dependent loads on every frame's tail chain.
+#define PEAC_BW 16
+__global__ void __launch_bounds__(256) k_peac_block_stats(const uint16_t* __restrict__ depth, int w, int h, int Nw, int nblk, float fx, float fy, float cx, float cy,
+                                                          float depthScale, double depthAlpha, double depthChangeTol, PeacBlockStats* __restrict__ out) {
+    __shared__ float pz[4][PEAC_BW * PEAC_BW];                      // zf per point (x, y follow from the pixel position)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, blk = blockIdx.x * 4 + wv;
+    if (blk >= nblk) return;                                        // whole waves leave; no block-wide barrier below
     const int by = blk / Nw, bx = blk - by * Nw;
-    PeacBlockStats S; S.sx = S.sy = S.sz = S.sxx = S.syy = S.szz = S.sxy = S.syz = S.sxz = 0; S.N = 0; S.valid = 1;
-    auto getz = [&](int i, int j, double& x, double& y, double& z) -> bool {
-        const float d = (float)depth[i * w + j];
-        if (d < 1e-3f) return false;                     // NaN point in the reference's organised cloud
-        const float zf = d * (1.0f / depthScale);
-        x = (double)((j - cx) * zf / fx); y = (double)((i - cy) * zf / fy); z = (double)zf;
-        return true;
-    };
-    for (int i = by * bh; i < (by + 1) * bh && i < h && S.valid; i++)
-        for (int j = bx * bw; j < (bx + 1) * bw && j < w; j++) {
-            double x, y, z, xn, yn, zn;
-            if (!getz(i, j, x, y, z)) { S.valid = 0; break; }
-            if (j + 1 < w && getz(i, j + 1, xn, yn, zn) && fabs(z - zn) > depthAlpha * fabs(z) + depthChangeTol) { S.valid = 0; break; }
-            if (i + 1 < h && getz(i + 1, j, xn, yn, zn) && fabs(z - zn) > depthAlpha * fabs(z) + depthChangeTol) { S.valid = 0; break; }
-            S.sx += x; S.sy += y; S.sz += z; S.sxx += x * x; S.syy += y * y; S.szz += z * z; S.sxy += x * y; S.syz += y * z; S.sxz += x * z; S.N++;
+    const float inv = 1.0f / depthScale;
+    auto zat = [&](int i, int j, float& zf) -> bool { const float d = (float)depth[i * w + j]; if (d < 1e-3f) return false; zf = d * inv; return true; };
+    bool ok = true;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = k * 64 + lane, i = by * PEAC_BW + (p >> 4), j = bx * PEAC_BW + (p & 15);
+        float zf = 0.f, zn;
+        if (!zat(i, j, zf)) ok = false;
+        else {
+            const double z = (double)zf, tol = depthAlpha * fabs(z) + depthChangeTol;
+            if (j + 1 < w && zat(i, j + 1, zn) && fabs(z - (double)zn) > tol) ok = false;
+            if (i + 1 < h && zat(i + 1, j, zn) && fabs(z - (double)zn) > tol) ok = false;
         }
-    out[blk] = S;
+        pz[wv][p] = zf;
+    }
+    const bool valid = __all(ok);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                             // lgkmcnt(0): the wave's own LDS stores (wave-synchronous, no barrier needed)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 9 && valid) {
+        // lane m accumulates moment m: sx sy sz sxx syy szz sxy syz sxz
+        double acc = 0;
+        for (int p = 0; p < PEAC_BW * PEAC_BW; p++) {
+            const int i = by * PEAC_BW + (p >> 4), j = bx * PEAC_BW + (p & 15);
+            const float zf = pz[wv][p];
+            const double x = (double)((j - cx) * zf / fx), y = (double)((i - cy) * zf / fy), z = (double)zf;
+            double t;
+            switch (lane) { case 0: t = x; break; case 1: t = y; break; case 2: t = z; break; case 3: t = x * x; break; case 4: t = y * y; break;
+                            case 5: t = z * z; break; case 6: t = x * y; break; case 7: t = y * z; break; default: t = x * z; }
+            acc += t;
+        }
+        double* o = &out[blk].sx; o[lane] = acc;
+    }
+    if (lane == 0) { out[blk].N = valid ? PEAC_BW * PEAC_BW : 0; out[blk].valid = valid ? 1 : 0; }
+    if (lane < 9 && !valid) { double* o = &out[blk].sx; o[lane] = 0; }
 }
 
 // ---------------------------------------------------------------- imgDepth/depth_max*255 -> 8U (DD:765-768): u16 * (float)((1/max)*255), cvRound, saturate
@@ -736,8 +756,9 @@ MorphElem make_ellipse(int n) {
 int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, int n, bool dilate) {
     hipLaunchKernelGGL(k_morph, dim3(divup(w, 128), h), dim3(128), 0, s, src, dst, w, h, make_ellipse(n), dilate ? 1 : 0); return SIND_OK; }
 int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out) {
+    if (bw != PEAC_BW || bh != PEAC_BW) { sind_set_error("peac_block_stats: %d x %d blocks (only %d x %d)", bw, bh, PEAC_BW, PEAC_BW); return SIND_E_ARG; }
     const int nb = (w / bw) * (h / bh);
-    hipLaunchKernelGGL(k_peac_block_stats, dim3(divup(nb, 64)), dim3(64), 0, s, depth, w, h, bw, bh, fx, fy, cx, cy, depthScale, 0.04, 0.02 * 1000, out); return SIND_OK; }
+    hipLaunchKernelGGL(k_peac_block_stats, dim3(divup(nb, 4)), dim3(256), 0, s, depth, w, h, w / bw, nb, fx, fy, cx, cy, depthScale, 0.04, 0.02 * 1000, out); return SIND_OK; }
 int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n) { hipLaunchKernelGGL(k_depth_norm, dim3(divup(n, 256)), dim3(256), 0, s, depth, dmax, out, n); return SIND_OK; }
 int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int w, int h, int wpr, const uint8_t* occ2, const uint8_t* depthN,
                      int* overlap, int* overlapPlane, int* ljOverlap, int* ljArea, int* hist) {

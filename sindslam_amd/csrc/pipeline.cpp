@@ -141,7 +141,7 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { long long q = 0, per = 0; if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) cpu_share = (int)std::max<long long>(1, std::min<long long>(cpu_share, q / per)); fclose(f); }
     if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int lw = atoi(e); if (lw > 1) cpu_share = std::max(2, cpu_share / lw); }      // ranks of one node (torch.distributed.run) share the quota
     cpu_share = std::min(cpu_share, 16);                                          // more host threads than this per GPU bring nothing (measured)
-    const int nworkers = cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 2);         // default: 2x the CPU share (workers sleep while they wait for the GPU)
+    const int nworkers = getenv("SIND_WORKERS") ? std::max(2, atoi(getenv("SIND_WORKERS"))) : cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 2);         // default: 2x the CPU share (workers sleep while they wait for the GPU)
     // A task leaves its stream idle (every GPU section ends in a wait), so the HIP streams belong to the workers, not to the camera
     // streams: their number does not grow with S.
     p->worker_streams.resize(nworkers); p->occ_tails.resize(nworkers); p->tails.resize(p->S);

@@ -240,7 +240,7 @@ def pmc_profile():
     """The committed rocprofv3 PMC passes of the solver kernel for the default config (separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per
     the gfx950 correction): newest profiles/rNN/*pmc_k_sor*.json, or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_k_sor*.json")), key=lambda f: (os.path.basename(os.path.dirname(f)), os.path.getmtime(f)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_k_sor*.json")), key=lambda f: (os.path.basename(os.path.dirname(f)), os.path.basename(f)))        # rNN, then vK_ (file times do not survive a checkout)
     if not files:
         return None
     d = json.load(open(files[-1])); d["file"] = os.path.relpath(files[-1], ROOT)

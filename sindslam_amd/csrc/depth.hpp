@@ -28,12 +28,12 @@ int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const f
                         int maxCount, double eps2, int B = 1, size_t pt_stride = 0, size_t lab_stride = 0, size_t seg_stride = 0, size_t comp_stride = 0, size_t st_stride = 0);
 int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev, float* out_host);
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n, int B = 1, size_t lab_stride = 0, size_t out_stride = 0);
-int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h);
-int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out);
-int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, uint8_t* edge, uint8_t* total_area, int w, int h, float depthScale);
-int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, int n, bool dilate);
-int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out);
-int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n);
+int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h, int B = 1);
+int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out, int B = 1, int out_stride = 1);
+int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, uint8_t* edge, uint8_t* total_area, int w, int h, float depthScale, int B = 1, int dmax_stride = 1);
+int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, int n, bool dilate, int B = 1);
+int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out, int B = 1);
+int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n, int B = 1, int dmax_stride = 1);
 int launch_dilate_planes(hipStream_t s, const unsigned long long* src, unsigned long long* dst, int nplanes, int w, int h, int n);
 int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int w, int h, int wpr, const uint8_t* occ2, const uint8_t* depthN,
                      int* overlap, int* overlapPlane, int* ljOverlap, int* ljArea, int* hist);

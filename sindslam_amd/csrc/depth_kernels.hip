@@ -470,9 +470,11 @@ __global__ void k_labels_to_u8(const int* __restrict__ labels, uint8_t* __restri
 }
 
 // ---------------------------------------------------------------- medianBlur(5) on the depth image (values are integers, so the float median == u16 median)
+// (the CalOccluded kernels take the frame from blockIdx.z: the pipeline runs them once for all frames of a step)
 __global__ void k_median5_u16(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int w, int h) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    src += (size_t)blockIdx.z * w * h; dst += (size_t)blockIdx.z * w * h;
     int v[25];
     #pragma unroll
     for (int dy = -2; dy <= 2; dy++) {
@@ -490,7 +492,8 @@ __global__ void k_median5_u16(const uint16_t* __restrict__ src, uint16_t* __rest
     }
     dst[y * w + x] = (uint16_t)med;
 }
-__global__ void k_max_u16(const uint16_t* __restrict__ src, int n, unsigned* __restrict__ out) {
+__global__ void k_max_u16(const uint16_t* __restrict__ src, int n, unsigned* __restrict__ out, int out_stride) {
+    src += (size_t)blockIdx.y * n; out += (size_t)blockIdx.y * out_stride;
     unsigned m = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, (unsigned)src[i]);
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
@@ -498,9 +501,10 @@ __global__ void k_max_u16(const uint16_t* __restrict__ src, int n, unsigned* __r
 }
 // 5x5 max-difference depth edge + valid-area mask (DD:443-482); the 3-px frame is left 0 in both outputs
 __global__ void k_grad_edge(const uint16_t* __restrict__ filt, const unsigned* __restrict__ dmax, uint8_t* __restrict__ edge,
-                            uint8_t* __restrict__ total_area, int w, int h, float depthScale) {
+                            uint8_t* __restrict__ total_area, int w, int h, float depthScale, int dmax_stride) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
     if (col >= w) return;
+    { const size_t fo = (size_t)blockIdx.z * w * h; filt += fo; edge += fo; total_area += fo; dmax += (size_t)blockIdx.z * dmax_stride; }
     uint8_t e = 0, t = 0;
     if (row >= 3 && row < h - 3 && col >= 3 && col < w - 3) {
         const float depth_max = (float)(*dmax);
@@ -525,6 +529,7 @@ __global__ void k_grad_edge(const uint16_t* __restrict__ filt, const unsigned* _
 __global__ void k_morph(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int w, int h, MorphElem E, int is_dilate) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    src += (size_t)blockIdx.z * w * h; dst += (size_t)blockIdx.z * w * h;
     int m = is_dilate ? 0 : 255;
     for (int i = 0; i < E.n; i++) {
         const int yy = y + i - E.ay;
@@ -546,6 +551,7 @@ __global__ void __launch_bounds__(256) k_peac_block_stats(const uint16_t* __rest
     __shared__ float pz[4][PEAC_BW * PEAC_BW];                      // zf per point (x, y follow from the pixel position)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, blk = blockIdx.x * 4 + wv;
     if (blk >= nblk) return;                                        // whole waves leave; no block-wide barrier below
+    depth += (size_t)blockIdx.y * w * h; out += (size_t)blockIdx.y * nblk;
     const int by = blk / Nw, bx = blk - by * Nw;
     const float inv = 1.0f / depthScale;
     auto zat = [&](int i, int j, float& zf) -> bool { const float d = (float)depth[i * w + j]; if (d < 1e-3f) return false; zf = d * inv; return true; };
@@ -584,9 +590,10 @@ __global__ void __launch_bounds__(256) k_peac_block_stats(const uint16_t* __rest
 }
 
 // ---------------------------------------------------------------- imgDepth/depth_max*255 -> 8U (DD:765-768): u16 * (float)((1/max)*255), cvRound, saturate
-__global__ void k_depth_norm(const uint16_t* __restrict__ depth, const unsigned* __restrict__ dmax, uint8_t* __restrict__ out, int n) {
+__global__ void k_depth_norm(const uint16_t* __restrict__ depth, const unsigned* __restrict__ dmax, uint8_t* __restrict__ out, int n, int dmax_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    depth += (size_t)blockIdx.y * n; out += (size_t)blockIdx.y * n; dmax += (size_t)blockIdx.y * dmax_stride;
     const float a = (float)((1.0 / (double)(*dmax)) * 255);
     int v = d_cvRound((float)depth[i] * a);
     v = min(max(v, 0), 65535);
@@ -736,12 +743,14 @@ int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev /* 2
 }
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n, int B, size_t lab_stride, size_t out_stride) {
     hipLaunchKernelGGL(k_labels_to_u8, dim3(divup(n, 256), B), dim3(256), 0, s, labels, out, n, lab_stride, out_stride); return SIND_OK; }
-int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h) { hipLaunchKernelGGL(k_median5_u16, dim3(divup(w, 64), h), dim3(64), 0, s, src, dst, w, h); return SIND_OK; }
-int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out) {
-    HIP_TRY(hipMemsetAsync(out, 0, sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_max_u16, dim3(std::min(divup(n, 256), 256)), dim3(256), 0, s, src, n, out); return SIND_OK; }
-int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, uint8_t* edge, uint8_t* total_area, int w, int h, float depthScale) {
-    hipLaunchKernelGGL(k_grad_edge, dim3(divup(w, 128), h), dim3(128), 0, s, filt, dmax, edge, total_area, w, h, depthScale); return SIND_OK; }
+// B frames per launch (frame b at offset b * w * h of every image argument; maxima at out + b * out_stride)
+int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h, int B) { hipLaunchKernelGGL(k_median5_u16, dim3(divup(w, 64), h, B), dim3(64), 0, s, src, dst, w, h); return SIND_OK; }
+int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out, int B, int out_stride) {
+    if (B == 1 || out_stride == 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * sizeof(unsigned), s));
+    else for (int b = 0; b < B; b++) HIP_TRY(hipMemsetAsync(out + (size_t)b * out_stride, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_max_u16, dim3(std::min(divup(n, 256), 256), B), dim3(256), 0, s, src, n, out, out_stride); return SIND_OK; }
+int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, uint8_t* edge, uint8_t* total_area, int w, int h, float depthScale, int B, int dmax_stride) {
+    hipLaunchKernelGGL(k_grad_edge, dim3(divup(w, 128), h, B), dim3(128), 0, s, filt, dmax, edge, total_area, w, h, depthScale, dmax_stride); return SIND_OK; }
 MorphElem make_ellipse(int n) {
     MorphElem e; e.n = n; e.ax = n / 2; e.ay = n / 2;
     for (int i = 0; i < MORPH_MAX; i++) { e.j1[i] = 0; e.j2[i] = 0; }
@@ -753,13 +762,14 @@ MorphElem make_ellipse(int n) {
     }
     return e;
 }
-int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, int n, bool dilate) {
-    hipLaunchKernelGGL(k_morph, dim3(divup(w, 128), h), dim3(128), 0, s, src, dst, w, h, make_ellipse(n), dilate ? 1 : 0); return SIND_OK; }
-int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out) {
+int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, int n, bool dilate, int B) {
+    hipLaunchKernelGGL(k_morph, dim3(divup(w, 128), h, B), dim3(128), 0, s, src, dst, w, h, make_ellipse(n), dilate ? 1 : 0); return SIND_OK; }
+int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out, int B) {
     if (bw != PEAC_BW || bh != PEAC_BW) { sind_set_error("peac_block_stats: %d x %d blocks (only %d x %d)", bw, bh, PEAC_BW, PEAC_BW); return SIND_E_ARG; }
     const int nb = (w / bw) * (h / bh);
-    hipLaunchKernelGGL(k_peac_block_stats, dim3(divup(nb, 4)), dim3(256), 0, s, depth, w, h, w / bw, nb, fx, fy, cx, cy, depthScale, 0.04, 0.02 * 1000, out); return SIND_OK; }
-int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n) { hipLaunchKernelGGL(k_depth_norm, dim3(divup(n, 256)), dim3(256), 0, s, depth, dmax, out, n); return SIND_OK; }
+    hipLaunchKernelGGL(k_peac_block_stats, dim3(divup(nb, 4), B), dim3(256), 0, s, depth, w, h, w / bw, nb, fx, fy, cx, cy, depthScale, 0.04, 0.02 * 1000, out); return SIND_OK; }
+int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n, int B, int dmax_stride) {
+    hipLaunchKernelGGL(k_depth_norm, dim3(divup(n, 256), B), dim3(256), 0, s, depth, dmax, out, n, dmax_stride); return SIND_OK; }
 int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int w, int h, int wpr, const uint8_t* occ2, const uint8_t* depthN,
                      int* overlap, int* overlapPlane, int* ljOverlap, int* ljArea, int* hist) {
     if (C < 1 || C > 254) { sind_set_error("rag_stats: %d pieces unsupported (1..254)", C); return SIND_E_ARG; }

@@ -37,7 +37,18 @@ struct DynaDebug {           // stage outputs of the last tail call (parity test
 };
 
 struct OccResult { BitImg totalArea, occ1, occ2; bool ready = false; const float* gridFlow = nullptr;
-                   uint8_t* occ2_dev = nullptr; uint8_t* depthN_dev = nullptr; };          // optional device slots the producer fills: plane-edge mask and 8-bit normalised depth for the RAG statistics     // state-free per-frame results computed ahead of the tail: CalOccluded outputs, flow at the 10-px sample grid (host)
+                   uint8_t* occ2_dev = nullptr; uint8_t* depthN_dev = nullptr; hipEvent_t occ2_event = nullptr; };          // optional device slots the producer fills: plane-edge mask and 8-bit normalised depth for the RAG statistics     // state-free per-frame results computed ahead of the tail: CalOccluded outputs, flow at the 10-px sample grid (host)
+
+// ---- GPU half of CalOccluded for a chunk of frames at once (state free: depth only).  Host-side results of one frame: OccGpuOut.
+struct OccGpuOut { const uint8_t* edge; const uint8_t* total; const PeacBlockStats* blocks;
+                   uint8_t* occ2_stage = nullptr; hipEvent_t occ2_event = nullptr; };      // optional: page-locked N bytes for the occ2 upload and the event recorded behind it
+struct OccBatch {
+    DynaConfig cfg; int cap = 0;
+    DevBuf<uint16_t> filt; DevBuf<uint8_t> edge, edgeTmp, total; DevBuf<unsigned> umax; DevBuf<PeacBlockStats> blocks;
+    int init(const DynaConfig& c, int chunk);
+    // frames at depth_dev + b * W * H; outputs (host, page-locked): edge / valid-area masks and block statistics per frame; depthN_dev (device, optional)
+    int run(hipStream_t s, const uint16_t* depth_dev, int B, uint8_t* depthN_dev, uint8_t* edge_h, uint8_t* total_h, PeacBlockStats* blocks_h);
+};
 
 // ---- stateful tail of one stream (reference DynaDetect.cc:1377-1666 minus the dense flow) ---------------------------------
 // Output of the flow-independent half of a frame (k-means on the depth, CalOccluded, SegAndMerge): everything the flow-dependent
@@ -83,7 +94,7 @@ public:
     int flow_stage(const float* U, const float* V, const DepthStageOut& d, uint8_t* dyna_out, uint8_t* label_out, const float* gridFlowPre = nullptr);
     // CalOccluded (DD:429-642) depends on the depth frame only: the pipeline runs it on this tail's stream while the dense flow
     // of the step is still on the GPU and the host cores are idle
-    int compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out);
+    int compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out, const OccGpuOut* pre = nullptr);
     void reset();
     // Inter-frame state (reference DynaDetect.h:172-178, rolled at DynaDetect.cc:1660-1664) as one flat blob, so that a sequence can
     // continue on another handle / rank exactly where this one stopped ("phase B strictly in frame order"):
@@ -111,7 +122,7 @@ private:
     int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
     DevBuf<KmState> kstate; DevBuf<uint16_t> depth_fix; hipGraphExec_t kmGraph[2] = {nullptr, nullptr}; bool kmGraphBroken = false;
     int kmeans_enqueue(const uint16_t* depth0, bool prevLabels);
-    int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2);
+    int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2, const OccGpuOut* pre = nullptr);
     int seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,
                       const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew, const OccResult* pre = nullptr);
 };

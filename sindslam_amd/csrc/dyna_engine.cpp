@@ -110,14 +110,14 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc((size_t)2 * N)); SIND_TRY(mag.alloc(N));       // low_d: low mask, then high mask (one D2H)
     SIND_TRY(kpart.alloc((size_t)(KM_MAX_BLOCKS * 4 + 1) * KM_K + 64));       // count table, totals row, the 36 sums
     SIND_TRY(kcomp.alloc((size_t)3 * N + 8)); /* + 8: k_km_seqsum's window loads may touch up to 7 floats behind the last run */ SIND_TRY(umax_d.alloc(2));
-    SIND_TRY(h_grid.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(h_hist.alloc(257)); SIND_TRY(h_ab.alloc((size_t)2 * N)); SIND_TRY(h_lab8.alloc(N));
+    SIND_TRY(h_grid.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(h_hist.alloc(261)); SIND_TRY(h_ab.alloc((size_t)2 * N)); SIND_TRY(h_lab8.alloc(N));
     SIND_TRY(h_kstate.alloc(4)); SIND_TRY(h_blocks.alloc((size_t)(W / 16) * (H / 16)));
     { // RAG workspaces for up to 64 pieces up front: a later (re)allocation synchronises the whole device, i.e. waits for the
       // flow solver of the next step when tails and dense flow overlap
       const size_t cap = 64, pw = (size_t)H * (W / 64), nr = 3 * cap * cap + cap + cap * 256;
       SIND_TRY(h_planes.alloc(3 * cap * pw)); SIND_TRY(planes_d.alloc(3 * cap * pw)); SIND_TRY(h_rag.alloc(nr)); SIND_TRY(rag_d.alloc(nr)); }
     SIND_TRY(kstate.alloc(4)); SIND_TRY(depth_fix.alloc(N));
-    SIND_TRY(hist_d.alloc(257));       // [256] = residual maximum (float bits)
+    SIND_TRY(hist_d.alloc(261));       // [256] = residual maximum (float bits), [257..260] = thresholds lo, hi, otsu, triangle (floats)
     SIND_TRY(grid_d.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
     // every kernel operand of the tail must exist before the first launch (a missing workspace would be a wild device write)
     const void* ws[] = {dpyr[1].p, dpyr[2].p, dpyr[3].p, lab[0].p, lab[1].p, lab[2].p, lab[3].p, filt.p, px.p, py.p, pz.p, lab8.p, labPrev8.p, edge.p, edgeTmp.p, total.p,
@@ -184,61 +184,16 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     find_homography_rho(in, inLast, Hm);
     QLAP(22)
     SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, (unsigned*)(hist_d.p + 256), hist_d.p, magu8.p, W, H));
-    HIP_TRY(hipMemcpyAsync(h_hist.p, hist_d.p, 257 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(sind_stream_wait(stream));
-    unsigned mb; std::memcpy(&mb, h_hist.p + 256, 4); int hist[256]; std::memcpy(hist, h_hist.p, sizeof(hist));
-    float maxErrorf; std::memcpy(&maxErrorf, &mb, 4);
-    // cv::threshold(THRESH_OTSU / THRESH_TRIANGLE) return values from the 256-bin histogram (imgproc/thresh.cpp)
-    auto otsu = [&]() {
-        double mu = 0; const double scale = 1. / N;
-        for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
-        mu *= scale;
-        double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-        for (int i = 0; i < 256; i++) {
-            const double p_i = hist[i] * scale; mu1 *= q1; q1 += p_i; const double q2 = 1. - q1;
-            if (std::min(q1, q2) < FLT_EPSILON || std::max(q1, q2) > 1. - FLT_EPSILON) continue;
-            mu1 = (mu1 + i * p_i) / q1; const double mu2 = (mu - q1 * mu1) / q2, sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-            if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
-        }
-        return max_val;
-    };
-    auto triangle = [&]() {
-        int h[256]; std::memcpy(h, hist, sizeof(h));
-        int left = 0, right = 0, max_ind = 0, mx = 0; bool flipped = false;
-        for (int i = 0; i < 256; i++) if (h[i] > 0) { left = i; break; }
-        if (left > 0) left--;
-        for (int i = 255; i > 0; i--) if (h[i] > 0) { right = i; break; }
-        if (right < 255) right++;
-        for (int i = 0; i < 256; i++) if (h[i] > mx) { mx = h[i]; max_ind = i; }
-        if (max_ind - left < right - max_ind) { flipped = true; std::reverse(h, h + 256); left = 255 - right; max_ind = 255 - max_ind; }
-        double thresh = left, a = mx, b = left - max_ind, dist = 0;
-        for (int i = left + 1; i <= max_ind; i++) { const double t = a * i + b * h[i]; if (t > dist) { dist = t; thresh = i; } }
-        thresh--;
-        if (flipped) thresh = 255 - thresh;
-        return thresh;
-    };
-    float thred1 = (float)otsu(), thred2 = (float)triangle();
-    dbg.maxError = maxErrorf; dbg.otsu = thred1; dbg.triangle = thred2; dbg.nPairs = (int)in.size(); std::copy(Hm, Hm + 9, dbg.H); std::copy(hist, hist + 256, dbg.hist);
-    auto count_gt = [&](float t) { int n = 0; for (int v = 0; v < 256; v++) if ((double)v > (double)t) n += hist[v]; return n; };
-    float lo, hi;
-    if (thred1 < thred2) {                                    // DD:1309-1336
-        if (thred1 < 1.7f * 255.0f / maxErrorf) thred1 = 1.7f * 255.0f / maxErrorf;
-        else if (thred1 > 3.0f * 255.0f / maxErrorf) thred1 = 3.0f * 255.0f / maxErrorf;
-        if (count_gt(thred1) > 0.5 * W * H) thred1 = thred1 + 0.2f * 255.0f / maxErrorf;
-        if (thred2 < std::max(3.0f * 255.0f / maxErrorf, thred1 * 1.2f)) thred2 = std::max(3.0f * 255.0f / maxErrorf, thred1 * 1.2f);
-        else if (thred2 > 10.0f * 255.0f / maxErrorf) thred2 = 10.0f * 255.0f / maxErrorf;
-        lo = thred1; hi = thred2;
-    } else {                                                  // DD:1337-1367 (the relaxation test there is dead code)
-        if (thred2 < 1.7f * 255.0f / maxErrorf) thred2 = 1.7f * 255.0f / maxErrorf;
-        else if (thred2 > 3.0f * 255.0f / maxErrorf) thred2 = 3.0f * 255.0f / maxErrorf;
-        if (thred1 < std::max(3.0f * 255.0f / maxErrorf, thred2 * 1.2f)) thred1 = std::max(3.0f * 255.0f / maxErrorf, thred2 * 1.2f);
-        else if (thred1 > 10.0f * 255.0f / maxErrorf) thred1 = 10.0f * 255.0f / maxErrorf;
-        lo = thred2; hi = thred1;
-    }
-    dbg.thr_low = lo; dbg.thr_high = hi;
-    SIND_TRY(launch_threshold_masks(stream, magu8.p, lo, hi, low_d.p, (low_d.p + N), N));
+    // thresholds (Otsu / triangle + the clamping of DD:1309-1367) and the two masks on the device: one host round trip for the stage
+    SIND_TRY(launch_flow_thresholds_and_masks(stream, hist_d.p, W, H, reinterpret_cast<float*>(hist_d.p + 257), magu8.p, low_d.p, (low_d.p + N)));
+    HIP_TRY(hipMemcpyAsync(h_hist.p, hist_d.p, 261 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h_ab.p, low_d.p, (size_t)2 * N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
+    {
+        float f[5]; std::memcpy(&f[0], h_hist.p + 256, 4); std::memcpy(&f[1], h_hist.p + 257, 16);
+        dbg.maxError = f[0]; dbg.thr_low = f[1]; dbg.thr_high = f[2]; dbg.otsu = f[3]; dbg.triangle = f[4];
+        dbg.nPairs = (int)in.size(); std::copy(Hm, Hm + 9, dbg.H); std::copy(h_hist.p, h_hist.p + 256, dbg.hist);
+    }
     tq = tick_ms();
     low = BitImg::from_u8(h_ab.p, W, H, W); high = BitImg::from_u8((h_ab.p + N), W, H, W);
     QLAP(23)
@@ -339,9 +294,12 @@ int KMeansBatch::run(const uint16_t* depth_base, size_t depth_stride, int B, con
 }
 
 // ---- DD:429-642: depth-gradient edges (GPU), end points, PEAC plane contours, plane-edge filtering (host)
-int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2) {
+int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2, const OccGpuOut* pre) {
     double tf = tick_ms();
     #define FLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tf; tf = t_; }
+    const uint8_t* edge_h = h_ab.p; const uint8_t* total_h = h_ab.p + N; const PeacBlockStats* blocks_h = h_blocks.data();
+    if (pre) { edge_h = pre->edge; total_h = pre->total; blocks_h = pre->blocks; }      // the GPU half ran for all frames of the step at once (OccBatch)
+    else {
     SIND_TRY(launch_median5(stream, depth_dev, filt.p, W, H));
     SIND_TRY(launch_max_u16(stream, filt.p, N, umax_d.p));
     SIND_TRY(launch_grad_edge(stream, filt.p, umax_d.p, edge.p, total.p, W, H, cfg.depthScale));
@@ -353,9 +311,10 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     HIP_TRY(hipMemcpyAsync((h_ab.p + N), total.p, N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(blocks.data(), blocks_d.p, blocks.n * sizeof(PeacBlockStats), hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
+    }
     FLAP(0)
-    const BitImg occ = BitImg::from_u8(h_ab.p, W, H, W);
-    totalArea = BitImg::from_u8((h_ab.p + N), W, H, W);
+    const BitImg occ = BitImg::from_u8(edge_h, W, H, W);
+    totalArea = BitImg::from_u8(total_h, W, H, W);
     FLAP(1)
     // end points: edge pixels with at most 4 of the 12 radius-2 ring pixels set (DD:498-532), greedy NMS radius 6 in scan order
     static const int ring[12][2] = {{0,-2},{1,-2},{2,-1},{2,0},{2,1},{1,2},{0,2},{-1,2},{-2,1},{-2,0},{-2,-1},{-1,-2}};
@@ -368,7 +327,7 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     { std::vector<PtI> sel; for (const PtI& e : endPoints) { bool ov = false; for (const PtI& q : sel) { const int dx = e.x - q.x, dy = e.y - q.y; if ((float)dx * dx + dy * dy < 6.0f * 6.0f) { ov = true; break; } } if (!ov) sel.push_back(e); } endPoints.swap(sel); }
     FLAP(2)
     // PEAC plane contours (DD:558-593)
-    BitImg planeC; PeacInput pin{blocks.data(), depth_host, W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale};
+    BitImg planeC; PeacInput pin{blocks_h, depth_host, W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale};
     peac_plane_contours(pin, planeC);
     FLAP(3)
     BitImg edgeByPlane = planeC; edgeByPlane.andnot(occ);                       // DD:599
@@ -388,7 +347,7 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     BitImg u = occ; u |= acc; occ1 = u.closed(e3);
     FLAP(5)
     #undef FLAP
-    if (keep_debug) { dbg.gradEdge.assign(h_ab.p, h_ab.p + N); dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
+    if (keep_debug) { dbg.gradEdge.assign(edge_h, edge_h + N); dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
     return SIND_OK;
 }
 
@@ -478,6 +437,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     HIP_TRY(hipMemcpyAsync(planes_d.p + (size_t)2 * C * pw, planes + (size_t)2 * C * pw, (size_t)C * pw * 8, hipMemcpyHostToDevice, stream));
     SIND_TRY(launch_dilate_planes(stream, planes_d.p, planes_d.p + (size_t)C * pw, C, W, H, 7));
     const uint8_t* occ2_use = pre && pre->occ2_dev ? pre->occ2_dev : occ2_d.p;
+    if (pre && pre->occ2_dev && pre->occ2_event) HIP_TRY(hipStreamWaitEvent(stream, pre->occ2_event, 0));       // uploaded on the CalOccluded runner's stream without a host wait
     if (!(pre && pre->occ2_dev)) { occ2.to_u8((h_ab.p + N), W, 255); HIP_TRY(hipMemcpyAsync(occ2_d.p, (h_ab.p + N), N, hipMemcpyHostToDevice, stream)); }
     FLAP(7)
     const uint8_t* depthN_use = pre && pre->depthN_dev ? pre->depthN_dev : depthN.p;
@@ -567,12 +527,39 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
 }
 
 // ---- DD:1377-1666
-int DynaTail::compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out) {
+// ---- GPU half of CalOccluded (and the 8-bit normalised depth of the RAG statistics) for a chunk of frames in seven launches: the stage has no
+// state, so the pipeline runs it for all frames of a step at the step's start instead of seven launches + a stream wait per frame (DD:429-482, 765-768)
+int OccBatch::init(const DynaConfig& c, int chunk) {
+    cfg = c; cap = chunk; const size_t n = (size_t)c.W * c.H;
+    SIND_TRY(filt.alloc(n * cap)); SIND_TRY(edge.alloc(n * cap)); SIND_TRY(edgeTmp.alloc(n * cap)); SIND_TRY(total.alloc(n * cap));
+    SIND_TRY(umax.alloc((size_t)2 * cap)); SIND_TRY(blocks.alloc((size_t)(c.W / 16) * (c.H / 16) * cap));
+    return SIND_OK;
+}
+int OccBatch::run(hipStream_t s, const uint16_t* depth_dev, int B, uint8_t* depthN_dev, uint8_t* edge_h, uint8_t* total_h, PeacBlockStats* blocks_h) {
+    if (B < 1 || B > cap) { sind_set_error("OccBatch::run: %d frames (capacity %d)", B, cap); return SIND_E_ARG; }
+    const int W = cfg.W, H = cfg.H, N = W * H; const size_t nb = (size_t)(W / 16) * (H / 16);
+    if (depthN_dev) { SIND_TRY(launch_max_u16(s, depth_dev, N, umax.p + cap, B, 1)); SIND_TRY(launch_depth_norm(s, depth_dev, umax.p + cap, depthN_dev, N, B, 1)); }
+    SIND_TRY(launch_median5(s, depth_dev, filt.p, W, H, B));
+    SIND_TRY(launch_max_u16(s, filt.p, N, umax.p, B, 1));
+    SIND_TRY(launch_grad_edge(s, filt.p, umax.p, edge.p, total.p, W, H, cfg.depthScale, B, 1));
+    SIND_TRY(launch_morph(s, edge.p, edgeTmp.p, W, H, 4, false, B));       // MORPH_OPEN, element4 = erode then dilate
+    SIND_TRY(launch_morph(s, edgeTmp.p, edge.p, W, H, 4, true, B));
+    SIND_TRY(launch_peac_block_stats(s, depth_dev, W, H, 16, 16, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale, blocks.p, B));
+    HIP_TRY(hipMemcpyAsync(edge_h, edge.p, (size_t)N * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(total_h, total.p, (size_t)N * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(blocks_h, blocks.p, nb * B * sizeof(PeacBlockStats), hipMemcpyDeviceToHost, s));
+    return SIND_OK;
+}
+
+int DynaTail::compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out, const OccGpuOut* pre) {
     HIP_TRY(hipSetDevice(cfg.device));
     // the depth-only inputs of the RAG statistics go first so that they are finished by the time cal_occluded waits on the stream
-    if (out.depthN_dev) { SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1)); SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, out.depthN_dev, N)); }
-    SIND_TRY(cal_occluded(depth_host, depth_dev, out.totalArea, out.occ1, out.occ2));
-    if (out.occ2_dev) { out.occ2.to_u8(h_ab.p + N, W, 255); HIP_TRY(hipMemcpyAsync(out.occ2_dev, h_ab.p + N, N, hipMemcpyHostToDevice, stream)); HIP_TRY(sind_stream_wait(stream)); }
+    if (out.depthN_dev && !pre) { SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1)); SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, out.depthN_dev, N)); }
+    SIND_TRY(cal_occluded(depth_host, depth_dev, out.totalArea, out.occ1, out.occ2, pre));
+    if (out.occ2_dev && pre && pre->occ2_stage && pre->occ2_event) {      // batched path: page-locked staging of the frame's own, consumers wait on the event, not this thread
+        out.occ2.to_u8(pre->occ2_stage, W, 255); HIP_TRY(hipMemcpyAsync(out.occ2_dev, pre->occ2_stage, N, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(pre->occ2_event, stream)); out.occ2_event = pre->occ2_event;
+    } else if (out.occ2_dev) { out.occ2.to_u8(h_ab.p + N, W, 255); HIP_TRY(hipMemcpyAsync(out.occ2_dev, h_ab.p + N, N, hipMemcpyHostToDevice, stream)); HIP_TRY(sind_stream_wait(stream)); out.occ2_event = nullptr; }
     out.ready = true; return SIND_OK;
 }
 

@@ -44,6 +44,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
 int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr);
 int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, unsigned* maxbits, int* hist, uint8_t* out_u8, int n, int B);
 int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h);
+int launch_flow_thresholds_and_masks(hipStream_t s, const int* hist, int W, int H, float* thr, const uint8_t* magu8, uint8_t* low, uint8_t* high);
 int launch_threshold_masks(hipStream_t s, const uint8_t* magu8, float lo, float hi, uint8_t* low, uint8_t* high, int n);
 int launch_gather_grid(hipStream_t s, const float* u, const float* v, float* out, int w, int h, int step, int B = 1);
 int launch_scale2(hipStream_t s, float* a, float* b, float sc, size_t n);

@@ -620,6 +620,70 @@ __global__ void k_threshold_masks(const uint8_t* __restrict__ magu8, float thr_l
     low[i] = q > (double)thr_low ? 128 : 0;
     high[i] = q > (double)thr_high ? 255 : 0;
 }
+// The two thresholds of stImgMasks from the residual's 256-bin histogram, on the device so that the flow-mask stage needs ONE host round trip (masks,
+// histogram and thresholds come back together): cv::threshold's THRESH_OTSU / THRESH_TRIANGLE return values (imgproc/thresh.cpp) and the clamping of
+// DD:1309-1367, one thread, the host code's FP64 / FP32 operations in the same order (no contraction: the library is built with -ffp-contract=off).
+// hist[256] = bit pattern of the maximal residual.  out: lo, hi, otsu, triangle.
+__global__ void k_flow_thresholds(const int* __restrict__ hist, int W, int H, float* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int N = W * H;
+    const float maxErrorf = __int_as_float(hist[256]);
+    double otsu_v;
+    {
+        double mu = 0; const double scale = 1. / N;
+        for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
+        mu *= scale;
+        double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+        for (int i = 0; i < 256; i++) {
+            const double p_i = hist[i] * scale; mu1 *= q1; q1 += p_i; const double q2 = 1. - q1;
+            if (fmin(q1, q2) < (double)1.1920928955078125e-7f || fmax(q1, q2) > 1. - (double)1.1920928955078125e-7f) continue;
+            mu1 = (mu1 + i * p_i) / q1; const double mu2 = (mu - q1 * mu1) / q2, sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+            if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+        }
+        otsu_v = max_val;
+    }
+    double tri_v;
+    {
+        int left = 0, right = 0, max_ind = 0, mx = 0; bool flipped = false;
+        for (int i = 0; i < 256; i++) if (hist[i] > 0) { left = i; break; }
+        if (left > 0) left--;
+        for (int i = 255; i > 0; i--) if (hist[i] > 0) { right = i; break; }
+        if (right < 255) right++;
+        for (int i = 0; i < 256; i++) if (hist[i] > mx) { mx = hist[i]; max_ind = i; }
+        if (max_ind - left < right - max_ind) { flipped = true; left = 255 - right; max_ind = 255 - max_ind; }
+        double thresh = left, a = mx, b = left - max_ind, dist = 0;
+        for (int i = left + 1; i <= max_ind; i++) { const double t = a * i + b * hist[flipped ? 255 - i : i]; if (t > dist) { dist = t; thresh = i; } }
+        thresh--;
+        if (flipped) thresh = 255 - thresh;
+        tri_v = thresh;
+    }
+    float thred1 = (float)otsu_v, thred2 = (float)tri_v;
+    out[2] = thred1; out[3] = thred2;
+    auto count_gt = [&](float t) { int n = 0; for (int v = 0; v < 256; v++) if ((double)v > (double)t) n += hist[v]; return n; };
+    float lo, hi;
+    if (thred1 < thred2) {                                    // DD:1309-1336
+        if (thred1 < 1.7f * 255.0f / maxErrorf) thred1 = 1.7f * 255.0f / maxErrorf;
+        else if (thred1 > 3.0f * 255.0f / maxErrorf) thred1 = 3.0f * 255.0f / maxErrorf;
+        if (count_gt(thred1) > 0.5 * W * H) thred1 = thred1 + 0.2f * 255.0f / maxErrorf;
+        if (thred2 < fmaxf(3.0f * 255.0f / maxErrorf, thred1 * 1.2f)) thred2 = fmaxf(3.0f * 255.0f / maxErrorf, thred1 * 1.2f);
+        else if (thred2 > 10.0f * 255.0f / maxErrorf) thred2 = 10.0f * 255.0f / maxErrorf;
+        lo = thred1; hi = thred2;
+    } else {                                                  // DD:1337-1367 (the relaxation test there is dead code)
+        if (thred2 < 1.7f * 255.0f / maxErrorf) thred2 = 1.7f * 255.0f / maxErrorf;
+        else if (thred2 > 3.0f * 255.0f / maxErrorf) thred2 = 3.0f * 255.0f / maxErrorf;
+        if (thred1 < fmaxf(3.0f * 255.0f / maxErrorf, thred2 * 1.2f)) thred1 = fmaxf(3.0f * 255.0f / maxErrorf, thred2 * 1.2f);
+        else if (thred1 > 10.0f * 255.0f / maxErrorf) thred1 = 10.0f * 255.0f / maxErrorf;
+        lo = thred2; hi = thred1;
+    }
+    out[0] = lo; out[1] = hi;
+}
+__global__ void k_threshold_masks_dev(const uint8_t* __restrict__ magu8, const float* __restrict__ thr, uint8_t* __restrict__ low, uint8_t* __restrict__ high, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double q = (double)magu8[i];
+    low[i] = q > (double)thr[0] ? 128 : 0;
+    high[i] = q > (double)thr[1] ? 255 : 0;
+}
 // gather flow at the 63x47 sample grid (DD:1182-1204) so the host can build the PROSAC-ordered pairs
 __global__ void k_gather_grid(const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ out, int w, int h, int step) {
     const int gx = (w - 1) / step, gy = (h - 1) / step;   // points at step, 2*step, ... < w
@@ -817,6 +881,11 @@ int launch_residual(hipStream_t s, const float* u, const float* v, const double 
 }
 int launch_threshold_masks(hipStream_t s, const uint8_t* magu8, float lo, float hi, uint8_t* low, uint8_t* high, int n) {
     hipLaunchKernelGGL(k_threshold_masks, dim3(divup(n, 256)), dim3(256), 0, s, magu8, lo, hi, low, high, n);
+    return SIND_OK;
+}
+int launch_flow_thresholds_and_masks(hipStream_t s, const int* hist, int W, int H, float* thr, const uint8_t* magu8, uint8_t* low, uint8_t* high) {
+    hipLaunchKernelGGL(k_flow_thresholds, dim3(1), dim3(64), 0, s, hist, W, H, thr);
+    hipLaunchKernelGGL(k_threshold_masks_dev, dim3(divup(W * H, 256)), dim3(256), 0, s, magu8, thr, low, high, W * H);
     return SIND_OK;
 }
 int launch_gather_grid(hipStream_t s, const float* u, const float* v, float* out, int w, int h, int step, int B) {

@@ -70,6 +70,9 @@ struct sind_pipe {
     KMeansBatch kmb; hipStream_t km_stream = nullptr; bool batch_km = false; std::thread round_thread; double km_round_ms = 0; long km_rounds = 0;
     std::vector<std::unique_ptr<PinnedBuf<uint8_t>>> upload_stage;        // page-locked staging of sind_pipe_process (host-buffer entry point), two 4 MB buffers per uploading worker
     std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
+    // GPU half of CalOccluded for all frames of a step, in chunks, on a stream of its own at the start of phase A (seven launches per chunk instead
+    // of seven launches + a stream wait per frame); the runner tasks wait for their frame's chunk and do the host half
+    OccBatch occb; hipStream_t occ_stream = nullptr; bool batch_occ = false; int occ_chunk = 64;
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
     struct StepBuf {
@@ -77,6 +80,7 @@ struct sind_pipe {
         DevBuf<uint8_t> occ2_dev, depthN_dev;                  // per frame: plane-edge mask and normalised depth for the tails' RAG statistics (filled by the CalOccluded tasks)
         DevBuf<float> grid_dev; PinnedBuf<float> grid_h;       // flow at the 10-px sample grid of every frame (DD:1182-1204), gathered right after the dense flow
         std::atomic<int> occ_next{0};                          // next frame for the CalOccluded runner tasks
+        PinnedBuf<uint8_t> occ_edge_h, occ_total_h; PinnedBuf<PeacBlockStats> occ_blocks_h; std::vector<hipEvent_t> occ_ev, occ2_ev;      // batched GPU half: per-frame host results, one event per chunk; one event per frame behind its occ2 upload
         // depth half of the tails (k-means, SegAndMerge) run ahead, underneath the dense flow (synchronous steps only): per-frame results,
         // and a gate per frame that opens when both its CalOccluded result and the stream's previous depth stage are there
         bool depth_ahead = false; std::vector<DepthStageOut> dout; std::unique_ptr<std::atomic<int>[]> gate; TaskGroup depth_group;
@@ -166,6 +170,19 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     if (p->depth_ahead) SIND_TRY(ensure_dtails(p));
     p->batch_km = p->S >= 2 && !(getenv("SIND_KM_BATCH") && atoi(getenv("SIND_KM_BATCH")) == 0);
     if (p->batch_km) { SIND_TRY(make_stream(&p->km_stream, true)); SIND_TRY(p->kmb.init(p->dc, p->S, p->km_stream)); }
+    p->batch_occ = B >= 4 && !(getenv("SIND_OCC_BATCH") && atoi(getenv("SIND_OCC_BATCH")) == 0);
+    if (p->batch_occ) {
+        p->occ_chunk = std::min(B, std::max(1, getenv("SIND_OCC_CHUNK") ? atoi(getenv("SIND_OCC_CHUNK")) : 64));
+        SIND_TRY(make_stream(&p->occ_stream, true)); SIND_TRY(p->occb.init(p->dc, p->occ_chunk));
+        const size_t nblk = (size_t)(cfg->width / 16) * (cfg->height / 16); const int nch = (B + p->occ_chunk - 1) / p->occ_chunk;
+        for (int k = 0; k < 2; k++) {
+            SIND_TRY(p->sb[k].occ_edge_h.alloc(np * B)); SIND_TRY(p->sb[k].occ_total_h.alloc(np * B)); SIND_TRY(p->sb[k].occ_blocks_h.alloc(nblk * B));
+            p->sb[k].occ_ev.assign(nch, nullptr);
+            for (int c = 0; c < nch; c++) HIP_TRY(hipEventCreateWithFlags(&p->sb[k].occ_ev[c], hipEventDisableTiming));
+            p->sb[k].occ2_ev.assign(B, nullptr);
+            for (int f = 0; f < B; f++) HIP_TRY(hipEventCreateWithFlags(&p->sb[k].occ2_ev[f], hipEventDisableTiming));
+        }
+    }
     p->workers.start(nworkers, cfg->device);
     SIND_TRY(p->gray.alloc(np * std::max(B, 2)));          // sind_pipe_prime converts the two priming frames through this scratch, also when S * T == 1
     SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
@@ -203,7 +220,8 @@ int sind_pipe_destroy(sind_pipe* p) {
     (void)hipSetDevice(p->c.device);
     (void)hipDeviceSynchronize();
     if (p->round_thread.joinable()) p->round_thread.join();
-    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream); ss.push_back(p->km_stream);
+    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream); ss.push_back(p->km_stream); ss.push_back(p->occ_stream);
+    for (auto& b : p->sb) { for (hipEvent_t e : b.occ_ev) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : b.occ2_ev) if (e) (void)hipEventDestroy(e); }
     for (size_t w = 0; w < p->worker_streams_lo.size(); w++) if (w >= p->worker_streams.size() || p->worker_streams_lo[w] != p->worker_streams[w]) ss.push_back(p->worker_streams_lo[w]); ss.push_back(p->orb_stream); ss.insert(ss.end(), p->extra_streams.begin(), p->extra_streams.end());
     if (p->ev_pool) (void)hipEventDestroy(p->ev_pool);
     if (p->ev_gray) (void)hipEventDestroy(p->ev_gray);
@@ -273,6 +291,16 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     SIND_TRY(sb.occ2_dev.alloc(np * B)); SIND_TRY(sb.depthN_dev.alloc(np * B));
     for (int k = 0; k < B; k++) { sb.occ[k].occ2_dev = sb.occ2_dev.p + np * k; sb.occ[k].depthN_dev = sb.depthN_dev.p + np * k; }
     sb.occ_rc.assign(B, SIND_OK); sb.occ_err.assign(B, std::string());
+    if (p->batch_occ) {                                   // GPU half of CalOccluded, chunk by chunk, behind the depth copies
+        HIP_TRY(hipStreamWaitEvent(p->occ_stream, p->ev_depth, 0));
+        const size_t nblk = (size_t)(W / 16) * (H / 16);
+        for (int c0 = 0, c = 0; c0 < B; c0 += p->occ_chunk, c++) {
+            const int nb = std::min(p->occ_chunk, B - c0);
+            SIND_TRY(p->occb.run(p->occ_stream, sb.depth_dev.p + np * c0, nb, sb.depthN_dev.p + np * c0, sb.occ_edge_h.data() + np * c0, sb.occ_total_h.data() + np * c0,
+                                 sb.occ_blocks_h.data() + nblk * c0));
+            HIP_TRY(hipEventRecord(sb.occ_ev[c], p->occ_stream));
+        }
+    }
     struct Waiter { TaskGroup& g; ~Waiter() { WorkerPool::wait(g); } };       // no task may outlive this call's buffers on an error return
     Waiter depth_waiter{sb.depth_group}, waiter{sb.occ_group};                // destroyed in reverse order: CalOccluded runners first (they open the last gates), then the depth chains
     sb.depth_ahead = depth_ahead;
@@ -287,7 +315,14 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     sb.occ_next.store(0);
     auto push_occ = [&] { for (int r = 0; r < std::min(p->occ_workers, B); r++) p->workers.push(sb.occ_group, [p, &sb, B, np](int w) {
         for (int k; (k = sb.occ_next.fetch_add(1)) < B;) {
-            const int rc = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
+            int rc = SIND_OK;
+            if (p->batch_occ) {
+                const size_t nblk = (size_t)(p->c.width / 16) * (p->c.height / 16);
+                if (sind_event_wait(sb.occ_ev[k / p->occ_chunk]) != hipSuccess) { (void)hipGetLastError(); sind_set_error("batched CalOccluded stage failed"); rc = SIND_E_HIP; }
+                else { const OccGpuOut pre{sb.occ_edge_h.data() + np * k, sb.occ_total_h.data() + np * k, sb.occ_blocks_h.data() + nblk * k,
+                                           sb.occ_edge_h.data() + np * k /* the edge image has been packed by then */, sb.occ2_ev[k]};
+                       rc = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k], &pre); }
+            } else rc = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
             if (rc != SIND_OK) { sb.occ_rc[k] = rc; sb.occ_err[k] = sind_last_error(); }
             if (sb.depth_ahead && sb.gate[k].fetch_add(1) == 1) { sind_pipe::StepBuf* sbp = &sb; p->workers.push(sb.depth_group, [p, sbp, k](int w2) { depth_task(p, sbp, k, w2); }); }
         } }); };

@@ -42,3 +42,13 @@ for k in range(len(steps)):
             if e > a and s < b: inside[n.split('(')[0].replace('void ', '').replace('sind::', '')[:28]] += min(e, b) - max(s, a)
         top = ', '.join(f'{n} {v / 1e6:.1f}' for n, v in inside.most_common(5))
         print(f'    gap {(a - lo) / 1e6:7.1f} .. {(b - lo) / 1e6:7.1f} ms ({(b - a) / 1e6:5.1f} ms): {top}')
+
+# optional: python3 solver_gaps.py <dir> --timeline K  -> the first 70 ms of step K in 5-ms bins: busy time per kernel name inside each bin
+if len(sys.argv) > 3 and sys.argv[2] == '--timeline':
+    K = int(sys.argv[3]); lo = steps[K]
+    for b in range(14):
+        a0, a1 = lo + b * 5e6, lo + (b + 1) * 5e6
+        inside = Counter()
+        for s_, e_, n in rows:
+            if e_ > a0 and s_ < a1: inside[n.split('(')[0].replace('void ', '').replace('sind::', '')[:26]] += min(e_, a1) - max(s_, a0)
+        print(f'  {b * 5:3d}-{b * 5 + 5:3d} ms: ' + ', '.join(f'{n} {v / 1e6:.1f}' for n, v in inside.most_common(7)))

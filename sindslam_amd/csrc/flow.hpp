@@ -35,6 +35,8 @@ struct SorTimer {
 
 int launch_gather_frames(hipStream_t s, const uint8_t* pool, const int* idx_host, int B, uint8_t* out, size_t frame_bytes);
 int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w, int h, int B, float k0, float k1, bool blur);
+int launch_resize_f32_pair(hipStream_t s, const float* srcA, float* dstA, const float* srcB, float* dstB, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
+int launch_pyramid_tail(hipStream_t s, float* pyrA, float* pyrB, const std::vector<std::pair<int, int>>& levels, const std::vector<size_t>& level_off, int first, int last, int B);
 int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img);
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb);

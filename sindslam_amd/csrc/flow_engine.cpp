@@ -47,10 +47,13 @@ int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, 
     const int L = max_levels > 0 ? std::min(max_levels, (int)levels.size()) : (int)levels.size();
     SIND_TRY(launch_u8_to_f32_blur3(stream, g0, level_ptr(pyr0, 0, B), fw, fh, B, k0, k1, true));
     SIND_TRY(launch_u8_to_f32_blur3(stream, g1, level_ptr(pyr1, 0, B), fw, fh, B, k0, k1, true));
-    for (int l = 1; l < L; l++) {
-        SIND_TRY(launch_resize_f32(stream, level_ptr(pyr0, l - 1, B), level_ptr(pyr0, l, B), levels[l - 1].first, levels[l - 1].second, levels[l].first, levels[l].second, B, 1.f, false));
-        SIND_TRY(launch_resize_f32(stream, level_ptr(pyr1, l - 1, B), level_ptr(pyr1, l, B), levels[l - 1].first, levels[l - 1].second, levels[l].first, levels[l].second, B, 1.f, false));
-    }
+    // 0.95 pyramid of both images: one launch per level for the pair while the level is large, the small levels (<= 12 k pixels) in one launch
+    int lt = 1; while (lt < L && (size_t)levels[lt - 1].first * levels[lt - 1].second > 12288) lt++;
+    lt = std::max(lt, L - 1 - 40 + 1);                          // the tail kernel takes at most 40 levels
+    for (int l = 1; l < std::min(lt, L); l++)
+        SIND_TRY(launch_resize_f32_pair(stream, level_ptr(pyr0, l - 1, B), level_ptr(pyr0, l, B), level_ptr(pyr1, l - 1, B), level_ptr(pyr1, l, B), levels[l - 1].first, levels[l - 1].second,
+                                        levels[l].first, levels[l].second, B, 1.f, false));
+    if (lt < L) SIND_TRY(launch_pyramid_tail(stream, pyr0.p, pyr1.p, levels, level_off, lt - 1, L - 1, B));
     VarParams V;   // OpticalFlowDeepFlow defaults: alpha 1, delta 0.5, gamma 5 -> 4*alpha, delta/3, gamma/3; 5 x 25, omega 1.6
     V.alpha = 4 * 1.0f; V.delta = 0.5f / 3; V.gamma = 5.0f / 3; V.fixedPointIterations = 5; V.sorIterations = 25; V.omega = 1.6f;
     const float inv_scale = 1.0f / 0.95f;
@@ -69,8 +72,7 @@ int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, 
         HIP_TRY(hipEventRecord(level_done[l], stream));
         if (l > 0) {
             const int nw = levels[l - 1].first, nh = levels[l - 1].second;
-            SIND_TRY(launch_resize_f32(stream, P.Wu, P.tWu, w, h, nw, nh, B, inv_scale, true));
-            SIND_TRY(launch_resize_f32(stream, P.Wv, P.tWv, w, h, nw, nh, B, inv_scale, true));
+            SIND_TRY(launch_resize_f32_pair(stream, P.Wu, P.tWu, P.Wv, P.tWv, w, h, nw, nh, B, inv_scale, true));
             std::swap(P.Wu, P.tWu); std::swap(P.Wv, P.tWv);
         }
     }

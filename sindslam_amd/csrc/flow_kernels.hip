@@ -34,6 +34,50 @@ __global__ void k_u8_to_f32_blur3(const uint8_t* __restrict__ src, float* __rest
 // cv::resize(INTER_LINEAR) on CV_32F (resize.cpp): used for the 0.95 pyramid, the flow up-sampling between
 // levels (post = 1/0.95) and the final 384x288 -> 640x480 up-scale (post = 1/0.6).  scale_* are doubles computed
 // on the host exactly as OpenCV does (1 / ((double)dsize/ssize)).
+// One output pixel of cv::resize(INTER_LINEAR, CV_32F): S = source image, (dx, dy) = destination pixel.
+__device__ __forceinline__ float resize_px(const float* __restrict__ S, int sw, int sh, int dx, int dy, double scale_x, double scale_y) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = d_cvFloorf(fx); fx -= sx;
+    const bool two = sx + 1 < sw;            // dx < xmax in OpenCV's HResizeLinear
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = d_cvFloorf(fy); fy -= sy;
+    const int y0 = d_clip(sy, 0, sh), y1 = d_clip(sy + 1, 0, sh);
+    const float a1 = fx, a0 = 1.f - a1, b1 = fy, b0 = 1.f - b1;
+    const float* R0 = S + (size_t)y0 * sw; const float* R1 = S + (size_t)y1 * sw;
+    float r0, r1;
+    if (two) { r0 = R0[sx] * a0 + R0[sx + 1] * a1; r1 = R1[sx] * a0 + R1[sx + 1] * a1; }
+    else     { r0 = R0[sx] * 1.f;                  r1 = R1[sx] * 1.f; }
+    return r0 * b0 + r1 * b1;
+}
+// Two batches with the same geometry in one launch (both images of the pairs for the pyramid, both flow components for the up-sampling): blockIdx.z =
+// image + B * (0 | 1).
+__global__ void k_resize_f32_pair(const float* __restrict__ srcA, float* __restrict__ dstA, const float* __restrict__ srcB, float* __restrict__ dstB, int B,
+                                  int sw, int sh, int dw, int dh, double scale_x, double scale_y, float post, int has_post) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y; int b = blockIdx.z;
+    if (dx >= dw) return;
+    const float* src = srcA; float* dst = dstA;
+    if (b >= B) { b -= B; src = srcB; dst = dstB; }
+    float v = resize_px(src + (size_t)b * sw * sh, sw, sh, dx, dy, scale_x, scale_y);
+    if (has_post) v = v * post;
+    dst[(size_t)b * dw * dh + (size_t)dy * dw + dx] = v;
+}
+// The small levels of the 0.95 pyramid in ONE launch: a workgroup walks levels first+1 .. first+n of one image (level l from level l-1, a barrier in
+// between; the image is <= 12 k pixels there) instead of one launch per level and image -- the chain of ~2 x 27 dependent launches per slice sat at the
+// start of every step, when nothing else of the step can run yet.
+#define PYR_TAIL_MAX 40
+struct PyrTail { int n, B; int w[PYR_TAIL_MAX + 1], h[PYR_TAIL_MAX + 1]; unsigned long long off[PYR_TAIL_MAX + 1]; double sx[PYR_TAIL_MAX + 1], sy[PYR_TAIL_MAX + 1]; };
+__global__ void __launch_bounds__(256) k_pyramid_tail(float* __restrict__ pyrA, float* __restrict__ pyrB, PyrTail T) {
+    int b = blockIdx.x; float* pyr = pyrA;
+    if (b >= T.B) { b -= T.B; pyr = pyrB; }
+    for (int k = 1; k <= T.n; k++) {
+        const int sw = T.w[k - 1], sh = T.h[k - 1], dw = T.w[k], dh = T.h[k];
+        const float* S = pyr + T.off[k - 1] + (size_t)b * sw * sh; float* D = pyr + T.off[k] + (size_t)b * dw * dh;
+        for (int i = threadIdx.x; i < dw * dh; i += 256) { const int dy = i / dw, dx = i - dy * dw; D[i] = resize_px(S, sw, sh, dx, dy, T.sx[k], T.sy[k]); }
+        __syncthreads();                     // level k complete (and visible to the workgroup) before level k + 1 reads it
+    }
+}
 __global__ void k_resize_f32(const float* __restrict__ src, float* __restrict__ dst, int sw, int sh, int dw, int dh,
                              double scale_x, double scale_y, float post, int has_post) {
     const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, b = blockIdx.z;
@@ -755,6 +799,23 @@ int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w,
 int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post) {
     const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
     hipLaunchKernelGGL(k_resize_f32, grid2d(dw, dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, scale_x, scale_y, post, has_post ? 1 : 0);
+    return SIND_OK;
+}
+int launch_resize_f32_pair(hipStream_t s, const float* srcA, float* dstA, const float* srcB, float* dstB, int sw, int sh, int dw, int dh, int B, float post, bool has_post) {
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    hipLaunchKernelGGL(k_resize_f32_pair, grid2d(dw, dh, 2 * B), dim3(128), 0, s, srcA, dstA, srcB, dstB, B, sw, sh, dw, dh, scale_x, scale_y, post, has_post ? 1 : 0);
+    return SIND_OK;
+}
+// levels first+1 .. last of both pyramids (level l of image b at pyr + off[l] * B + b * w[l] * h[l]) from level `first`, which must be complete
+int launch_pyramid_tail(hipStream_t s, float* pyrA, float* pyrB, const std::vector<std::pair<int, int>>& levels, const std::vector<size_t>& level_off, int first, int last, int B) {
+    if (last <= first) return SIND_OK;
+    if (last - first > PYR_TAIL_MAX) { sind_set_error("launch_pyramid_tail: %d levels (at most %d)", last - first, PYR_TAIL_MAX); return SIND_E_ARG; }
+    PyrTail T; T.n = last - first; T.B = B;
+    for (int k = 0; k <= T.n; k++) {
+        const int l = first + k; T.w[k] = levels[l].first; T.h[k] = levels[l].second; T.off[k] = (unsigned long long)level_off[l] * B;
+        if (k > 0) { T.sx[k] = 1. / ((double)T.w[k] / T.w[k - 1]); T.sy[k] = 1. / ((double)T.h[k] / T.h[k - 1]); } else { T.sx[k] = T.sy[k] = 1; }
+    }
+    hipLaunchKernelGGL(k_pyramid_tail, dim3(2 * B), dim3(256), 0, s, pyrA, pyrB, T);
     return SIND_OK;
 }
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img) {

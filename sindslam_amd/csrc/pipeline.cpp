@@ -173,7 +173,7 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     p->batch_occ = B >= 4 && !(getenv("SIND_OCC_BATCH") && atoi(getenv("SIND_OCC_BATCH")) == 0);
     if (p->batch_occ) {
         p->occ_chunk = std::min(B, std::max(1, getenv("SIND_OCC_CHUNK") ? atoi(getenv("SIND_OCC_CHUNK")) : 64));
-        SIND_TRY(make_stream(&p->occ_stream, true)); SIND_TRY(p->occb.init(p->dc, p->occ_chunk));
+        SIND_TRY(make_stream(&p->occ_stream, !(getenv("SIND_OCC_PRIORITY") && atoi(getenv("SIND_OCC_PRIORITY")) == 0))); SIND_TRY(p->occb.init(p->dc, p->occ_chunk));
         const size_t nblk = (size_t)(cfg->width / 16) * (cfg->height / 16); const int nch = (B + p->occ_chunk - 1) / p->occ_chunk;
         for (int k = 0; k < 2; k++) {
             SIND_TRY(p->sb[k].occ_edge_h.alloc(np * B)); SIND_TRY(p->sb[k].occ_total_h.alloc(np * B)); SIND_TRY(p->sb[k].occ_blocks_h.alloc(nblk * B));

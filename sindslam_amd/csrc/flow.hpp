@@ -38,7 +38,7 @@ int launch_u8_to_f32_blur3(hipStream_t s, const uint8_t* src, float* dst, int w,
 int launch_resize_f32_pair(hipStream_t s, const float* srcA, float* dstA, const float* srcB, float* dstB, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
 int launch_pyramid_tail(hipStream_t s, float* pyrA, float* pyrB, const std::vector<std::pair<int, int>>& levels, const std::vector<size_t>& level_off, int first, int last, int B);
 int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
-int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img);
+int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img, int d_group = 0, int d_skip = 0);       // d_group > 0: d_skip destination slots stay free after every d_group images
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb);
 extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd, g_sor_tile_h;
 int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev);

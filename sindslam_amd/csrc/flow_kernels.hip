@@ -747,10 +747,11 @@ __global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict_
     gray[i] = (uint8_t)((p[0] * cb + p[1] * 9617 + p[2] * cr + 8192) >> 14);
 }
 __global__ void k_resize_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int sw, int sh, int dw, int dh,
-                            double scale_x, double scale_y, int s_stride, int d_stride, size_t s_img, size_t d_img) {
+                            double scale_x, double scale_y, int s_stride, int d_stride, size_t s_img, size_t d_img, int d_group, int d_skip) {
     const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, b = blockIdx.z;
     if (dx >= dw) return;
     const uint8_t* S = src + (size_t)b * s_img;
+    const int db = d_group > 0 ? b + (b / d_group) * d_skip : b;       // destination slot: groups of d_group images, d_skip slots left free after each group
     float fx = (float)((dx + 0.5) * scale_x - 0.5);
     int sx = d_cvFloorf(fx); fx -= sx;
     const bool two = sx + 1 < sw;
@@ -765,7 +766,7 @@ __global__ void k_resize_u8(const uint8_t* __restrict__ src, uint8_t* __restrict
     int r0, r1;
     if (two) { r0 = R0[sx] * ax0 + R0[sx + 1] * ax1; r1 = R1[sx] * ax0 + R1[sx + 1] * ax1; }
     else     { r0 = R0[sx] * 2048;                   r1 = R1[sx] * 2048; }
-    dst[(size_t)b * d_img + (size_t)dy * d_stride + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    dst[(size_t)db * d_img + (size_t)dy * d_stride + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
 }
 
 // frames of the gray history pool picked by index into a dense batch: out[b] = pool[idx[b]] (16 bytes per thread; the indices travel as
@@ -818,9 +819,9 @@ int launch_pyramid_tail(hipStream_t s, float* pyrA, float* pyrB, const std::vect
     hipLaunchKernelGGL(k_pyramid_tail, dim3(2 * B), dim3(256), 0, s, pyrA, pyrB, T);
     return SIND_OK;
 }
-int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img) {
+int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img, int d_group, int d_skip) {
     const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
-    hipLaunchKernelGGL(k_resize_u8, grid2d(dw, dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, scale_x, scale_y, s_stride, d_stride, s_img, d_img);
+    hipLaunchKernelGGL(k_resize_u8, grid2d(dw, dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, scale_x, scale_y, s_stride, d_stride, s_img, d_img, d_group, d_skip);
     return SIND_OK;
 }
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb) {

@@ -1,6 +1,7 @@
 // ORB extractor engine interface (host side of orb_kernels.hip).
 #pragma once
 #include "common.hpp"
+#include "flow.hpp"
 
 namespace sind {
 
@@ -25,7 +26,7 @@ int launch_blur7(hipStream_t s, const uint8_t* slab, size_t slab_stride, size_t 
                  size_t tmp_stride, size_t tmp_off, uint8_t* blurred, size_t bl_stride, size_t bl_off, int B);
 int launch_brief(hipStream_t s, const uint8_t* blurred, size_t bl_stride, const OrbLevel* levels, const OrbSelKp* sel, const int* nsel, int cap,
                  int max_n, const float* angle, uint8_t* desc, int B);
-int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img);
+// launch_resize_u8: declared in flow.hpp (the pyramid and the flow front share it)
 
 // host: quadtree distribution of one level's keypoints (reference ORBextractor.cc:481-763)
 struct OctKp { float x, y, response; };

@@ -264,8 +264,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     t[0] = now_ms();
     // gray for all frames, 0.6-scaled gray into the per-stream pools behind the two history slots
     SIND_TRY(launch_bgr2gray(p->stream, bgr_dev, p->gray.p, np * B, false));
-    for (int s = 0; s < S; s++)
-        SIND_TRY(launch_resize_u8(p->stream, p->gray.p + np * (size_t)s * T, p->pool.p + fb * ((size_t)s * (T + 2) + 2), W, H, p->fw, p->fh, T, W, p->fw, np, fb));
+    // frame t of stream s goes to pool slot s * (T + 2) + 2 + t: one launch, T frames per group, two history slots skipped between the groups
+    SIND_TRY(launch_resize_u8(p->stream, p->gray.p, p->pool.p + fb * 2, W, H, p->fw, p->fh, B, W, p->fw, np, fb, T, 2));
     const uint8_t* gray_for_orb = p->gray.p;
     if (p->c.orb_gray_rgb_order) { SIND_TRY(launch_bgr2gray(p->stream, bgr_dev, p->gray_orb.p, np * B, true)); gray_for_orb = p->gray_orb.p; }
     // ORB front (pyramid, FAST, octree, orientation, blur, BRIEF) of all frames: independent of the flow, so it runs on its own HIP

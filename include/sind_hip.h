@@ -54,7 +54,8 @@ int sind_flow_set_max_levels(sind_flow* f, int n);
  * through a reciprocal formed on the fly (hardware estimate + one Newton step, then Markstein's correction; default: 5 iterations per launch on
  * 64 x 64 tiles), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in registers (three waves per SIMD; instances for
  * tiles of 256, 384 and 768 threads); 2 = fused, 1x4 strips + reciprocal division; 0 = one launch per colour (cross-check).  fuse = iterations
- * per launch on tiled levels; tile_w x tile_h = extended tile (tile_w * tile_h / 8 threads).  sind_flow_set_sor keeps the round-1 signature
+ * per launch on tiled levels (default 5), 0 = a plan per level that minimises tiles x (prologue + iterations) over the partitions of the 25
+ * iterations; tile_w x tile_h = extended tile (tile_w * tile_h / 8 threads).  sind_flow_set_sor keeps the round-1 signature
  * (tile height 48 for mode 3, 64 otherwise). */
 int sind_flow_set_sor(int mode, int fuse, int tile_w);
 int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h);

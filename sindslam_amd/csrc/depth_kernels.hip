@@ -779,8 +779,9 @@ int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int
     }
     if (C <= 64) {
         const size_t shm = ((size_t)C * 256 + 3 * (size_t)C * C + C) * sizeof(int);      // <= 64 KB + 48 KB + 256 B of the 160 KB LDS
-        static bool attr_set = false;
-        if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)k_rag_stats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024)); attr_set = true; }
+        static std::once_flag attr_once; static hipError_t attr_rc = hipSuccess;       // the pool's workers call this concurrently
+        std::call_once(attr_once, [] { attr_rc = hipFuncSetAttribute((const void*)k_rag_stats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); });
+        HIP_TRY(attr_rc);
         hipLaunchKernelGGL(k_rag_stats<true>, dim3(128), dim3(256), shm, s, planes, C, w, h, wpr, occ2, depthN, overlap, overlapPlane, ljOverlap, ljArea, hist);
     } else {
         hipLaunchKernelGGL(k_rag_stats<false>, dim3(256), dim3(256), 0, s, planes, C, w, h, wpr, occ2, depthN, overlap, overlapPlane, ljOverlap, ljArea, hist);

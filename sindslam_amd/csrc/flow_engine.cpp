@@ -22,7 +22,8 @@ int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     fw = fw_; fh = fh_; maxB = maxB_; stream = s;
     if (const char* e = getenv("SIND_SOR_MODE")) g_sor_mode = atoi(e);       // see g_sor_mode (flow_kernels.hip); the tile / fuse variables are for A/B timing
     if (const char* e = getenv("SIND_SOR_TILEW")) g_sor_tile_w = atoi(e);
-    if (const char* e = getenv("SIND_SOR_FUSE")) g_sor_fuse = std::max(1, std::min(atoi(e), 12));
+    if (const char* e = getenv("SIND_SOR_FUSE")) g_sor_fuse = std::max(0, std::min(atoi(e), 12));
+    if (const char* e = getenv("SIND_SOR_PLAN_COST")) g_sor_plan_cost = std::max(0.0, atof(e));
     if (const char* e = getenv("SIND_SOR_XCD")) g_sor_xcd = atoi(e) != 0;
     if (const char* e = getenv("SIND_SOR_TILEH")) g_sor_tile_h = atoi(e);
     if (const char* e = getenv("SIND_LAUNCH_AHEAD")) launch_ahead = std::max(0, atoi(e));       // 0: unbounded

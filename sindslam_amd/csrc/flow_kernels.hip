@@ -11,6 +11,9 @@
 #include <mutex>
 #include "common.hpp"
 #include "flow.hpp"
+#include <functional>
+#include <array>
+#include <map>
 
 namespace sind {
 
@@ -835,10 +838,42 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 int g_sor_mode = 4;          // fused register-resident SOR with 1x8 strips: 4 = divisions through a reciprocal formed on the fly (hardware estimate + Newton step,
                              // then Markstein's correction; default, fastest), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in
                              // registers (three waves per SIMD); 2 = fused, 1x4 strips + reciprocal division; 0 = one launch per colour (A/B timing, cross-check)
-int g_sor_fuse = 5;
+int g_sor_fuse = 5;          // iterations per launch on the tiled levels; 0 = per-level plan (sor_fuse_plan: measured 1-2 % faster, 10 % more launches; not the default)
+double g_sor_plan_cost = 14; // prologue of a tile in iterations (sor_fuse_plan)
 int g_sor_xcd = 1;           // XCD-aware tile order of the fused kernel (0 = plain blockIdx order, for A/B timing)
 int g_sor_tile_w = 64;       // extended tile (multiple of 8 wide, even height, tile_w * tile_h / 8 threads)
 int g_sor_tile_h = 64;
+// How the `total` iterations of a level are cut into launches.  A launch of f iterations needs a halo of 2 f pixels, so it covers the level with
+// ceil(w / (EW - 4 f)) x ceil(h / (EH - 4 f)) tiles, and a tile costs its prologue (coefficient loads, LDS set-up, write-back: g_sor_plan_cost iterations'
+// worth, fitted to the measured 4 / 5 / 6-iteration runs) plus f iterations.  With a fixed f = 5 the 26 tiled levels of the 384 x 288 pyramid compute
+// 2.5 x their pixels (levels just above a multiple of the 44-pixel interior up to 3.5 x); the cheapest partition per level (dynamic programme over
+// the remaining iterations) picks e.g. 1 + 6 x 4 iterations for 178 x 133: 12 tiles per launch instead of 20.  Measured (bench --sync, solver busy per step):
+// 370 ms with f = 5 everywhere, 364-369 ms with the plans for a prologue cost of 7-20 iterations, 392 ms for 4 -- the model's 6 % shrink to 1-2 %, so the plan
+// is an option (g_sor_fuse = 0), not the default.
+static std::vector<int> sor_fuse_plan(int w, int h, int EW, int EH, int total) {
+    if (g_sor_fuse > 0) return std::vector<int>((size_t)divup(total, g_sor_fuse), g_sor_fuse);
+    static std::mutex mu; static std::map<std::array<int, 6>, std::vector<int>> cache;
+    const std::array<int, 6> key{w, h, EW, EH, total, (int)std::lrint(g_sor_plan_cost * 16)};
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const int fmax = std::min(10, (std::min(EW, EH) - 1) / 4);
+    std::vector<double> cost((size_t)total + 1, 0.0); std::vector<int> pick((size_t)total + 1, 1);
+    for (int rem = 1; rem <= total; rem++) {
+        double best = -1; int bf = 1;
+        for (int f = 1; f <= std::min(fmax, rem); f++) {
+            const int IW = EW - 4 * f, IH = EH - 4 * f;
+            const double c = (double)divup(w, IW) * divup(h, IH) * (g_sor_plan_cost + f) + cost[(size_t)rem - f];
+            if (best < 0 || c < best) { best = c; bf = f; }
+        }
+        cost[(size_t)rem] = best; pick[(size_t)rem] = bf;
+    }
+    std::vector<int> plan;
+    for (int rem = total; rem > 0; rem -= pick[(size_t)rem]) plan.push_back(pick[(size_t)rem]);
+    std::sort(plan.begin(), plan.end(), std::greater<int>());            // the order of the launches is free: same iterations, same bits
+    cache[key] = plan;
+    return plan;
+}
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch) {
     if (g_sor_mode == 0) {
         const dim3 gs(divup(divup(w, 2), 64), h, B), bs(64);
@@ -875,7 +910,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         const int EW = 64, EH = 64, nt = 1024;
         const size_t shm = (size_t)4 * (EH + 2) * (EW / 4 + 2) * sizeof(float2);
         for (int done = 0; done < total;) {
-            const int k = std::min(g_sor_fuse, total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
+            const int k = std::min(g_sor_fuse > 0 ? g_sor_fuse : 5, total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
             const int ntx = divup(w, IW), nty = divup(h, IH);
             hipLaunchKernelGGL(k_sor_fused4, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
                                P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
@@ -888,11 +923,13 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     const int EW = g_sor_tile_w, EH = g_sor_tile_h, nt = threads_for(EW, EH);
     const bool rcp = g_sor_mode == 3;
     if (rcp && nt != 256 && nt != 384 && nt != 768) { sind_set_error("sor_iterations: %d x %d tiles (%d threads) have no reciprocal-solver instance", EW, EH, nt); return SIND_E_ARG; }
-    if (nt > SOR_NT || 2 * 2 * g_sor_fuse >= std::min(EW, EH)) { sind_set_error("sor_iterations: tile %d x %d / %d fused iterations not supported", EW, EH, g_sor_fuse); return SIND_E_ARG; }
+    if (nt > SOR_NT || (g_sor_fuse > 0 && 2 * 2 * g_sor_fuse >= std::min(EW, EH))) { sind_set_error("sor_iterations: tile %d x %d / %d fused iterations not supported", EW, EH, g_sor_fuse); return SIND_E_ARG; }
     const size_t shm = sor_lds_bytes(EW, nt);
     if (shm > 150 * 1024) { sind_set_error("sor_iterations: %d x %d tiles need %zu bytes of LDS", EW, EH, shm); return SIND_E_ARG; }
+    const std::vector<int> plan = sor_fuse_plan(w, h, EW, EH, total);
+    size_t step = 0;
     for (int done = 0; done < total;) {
-        const int k = std::min(g_sor_fuse, total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
+        const int k = std::min(plan[step++], total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
         const int ntx = divup(w, IW), nty = divup(h, IH);
         const bool t64 = EW == 64 && EH == 64 && nt == 512;           // the default tile has instances with compile-time sizes
         auto kern = g_sor_mode == 4 ? (t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>) : !rcp ? (t64 ? k_sor_fused<0, 512, 4, 64, 64> : k_sor_fused<0, 1024, 4, 0, 0>)

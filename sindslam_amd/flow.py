@@ -11,7 +11,8 @@ from ._lib import check, lib, ptr
 def set_sor_variant(mode: int = 4, fuse: int = 5, tile_w: int = 64, tile_h: int | None = None):
     """process-wide solver variant (all return the same bits).  Fused register-resident SOR with 1x8 strips: mode 4 = divisions through a reciprocal
     formed on the fly (default), 1 = IEEE division, 3 = reciprocal planes held in registers (three waves per SIMD; 256/384/768-thread tiles);
-    2 = fused with 1x4 strips and reciprocal division; 0 = one launch per colour (cross-check).  tile_h defaults to 48 (mode 3) / 64."""
+    2 = fused with 1x4 strips and reciprocal division; 0 = one launch per colour (cross-check).  fuse = iterations per launch on the tiled levels,
+    0 = a per-level plan (1-2 % faster, more launches).  tile_h defaults to 48 (mode 3) / 64."""
     if tile_h is None:
         tile_h = 48 if mode == 3 else 64
     check(lib().sind_flow_set_sor_tiled(mode, fuse, tile_w, tile_h), "sind_flow_set_sor_tiled")

@@ -934,7 +934,8 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         const bool t64 = EW == 64 && EH == 64 && nt == 512;           // the default tile has instances with compile-time sizes
         auto kern = g_sor_mode == 4 ? (t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>) : !rcp ? (t64 ? k_sor_fused<0, 512, 4, 64, 64> : k_sor_fused<0, 1024, 4, 0, 0>)
                     : nt == 384 ? k_sor_fused<1, 384, 3, 0, 0> : nt == 768 ? k_sor_fused<1, 768, 3, 0, 0> : k_sor_fused<1, 256, 3, 0, 0>;
-        hipLaunchKernelGGL(kern, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
+        static const int dry = getenv("SIND_SOR_DRY") ? atoi(getenv("SIND_SOR_DRY")) : 0;       // timing experiment: 1 = no iterations (prologue + write-back only; results are wrong)
+        hipLaunchKernelGGL(kern, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, dry ? 0 : k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
                            P.wgt, P.r11, P.r22, P.dWu, P.dWv, P.dWu2, P.dWv2);
         std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);
         done += k; *nlaunch += 1;

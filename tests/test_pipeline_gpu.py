@@ -145,3 +145,29 @@ def test_pipelined_depth_ahead_equals_sync(frames):
         for x, y in zip(e, g):
             assert np.array_equal(x, y)
     ref.close(); pip.close()
+
+
+def test_batched_caloccluded_stage_equals_the_per_frame_chain(frames, monkeypatch):
+    """the GPU half of CalOccluded run once per chunk of frames at the start of a step (default for >= 4 frames per step; here in chunks of 3, so that
+    a ragged last chunk is covered) returns what the per-frame launches of the worker tasks return (SIND_OCC_BATCH=0), output for output"""
+    from sindslam_amd.pipeline import Pipeline
+    bgr, depth = frames
+    S, T = 2, 2
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    sb = np.stack([bgr, bgr[:, :, ::-1]]); sd = np.stack([depth, depth[:, :, ::-1]])
+    out = {}
+    for batch in ("1", "0"):
+        monkeypatch.setenv("SIND_OCC_BATCH", batch); monkeypatch.setenv("SIND_OCC_CHUNK", "3")
+        pipe = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5)
+        for s in range(S):
+            pipe.prime(s, sb[s, 1], sb[s, 0])
+        res = []
+        for step in range(2):
+            lo = 2 + step * T
+            pipe.process(sb[:, lo:lo + T], sd[:, lo:lo + T])
+            res.append((pipe.dyna.copy(), pipe.label.copy(), pipe.mask.copy(), pipe.nkp.copy()))
+        out[batch] = res; pipe.close()
+    for a, b in zip(out["1"], out["0"]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert (out["1"][1][0] == 255).any()

@@ -44,8 +44,8 @@ CONFIGS = {
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)            # a pipelined run ends with one drained tail phase (~160 ms): 12 steps keep it at 3 % of the timed region
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="tum3", help="BASELINE.json config (default: the one the metric is quoted on)")
     ap.add_argument("--workload", choices=["auto", "streams", "sequence"], default="auto", help="auto: streams at 1 GPU, sequence (frame-sharded, RCCL mask gather) at N > 1")
     ap.add_argument("--streams", type=int, default=0, help="streams (= sequence chunks) per GPU; 0 = the config's default")
@@ -375,7 +375,7 @@ def main():
     torch.cuda.synchronize()
     thr0 = cgroup_throttle()
     t0 = time.perf_counter(); c0 = time.process_time(); th0 = thread_cpu_seconds() if args.thread_cpu else None
-    sor_ms = sor_bytes = sor_union = 0.0; sor_launches = 0; sor_slices = 1; stages = np.zeros(6)
+    sor_ms = sor_bytes = sor_union = 0.0; sor_launches = 0; sor_slices = 1; stages = np.zeros(6); tail_wait = 0.0; submit_wall = 0.0
     pending_step = None
     for i in range(Wm, Wm + K):             # timed steps
         if args.host_input:
@@ -383,17 +383,20 @@ def main():
         elif not args.pipelined:
             pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather(i)
         else:                               # software-pipelined: phase A of step i overlaps the tails of step i-1, whose results arrive now
-            if pipe.submit_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()):
+            _ts = time.perf_counter(); _hv = pipe.submit_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); submit_wall += time.perf_counter() - _ts
+            if _hv:
                 gather(pending_step)
             pending_step = i
         if first_dyna is None and not args.pipelined:     # --warmup 0: take the parity sample from the first timed step (a few MB copied)
             first_dyna, first_kps = parity_sample()
         st = pipe.stats()
         sor_ms += st["sor_ms"]; sor_bytes += st["sor_alg_bytes"]; sor_launches += st["sor_launches"]; sor_union += st["sor_union_ms"]; sor_slices = st["sor_slices"]
-        stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"], st["upload_ms"]])
+        stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"], st["upload_ms"]]); tail_wait += st["tail_wait_ms"] if args.pipelined else 0.0
+    t_flush0 = time.perf_counter()
     if args.pipelined and pipe.flush():      # drain the last step inside the timed region
         gather(pending_step)
-    torch.cuda.synchronize()
+    flush_ms = (time.perf_counter() - t_flush0) * 1e3; loop_ms = (t_flush0 - t0) * 1e3
+    _tsy = time.perf_counter(); torch.cuda.synchronize(); sync_ms = (time.perf_counter() - _tsy) * 1e3
     if pg:
         dist.barrier()
     th1 = thread_cpu_seconds() if args.thread_cpu else None
@@ -490,7 +493,7 @@ def main():
                        "inputs": "host buffers, H2D inside the timed region" if args.host_input else "resident in HBM"},
             "ranks_seen": ranks_seen,
             "roofline": roof,
-            "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "host_upload": stages[5] / K, "total": stages[4] / K},
+            "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "host_upload": stages[5] / K, "total": stages[4] / K, "tails_wait_after_phase_a": tail_wait / K, "final_flush_total": flush_ms, "submit_call_wall": submit_wall * 1e3 / K, "loop_total": loop_ms, "final_sync": sync_ms},
             "host_cores_busy": cpu_busy,
             "cpu_quota": None if not (thr0 and thr1) else {"periods": thr1[0] - thr0[0], "throttled_periods": thr1[1] - thr0[1], "throttled_ms": (thr1[2] - thr0[2]) / 1e3},
         }

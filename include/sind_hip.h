@@ -181,6 +181,8 @@ int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, do
  * bytes of all slices, sum_ms = sum of the event-bracketed launch groups, union_ms = time during which at least one slice had solver
  * launches in flight (union of those intervals on a common event time base), slices = number of concurrent streams */
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices);
+/* last sind_pipe_submit(_dev): time the call still waited for the previous step's tails after its own phase A had finished (0 = hidden) */
+int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Frame post-ORB steps: what the reference's RGB-D Frame constructor does with the extractor's output

@@ -96,7 +96,7 @@ struct sind_pipe {
     // launches it then shares the GPU with (dense flow 232 -> 287 ms at high stream priority; at normal priority the chains starve).
     bool depth_ahead = false;
     std::vector<char> primed;
-    double stage_ms[6] = {0}; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;
+    double stage_ms[6] = {0}; double tail_wait_ms = 0; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;
     WorkerPool workers;          // declared last: joined first
 };
 
@@ -494,7 +494,7 @@ int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* d
     if (has_prev) phase_b_start(p, p->sb[prev], o);            // queued ahead of this step's CalOccluded tasks
     double t[4]; const double t0 = now_ms();
     const int ra = phase_a(p, p->sb[p->cur], bgr_dev, depth_dev, t, p->depth_ahead);      // with depth-ahead the depth chain of this step runs next to the flow chain of the previous one
-    int rb = SIND_OK;
+    int rb = SIND_OK; const double ta1 = now_ms();
     if (has_prev) { rb = phase_b_finish(p, p->sb[prev]); tb1 = now_ms(); }
     const double t4 = now_ms();
     if (rb != SIND_OK || ra != SIND_OK) {          // a failed step leaves nothing pending: the next call starts from a clean two-buffer state
@@ -503,7 +503,8 @@ int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* d
         sind_set_error("%s", keep.c_str());
         return rb != SIND_OK ? rb : ra;
     }
-    p->stage_ms[0] = t[1] - t[0]; p->stage_ms[1] = t[2] - t[1]; p->stage_ms[2] = t[3] - t[2]; p->stage_ms[3] = 0; p->stage_ms[4] = tb1 - tb0; p->stage_ms[5] = t4 - t0;
+    // tail_wait_ms: how long this call still waited for the previous step's tails after its own phase A was done (0 = the tails are hidden)
+    p->stage_ms[0] = t[1] - t[0]; p->stage_ms[1] = t[2] - t[1]; p->stage_ms[2] = t[3] - t[2]; p->stage_ms[3] = 0; p->tail_wait_ms = has_prev ? t4 - ta1 : 0; p->stage_ms[4] = tb1 - tb0; p->stage_ms[5] = t4 - t0;
     p->cur ^= 1;
     return SIND_OK;
 }
@@ -581,6 +582,7 @@ int sind_pipe_set_state(sind_pipe* p, int s, const uint8_t* buf, size_t n) {
     return SIND_OK;
 }
 
+int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms) { if (!p || !ms) return SIND_E_ARG; *ms = p->tail_wait_ms; return SIND_OK; }
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices) {
     if (!p) return SIND_E_ARG;
     if (launches) *launches = p->sor_launches;

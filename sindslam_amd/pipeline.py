@@ -105,5 +105,6 @@ class Pipeline:
         check(lib().sind_pipe_stats(self._h, ptr(st), C.byref(nl), C.byref(ms), C.byref(by)))
         un = C.c_double(); sl = C.c_int(); sm = C.c_double()
         check(lib().sind_pipe_sor_stats(self._h, C.byref(nl), C.byref(sm), C.byref(un), C.byref(by), C.byref(sl)))
-        return dict(front_ms=st[0], flow_ms=st[1], orb_ms=st[2], upload_ms=st[3], tails_ms=st[4], total_ms=st[5], sor_launches=nl.value, sor_ms=sm.value, sor_alg_bytes=by.value,
+        tw = C.c_double(); check(lib().sind_pipe_tail_wait_ms(self._h, C.byref(tw)))
+        return dict(front_ms=st[0], flow_ms=st[1], orb_ms=st[2], upload_ms=st[3], tails_ms=st[4], total_ms=st[5], tail_wait_ms=tw.value, sor_launches=nl.value, sor_ms=sm.value, sor_alg_bytes=by.value,
                     sor_union_ms=un.value, sor_slices=sl.value)

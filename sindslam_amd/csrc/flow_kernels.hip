@@ -137,6 +137,11 @@ __global__ void k_warp_avg_iz(const float* __restrict__ I0, const float* __restr
 // neighbour's "upper" weight, so the left one comes from the neighbouring lane (wave shuffle; the first lane of a wave computes it) and the upper one
 // from the thread's previous row (the first row of a block computes it) -- 1.3 instead of 3 weight evaluations (two loads rows, a square root and a
 // division each) per pixel, same values bit for bit.
+// Divisions that share a divisor (the three gradient norms of a pixel divide 14 numerators) go through the divisor's reciprocal: hardware estimate +
+// one Newton step = exactly RN(1 / a) for every float significand, then Markstein's correction = the correctly rounded quotient (sor_rcp / sor_div
+// below the solver kernels; checked exhaustively by sind_debug_rcp_scan) -- 3 instructions per quotient instead of the 10 of an IEEE division.
+__device__ __forceinline__ float kc_rcp(float a) { const float y0 = __builtin_amdgcn_rcpf(a); const float e = fmaf(-a, y0, 1.f); return fmaf(e, y0, y0); }
+__device__ __forceinline__ float kc_div(float n, float a, float r) { const float q0 = n * r; const float e = fmaf(-a, q0, n); return fmaf(e, r, q0); }
 #define KC_ROWS 4
 __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
                        const float* __restrict__ gWv,
@@ -181,7 +186,8 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
         const float dU = gdWu[base + i], dV = gdWv[base + i];
         float derivNorm = Ix * Ix + Iy * Iy + zeta2;
         const float Ik1z = Iz + Ix * dU + Iy * dV;
-        float weight = (delta2 / sqrtf(Ik1z * Ik1z / derivNorm + eps2)) / derivNorm;
+        const float rN0 = kc_rcp(derivNorm);
+        float weight = kc_div(delta2 / sqrtf(kc_div(Ik1z * Ik1z, derivNorm, rN0) + eps2), derivNorm, rN0);
         float a11 = weight * (Ix * Ix) + zeta2;
         float a12 = weight * (Ix * Iy);
         float a22 = weight * (Iy * Iy) + zeta2;
@@ -191,12 +197,17 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
         const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
         const float Ik1zx = Ixz + Ixx * dU + Ixy * dV;
         const float Ik1zy = Iyz + Ixy * dU + Iyy * dV;
-        weight = gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
-        a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
-        a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
-        a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
-        b1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
-        b2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+        const float rN1 = kc_rcp(derivNorm), rN2 = kc_rcp(derivNorm2);
+        #define D1(n) kc_div((n), derivNorm, rN1)
+        #define D2(n) kc_div((n), derivNorm2, rN2)
+        weight = gamma2 / sqrtf(D1(Ik1zx * Ik1zx) + D2(Ik1zy * Ik1zy) + eps2);
+        a11 += weight * (D1(Ixx * Ixx) + D2(Ixy * Ixy));
+        a12 += weight * (D1(Ixx * Ixy) + D2(Ixy * Iyy));
+        a22 += weight * (D1(Ixy * Ixy) + D2(Iyy * Iyy));
+        b1 += -weight * (D1(Ixx * Ixz) + D2(Ixy * Iyz));
+        b2 += -weight * (D1(Ixy * Ixz) + D2(Iyy * Iyz));
+        #undef D1
+        #undef D2
 
         const float wp = wgt_at(y, x);
         const float w_from_lane = __shfl_up(wp, 1);          // the left neighbour's own weight (same row, lane - 1)
@@ -290,7 +301,7 @@ __global__ void k_debug_rcp_scan(int exp_lo, int exp_hi, unsigned long long* __r
         if (__float_as_uint(y) != __float_as_uint(ref)) bad_r++;
         for (int k = 0; k < 8; k++) {                                   // quotients through the reciprocal (Markstein) against the IEEE division
             rng = rng * 1664525u + 1013904223u;
-            const float n = __uint_as_float((rng & 0x807fffffu) | ((unsigned)(127 + e - 16 + (int)((rng >> 23) & 31)) << 23));
+            const float n = __uint_as_float((rng & 0x807fffffu) | ((unsigned)(127 + e - 40 + (int)(((rng >> 23) & 127) % 81)) << 23));
             const float q = sor_div(n, a, y), qr = n / a;
             if (__float_as_uint(q) != __float_as_uint(qr)) bad_q++;
             const float q2 = sor_div(n, -a, -y), qr2 = n / -a;

@@ -909,7 +909,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     // the flow slices call this concurrently from their own threads: set the (idempotent) attribute exactly once
     static std::once_flag attr_once; static hipError_t attr_rc = hipSuccess;
     std::call_once(attr_once, [] {
-        const void* fs[] = {(const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>,
+        const void* fs[] = {(const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 512, 2, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>,
                             (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_fused<1, 384, 3, 0, 0>, (const void*)k_sor_fused<1, 768, 3, 0, 0>,
                             (const void*)k_sor_fused<1, 256, 3, 0, 0>};
         for (const void* f : fs) if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -922,7 +922,10 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         const int EW = EWw, EH = h, nt = threads_for(EW, EH);
         const size_t shm = sor_lds_bytes(EW, nt);
         if (shm > 150 * 1024) { sind_set_error("sor_iterations: a %d x %d level needs %zu bytes of LDS", w, h, shm); return SIND_E_ARG; }
-        hipLaunchKernelGGL((k_sor_fused<0, 1024, 4, 0, 0>), dim3(1, B), dim3(nt), shm, s, w, h, EW, EH, EW, EH, 0, 0, 1, total, 0, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt,
+        // <= 512 threads: two waves per SIMD, i.e. up to 256 registers -- room for the run-time tile sizes AND the reciprocal division without spills
+        // (all 25 iterations run in this launch, so here the loop is the cost); larger blocks keep the four-waves-per-SIMD IEEE instance
+        auto kern1 = (nt <= 512 && g_sor_mode == 4) ? k_sor_fused<2, 512, 2, 0, 0> : k_sor_fused<0, 1024, 4, 0, 0>;
+        hipLaunchKernelGGL(kern1, dim3(1, B), dim3(nt), shm, s, w, h, EW, EH, EW, EH, 0, 0, 1, total, 0, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt,
                            P.r11, P.r22, P.dWu, P.dWv, P.dWu, P.dWv);
         *nlaunch += 1; return SIND_OK;
     }

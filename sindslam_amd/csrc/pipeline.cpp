@@ -338,6 +338,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         std::vector<DynaFront*> fr(1, &p->front); for (auto& f : p->extra_fronts) fr.push_back(f.get());
         HIP_TRY(hipEventRecord(p->ev_pool, p->stream));
         std::vector<int> rc(nsl, SIND_OK); std::vector<std::string> er(nsl); std::vector<std::thread> th;
+        std::vector<double> slice_ms(nsl, 0.0); std::vector<std::vector<std::pair<double, double>>> slice_iv(nsl);
         auto run = [&](int i) {
             const int b0 = i * Bs, nb = std::min(Bs, B - b0); if (nb <= 0) return;
             DynaFront& f = *fr[i]; f.flow.sor_timer.enabled = true; f.flow.sor_timer.reset();
@@ -349,6 +350,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
             }
             if (rc[i] == SIND_OK && sind_stream_wait(f.stream) != hipSuccess) rc[i] = SIND_E_HIP;
             if (rc[i] != SIND_OK) er[i] = sind_last_error();
+            // the slice reads its own event brackets (three hipEventElapsedTime per bracket, ~150 brackets) while the other slices still run
+            else { slice_ms[i] = f.flow.sor_timer.collect_ms(); f.flow.sor_timer.intervals(p->ev_pool, slice_iv[i]); }
         };
         for (int i = 0; i < nsl; i++) th.emplace_back([&, i] { (void)pthread_setname_np(pthread_self(), "sind-flow"); (void)hipSetDevice(p->c.device); run(i); g_cpu_us_flow += (long long)(thread_cpu_ms() * 1e3); });
         g_cpu_steps++;
@@ -361,7 +364,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         for (int k = 0; k < B; k++) sb.occ[k].gridFlow = sb.grid_h.p + gsz * k;
         p->sor_ms = 0; p->sor_bytes = 0; p->sor_launches = 0; p->sor_slices = nsl;
         std::vector<std::pair<double, double>> iv;
-        for (DynaFront* f : fr) { p->sor_ms += f->flow.sor_timer.collect_ms(); p->sor_bytes += f->flow.sor_timer.alg_bytes; p->sor_launches += f->flow.sor_timer.launches; f->flow.sor_timer.intervals(p->ev_pool, iv); }
+        for (int i = 0; i < nsl; i++) { p->sor_ms += slice_ms[i]; p->sor_bytes += fr[i]->flow.sor_timer.alg_bytes; p->sor_launches += fr[i]->flow.sor_timer.launches; iv.insert(iv.end(), slice_iv[i].begin(), slice_iv[i].end()); }
         // time during which at least one slice had solver launches in flight (union of the event-bracketed intervals of all slices)
         std::sort(iv.begin(), iv.end()); double un = 0, cs = 0, ce = -1;
         for (const auto& q : iv) { if (q.first > ce) { if (ce > cs) un += ce - cs; cs = q.first; ce = q.second; } else ce = std::max(ce, q.second); }

@@ -5,14 +5,17 @@ One step = one pass of the batched pipeline over S streams x T frames (S*T frame
 region.  Two workloads:
 
   streams   (default at --gpus 1)  S independent TUM-shaped camera streams per GPU (BASELINE.json configs[1] shape: 640x480, TUM3
-            intrinsics, depth factor 5000, FAST 15/5, 1500 features; the real TUM frames are not available offline).
-  sequence  (default at --gpus N > 1; BASELINE.json configs[3]) ONE synthetic RGB-D sequence sharded by frame: the owned frames are cut
-            into N*S contiguous chunks, chunk g = rank*S + s is stream s of rank `rank`; the W warm-up steps of the bench are the chunks'
-            state warm-up frames (sindslam_amd/sequence.py), the K timed steps process the owned frames, and after every step the per-frame
-            dynamic masks of all ranks are gathered with one RCCL all_gather over xGMI and written into the sequence-ordered mask array
-            that every rank holds.  Weak scaling: K*S*T owned frames per GPU, sequence length 2 + N*S*K*T + W*T (4098 frames at
-            --gpus 8 --steps 1).  After the timed region rank 0 re-runs the first chunks in the in-order ("exact") mode and reports the
-            chunk-seam IoU and the exact mode's own rate.
+            intrinsics, depth factor 5000, FAST 15/5, 1500 features; the real TUM frames are not available offline); W untimed warm-up
+            steps, K timed steps, weak scaling.  On one GPU the line also carries `sequence`: the fixed-length job below, run after
+            the timed region, i.e. the N = 1 point of the curve that --gpus N > 1 reports.
+  sequence  (default at --gpus N > 1; BASELINE.json configs[3]) ONE synthetic RGB-D sequence of --sequence-frames (4000) frames sharded by
+            frame into N*S lock-step chunks (sindslam_amd.sequence.plan_lockstep): every chunk processes K*T frames, chunk 0 from the first
+            frame on, chunk g > 0 starts 24 frames before its first owned frame to rebuild the tail state.  The W warm-up steps are
+            untimed and their state is dropped (all streams are primed again); the K timed steps are the WHOLE job, chunk warm-up
+            frames included, software-pipelined, and after every step the per-frame dynamic masks of all ranks are gathered with one
+            RCCL all_gather over xGMI into the sequence-ordered mask array every rank holds.  value = sequence frames / wall time:
+            strong scaling (the sequence length does not grow with N).  Rank 0 then re-runs the first frames in the in-order
+            ("exact") mode and reports the chunk-seam IoU and the exact mode's own rate.
 
 --gpus N without a launcher (WORLD_SIZE unset): this process starts N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set)
 BEFORE anything touches torch or the GPU and only waits for them; under torch.distributed.run the ranks are already there.
@@ -52,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the first cpu_baseline setting (the reference pins its OpenMP loops to 8)")
+    ap.add_argument("--sequence-frames", type=int, default=4000, help="sequence workload: length of the ONE sequence (BASELINE.json configs[3]: 4000 frames); fixed as --gpus grows = strong scaling")
+    ap.add_argument("--no-sequence-leg", action="store_true", help="streams workload on one GPU: skip the fixed-length sequence job that is run after the timed region (line field `sequence`)")
     ap.add_argument("--no-exact-leg", action="store_true", help="sequence workload: skip the in-order re-run of the first chunks (seam IoU, exact-mode rate)")
     ap.add_argument("--host-input", action="store_true", help="hand over HOST buffers each step (sind_pipe_process, PCIe-inclusive rate; DESIGN.md 6) instead of HBM-resident inputs")
     ap.add_argument("--thread-cpu", action="store_true", help="print the CPU seconds the live threads used inside the timed region, by thread name (stderr)")
@@ -247,6 +252,230 @@ def pmc_profile():
     return d
 
 
+# ------------------------------------------------------------------------------------------------------------------ measurement helpers
+class StepAcc:
+    """sums of the per-step pipeline statistics (solver HIP-event brackets, stage times) over the timed steps"""
+    def __init__(self):
+        import numpy as np
+        self.sor_ms = self.sor_bytes = self.sor_union = 0.0; self.sor_launches = 0; self.sor_slices = 1
+        self.stages = np.zeros(6); self.tail_wait = 0.0; self.submit_wall = 0.0
+
+    def add(self, st, pipelined):
+        import numpy as np
+        self.sor_ms += st["sor_ms"]; self.sor_bytes += st["sor_alg_bytes"]; self.sor_launches += st["sor_launches"]; self.sor_union += st["sor_union_ms"]; self.sor_slices = st["sor_slices"]
+        self.stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"], st["upload_ms"]])
+        self.tail_wait += st["tail_wait_ms"] if pipelined else 0.0
+
+
+def roofline_of(acc, K, dt, pairs_per_launch, config_name):
+    """`roofline` object of the solver kernel.  The batch runs as `sor_slices` slices on concurrent HIP streams, so solver launches overlap on the GPU:
+    achieved = algorithmic bytes of all launches / time with at least one solver launch in flight (union of the HIP-event intervals of all slices on a
+    common time base); with one slice this is exactly bytes per launch / average launch duration.  The per-launch figures (a launch that shares the GPU
+    with the other slices) are reported next to it, and frac_wall prices the same bytes against the whole timed region."""
+    achieved = acc.sor_bytes / (acc.sor_union * 1e-3) / 1e9 if acc.sor_union > 0 else 0.0      # GB/s
+    per_launch = acc.sor_bytes / (acc.sor_ms * 1e-3) / 1e9 if acc.sor_ms > 0 else 0.0
+    pmc = pmc_profile() if config_name == "tum3" else None
+    traffic = pmc["hbm_bytes_per_launch_per_pair"] * pairs_per_launch if pmc else None
+    # bound: the contract's yardstick is the HBM roofline on the ALGORITHMIC bytes (44 B per pixel and iteration, SURVEY 8d) and `frac` keeps that meaning;
+    # the fused kernel moves ~0.18 of those bytes and its SQ counters show the VALU pipes as the busiest unit, so the binding resource is named here
+    roof = {"bound": "valu", "bound_note": "frac = algorithmic bytes (44 B per pixel update, SURVEY 8d) against the HBM peak, the yardstick of the metric; the fused solver keeps a tile's "
+                                           "system in registers for five iterations and really moves hbm_frac_measured of the peak -- the busiest unit by the SQ counters is the VALU (valu_busy_measured)",
+            "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "frac_wall": (acc.sor_bytes / dt / 1e9 / 8000.0) if dt > 0 else None, "traffic": traffic,
+            "traffic_source": (pmc["file"] + " (committed rocprofv3 --pmc passes of this command, per pair x pairs per launch; not re-measured in this run)") if pmc else None,
+            "kernel": "k_sor_fused", "launches": acc.sor_launches, "avg_launch_us": (acc.sor_ms * 1e3 / acc.sor_launches) if acc.sor_launches else None,
+            "alg_bytes_per_launch": (acc.sor_bytes / acc.sor_launches) if acc.sor_launches else None,
+            "concurrent_launches": acc.sor_slices, "achieved_per_launch": per_launch, "solver_busy_ms_per_step": acc.sor_union / K}
+    if pmc and acc.sor_launches and acc.sor_union > 0:
+        # real HBM bytes of all launches over the time the solver was busy, against the 8 TB/s peak
+        roof["hbm_frac_measured"] = traffic * acc.sor_launches / (acc.sor_union * 1e-3) / 8e12
+    if pmc and pmc.get("valu_busy_measured") is not None:
+        roof["valu_busy_measured"] = pmc["valu_busy_measured"]; roof["valu_busy_source"] = pmc.get("sq_counters")
+    # VALU floor: pixel updates (algorithmic bytes / 44 B) x VALU lane-operations per update (ISA count of the inner loop) x halo redundancy of the tiling,
+    # over the FP32 vector peak of 78.6e12 lane-operations/s (157.3 TFLOP/s / 2 flops per FMA lane; MI355X_MICROARCH.md)
+    valu_ops_per_update = (pmc or {}).get("valu_ops_per_pixel_update", 44); halo = (pmc or {}).get("halo_redundancy", 2.1)
+    if acc.sor_union > 0:
+        roof["valu_frac"] = (acc.sor_bytes / 44.0) * valu_ops_per_update * halo / 78.6e12 / (acc.sor_union * 1e-3)
+    return roof
+
+
+def host_load(c0, t0, thr0):
+    """host cores this rank kept busy since (c0, t0) and the cgroup quota's throttle counters since thr0, as four floats (all-gathered over the ranks)"""
+    dt = time.perf_counter() - t0; thr1 = cgroup_throttle()
+    q = [float(thr1[i] - thr0[i]) for i in range(3)] if (thr0 and thr1) else [-1.0, -1.0, -1.0]
+    return [(time.process_time() - c0) / dt, q[0], q[1], q[2] / 1e3 if q[2] >= 0 else -1.0]
+
+
+def gather_host_load(mine, pg, comm_dev):
+    """[cores busy, quota periods, throttled periods, throttled ms] of every rank"""
+    import torch
+    import torch.distributed as dist
+    if not pg:
+        return [mine]
+    t = torch.tensor(mine, dtype=torch.float64, device=comm_dev); parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [[float(x) for x in p.cpu()] for p in parts]
+
+
+def host_load_fields(loads):
+    quota = lambda l: None if l[1] < 0 else {"periods": int(l[1]), "throttled_periods": int(l[2]), "throttled_ms": l[3]}
+    return {"host_cores_busy": loads[0][0], "cpu_quota": quota(loads[0]),
+            "host_by_rank": [{"rank": r, "host_cores_busy": l[0], "cpu_quota": quota(l)} for r, l in enumerate(loads)]}
+
+
+def make_pipeline(cfg, intr, S, T, local, host_threads=0):
+    from sindslam_amd.pipeline import Pipeline
+    return Pipeline(S, T, cfg["width"], cfg["height"], intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],
+                    orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=host_threads, flow_max_levels=cfg["flow_max_levels"])
+
+
+SEQ_BASE_FRAMES = 50            # generated frames of the sequence workload, walked forth and back
+
+
+def sequence_streams(world, frames, cfg_streams, steps):
+    """chunks per GPU of the fixed-length sequence when --streams is not given.  Every chunk after the first re-processes 24 state warm-up frames, so the
+    chunk count trades batch size and tail parallelism (one tail chain per chunk) against warm-up work: start from the power of two that keeps the warm-up at
+    about a quarter of the sequence (>= 4 chunks per GPU), then take the count near it whose lock-step plan processes the fewest frames in `steps` steps."""
+    from sindslam_amd.sequence import plan_lockstep
+    s0 = 4
+    while s0 * 2 <= cfg_streams and s0 * 2 * world * 4 * SEQ_WARMUP_FRAMES <= frames:
+        s0 *= 2
+    best = None
+    for s in range(max(4, (3 * s0) // 4), 2 * s0):
+        tot = plan_lockstep(frames, world * s, steps, SEQ_WARMUP_FRAMES).processed_total
+        if best is None or tot <= best[0]:
+            best = (tot, s)
+    return best[1]
+
+
+SEQ_WARMUP_FRAMES = 24          # a rebuilt tail state re-synchronises with the sequential run within ~16-24 frames (profiles/r02/seam_iou_by_warmup.txt)
+
+
+def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_dev, S, K, Wm, exact_leg):
+    """BASELINE.json configs[3]: ONE synthetic RGB-D sequence of --sequence-frames frames, sharded by frame into world * S lock-step chunks (chunk g = stream
+    g % S of rank g // S; sindslam_amd.sequence.plan_lockstep).  Wm untimed steps warm the process up (their state is thrown away: every stream is primed
+    again), then the K timed steps process the WHOLE job -- the state warm-up frames of every chunk after the first included -- software-pipelined, with one
+    all_gather of the step's dynamic masks per step (RCCL over xGMI with --backend nccl) into the sequence-ordered mask array every rank holds.
+    Returns (seconds [max over ranks], StepAcc, info dict, host load of every rank)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sindslam_amd.parallel import gather_masks
+    from sindslam_amd.sequence import plan_lockstep
+    H, W = cfg["height"], cfg["width"]; P50 = base_b.shape[0]
+    plan = plan_lockstep(args.sequence_frames, world * S, K, SEQ_WARMUP_FRAMES); T = plan.T; n = world * S
+    if S * T > 4096:
+        raise SystemExit(f"sequence workload: {S} chunks x {T} frames per step is more than one step should hold; use more --steps, fewer --streams or a shorter --sequence-frames")
+    mine = plan.chunks[rank * S:(rank + 1) * S]
+    # sequence position q (0 = first processed frame) shows generated frame pingpong(q + 2): positions -2, -1 are the two priming frames of chunk 0
+    fidx = lambda q: pingpong(q + 2, P50)
+    pipe = make_pipeline(cfg, intr, S, T, local, args.host_threads)
+
+    def prime_all():
+        for s, c in enumerate(mine):
+            pipe.prime(s, base_b[fidx(c.start - 1)], base_b[fidx(c.start - 2)])
+    prime_all()
+    bb = torch.from_numpy(base_b).cuda(); bd = torch.from_numpy(base_d.view(np.int16)).cuda()
+    dev_b, dev_d = [], []
+    for i in range(K):
+        idx = torch.tensor([[fidx(c.start + i * T + t) for t in range(T)] for c in mine], device="cuda")
+        dev_b.append(bb[idx].contiguous()); dev_d.append(bd[idx].contiguous())
+    # dynamic masks of every processed frame of ALL chunks, on every rank: [chunk][step][t]
+    seq_masks = torch.zeros((world, S, K, T, H, W), dtype=torch.uint8, device="cuda" if comm_dev == "cuda" else "cpu")
+    gbuf = {}
+
+    def gather(step):
+        m = pipe.dyna_pinned if pipe.dyna_pinned is not None else torch.from_numpy(pipe.dyna)
+        if pg and comm_dev == "cuda":
+            if "dev" not in gbuf:
+                gbuf["dev"] = torch.empty_like(m, device="cuda"); gbuf["out"] = torch.empty((world,) + tuple(m.shape), dtype=m.dtype, device="cuda")
+            gbuf["dev"].copy_(m, non_blocking=True)
+            out = gather_masks(gbuf["dev"], out=gbuf["out"])
+            torch.cuda.current_stream().synchronize()            # the upload is complete before the next step may rewrite the page-locked source
+        elif pg:
+            out = gather_masks(m)
+        else:
+            out = m[None]
+        if step is not None:
+            seq_masks[:, :, step].copy_(out)
+
+    for i in range(Wm):                     # untimed: the first steps of the job, results and state dropped afterwards
+        pipe.process_dev(dev_b[i % K].data_ptr(), dev_d[i % K].data_ptr()); gather(None)
+    if Wm:
+        prime_all()                         # priming resets a stream's tail state: the timed region starts the job from scratch
+    if pg:
+        dist.barrier()
+    torch.cuda.synchronize()
+    thr0 = cgroup_throttle(); t0 = time.perf_counter(); c0 = time.process_time()
+    acc = StepAcc(); pending = None
+    for i in range(K):
+        ts = time.perf_counter(); have = pipe.submit_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()); acc.submit_wall += time.perf_counter() - ts
+        if have:
+            gather(pending)
+        pending = i
+        acc.add(pipe.stats(), True)
+    tf0 = time.perf_counter()
+    if pipe.flush():
+        gather(pending)
+    flush_ms = (time.perf_counter() - tf0) * 1e3
+    torch.cuda.synchronize()
+    if pg:
+        dist.barrier()
+    load = host_load(c0, t0, thr0); dt = time.perf_counter() - t0
+    if pg:
+        tt = torch.tensor([dt], device=comm_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    loads = gather_host_load(load, pg, comm_dev)
+    owned = sum(c.last - c.first for c in plan.chunks)
+    info = {"frames": plan.frames, "owned_frames": owned, "chunks": n, "chunks_per_gpu": S, "frames_per_step_per_chunk": T, "steps": K,
+            "processed_frames_per_chunk": plan.processed, "state_warmup_frames": SEQ_WARMUP_FRAMES, "state_warmup_steps": -(-SEQ_WARMUP_FRAMES // T),
+            "processed_frames": plan.processed_total, "warmup_overhead": plan.processed_total / owned - 1.0,
+            "value": owned / dt, "value_excl_warmup": plan.processed_total / dt, "seconds": dt, "final_flush_ms": flush_ms,
+            "note": "value = owned frames of the whole sequence / wall time of ALL the work (the 24 state warm-up frames of every chunk after the first run inside the timed "
+                    "region); value_excl_warmup counts every processed frame as if it were owned (the pipeline's processing rate)",
+            "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if pg else "single rank (no collective)",
+            "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
+    pipe.close()
+    # ---- rank 0: the first frames again in the in-order ("exact") mode -> IoU of the chunked masks at and behind the chunk seams, and the exact mode's own rate
+    if rank == 0 and exact_leg and n > 1:
+        from sindslam_amd.pipeline import Pipeline
+        P = plan.processed
+        E = min(max(320, P + 2 * (P - SEQ_WARMUP_FRAMES)), plan.frames, 480)      # chunk 0, chunks 1-2 and what else fits: long enough for a steady-state rate
+        Te = 32 if E >= 64 else 16
+        nst = -(-E // Te); E = nst * Te
+        ex = make_pipeline(cfg, intr, 1, Te, local)
+        ex.prime(0, base_b[fidx(-1)], base_b[fidx(-2)]); ex.set_depth_ahead(True)
+        eb = [bb[torch.tensor([fidx(k * Te + t) for t in range(Te)], device="cuda")].contiguous() for k in range(nst)]
+        ed = [bd[torch.tensor([fidx(k * Te + t) for t in range(Te)], device="cuda")].contiguous() for k in range(nst)]
+        torch.cuda.synchronize(); exact = np.zeros((E, H, W), np.uint8); te0 = time.perf_counter(); prev = None
+        for k in range(nst):
+            if ex.submit_dev(eb[k].data_ptr(), ed[k].data_ptr()):
+                exact[prev * Te:(prev + 1) * Te] = ex.dyna[0]
+            prev = k
+        if ex.flush():
+            exact[prev * Te:(prev + 1) * Te] = ex.dyna[0]
+        te = time.perf_counter() - te0; ex.close()
+        sm = seq_masks.reshape(n, P, H, W)
+        ious = []; seam = []; inter_sum = union_sum = 0
+        for g, c in enumerate(plan.chunks):
+            if g == 0:
+                continue                                          # chunk 0 starts like the sequential run: identical by construction
+            for q in range(c.first, min(c.last, E)):
+                a_ = sm[g, q - c.start].cpu().numpy() == 255; b_ = exact[q] == 255; u = np.logical_or(a_, b_).sum()
+                it_ = np.logical_and(a_, b_).sum(); inter_sum += int(it_); union_sum += int(u)
+                v = 1.0 if u == 0 else float(it_ / u); ious.append(v)
+                if q == c.first: seam.append(v)
+        info.update({"seam_iou_mean": float(np.mean(ious)) if ious else None, "seam_iou_min": float(np.min(ious)) if ious else None,
+                     "seam_iou_pooled": (inter_sum / union_sum) if union_sum else None, "seam_iou_below_0.99": int(sum(v < 0.99 for v in ious)),
+                     "seam_iou_first_frames": seam[:8], "seam_frames_compared": len(ious),
+                     "seam_note": "chunked (throughput) mode vs the in-order run on the same GPU code, owned frames of the chunks after the first; the chunked mode rebuilds the tail "
+                                  "state in the warm-up frames and returns valid but not identical masks -- parity (IoU >= 0.99 vs the oracle) holds for the in-order mode",
+                     "exact_mode": {"frames": E, "frames_per_step": Te, "fps": E / te,
+                                    "bound": "1 / per-frame latency of the slower tail chain (depth chain: k-means warm labels; flow chain: weights, previous high mask); "
+                                             "host + launch latency bound, does not grow with the number of GPUs"}})
+    del seq_masks, dev_b, dev_d, bb, bd
+    return dt, acc, info, loads
+
+
 # ------------------------------------------------------------------------------------------------------------------ main
 def main():
     args = parse_args()
@@ -258,45 +487,38 @@ def main():
     if args.rendezvous_only:                 # launcher test: meet, count, leave (no GPU needed)
         import torch
         import torch.distributed as dist
+        loads = [host_load(time.process_time(), time.perf_counter() - 1e-3, cgroup_throttle())]
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-            t = torch.ones(1); dist.all_reduce(t); seen = int(t.item()); dist.destroy_process_group()
+            t = torch.ones(1); dist.all_reduce(t); seen = int(t.item())
+            loads = gather_host_load(loads[0], True, "cpu"); dist.destroy_process_group()
         else:
             seen = 1
         if rank == 0:
-            print(json.dumps({"ranks_seen": seen, "n_gpus": world, "gpus_arg": args.gpus}))
+            print(json.dumps({"ranks_seen": seen, "n_gpus": world, "gpus_arg": args.gpus, "warmup": args.warmup, "steps": args.steps, **host_load_fields(loads)}))
         return
 
     import numpy as np
     cfg = dict(CONFIGS[args.config]); workload = args.workload if args.workload != "auto" else ("sequence" if world > 1 else "streams")
-    S = args.streams or cfg["streams"]; T, K, Wm = args.frames_per_step, args.steps, args.warmup
-    nsteps = K + Wm
+    T, K, Wm = args.frames_per_step, args.steps, args.warmup
+    S = args.streams or (cfg["streams"] if workload == "streams" else sequence_streams(world, args.sequence_frames, cfg["streams"], K))
+    seq_leg = workload == "streams" and world == 1 and not args.no_sequence_leg and not args.host_input       # N = 1 point of the sequence curve next to the streams headline
     import sindslam_amd.synth as SY
     intr0 = getattr(SY, cfg["intr"]); sc = cfg["width"] / 640.0
     intr = dict(intr0, fx=intr0["fx"] * sc, fy=intr0["fy"] * sc, cx=intr0["cx"] * sc, cy=intr0["cy"] * sc)
     # ---- synthetic input on the host, before torch / HIP are loaded (the frame generator forks workers)
+    seq_b = seq_d = None
+    if workload == "sequence" or seq_leg:
+        seq_b, seq_d = base_frames(cfg, SEQ_BASE_FRAMES, 12345)          # every rank builds the same sequence
     if workload == "streams":
+        nsteps = K + Wm
         ndata = min(nsteps, 12)             # distinct steps of input kept in host + device memory; longer runs cycle through them (the jump at the wrap is just another large-motion pair)
         base_b, base_d = base_frames(cfg, T * ndata + 2, 12345 + rank, nseeds=3)      # three scenes; the first eight streams (the parity sample) cover all of them
         bgr, depth = stream_variants(base_b, base_d, S)
 
         def frames_of_stream(s, count):
             return bgr[s, :count], depth[s, :count]
-    else:
-        # the warm-up steps are the chunks' state warm-up frames: a chunk re-synchronises with the sequential run within ~16-24 frames
-        # (profiles/r02/seam_iou_by_warmup.txt: 4 or 8 frames leave IoU 0.05-0.9 at some seams, 16 frames >= 0.98; bench: 20 frames -> mean 0.9995,
-        # 4 of 220 frames below 0.99), so at least 24 run untimed
-        Wm = max(Wm, -(-24 // T)); nsteps = K + Wm
-        P = 50; ndata = nsteps
-        base_b, base_d = base_frames(cfg, P, 12345)           # every rank builds the same sequence
-        chunk0 = rank * S
-        a_of = lambda g: 2 + g * K * T                        # first processed frame of chunk g; owned frames start W*T later
-        seq_frames = 2 + world * S * K * T + Wm * T
-
-        def frames_of_stream(s, count):
-            idx = [pingpong(a_of(chunk0 + s) - 2 + i, P) for i in range(count)]
-            return base_b[idx], base_d[idx]
 
     import torch
     import torch.distributed as dist
@@ -311,192 +533,119 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
         dist.init_process_group(args.backend, rank=rank, world_size=world)     # backend "nccl" is RCCL on ROCm
     comm_dev = "cuda" if (pg and args.backend == "nccl") else "cpu"
-
-    from sindslam_amd.pipeline import Pipeline
     H, W = cfg["height"], cfg["width"]
-    pipe = Pipeline(S, T, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],
-                    orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=args.host_threads, flow_max_levels=cfg["flow_max_levels"])
-    # inputs resident in HBM before the timed region, laid out [step][S][T]...
-    if workload == "streams":
+    seq_info = None; first_dyna = first_kps = None
+
+    if workload == "sequence":
+        dt, acc, seq_info, loads = sequence_job(args, cfg, intr, seq_b, seq_d, rank, world, local, pg, comm_dev, S, K, Wm, not args.no_exact_leg)
+        T = seq_info["frames_per_step_per_chunk"]; pairs = seq_info["owned_frames"]; flush_ms = seq_info["final_flush_ms"]; loop_ms = sync_ms = None
+        ranks_seen = 1
+        if pg:
+            rs = torch.ones(1, device=comm_dev); dist.all_reduce(rs); ranks_seen = int(rs.item())
+    else:
+        from sindslam_amd.parallel import gather_masks
+        pipe = make_pipeline(cfg, intr, S, T, local, args.host_threads)
+        # inputs resident in HBM before the timed region, laid out [step][S][T]...
         for s in range(S):
             pipe.prime(s, bgr[s, 1], bgr[s, 0])
         dev_b = [torch.from_numpy(np.ascontiguousarray(bgr[:, 2 + i * T: 2 + (i + 1) * T])).cuda() for i in range(ndata)]
         dev_d = [torch.from_numpy(np.ascontiguousarray(depth[:, 2 + i * T: 2 + (i + 1) * T]).view(np.int16)).cuda() for i in range(ndata)]
-    else:
-        for s in range(S):
-            a = a_of(chunk0 + s); pipe.prime(s, base_b[pingpong(a - 1, P)], base_b[pingpong(a - 2, P)])
-        bb = torch.from_numpy(base_b).cuda(); bd = torch.from_numpy(base_d.view(np.int16)).cuda()
-        dev_b, dev_d = [], []
-        for i in range(ndata):
-            idx = torch.tensor([[pingpong(a_of(chunk0 + s) + i * T + t, P) for t in range(T)] for s in range(S)], device="cuda")
-            dev_b.append(bb[idx].contiguous()); dev_d.append(bd[idx].contiguous())
-        # the sequence-ordered dynamic masks of ALL ranks' owned frames, on every rank: frame 2 + W*T + ((r*S + s)*K + k)*T + t
-        seq_masks = torch.zeros((world, S, K, T, H, W), dtype=torch.uint8, device="cuda" if comm_dev == "cuda" else "cpu")
-    torch.cuda.synchronize()
-    from sindslam_amd.parallel import gather_masks
+        torch.cuda.synchronize()
+        gbuf = {}
 
-    gbuf = {}
-
-    def gather(step_index=None):
-        """RCCL all_gather of this step's per-frame dynamic masks over xGMI (page-locked source, persistent device buffers); in the sequence
-        workload the gathered block lands in the sequence-ordered array.  The upload is complete before the next step may rewrite the source."""
-        if pg:
+        def gather():
+            """several ranks (stream-sharded replicas): RCCL all_gather of this step's per-frame dynamic masks (page-locked source, persistent device buffers)"""
+            if not pg:
+                return
             m = pipe.dyna_pinned if pipe.dyna_pinned is not None else torch.from_numpy(pipe.dyna)
             if comm_dev == "cuda":
                 if "dev" not in gbuf:
                     gbuf["dev"] = torch.empty_like(m, device="cuda"); gbuf["out"] = torch.empty((world,) + tuple(m.shape), dtype=m.dtype, device="cuda")
                 gbuf["dev"].copy_(m, non_blocking=True)
-                out = gather_masks(gbuf["dev"], out=gbuf["out"])
+                gather_masks(gbuf["dev"], out=gbuf["out"])
                 torch.cuda.current_stream().synchronize()
             else:
-                out = gather_masks(m)
-        elif workload == "sequence":
-            out = torch.from_numpy(pipe.dyna)[None]
-        else:
-            return
-        if workload == "sequence" and step_index is not None and step_index >= Wm:
-            seq_masks[:, :, step_index - Wm].copy_(out)
+                gather_masks(m)
 
-    NPS = min(S, args.cpu_threads) if (world == 1 and not args.no_cpu_baseline) else 0
+        NPS = min(S, args.cpu_threads) if (world == 1 and not args.no_cpu_baseline) else 0
 
-    def parity_sample():
-        return [pipe.dyna[s].copy() for s in range(NPS)], [[pipe.keypoints(s, t)[0].copy() for t in range(T)] for s in range(NPS)]
+        def parity_sample():
+            return [pipe.dyna[s].copy() for s in range(NPS)], [[pipe.keypoints(s, t)[0].copy() for t in range(T)] for s in range(NPS)]
 
-    host_b = host_d = None
-    if args.host_input:
-        host_b = [t_.cpu().numpy() for t_ in dev_b]; host_d = [t_.cpu().numpy().view(np.uint16) for t_ in dev_d]
-    first_dyna = first_kps = None
-    for i in range(Wm):                     # warm-up: synchronous steps
-        pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather(i)
-        if i == 0:                          # the first streams' first T results, for the parity figures below
-            first_dyna, first_kps = parity_sample()
-    if pg:
-        dist.barrier()
-    torch.cuda.synchronize()
-    thr0 = cgroup_throttle()
-    t0 = time.perf_counter(); c0 = time.process_time(); th0 = thread_cpu_seconds() if args.thread_cpu else None
-    sor_ms = sor_bytes = sor_union = 0.0; sor_launches = 0; sor_slices = 1; stages = np.zeros(6); tail_wait = 0.0; submit_wall = 0.0
-    pending_step = None
-    for i in range(Wm, Wm + K):             # timed steps
+        host_b = host_d = None
         if args.host_input:
-            pipe.process(host_b[i % ndata], host_d[i % ndata]); gather(i)
-        elif not args.pipelined:
-            pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather(i)
-        else:                               # software-pipelined: phase A of step i overlaps the tails of step i-1, whose results arrive now
-            _ts = time.perf_counter(); _hv = pipe.submit_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); submit_wall += time.perf_counter() - _ts
-            if _hv:
-                gather(pending_step)
-            pending_step = i
-        if first_dyna is None and not args.pipelined:     # --warmup 0: take the parity sample from the first timed step (a few MB copied)
-            first_dyna, first_kps = parity_sample()
-        st = pipe.stats()
-        sor_ms += st["sor_ms"]; sor_bytes += st["sor_alg_bytes"]; sor_launches += st["sor_launches"]; sor_union += st["sor_union_ms"]; sor_slices = st["sor_slices"]
-        stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"], st["upload_ms"]]); tail_wait += st["tail_wait_ms"] if args.pipelined else 0.0
-    t_flush0 = time.perf_counter()
-    if args.pipelined and pipe.flush():      # drain the last step inside the timed region
-        gather(pending_step)
-    flush_ms = (time.perf_counter() - t_flush0) * 1e3; loop_ms = (t_flush0 - t0) * 1e3
-    _tsy = time.perf_counter(); torch.cuda.synchronize(); sync_ms = (time.perf_counter() - _tsy) * 1e3
-    if pg:
-        dist.barrier()
-    th1 = thread_cpu_seconds() if args.thread_cpu else None
-    thr1 = cgroup_throttle()
-    dt = time.perf_counter() - t0; cpu_busy = (time.process_time() - c0) / dt      # host cores this rank kept busy (all threads)
-    ranks_seen = 1
-    if pg:
-        tt = torch.tensor([dt], device=comm_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
-        rs = torch.ones(1, device=comm_dev); dist.all_reduce(rs); ranks_seen = int(rs.item())
-    pairs = S * T * K * world
-    if args.thread_cpu and rank == 0:       # short-lived threads (flow slices, ORB, octree) that ended before the second sample are not listed
-        for name in sorted(th1, key=lambda n: -(th1[n] - th0.get(n, 0.0))):
-            print(f"[thread-cpu] {name:16s} {(th1[name] - th0.get(name, 0.0)) / K * 1e3:9.1f} core-ms per step", file=sys.stderr)
-        live = sum(th1[n] - th0.get(n, 0.0) for n in th1)
-        print(f"[thread-cpu] {'(exited threads)':16s} {(cpu_busy * dt - live) / K * 1e3:9.1f} core-ms per step   total {cpu_busy * dt / K * 1e3:.1f}", file=sys.stderr)
-
-    # ---- sequence workload, rank 0: the first chunks again in the in-order mode -> chunk-seam IoU and the exact mode's own rate
-    seq_info = None
-    if workload == "sequence":
-        seq_info = {"frames": seq_frames, "owned_frames": world * S * K * T, "chunks": world * S, "chunk_frames": K * T, "chunk_warmup_frames": Wm * T,
-                    "chunk_overhead": "every chunk after the first processes %d warm-up frames for %d owned ones (+%.0f %% work; they run in the bench's untimed warm-up steps)" % (Wm * T, K * T, 100.0 * Wm / K),
-                    "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if pg else "single rank (no collective)",
-                    "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
-        if rank == 0 and not args.no_exact_leg:
-            KT, WT = K * T, Wm * T
-            E = max(min(WT + 20 * KT, 320), min(KT + WT + 8, WT + 2 * KT))      # frames [2, 2 + E): chunk 0 and (part of) the chunks after it; long enough for a steady-state rate
-            E = min(E, WT + world * S * KT)
-            Te = 32 if E >= 64 else 16
-            ex = Pipeline(1, Te, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],
-                          orb_gray_rgb_order=cfg["rgb"], device=local, flow_max_levels=cfg["flow_max_levels"])
-            ex.prime(0, base_b[pingpong(1, P)], base_b[pingpong(0, P)]); ex.set_depth_ahead(True)
-            nst = (E + Te - 1) // Te; E = nst * Te
-            eb = [bb[torch.tensor([pingpong(2 + k * Te + t, P) for t in range(Te)], device="cuda")].contiguous() for k in range(nst)]
-            ed = [bd[torch.tensor([pingpong(2 + k * Te + t, P) for t in range(Te)], device="cuda")].contiguous() for k in range(nst)]
-            torch.cuda.synchronize(); exact = np.zeros((E, H, W), np.uint8); te0 = time.perf_counter(); prev = None
-            for k in range(nst):
-                if ex.submit_dev(eb[k].data_ptr(), ed[k].data_ptr()):
-                    exact[prev * Te:(prev + 1) * Te] = ex.dyna[0]
-                prev = k
-            if ex.flush():
-                exact[prev * Te:(prev + 1) * Te] = ex.dyna[0]
-            te = time.perf_counter() - te0; ex.close()
-            sm = seq_masks.reshape(world * S, K * T, H, W)
-            ious = []; seam = []; inter_sum = union_sum = 0
-            for f in range(2 + WT, 2 + E):                   # owned frame f belongs to chunk g at offset o
-                g, o = divmod(f - 2 - WT, KT)
-                if g < 1 or g >= world * S:
-                    continue                                  # chunk 0 starts like the sequential run: identical by construction
-                a_ = sm[g, o].cpu().numpy() == 255; b_ = exact[f - 2] == 255; u = np.logical_or(a_, b_).sum()
-                it_ = np.logical_and(a_, b_).sum(); inter_sum += int(it_); union_sum += int(u)
-                v = 1.0 if u == 0 else float(it_ / u); ious.append(v)
-                if o == 0: seam.append(v)
-            seq_info.update({"seam_iou_mean": float(np.mean(ious)) if ious else None, "seam_iou_min": float(np.min(ious)) if ious else None,
-                             "seam_iou_pooled": (inter_sum / union_sum) if union_sum else None, "seam_iou_below_0.99": int(sum(v < 0.99 for v in ious)),
-                             "seam_iou_first_frames": seam[:8], "seam_frames_compared": len(ious),
-                             "seam_note": "chunked (throughput) mode vs the in-order run on the same GPU code, frames of the chunks after the first; the chunked mode rebuilds the tail "
-                                          "state in the warm-up frames and returns valid but not identical masks -- parity (IoU >= 0.99 vs the oracle) holds for the in-order mode",
-                             "exact_mode": {"frames": E, "frames_per_step": Te, "fps": E / te,
-                                            "bound": "1 / per-frame latency of the slower tail chain (depth chain: k-means warm labels; flow chain: weights, previous high mask); "
-                                                     "host + launch latency bound, does not grow with the number of GPUs"}})
+            host_b = [t_.cpu().numpy() for t_ in dev_b]; host_d = [t_.cpu().numpy().view(np.uint16) for t_ in dev_d]
+        for i in range(Wm):                     # warm-up: synchronous steps
+            pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather()
+            if i == 0:                          # the first streams' first T results, for the parity figures below
+                first_dyna, first_kps = parity_sample()
+        if pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+        thr0 = cgroup_throttle()
+        t0 = time.perf_counter(); c0 = time.process_time(); th0 = thread_cpu_seconds() if args.thread_cpu else None
+        acc = StepAcc(); have_pending = False
+        for i in range(Wm, Wm + K):             # timed steps
+            if args.host_input:
+                pipe.process(host_b[i % ndata], host_d[i % ndata]); gather()
+            elif not args.pipelined:
+                pipe.process_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); gather()
+            else:                               # software-pipelined: phase A of step i overlaps the tails of step i-1, whose results arrive now
+                _ts = time.perf_counter(); _hv = pipe.submit_dev(dev_b[i % ndata].data_ptr(), dev_d[i % ndata].data_ptr()); acc.submit_wall += time.perf_counter() - _ts
+                if _hv:
+                    gather()
+                have_pending = True
+            if first_dyna is None and not args.pipelined:     # --warmup 0: take the parity sample from the first timed step (a few MB copied)
+                first_dyna, first_kps = parity_sample()
+            acc.add(pipe.stats(), args.pipelined)
+        t_flush0 = time.perf_counter()
+        if args.pipelined and have_pending and pipe.flush():      # drain the last step inside the timed region
+            gather()
+        flush_ms = (time.perf_counter() - t_flush0) * 1e3; loop_ms = (t_flush0 - t0) * 1e3
+        _tsy = time.perf_counter(); torch.cuda.synchronize(); sync_ms = (time.perf_counter() - _tsy) * 1e3
+        if pg:
+            dist.barrier()
+        th1 = thread_cpu_seconds() if args.thread_cpu else None
+        load = host_load(c0, t0, thr0); dt = time.perf_counter() - t0
+        ranks_seen = 1
+        if pg:
+            tt = torch.tensor([dt], device=comm_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+            rs = torch.ones(1, device=comm_dev); dist.all_reduce(rs); ranks_seen = int(rs.item())
+        loads = gather_host_load(load, pg, comm_dev)
+        pairs = S * T * K * world
+        if args.thread_cpu and rank == 0:       # short-lived threads (flow slices, ORB, octree) that ended before the second sample are not listed
+            cpu_s = load[0] * (time.perf_counter() - t0)
+            for name in sorted(th1, key=lambda n_: -(th1[n_] - th0.get(n_, 0.0))):
+                print(f"[thread-cpu] {name:16s} {(th1[name] - th0.get(name, 0.0)) / K * 1e3:9.1f} core-ms per step", file=sys.stderr)
+            live = sum(th1[n_] - th0.get(n_, 0.0) for n_ in th1)
+            print(f"[thread-cpu] {'(exited threads)':16s} {(cpu_s - live) / K * 1e3:9.1f} core-ms per step   total {cpu_s / K * 1e3:.1f}", file=sys.stderr)
+        pipe.close(); del dev_b, dev_d, pipe
+        # ---- one GPU: the fixed-length sequence job as well (the N = 1 point of the curve that --gpus N > 1 reports as its headline)
+        if seq_leg:
+            torch.cuda.empty_cache()
+            Ss = sequence_streams(1, args.sequence_frames, cfg["streams"], max(K, 10))
+            sdt, sacc, seq_info, _ = sequence_job(args, cfg, intr, seq_b, seq_d, 0, 1, local, False, "cpu", Ss, max(K, 10), min(Wm, 2), not args.no_exact_leg)
+            seq_info["solver_busy_ms_per_step"] = sacc.sor_union / max(K, 10); seq_info["ms_per_step"] = sdt / max(K, 10) * 1e3
+            seq_info["leg_note"] = "same job as the headline of --gpus N > 1 (strong scaling over the ranks), run here after the timed region of the streams workload"
 
     if rank == 0:
-        # The batch runs as `sor_slices` slices on concurrent HIP streams, so solver launches overlap on the GPU.  achieved = algorithmic
-        # bytes of all launches / time with at least one solver launch in flight (union of the HIP-event intervals of all slices on a
-        # common time base); with one slice this is exactly bytes per launch / average launch duration.  The per-launch figures
-        # (a launch that shares the GPU with the other slices) are reported next to it.
-        achieved = sor_bytes / (sor_union * 1e-3) / 1e9 if sor_union > 0 else 0.0      # GB/s
-        per_launch = sor_bytes / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
-        pmc = pmc_profile() if args.config == "tum3" else None
-        pairs_per_launch = S * T / max(sor_slices, 1)
-        traffic = pmc["hbm_bytes_per_launch_per_pair"] * pairs_per_launch if pmc else None
-        roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                "traffic_source": (pmc["file"] + " (committed rocprofv3 --pmc passes of this command, per pair x pairs per launch; not re-measured in this run)") if pmc else None,
-                "kernel": "k_sor_fused", "launches": sor_launches, "avg_launch_us": (sor_ms * 1e3 / sor_launches) if sor_launches else None,
-                "alg_bytes_per_launch": (sor_bytes / sor_launches) if sor_launches else None,
-                "concurrent_launches": sor_slices, "achieved_per_launch": per_launch, "solver_busy_ms_per_step": sor_union / K}
-        if pmc and sor_launches and sor_union > 0:
-            # real HBM bytes of all launches over the time the solver was busy, against the 8 TB/s peak: the kernel keeps the system in registers
-            # for several iterations, so this is far below `frac` (which prices the ALGORITHMIC bytes) -- the honest HBM utilisation
-            roof["hbm_frac_measured"] = traffic * sor_launches / (sor_union * 1e-3) / 8e12
-        # VALU floor: pixel updates (algorithmic bytes / 44 B) x VALU lane-operations per update (ISA count of the inner loop) x halo redundancy of the tiling,
-        # over the FP32 vector peak of 78.6e12 lane-operations/s (157.3 TFLOP/s / 2 flops per FMA lane; MI355X_MICROARCH.md)
-        valu_ops_per_update = (pmc or {}).get("valu_ops_per_pixel_update", 44); halo = (pmc or {}).get("halo_redundancy", 2.1)
-        if sor_union > 0:
-            roof["valu_frac"] = (sor_bytes / 44.0) * valu_ops_per_update * halo / 78.6e12 / (sor_union * 1e-3)
+        seq = workload == "sequence"
         out = {
             "metric": "DynaDetect+ORB frame-pairs/sec at 640x480; mask IoU vs CPU ref", "value": pairs / dt, "unit": "frame-pairs/s",
-            "n_gpus": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if seq else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["workload"] + ("; ONE sequence of %d frames, frame-sharded in %d chunks, per-step %s gather of the dynamic masks" % (seq_frames, world * S, "RCCL" if args.backend == "nccl" else args.backend) if workload == "sequence" else ""),
+            "config": {"workload": cfg["workload"] + ("; ONE sequence of %d frames, frame-sharded in %d lock-step chunks (24 state warm-up frames per chunk inside the timed region), per-step %s gather of the dynamic masks"
+                                                      % (args.sequence_frames, world * S, "RCCL" if args.backend == "nccl" else args.backend) if seq else ""),
                        "name": args.config, "mode": workload, "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world,
-                       "parallelism": ("frame-sharded x%d" if workload == "sequence" else "stream-sharded x%d") % world, "pipelined": bool(args.pipelined),
+                       "parallelism": ("frame-sharded x%d" if seq else "stream-sharded x%d") % world, "pipelined": bool(args.pipelined or seq),
                        "flow_pyramid_levels": cfg["flow_max_levels"] or "all (49 at 640x480)",
                        "inputs": "host buffers, H2D inside the timed region" if args.host_input else "resident in HBM"},
             "ranks_seen": ranks_seen,
-            "roofline": roof,
-            "stage_ms_per_step": {"front": stages[0] / K, "dense_flow": stages[1] / K, "orb_front": stages[2] / K, "tails": stages[3] / K, "host_upload": stages[5] / K, "total": stages[4] / K, "tails_wait_after_phase_a": tail_wait / K, "final_flush_total": flush_ms, "submit_call_wall": submit_wall * 1e3 / K, "loop_total": loop_ms, "final_sync": sync_ms},
-            "host_cores_busy": cpu_busy,
-            "cpu_quota": None if not (thr0 and thr1) else {"periods": thr1[0] - thr0[0], "throttled_periods": thr1[1] - thr0[1], "throttled_ms": (thr1[2] - thr0[2]) / 1e3},
+            "roofline": roofline_of(acc, K, dt, S * T / max(acc.sor_slices, 1), args.config),
+            "stage_ms_per_step": {"front": acc.stages[0] / K, "dense_flow": acc.stages[1] / K, "orb_front": acc.stages[2] / K, "tails": acc.stages[3] / K, "host_upload": acc.stages[5] / K, "total": acc.stages[4] / K,
+                                  "tails_wait_after_phase_a": acc.tail_wait / K, "final_flush_total": flush_ms, "submit_call_wall": acc.submit_wall * 1e3 / K, "loop_total": loop_ms, "final_sync": sync_ms},
         }
+        out.update(host_load_fields(loads))
         if seq_info:
             out["sequence"] = seq_info
         if not args.no_cpu_baseline and world == 1 and first_dyna is not None:
@@ -504,7 +653,6 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    pipe.close()
     if pg:
         dist.destroy_process_group()
 

@@ -48,10 +48,12 @@ struct SindHostGate {
     void acquire() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return free_tokens > 0; }); free_tokens--; }
     void release() { { std::lock_guard<std::mutex> lk(m); free_tokens++; } cv.notify_one(); }
 };
-extern SindHostGate g_sind_gate; extern thread_local bool t_sind_has_token;
+// every sind_pipe owns its gate (two handles driven from different threads must not re-base each other's token count); a pool worker names the gate
+// whose token it holds in t_sind_gate, so that the waits below can hand exactly that token back
+extern thread_local SindHostGate* t_sind_gate;
 struct SindTokenPause {        // scope in which a token holder does not need its token (a wait for the GPU)
-    bool had; SindTokenPause() : had(t_sind_has_token) { if (had) { t_sind_has_token = false; g_sind_gate.release(); } }
-    ~SindTokenPause() { if (had) { g_sind_gate.acquire(); t_sind_has_token = true; } }
+    SindHostGate* g; SindTokenPause() : g(t_sind_gate) { if (g) { t_sind_gate = nullptr; g->release(); } }
+    ~SindTokenPause() { if (g) { g->acquire(); t_sind_gate = g; } }
 };
 
 // Host wait for a stream that does not burn a core.  hipStreamSynchronize spins (measured on MI355X: CPU time == wall time), and a
@@ -74,6 +76,24 @@ static inline hipError_t sind_event_wait(hipEvent_t ev) {
     if (e == hipErrorNotReady) { SindTokenPause pause; while (e == hipErrorNotReady) { std::this_thread::sleep_for(std::chrono::microseconds(50)); e = hipEventQuery(ev); } }
     return e;
 }
+
+// One-time set-up PER DEVICE (hipFuncSetAttribute applies to the current device only, and every create function takes a device): the first caller on a
+// device runs fn under the lock, a failure is reported and not remembered, later callers take the lock-free path.
+struct SindPerDeviceInit {
+    std::mutex m; std::atomic<bool> done[32];
+    SindPerDeviceInit() { for (auto& d : done) d.store(false); }
+    template <class F> hipError_t run(F fn) {
+        int d = 0; const hipError_t e0 = hipGetDevice(&d);
+        if (e0 != hipSuccess) return e0;
+        if (d < 0 || d >= 32) return hipErrorInvalidDevice;
+        if (done[d].load(std::memory_order_acquire)) return hipSuccess;
+        std::lock_guard<std::mutex> lk(m);
+        if (done[d].load(std::memory_order_relaxed)) return hipSuccess;
+        const hipError_t e = fn();
+        if (e == hipSuccess) done[d].store(true, std::memory_order_release);
+        return e;
+    }
+};
 
 // simple owning device buffer
 template <class T>

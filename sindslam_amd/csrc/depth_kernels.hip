@@ -74,9 +74,10 @@ __global__ void k_labels_resize(const T* __restrict__ src, int* __restrict__ dst
 // frames later with the former FP64 tree sums), so the order is reproduced instead of approximated:
 //   k_km_count / k_km_assign_count   per wave-segment (a contiguous index range) counts of every cluster      -- parallel
 //   k_km_compact                     ordered scatter of the coordinates into per-cluster runs (stable partition) -- parallel
-//   k_km_update                      36 lanes of one wave add their run front to back (the only serial part: 4 cycles per sample of the
-//                                    largest cluster), then the centre step with cv::kmeans' operations: empty-cluster repair, scale,
-//                                    shift test, last-iteration decision.  One KmState per pyramid level.
+//   k_km_seqsum                      one workgroup per run (12 clusters x 3 coordinates): the sequential FP32 sum of the run, exactly, by windows of
+//                                    512 samples in integer arithmetic inside one binade; the LAST workgroup of a level to finish then
+//                                    takes the centre step with cv::kmeans' operations (km_try_finalize: empty-cluster repair, scale, shift test,
+//                                    last-iteration decision).  One KmState per pyramid level and frame.
 __device__ void km_try_finalize(KmState* st) {
     // look for an empty cluster; if there is one, request a farthest-point search and return
     for (int k = 0; k < KM_K; k++) {
@@ -779,9 +780,8 @@ int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int
     }
     if (C <= 64) {
         const size_t shm = ((size_t)C * 256 + 3 * (size_t)C * C + C) * sizeof(int);      // <= 64 KB + 48 KB + 256 B of the 160 KB LDS
-        static std::once_flag attr_once; static hipError_t attr_rc = hipSuccess;       // the pool's workers call this concurrently
-        std::call_once(attr_once, [] { attr_rc = hipFuncSetAttribute((const void*)k_rag_stats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); });
-        HIP_TRY(attr_rc);
+        static SindPerDeviceInit attr_init;       // the pool's workers call this concurrently; once per device
+        HIP_TRY(attr_init.run([] { return hipFuncSetAttribute((const void*)k_rag_stats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); }));
         hipLaunchKernelGGL(k_rag_stats<true>, dim3(128), dim3(256), shm, s, planes, C, w, h, wpr, occ2, depthN, overlap, overlapPlane, ljOverlap, ljArea, hist);
     } else {
         hipLaunchKernelGGL(k_rag_stats<false>, dim3(256), dim3(256), 0, s, planes, C, w, h, wpr, occ2, depthN, overlap, overlapPlane, ljOverlap, ljArea, hist);

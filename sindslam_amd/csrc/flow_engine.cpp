@@ -107,6 +107,6 @@ int FlowEngine::varref_f32(const float* I0, const float* I1, int w, int h, int B
 // ---------------------------------------------------------------- error string (shared by the whole library)
 static thread_local char g_err[512] = "";
 std::atomic<long long> g_sind_wait_ns{0}, g_sind_wait_calls{0};
-SindHostGate g_sind_gate; thread_local bool t_sind_has_token = false;
+thread_local SindHostGate* t_sind_gate = nullptr;
 void sind_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
 extern "C" const char* sind_last_error() { return g_err; }

@@ -906,15 +906,16 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         }
         *nlaunch += 2LL * total; return SIND_OK;
     }
-    // the flow slices call this concurrently from their own threads: set the (idempotent) attribute exactly once
-    static std::once_flag attr_once; static hipError_t attr_rc = hipSuccess;
-    std::call_once(attr_once, [] {
+    // the flow slices call this concurrently from their own threads: set the (idempotent) attribute once per device
+    static SindPerDeviceInit attr_init;
+    HIP_TRY(attr_init.run([] {
+        hipError_t attr_rc = hipSuccess;
         const void* fs[] = {(const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 512, 2, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>,
                             (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_fused<1, 384, 3, 0, 0>, (const void*)k_sor_fused<1, 768, 3, 0, 0>,
                             (const void*)k_sor_fused<1, 256, 3, 0, 0>};
         for (const void* f : fs) if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    });
-    HIP_TRY(attr_rc);
+        return attr_rc;
+    }));
     auto sor_lds_bytes = [](int EW, int nt) { const int NR = 2 * ((nt / 2) / (EW / SOR_PX)); return (size_t)6 * (NR + 2) * sor_row_stride(EW) * sizeof(float4); };
     auto threads_for = [](int EW, int EH) { const int halfn = (EW / SOR_PX) * ((EH + 1) / 2); return 2 * ((halfn + 63) / 64 * 64); };
     const int EWw = (w + SOR_PX - 1) / SOR_PX * SOR_PX;
@@ -930,9 +931,8 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         *nlaunch += 1; return SIND_OK;
     }
     if (g_sor_mode == 2) {                             // 1x4 strips + reciprocal division (k_sor_fused4), 64 x 64 tiles, 1024 threads
-        static std::once_flag attr4_once; static hipError_t attr4_rc = hipSuccess;
-        std::call_once(attr4_once, [] { attr4_rc = hipFuncSetAttribute((const void*)k_sor_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
-        HIP_TRY(attr4_rc);
+        static SindPerDeviceInit attr4_init;
+        HIP_TRY(attr4_init.run([] { return hipFuncSetAttribute((const void*)k_sor_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); }));
         const int EW = 64, EH = 64, nt = 1024;
         const size_t shm = (size_t)4 * (EH + 2) * (EW / 4 + 2) * sizeof(float2);
         for (int done = 0; done < total;) {

@@ -32,16 +32,16 @@ static std::atomic<long long> g_cpu_us_flow{0}, g_cpu_us_orb{0}, g_cpu_steps{0};
 struct TaskGroup { std::mutex m; std::condition_variable cv; int left = 0; };
 class WorkerPool {
 public:
-    void start(int n, int device) {
-        for (int i = 0; i < n; i++) th.emplace_back([this, i, device] {
+    void start(int n, int device, SindHostGate* gate) {
+        for (int i = 0; i < n; i++) th.emplace_back([this, i, device, gate] {
             (void)pthread_setname_np(pthread_self(), "sind-worker");      // names show up in /proc/<pid>/task/*/comm (bench.py --thread-cpu)
             (void)hipSetDevice(device);
             for (;;) {
                 std::pair<std::function<void(int)>, TaskGroup*> job;
                 { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return stop || !q.empty(); }); if (q.empty()) return; job = std::move(q.front()); q.pop_front(); }
-                g_sind_gate.acquire(); t_sind_has_token = true;          // a CPU token while the task computes (handed back inside every wait for the GPU)
+                gate->acquire(); t_sind_gate = gate;          // a CPU token while the task computes (handed back inside every wait for the GPU)
                 job.first(i);
-                t_sind_has_token = false; g_sind_gate.release();
+                t_sind_gate = nullptr; gate->release();
                 { std::lock_guard<std::mutex> lk(job.second->m); if (--job.second->left == 0) job.second->cv.notify_all(); }
             } });
     }
@@ -97,6 +97,7 @@ struct sind_pipe {
     bool depth_ahead = false;
     std::vector<char> primed;
     double stage_ms[6] = {0}; double tail_wait_ms = 0; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;
+    SindHostGate gate;           // CPU tokens of this handle's pool tasks (common.hpp)
     WorkerPool workers;          // declared last: joined first
 };
 
@@ -183,7 +184,7 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
             for (int f = 0; f < B; f++) HIP_TRY(hipEventCreateWithFlags(&p->sb[k].occ2_ev[f], hipEventDisableTiming));
         }
     }
-    p->workers.start(nworkers, cfg->device);
+    p->workers.start(nworkers, cfg->device, &p->gate);
     SIND_TRY(p->gray.alloc(np * std::max(B, 2)));          // sind_pipe_prime converts the two priming frames through this scratch, also when S * T == 1
     SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
     if (cfg->orb_gray_rgb_order) SIND_TRY(p->gray_orb.alloc(np * B));
@@ -473,7 +474,7 @@ int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* 
                           sind_keypoint* kps, int cap, int* nkp, uint8_t* desc) {
     SIND_TRY(check_inputs(p, bgr_dev, depth_dev));
     if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_process: a submitted step is still pending, call sind_pipe_flush first"); return SIND_E_STATE; }
-    g_sind_gate.set_capacity(1 << 20);                 // no pool task is running between two calls: safe to re-base the token count
+    p->gate.set_capacity(1 << 20);                 // no pool task is running between two calls: safe to re-base the token count
     double t[4]; const double t0 = now_ms();
     SIND_TRY(phase_a(p, p->sb[0], bgr_dev, depth_dev, t, p->depth_ahead));
     const PipeOut o{dyna, label, mask_dil, kps, cap, nkp, desc};
@@ -488,7 +489,7 @@ int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* 
 int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* depth_dev, uint8_t* dyna, uint8_t* label, uint8_t* mask_dil,
                          sind_keypoint* kps, int cap, int* nkp, uint8_t* desc, int* have_output) {
     SIND_TRY(check_inputs(p, bgr_dev, depth_dev));
-    g_sind_gate.set_capacity(p->cpu_tokens);
+    p->gate.set_capacity(p->cpu_tokens);
     const int prev = p->cur ^ 1;
     const bool has_prev = p->sb[prev].pending;
     if (have_output) *have_output = has_prev ? 1 : 0;

@@ -51,6 +51,46 @@ def plan_chunks(n_frames: int, n_chunks: int, warmup: int = 24) -> list[Chunk]:
     return chunks
 
 
+@dataclass
+class LockstepPlan:
+    """A fixed-length sequence on n lock-step chunks (bench.py --workload sequence): every chunk PROCESSES exactly `processed` = steps * T
+    frames, chunk 0 from the first frame on (it owns all of them, like the sequential loop), chunk g > 0 starts `warmup` frames before its
+    first owned frame.  Frame numbers are positions among the processed frames of the sequence (0 = the first frame DetectDynaArea sees)."""
+    frames: int                 # owned frames of the whole job (what throughput counts)
+    n_chunks: int
+    steps: int
+    T: int                      # frames of every chunk per step
+    warmup: int
+    chunks: list                # Chunk(first, last, start) per chunk; a chunk past the end of the sequence owns nothing (first == last)
+
+    @property
+    def processed(self) -> int:
+        return self.steps * self.T
+
+    @property
+    def processed_total(self) -> int:
+        return self.processed * self.n_chunks
+
+
+def plan_lockstep(frames: int, n_chunks: int, steps: int, warmup: int = 24) -> LockstepPlan:
+    """Cut `frames` owned frames into n_chunks chunks that all process the same number of frames in `steps` steps: P = steps * T with the
+    smallest T for which P + (n - 1) * (P - warmup) >= frames.  Chunk 0 owns [0, P), chunk g owns the next P - warmup frames; what lies
+    beyond `frames` is processed (the chunks run in lock-step) but owned by nobody."""
+    if frames < 1 or n_chunks < 1 or steps < 1 or warmup < 0:
+        raise ValueError("plan_lockstep: need at least one frame, chunk and step and a non-negative warm-up")
+    need = -(-(frames + warmup * (n_chunks - 1)) // n_chunks)            # smallest P that covers the sequence
+    if n_chunks > 1:
+        need = max(need, warmup + 1)                                      # a later chunk must own something
+    T = -(-need // steps); P = steps * T
+    chunks, first = [], 0
+    for g in range(n_chunks):
+        n = P if g == 0 else P - warmup
+        last = min(first + n, frames); f0 = min(first, frames)
+        chunks.append(Chunk(f0, last, first - (warmup if g else 0)))      # start may lie before `first` even when the chunk owns nothing: it still runs
+        first += n
+    return LockstepPlan(frames, n_chunks, steps, T, warmup, chunks)
+
+
 def process_sequence(bgr: np.ndarray, depth: np.ndarray, intr: dict, streams: int = 8, frames_per_step: int = 4, warmup: int = 24,
                      nfeatures: int = 1500, scale_factor: float = 1.2, nlevels: int = 8, orb_gray_rgb_order: int = 1, device: int = 0,
                      rank: int = 0, world: int = 1, want_keypoints: bool = True):
@@ -183,10 +223,12 @@ def process_sequence_exact(bgr: np.ndarray, depth: np.ndarray, intr: dict, frame
                 prev = f + k * t_len
             if p.flush(): collect(p, prev, t_len)
             state = p.get_state(0); f += run * t_len; i += run
-        if world > 1 and rank + 1 < world:
-            if state is None:               # a rank without frames forwards what it received
-                nb = Pipeline.state_bytes_for(w, h); state = recv_state(nb) if rank > 0 else np.zeros(nb, np.uint8)
-            send_state(state)
+        if world > 1:
+            if state is None:               # a rank without frames still takes what its predecessor sends (also the LAST rank: an unmatched send would
+                nb = Pipeline.state_bytes_for(w, h)          # block the predecessor forever) and forwards it
+                tw = time.perf_counter(); state = recv_state(nb) if rank > 0 else np.zeros(nb, np.uint8); t_wait += time.perf_counter() - tw
+            if rank + 1 < world:
+                send_state(state)
     finally:
         for p in pipes.values(): p.close()
     if timing is not None: timing["state_wait_s"] = t_wait

@@ -17,13 +17,16 @@ def _clean_env():
 
 
 def test_gpus_flag_spawns_the_ranks_and_the_launcher_never_touches_torch():
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rendezvous-only"], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rendezvous-only", "--warmup", "5", "--steps", "20"], env=_clean_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "spawned 2 ranks" in r.stderr and "torch imported in the launcher: False" in r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                      # ONE JSON line, from rank 0
     out = json.loads(lines[0])
     assert out["ranks_seen"] == 2 and out["n_gpus"] == 2
+    assert out["warmup"] == 5 and out["steps"] == 20                 # the line repeats the arguments, whatever the workload does inside
+    assert [h["rank"] for h in out["host_by_rank"]] == [0, 1]        # host load and CPU-quota counters of EVERY rank are gathered into the line
+    assert all("host_cores_busy" in h and "cpu_quota" in h for h in out["host_by_rank"])
 
 
 def test_under_a_launcher_no_second_set_of_ranks_is_started():
@@ -62,3 +65,15 @@ def test_pingpong_sequence_and_frame_generator():
     assert b3.shape == (3, 2, 480, 640, 3) and np.array_equal(b3[0], b[:2]) and not np.array_equal(b3[1], b3[0])
     v3, _ = bench.stream_variants(b3, d3, 7)
     assert np.array_equal(v3[1], b3[1]) and np.array_equal(v3[3], b3[0][:, :, ::-1]) and np.array_equal(v3[5], b3[2][:, :, ::-1])
+
+
+def test_sequence_chunk_count_heuristic():
+    """chunks per GPU of the 4000-frame job at the driver's 20 steps: the chunk count shrinks as the ranks grow (the warm-up work per chunk is fixed)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from sindslam_amd.sequence import plan_lockstep
+    got = {n: bench.sequence_streams(n, 4000, 128, 20) for n in (1, 2, 4, 8)}
+    assert got[1] > got[2] > got[4] > got[8] >= 4
+    for n, s in got.items():
+        p = plan_lockstep(4000, n * s, 20)
+        assert p.processed_total <= 1.3 * 4000 and sum(c.last - c.first for c in p.chunks) == 4000

@@ -13,16 +13,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.timeout(900)
 def test_two_ranks_frame_sharded_sequence_line():
+    """the fixed-length sequence job on two ranks: `warmup` is the argument, the chunks' state warm-up runs INSIDE the timed region (value counts owned
+    frames only), and the seam check against the in-order run holds the bar the bench reports"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
     env["MASTER_PORT"] = str(29400 + os.getpid() % 1500)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--streams", "4",
-                        "--frames-per-step", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=800)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--streams", "2",
+                        "--sequence-frames", "200", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "spawned 2 ranks" in r.stderr and "torch imported in the launcher: False" in r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0]); s = d["sequence"]
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["mode"] == "sequence" and d["config"]["parallelism"] == "frame-sharded x2"
-    assert d["value"] > 0 and d["roofline"]["launches"] > 0 and d["warmup"] >= 6                       # at least 24 state warm-up frames per chunk
-    assert s["chunks"] == 8 and s["chunk_frames"] == 8 and s["owned_frames"] == 64 and s["frames"] == 2 + 64 + d["warmup"] * 4
-    assert s["seam_frames_compared"] > 0 and s["seam_iou_mean"] >= 0.95 and s["exact_mode"]["fps"] > 0
+    assert d["warmup"] == 1 and d["steps"] == 4 and d["scaling"] == "strong"
+    # 200 frames on 4 chunks in 4 steps: P >= (200 + 3 * 24) / 4 = 68 -> T = 17, every chunk processes 68 frames, chunks 1.. own 44 each
+    assert s["chunks"] == 4 and s["frames_per_step_per_chunk"] == 17 and s["processed_frames_per_chunk"] == 68 and s["owned_frames"] == 200 and s["processed_frames"] == 272
+    assert s["state_warmup_frames"] == 24 and s["state_warmup_steps"] == 2
+    assert d["value"] > 0 and abs(d["value"] - s["value"]) < 1e-6 * d["value"] and s["value"] <= s["value_excl_warmup"]
+    assert abs(s["value_excl_warmup"] / s["value"] - 272 / 200) < 1e-6
+    assert d["roofline"]["launches"] > 0 and d["roofline"]["frac_wall"] <= d["roofline"]["frac"] * 1.001
+    assert len(d["host_by_rank"]) == 2 and all(h["host_cores_busy"] > 0 for h in d["host_by_rank"])
+    # chunked masks vs the in-order run of the same frames (owned frames of chunks 1..3 inside the first E frames)
+    assert s["seam_frames_compared"] >= 100 and s["exact_mode"]["fps"] > 0
+    assert s["seam_iou_min"] >= 0.97 and s["seam_iou_mean"] >= 0.99 and s["seam_iou_below_0.99"] <= 0.02 * s["seam_frames_compared"] + 1
+
+
+@pytest.mark.timeout(900)
+def test_one_gpu_line_carries_the_sequence_leg():
+    """--gpus 1: streams headline (weak) plus the fixed-length sequence job as `sequence` (the N = 1 point of the strong-scaling curve)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--streams", "8", "--sequence-frames", "300", "--no-cpu-baseline",
+                        "--no-exact-leg"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0]); s = d["sequence"]
+    assert d["config"]["mode"] == "streams" and d["scaling"] == "weak" and d["warmup"] == 1 and d["steps"] == 2 and d["config"]["frame_pairs_per_step"] == 32
+    assert s["frames"] == 300 and s["owned_frames"] == 300 and s["steps"] == 10 and 0 < s["value"] <= s["value_excl_warmup"]
+    assert d["roofline"]["bound"] == "valu" and d["roofline"]["frac_wall"] > 0

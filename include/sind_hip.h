@@ -122,6 +122,13 @@ int sind_debug_seqsum(const float* x, int n, int device, float* out);
  * from the IEEE division (16 numerators per divisor), out[2] = smallest failing significand (all ones if none) */
 int sind_debug_rcp_scan(int device, int exp_lo, int exp_hi, unsigned long long out[3]);
 
+/* parity-test access to the residual-threshold kernel (Otsu + Triangle of cv::threshold and the clamping of DynaDetect.cc:1309-1367 from a 256-bin
+ * histogram): hist = n blocks of 257 words (counts, then the float bits of the maximal residual), res = n blocks of 261 words (the 257 input words,
+ * then lo, hi, otsu, triangle as floats; variant 0 writes only n x 4 floats, packed at the start of res).  variant 0 = serial one-thread reference
+ * kernel, 1 = one-wave kernel, 2 = one-wave kernel in its production form, which clears the working histogram: the first 257 words of every result
+ * block then hold the cleared words.  mu1 (optional, variants 1 / 2): n x 256 values of Otsu's running class mean, the one rounding chain with a division. */
+int sind_debug_flow_thresholds(const int* hist, int n, int width, int height, int variant, int device, int* res, double* mu1);
+
 /* parity-test access to the bit-plane dilation used by the region-adjacency stage (7x7 ellipse on 64-pixel words, cv::dilate semantics):
  * planes / out are host arrays [nplanes][height][ceil(width / 64)] of 64-bit words, bit i of word k = pixel 64 k + i. */
 int sind_debug_dilate_planes(const unsigned long long* planes, int nplanes, int width, int height, int n, int device, unsigned long long* out);

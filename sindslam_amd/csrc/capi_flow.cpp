@@ -105,6 +105,21 @@ int sind_debug_rcp_scan(int device, int exp_lo, int exp_hi, unsigned long long o
     HIP_TRY(hipMemcpy(out, d.p, sizeof(init), hipMemcpyDeviceToHost));
     return SIND_OK;
 }
+int sind_debug_flow_thresholds(const int* hist, int n, int width, int height, int variant, int device, int* res, double* mu1) {
+    if (!hist || !res || n < 1 || variant < 0 || variant > 2 || width < 1 || height < 1) { sind_set_error("sind_debug_flow_thresholds: bad arguments"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<int> dh, dr; DevBuf<double> dm; SIND_TRY(dh.alloc((size_t)n * 257)); SIND_TRY(dr.alloc((size_t)n * 261)); if (mu1) SIND_TRY(dm.alloc((size_t)n * 256));
+    HIP_TRY(hipMemcpy(dh.p, hist, (size_t)n * 257 * sizeof(int), hipMemcpyHostToDevice)); HIP_TRY(hipMemset(dr.p, 0, (size_t)n * 261 * sizeof(int)));
+    SIND_TRY(sind::debug_flow_thresholds(nullptr, dh.p, n, width, height, variant, dr.p, mu1 ? dm.p : nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(res, dr.p, (size_t)n * 261 * sizeof(int), hipMemcpyDeviceToHost));
+    if (mu1) HIP_TRY(hipMemcpy(mu1, dm.p, (size_t)n * 256 * sizeof(double), hipMemcpyDeviceToHost));
+    if (variant == 2) {                                 // the working histograms must have been cleared: hand them back in the first words of every result block
+        std::vector<int> back((size_t)n * 257); HIP_TRY(hipMemcpy(back.data(), dh.p, back.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) for (int k = 0; k < 257; k++) res[(size_t)i * 261 + k] = back[(size_t)i * 257 + k];
+    }
+    return SIND_OK;
+}
 int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h) {
     const int nt = tile_w * tile_h / 8;
     if (mode < 0 || mode > 4 || fuse < 0 || fuse > 12 || tile_w < 16 || tile_w % 8 || tile_h < 8 || tile_h % 2 || nt % 128 || nt > 1024 || 4 * fuse >= tile_w || 4 * fuse >= tile_h ||

@@ -34,8 +34,8 @@ int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, 
 int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, int n, bool dilate, int B = 1);
 int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out, int B = 1);
 int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n, int B = 1, int dmax_stride = 1);
-int launch_dilate_planes(hipStream_t s, const unsigned long long* src, unsigned long long* dst, int nplanes, int w, int h, int n);
+int launch_dilate_planes(hipStream_t s, const unsigned long long* src, unsigned long long* dst, int nplanes, int w, int h, int n, int* zero = nullptr, int nzero = 0);
 int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int w, int h, int wpr, const uint8_t* occ2, const uint8_t* depthN,
-                     int* overlap, int* overlapPlane, int* ljOverlap, int* ljArea, int* hist);
+                     int* overlap, int* overlapPlane, int* ljOverlap, int* ljArea, int* hist, bool already_zero = false);
 
 }  // namespace sind

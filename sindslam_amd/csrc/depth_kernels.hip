@@ -670,9 +670,11 @@ __global__ void __launch_bounds__(256) k_rag_stats(const unsigned long long* __r
 // Elliptical dilation of bit planes (64 pixels per word), dst(x, y) = OR over the element of src(x + j - ax, y + i - ay) with positions
 // outside the image ignored: the 7x7 dilation of every piece of SegAndMergeV2 (DD:760-ish "imgEachClusterDilate") for the region-adjacency
 // statistics.  One thread per output word; a row of the element is a run of <= 15 shifts over a three-word window.
+// zero / nzero (optional): a block of ints cleared on the way -- the accumulators of k_rag_stats, which follows on the same stream (one fill launch less per frame).
 __global__ void k_dilate_planes(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, int nplanes, int wpr, int H, MorphElem e,
-                                unsigned long long tail_mask) {
+                                unsigned long long tail_mask, int* __restrict__ zero, int nzero) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, pw = (size_t)wpr * H;
+    for (size_t z = idx; z < (size_t)nzero; z += (size_t)gridDim.x * blockDim.x) zero[z] = 0;
     if (idx >= pw * nplanes) return;
     const int c = (int)(idx / pw), rem = (int)(idx - (size_t)c * pw), y = rem / wpr, k = rem - y * wpr;
     const unsigned long long* sp = src + (size_t)c * pw;
@@ -692,10 +694,10 @@ __global__ void k_dilate_planes(const unsigned long long* __restrict__ src, unsi
     if (k == wpr - 1) acc &= tail_mask;
     dst[idx] = acc;
 }
-int launch_dilate_planes(hipStream_t s, const unsigned long long* src, unsigned long long* dst, int nplanes, int w, int h, int n) {
+int launch_dilate_planes(hipStream_t s, const unsigned long long* src, unsigned long long* dst, int nplanes, int w, int h, int n, int* zero, int nzero) {
     const int wpr = (w + 63) / 64; const size_t total = (size_t)wpr * h * nplanes;
     const unsigned long long tm = (w & 63) ? ((1ull << (w & 63)) - 1) : ~0ull;
-    hipLaunchKernelGGL(k_dilate_planes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, nplanes, wpr, h, make_ellipse(n), tm);
+    hipLaunchKernelGGL(k_dilate_planes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, nplanes, wpr, h, make_ellipse(n), tm, zero, zero ? nzero : 0);
     return SIND_OK;
 }
 
@@ -769,9 +771,10 @@ int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, 
 int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n, int B, int dmax_stride) {
     hipLaunchKernelGGL(k_depth_norm, dim3(divup(n, 256), B), dim3(256), 0, s, depth, dmax, out, n, dmax_stride); return SIND_OK; }
 int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int w, int h, int wpr, const uint8_t* occ2, const uint8_t* depthN,
-                     int* overlap, int* overlapPlane, int* ljOverlap, int* ljArea, int* hist) {
+                     int* overlap, int* overlapPlane, int* ljOverlap, int* ljArea, int* hist, bool already_zero) {
     if (C < 1 || C > 254) { sind_set_error("rag_stats: %d pieces unsupported (1..254)", C); return SIND_E_ARG; }
-    if (overlapPlane == overlap + C * C && ljOverlap == overlapPlane + C * C && ljArea == ljOverlap + C * C && hist == ljArea + C)
+    if (already_zero) {}                                  // cleared by the dilation kernel ahead of this one on the stream
+    else if (overlapPlane == overlap + C * C && ljOverlap == overlapPlane + C * C && ljArea == ljOverlap + C * C && hist == ljArea + C)
         HIP_TRY(hipMemsetAsync(overlap, 0, ((size_t)3 * C * C + C + (size_t)C * 256) * sizeof(int), s));        // the caller's five outputs are one block: one fill
     else {
         HIP_TRY(hipMemsetAsync(overlap, 0, (size_t)C * C * sizeof(int), s)); HIP_TRY(hipMemsetAsync(overlapPlane, 0, (size_t)C * C * sizeof(int), s));

@@ -120,6 +120,7 @@ private:
     int flow_masks(const float* U, const float* V, BitImg& low, BitImg& high, const float* gridFlowPre = nullptr);
     int fuse(const BitImg& maskLow, const BitImg& maskHigh, const DepthStageOut& d, uint8_t* dyna_out, uint8_t* label_out);
     int kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]);
+    bool hist_clean = false;      // hist_d's working block is known to be zero (left so by k_flow_thresholds)
     DevBuf<KmState> kstate; DevBuf<uint16_t> depth_fix; hipGraphExec_t kmGraph[2] = {nullptr, nullptr}; bool kmGraphBroken = false;
     int kmeans_enqueue(const uint16_t* depth0, bool prevLabels);
     int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2, const OccGpuOut* pre = nullptr);

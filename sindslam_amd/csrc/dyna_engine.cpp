@@ -117,7 +117,7 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
       const size_t cap = 64, pw = (size_t)H * (W / 64), nr = 3 * cap * cap + cap + cap * 256;
       SIND_TRY(h_planes.alloc(3 * cap * pw)); SIND_TRY(planes_d.alloc(3 * cap * pw)); SIND_TRY(h_rag.alloc(nr)); SIND_TRY(rag_d.alloc(nr)); }
     SIND_TRY(kstate.alloc(4)); SIND_TRY(depth_fix.alloc(N));
-    SIND_TRY(hist_d.alloc(261));       // [256] = residual maximum (float bits), [257..260] = thresholds lo, hi, otsu, triangle (floats)
+    SIND_TRY(hist_d.alloc(264 + 261));       // working block [0..256] = residual histogram + maximum (float bits); result block at 264: the same + thresholds lo, hi, otsu, triangle (floats)
     SIND_TRY(grid_d.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(blocks_d.alloc((size_t)(W / 16) * (H / 16)));
     // every kernel operand of the tail must exist before the first launch (a missing workspace would be a wild device write)
     const void* ws[] = {dpyr[1].p, dpyr[2].p, dpyr[3].p, lab[0].p, lab[1].p, lab[2].p, lab[3].p, filt.p, px.p, py.p, pz.p, lab8.p, labPrev8.p, edge.p, edgeTmp.p, total.p,
@@ -183,12 +183,17 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     tq = tick_ms();
     find_homography_rho(in, inLast, Hm);
     QLAP(22)
-    SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, (unsigned*)(hist_d.p + 256), hist_d.p, magu8.p, W, H));
+    // working histogram hist_d[0..256] (+ maximum): zero whenever the previous frame's threshold kernel completed (it clears what it read); a frame that
+    // failed in between leaves it unknown, hence the flag
+    SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, (unsigned*)(hist_d.p + 256), hist_d.p, magu8.p, W, H, hist_clean));
+    hist_clean = false;
     // thresholds (Otsu / triangle + the clamping of DD:1309-1367) and the two masks on the device: one host round trip for the stage
-    SIND_TRY(launch_flow_thresholds_and_masks(stream, hist_d.p, W, H, reinterpret_cast<float*>(hist_d.p + 257), magu8.p, low_d.p, (low_d.p + N)));
-    HIP_TRY(hipMemcpyAsync(h_hist.p, hist_d.p, 261 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    int* res = hist_d.p + 264;                              // result block: histogram, maximum, four thresholds
+    SIND_TRY(launch_flow_thresholds_and_masks(stream, hist_d.p, W, H, res, magu8.p, low_d.p, (low_d.p + N)));
+    HIP_TRY(hipMemcpyAsync(h_hist.p, res, 261 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(h_ab.p, low_d.p, (size_t)2 * N, hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
+    hist_clean = true;
     {
         float f[5]; std::memcpy(&f[0], h_hist.p + 256, 4); std::memcpy(&f[1], h_hist.p + 257, 16);
         dbg.maxError = f[0]; dbg.thr_low = f[1]; dbg.thr_high = f[2]; dbg.otsu = f[3]; dbg.triangle = f[4];
@@ -435,7 +440,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     FLAP(11)
     HIP_TRY(hipMemcpyAsync(planes_d.p, planes, (size_t)C * pw * 8, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(planes_d.p + (size_t)2 * C * pw, planes + (size_t)2 * C * pw, (size_t)C * pw * 8, hipMemcpyHostToDevice, stream));
-    SIND_TRY(launch_dilate_planes(stream, planes_d.p, planes_d.p + (size_t)C * pw, C, W, H, 7));
+    SIND_TRY(launch_dilate_planes(stream, planes_d.p, planes_d.p + (size_t)C * pw, C, W, H, 7, rag_d.p, (int)((size_t)3 * C * C + C + (size_t)C * 256)));      // also clears the RAG accumulators
     const uint8_t* occ2_use = pre && pre->occ2_dev ? pre->occ2_dev : occ2_d.p;
     if (pre && pre->occ2_dev && pre->occ2_event) HIP_TRY(hipStreamWaitEvent(stream, pre->occ2_event, 0));       // uploaded on the CalOccluded runner's stream without a host wait
     if (!(pre && pre->occ2_dev)) { occ2.to_u8((h_ab.p + N), W, 255); HIP_TRY(hipMemcpyAsync(occ2_d.p, (h_ab.p + N), N, hipMemcpyHostToDevice, stream)); }
@@ -443,7 +448,7 @@ int DynaTail::seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& 
     const uint8_t* depthN_use = pre && pre->depthN_dev ? pre->depthN_dev : depthN.p;
     if (!(pre && pre->depthN_dev)) { SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1)); SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, depthN.p, N)); }
     int* ov_d = rag_d.p; int* ovp_d = ov_d + C * C; int* lj_d = ovp_d + C * C; int* la_d = lj_d + C * C; int* hist_dd = la_d + C;
-    SIND_TRY(launch_rag_stats(stream, planes_d.p, C, W, H, wpr, occ2_use, depthN_use, ov_d, ovp_d, lj_d, la_d, hist_dd));
+    SIND_TRY(launch_rag_stats(stream, planes_d.p, C, W, H, wpr, occ2_use, depthN_use, ov_d, ovp_d, lj_d, la_d, hist_dd, true));
     PinnedBuf<int>& rag = h_rag;
     HIP_TRY(hipMemcpyAsync(rag.data(), rag_d.p, ((size_t)3 * C * C + C + (size_t)C * 256) * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));

@@ -39,14 +39,17 @@ int launch_resize_f32_pair(hipStream_t s, const float* srcA, float* dstA, const 
 int launch_pyramid_tail(hipStream_t s, float* pyrA, float* pyrB, const std::vector<std::pair<int, int>>& levels, const std::vector<size_t>& level_off, int first, int last, int B);
 int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int sh, int dw, int dh, int B, float post, bool has_post);
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img, int d_group = 0, int d_skip = 0);       // d_group > 0: d_skip destination slots stay free after every d_group images
+int launch_roll_history(hipStream_t s, uint8_t* pool, int S, int T, size_t frame_bytes);      // history slots 0, 1 <- slots T, T + 1 of every stream's T + 2 pool slots
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb);
 extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd, g_sor_tile_h; extern double g_sor_plan_cost;
 int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev);
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch);
 int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr);
 int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, unsigned* maxbits, int* hist, uint8_t* out_u8, int n, int B);
-int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h);
-int launch_flow_thresholds_and_masks(hipStream_t s, const int* hist, int W, int H, float* thr, const uint8_t* magu8, uint8_t* low, uint8_t* high);
+int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h, bool already_zero = false);
+// hist: 257 working words (zeroed again by the kernel), res: 261 words = histogram, maximum, lo / hi / otsu / triangle
+int launch_flow_thresholds_and_masks(hipStream_t s, int* hist, int W, int H, int* res, const uint8_t* magu8, uint8_t* low, uint8_t* high);
+int debug_flow_thresholds(hipStream_t s, int* hist, int n, int W, int H, int variant, int* res, double* mu1);
 int launch_threshold_masks(hipStream_t s, const uint8_t* magu8, float lo, float hi, uint8_t* low, uint8_t* high, int n);
 int launch_gather_grid(hipStream_t s, const float* u, const float* v, float* out, int w, int h, int step, int B = 1);
 int launch_scale2(hipStream_t s, float* a, float* b, float sc, size_t n);

@@ -692,10 +692,21 @@ __global__ void k_threshold_masks(const uint8_t* __restrict__ magu8, float thr_l
 }
 // The two thresholds of stImgMasks from the residual's 256-bin histogram, on the device so that the flow-mask stage needs ONE host round trip (masks,
 // histogram and thresholds come back together): cv::threshold's THRESH_OTSU / THRESH_TRIANGLE return values (imgproc/thresh.cpp) and the clamping of
-// DD:1309-1367, one thread, the host code's FP64 / FP32 operations in the same order (no contraction: the library is built with -ffp-contract=off).
-// hist[256] = bit pattern of the maximal residual.  out: lo, hi, otsu, triangle.
-__global__ void k_flow_thresholds(const int* __restrict__ hist, int W, int H, float* __restrict__ out) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// DD:1309-1367, with the host code's FP64 / FP32 operations in the same order (no contraction: the library is built with -ffp-contract=off).
+// k_flow_thresholds_serial is the one-thread statement of it (83 us per frame: every iteration of Otsu's loop carries an FP64 division) and stays as the
+// in-library reference; k_flow_thresholds gives the same bits from ONE WAVE:
+//   * sums of integers below 2^53 (the mean, Triangle's distances, the pixel counts) are exact in FP64 in any order -> lane-parallel + wave reduction;
+//   * q1 += p_i is a rounding chain -> walked in order, but it does not depend on mu1, so it runs first (one dependent add per bin);
+//   * mu1 = (mu1 * q1_old + i * p_i) / q1 is the only chain with a division: the divisor q1_i is known beforehand, so every lane prepares the refined
+//     reciprocal y_i of its four bins with the compiler's own FP64 division sequence (v_rcp_f64 + two Newton steps), and the chain keeps only that
+//     sequence's last three operations (q0 = n y, r = fma(-q1, q0, n), q = fma(r, y, q0)); operands are far from the exponent range where
+//     v_div_scale / v_div_fixup would act (q1 in [1.2e-7, 1], n in [0, 255]);
+//   * sigma, its arg max (first maximum wins, like the sequential `>` test) and Triangle's arg max are lane-parallel again.
+// hist: [256] counts + [256] = bit pattern of the maximal residual; res: [261] = the same 257 words + lo, hi, otsu, triangle; the kernel leaves hist
+// ZEROED for the next frame (the residual kernels accumulate into it).  dbg_mu1 (optional): the 256 values of the mu1 chain.  One block = one histogram.
+__global__ void k_flow_thresholds_serial(const int* __restrict__ hist, int W, int H, float* __restrict__ out) {
+    hist += (size_t)blockIdx.x * 257; out += (size_t)blockIdx.x * 4;
+    if (threadIdx.x != 0) return;
     const int N = W * H;
     const float maxErrorf = __int_as_float(hist[256]);
     double otsu_v;
@@ -746,6 +757,152 @@ __global__ void k_flow_thresholds(const int* __restrict__ hist, int W, int H, fl
         lo = thred2; hi = thred1;
     }
     out[0] = lo; out[1] = hi;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }      // exact when every partial sum is an integer below 2^53
+__device__ __forceinline__ int wave_sum_i32(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ int wave_min_i32(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_max_i32(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+// arg max with "first maximum wins": larger value, on equal values the smaller index
+__device__ __forceinline__ void wave_argmax_f64(double& v, int& idx) {
+    for (int o = 32; o > 0; o >>= 1) { const double ov = __shfl_xor(v, o); const int oi = __shfl_xor(idx, o); if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; } }
+}
+__global__ void __launch_bounds__(64) k_flow_thresholds(int* __restrict__ hist, int W, int H, int* __restrict__ res, double* __restrict__ dbg_mu1, int keep_hist) {
+    hist += (size_t)blockIdx.x * 257; res += (size_t)blockIdx.x * 261; if (dbg_mu1) dbg_mu1 += (size_t)blockIdx.x * 256;
+    __shared__ double s_p[256];
+    __shared__ double4 s_c[256];                        // per bin: q1_i, i * p_i, y_i, skip flag
+    const int lane = threadIdx.x, N = W * H;
+    const int4 h4 = *reinterpret_cast<const int4*>(hist + 4 * lane);
+    const int hmax_bits = hist[256];
+    const int h[4] = {h4.x, h4.y, h4.z, h4.w};
+    // result block (the working histogram is zeroed at the very end, when every lane's loads have long been consumed)
+    *reinterpret_cast<int4*>(res + 4 * lane) = h4; if (lane == 0) res[256] = hmax_bits;
+    const float maxErrorf = __int_as_float(hmax_bits);
+    // ---- Otsu
+    const double scale = 1. / N;
+    double mu = 0, pv[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) { mu += (4 * lane + k) * (double)h[k]; pv[k] = h[k] * scale; s_p[4 * lane + k] = pv[k]; }
+    mu = wave_sum_f64(mu) * scale;
+    __syncthreads();
+    // The chains below are walked by every lane (wave-uniform values); a lane keeps the four values of its own bins.  No LDS store inside the loops: the
+    // loads of the coming bins do not depend on the chain and must be free to move ahead of it (an LDS store in between pins them behind it: measured
+    // 37 us for the kernel with the stores, the LDS latency then sits on the chain 512 times).
+    double q1v[4] = {0, 0, 0, 0};
+    {   // q1 chain (same hand pipelining as the mu1 chain below)
+        double q1 = 0;
+        double4 cur = *reinterpret_cast<const double4*>(&s_p[0]), nxt;
+        for (int L = 0; L < 64; L++) {
+            nxt = *reinterpret_cast<const double4*>(&s_p[4 * min(L + 1, 63)]);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool mine = L == lane;
+            q1 += cur.x; if (mine) q1v[0] = q1;
+            q1 += cur.y; if (mine) q1v[1] = q1;
+            q1 += cur.z; if (mine) q1v[2] = q1;
+            q1 += cur.w; if (mine) q1v[3] = q1;
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    }
+    double q2v[4]; bool skip[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = 4 * lane + k; const double q1 = q1v[k], q2 = 1. - q1; q2v[k] = q2;
+        skip[k] = fmin(q1, q2) < (double)1.1920928955078125e-7f || fmax(q1, q2) > 1. - (double)1.1920928955078125e-7f;
+        // the compiler's FP64 division up to the refined reciprocal (AMDGPU legalizeFDIV64: rcp, two Newton steps in FMA arithmetic)
+        const double b = skip[k] ? 1.0 : q1, r0 = __builtin_amdgcn_rcp(b), e0 = fma(-b, r0, 1.0), r1 = fma(r0, e0, r0), e1 = fma(-b, r1, 1.0), y = fma(r1, e1, r1);
+        s_c[i] = make_double4(q1, i * pv[k], y, skip[k] ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    double mu1v[4] = {0, 0, 0, 0};
+    {   // mu1 chain: mu1 *= q1_old; then either stays (skipped bin) or becomes (mu1 + i p_i) / q1_i.  Software-pipelined by hand: the four bins of lane
+        // L + 1 are fetched before the chain walks the bins of lane L (the scheduler otherwise issues each read right before its use)
+        double mu1 = 0, q1_old = 0;
+        double4 cur[4], nxt[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = s_c[k];
+        for (int L = 0; L < 64; L++) {
+            const int Ln = min(L + 1, 63);
+            #pragma unroll
+            for (int k = 0; k < 4; k++) nxt[k] = s_c[4 * Ln + k];
+            __builtin_amdgcn_sched_barrier(0);
+            const bool mine = L == lane;
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double4 c = cur[k];
+                const double m = mu1 * q1_old, n = m + c.y, q0 = n * c.z, r = fma(-c.x, q0, n), q = fma(r, c.z, q0);
+                mu1 = c.w != 0.0 ? m : q; q1_old = c.x;
+                if (mine) mu1v[k] = mu1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            #pragma unroll
+            for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+        }
+    }
+    double best = 0; int best_i = 0x7fffffff;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = 4 * lane + k; const double mu1 = mu1v[k];
+        if (dbg_mu1) dbg_mu1[i] = mu1;
+        if (skip[k]) continue;
+        const double q1 = q1v[k], q2 = q2v[k], mu2 = (mu - q1 * mu1) / q2, sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > best) { best = sigma; best_i = i; }
+    }
+    wave_argmax_f64(best, best_i);
+    const double otsu_v = best > 0 ? (double)best_i : 0.0;
+    // ---- Triangle
+    double tri_v;
+    {
+        int lf = 256, rt = 0, mx = 0, mi = 0;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = 4 * lane + k; if (h[k] > 0) { lf = min(lf, i); if (i > 0) rt = max(rt, i); } if (h[k] > mx) { mx = h[k]; mi = i; } }
+        int left = wave_min_i32(lf); if (left == 256) left = 0;
+        int right = wave_max_i32(rt);
+        { double mxd = mx; int mid = mx > 0 ? mi : 0x7fffffff; wave_argmax_f64(mxd, mid); mx = (int)mxd; mi = mx > 0 ? mid : 0; }
+        int max_ind = mi;
+        if (left > 0) left--;
+        if (right < 255) right++;
+        bool flipped = false;
+        if (max_ind - left < right - max_ind) { flipped = true; left = 255 - right; max_ind = 255 - max_ind; }
+        const double a = mx, b = left - max_ind;
+        double dist = 0; int thr_i = 0x7fffffff;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = 4 * lane + k, i = flipped ? 255 - j : j;          // position i of the (possibly mirrored) histogram holds bin j
+            if (i < left + 1 || i > max_ind) continue;
+            const double t = a * i + b * h[k];
+            if (t > dist || (t == dist && t > 0 && i < thr_i)) { dist = t; thr_i = i; }
+        }
+        wave_argmax_f64(dist, thr_i);
+        double thresh = dist > 0 ? (double)thr_i : (double)left;
+        thresh--;
+        if (flipped) thresh = 255 - thresh;
+        tri_v = thresh;
+    }
+    // ---- clamping (wave-uniform scalars)
+    float thred1 = (float)otsu_v, thred2 = (float)tri_v;
+    const float otsu_f = thred1, tri_f = thred2;
+    float lo, hi;
+    if (thred1 < thred2) {                                    // DD:1309-1336
+        if (thred1 < 1.7f * 255.0f / maxErrorf) thred1 = 1.7f * 255.0f / maxErrorf;
+        else if (thred1 > 3.0f * 255.0f / maxErrorf) thred1 = 3.0f * 255.0f / maxErrorf;
+        int cnt = 0;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) if ((double)(4 * lane + k) > (double)thred1) cnt += h[k];
+        cnt = wave_sum_i32(cnt);
+        if (cnt > 0.5 * W * H) thred1 = thred1 + 0.2f * 255.0f / maxErrorf;
+        if (thred2 < fmaxf(3.0f * 255.0f / maxErrorf, thred1 * 1.2f)) thred2 = fmaxf(3.0f * 255.0f / maxErrorf, thred1 * 1.2f);
+        else if (thred2 > 10.0f * 255.0f / maxErrorf) thred2 = 10.0f * 255.0f / maxErrorf;
+        lo = thred1; hi = thred2;
+    } else {                                                  // DD:1337-1367 (the relaxation test there is dead code)
+        if (thred2 < 1.7f * 255.0f / maxErrorf) thred2 = 1.7f * 255.0f / maxErrorf;
+        else if (thred2 > 3.0f * 255.0f / maxErrorf) thred2 = 3.0f * 255.0f / maxErrorf;
+        if (thred1 < fmaxf(3.0f * 255.0f / maxErrorf, thred2 * 1.2f)) thred1 = fmaxf(3.0f * 255.0f / maxErrorf, thred2 * 1.2f);
+        else if (thred1 > 10.0f * 255.0f / maxErrorf) thred1 = 10.0f * 255.0f / maxErrorf;
+        lo = thred2; hi = thred1;
+    }
+    if (lane == 0) { float* out = reinterpret_cast<float*>(res + 257); out[0] = lo; out[1] = hi; out[2] = otsu_f; out[3] = tri_f; }
+    if (!keep_hist) { *reinterpret_cast<int4*>(hist + 4 * lane) = make_int4(0, 0, 0, 0); if (lane == 0) hist[256] = 0; }
 }
 __global__ void k_threshold_masks_dev(const uint8_t* __restrict__ magu8, const float* __restrict__ thr, uint8_t* __restrict__ low, uint8_t* __restrict__ high, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -798,6 +955,15 @@ __global__ void k_resize_u8(const uint8_t* __restrict__ src, uint8_t* __restrict
 // frames of the gray history pool picked by index into a dense batch: out[b] = pool[idx[b]] (16 bytes per thread; the indices travel as
 // kernel arguments, up to 256 per launch) -- one launch instead of one device-to-device copy per frame (3 000 copies per 512-pair step)
 struct GatherIdx { int v[256]; };
+// End of a step: the last two flow-grid frames of every stream become its history slots 0, 1 (the pool holds T + 2 slots per stream).  One thread moves the
+// same 16 bytes of both frames and reads before it writes, so T = 1 (slot 1 is source and destination) needs no second buffer.
+__global__ void k_roll_history(uint8_t* __restrict__ pool, int T, size_t fb16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fb16) return;
+    uint4* base = reinterpret_cast<uint4*>(pool) + (size_t)blockIdx.y * (T + 2) * fb16;
+    const uint4 a = base[(size_t)T * fb16 + i], b = base[(size_t)(T + 1) * fb16 + i];
+    base[i] = a; base[fb16 + i] = b;
+}
 __global__ void k_gather_frames(const uint8_t* __restrict__ pool, GatherIdx idx, uint8_t* __restrict__ out, size_t fb) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (i >= fb) return;
@@ -843,6 +1009,12 @@ int launch_pyramid_tail(hipStream_t s, float* pyrA, float* pyrB, const std::vect
         if (k > 0) { T.sx[k] = 1. / ((double)T.w[k] / T.w[k - 1]); T.sy[k] = 1. / ((double)T.h[k] / T.h[k - 1]); } else { T.sx[k] = T.sy[k] = 1; }
     }
     hipLaunchKernelGGL(k_pyramid_tail, dim3(2 * B), dim3(256), 0, s, pyrA, pyrB, T);
+    return SIND_OK;
+}
+int launch_roll_history(hipStream_t s, uint8_t* pool, int S, int T, size_t frame_bytes) {
+    if (frame_bytes % 16) { sind_set_error("roll_history: frame size %zu is not a multiple of 16", frame_bytes); return SIND_E_ARG; }
+    const size_t fb16 = frame_bytes / 16;
+    hipLaunchKernelGGL(k_roll_history, dim3((unsigned)((fb16 + 255) / 256), S), dim3(256), 0, s, pool, T, fb16);
     return SIND_OK;
 }
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img, int d_group, int d_skip) {
@@ -996,9 +1168,10 @@ int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, 
     hipLaunchKernelGGL(k_mag_hist, dim3(gx, B), dim3(256), 0, s, mag, maxbits, hist, out_u8, n);
     return SIND_OK;
 }
-int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h) {
+int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h, bool already_zero) {
     HMat Hm; for (int i = 0; i < 9; i++) Hm.h[i] = H[i];
-    if ((const void*)maxbits == (const void*)(hist + 256)) HIP_TRY(hipMemsetAsync(hist, 0, 257 * sizeof(int), s));       // histogram and maximum in one block: one fill
+    if (already_zero) {}                                  // the consumer of the previous frame (k_flow_thresholds) left the block zeroed
+    else if ((const void*)maxbits == (const void*)(hist + 256)) HIP_TRY(hipMemsetAsync(hist, 0, 257 * sizeof(int), s));       // histogram and maximum in one block: one fill
     else { HIP_TRY(hipMemsetAsync(maxbits, 0, sizeof(unsigned), s)); HIP_TRY(hipMemsetAsync(hist, 0, 256 * sizeof(int), s)); }
     hipLaunchKernelGGL(k_residual_mag, dim3(divup(w, 128), h), dim3(128), 0, s, u, v, Hm, mag, maxbits, w, h);
     const int n = w * h, gx = std::min(divup(n, 256), 64);
@@ -1009,9 +1182,16 @@ int launch_threshold_masks(hipStream_t s, const uint8_t* magu8, float lo, float 
     hipLaunchKernelGGL(k_threshold_masks, dim3(divup(n, 256)), dim3(256), 0, s, magu8, lo, hi, low, high, n);
     return SIND_OK;
 }
-int launch_flow_thresholds_and_masks(hipStream_t s, const int* hist, int W, int H, float* thr, const uint8_t* magu8, uint8_t* low, uint8_t* high) {
-    hipLaunchKernelGGL(k_flow_thresholds, dim3(1), dim3(64), 0, s, hist, W, H, thr);
-    hipLaunchKernelGGL(k_threshold_masks_dev, dim3(divup(W * H, 256)), dim3(256), 0, s, magu8, thr, low, high, W * H);
+int launch_flow_thresholds_and_masks(hipStream_t s, int* hist, int W, int H, int* res, const uint8_t* magu8, uint8_t* low, uint8_t* high) {
+    hipLaunchKernelGGL(k_flow_thresholds, dim3(1), dim3(64), 0, s, hist, W, H, res, (double*)nullptr, 0);
+    hipLaunchKernelGGL(k_threshold_masks_dev, dim3(divup(W * H, 256)), dim3(256), 0, s, magu8, reinterpret_cast<const float*>(res + 257), low, high, W * H);
+    return SIND_OK;
+}
+// test entry: n histograms (257 words each, device) through the one-wave kernel (variant 1; mu1 chain optionally dumped) or the serial reference (variant 0)
+int debug_flow_thresholds(hipStream_t s, int* hist, int n, int W, int H, int variant, int* res, double* mu1) {
+    if (variant == 0) hipLaunchKernelGGL(k_flow_thresholds_serial, dim3(n), dim3(64), 0, s, hist, W, H, reinterpret_cast<float*>(res));
+    else hipLaunchKernelGGL(k_flow_thresholds, dim3(n), dim3(64), 0, s, hist, W, H, res, mu1, variant == 2 ? 0 : 1);
+    HIP_TRY(hipGetLastError());
     return SIND_OK;
 }
 int launch_gather_grid(hipStream_t s, const float* u, const float* v, float* out, int w, int h, int step, int B) {

@@ -375,8 +375,10 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     t[2] = now_ms();
     orb_thread.join();
     if (orb_rc != SIND_OK) { sind_set_error("ORB front: %s", orb_err.c_str()); return orb_rc; }
-    // roll the gray history: the last two frames of every stream become slots 0, 1
-    for (int s = 0; s < S; s++) {
+    // roll the gray history: the last two frames of every stream become slots 0, 1 (one launch; the flow grid is a multiple of 16 bytes for every
+    // supported size -- width % 64 == 0 -- and the copy-per-stream path stays for anything else)
+    if (fb % 16 == 0) SIND_TRY(launch_roll_history(p->stream, p->pool.p, S, T, fb));
+    else for (int s = 0; s < S; s++) {
         uint8_t* base = p->pool.p + fb * (size_t)s * (T + 2);
         if (T >= 2) { HIP_TRY(hipMemcpyAsync(base, base + fb * T, fb * 2, hipMemcpyDeviceToDevice, p->stream)); }
         else { HIP_TRY(hipMemcpyAsync(base, base + fb, fb, hipMemcpyDeviceToDevice, p->stream)); HIP_TRY(hipMemcpyAsync(base + fb, base + fb * 2, fb, hipMemcpyDeviceToDevice, p->stream)); }

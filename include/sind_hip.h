@@ -129,6 +129,13 @@ int sind_debug_rcp_scan(int device, int exp_lo, int exp_hi, unsigned long long o
  * block then hold the cleared words.  mu1 (optional, variants 1 / 2): n x 256 values of Otsu's running class mean, the one rounding chain with a division. */
 int sind_debug_flow_thresholds(const int* hist, int n, int width, int height, int variant, int device, int* res, double* mu1);
 
+/* parity-test access to the GPU region grow of the PEAC plane refinement (AHCPlaneFitter.hpp:546-601 floodFill; csrc/peac_kernels.hip): n depth frames
+ * (host u16 [n][height][width]) -> membership map per pixel (plane index or -1) from ONE kernel launch over all frames (member_gpu) and from the host
+ * statement of the same FIFO (member_host), both int8 [n][height * width]; pair_* [n][127 * 127]: which planes met (row stride = the frame's plane count);
+ * status [n][4] = kernel status (0 ok, 1..3 capacity errors, 4 skipped), BFS levels, seeds processed, planes. */
+int sind_debug_peac_grow(const uint16_t* depth, int n, int width, int height, float fx, float fy, float cx, float cy, float depth_scale, int device,
+                         int8_t* member_gpu, int8_t* member_host, uint8_t* pair_gpu, uint8_t* pair_host, int* status);
+
 /* parity-test access to the bit-plane dilation used by the region-adjacency stage (7x7 ellipse on 64-pixel words, cv::dilate semantics):
  * planes / out are host arrays [nplanes][height][ceil(width / 64)] of 64-bit words, bit i of word k = pixel 64 k + i. */
 int sind_debug_dilate_planes(const unsigned long long* planes, int nplanes, int width, int height, int n, int device, unsigned long long* out);

@@ -2,6 +2,7 @@
 #include <cstring>
 #include "../../include/sind_hip.h"
 #include "dyna.hpp"
+#include "peac_grow.hpp"
 
 struct sind_dyna {
     sind::DynaConfig cfg; hipStream_t stream = nullptr; sind::DynaFront front; sind::DynaTail tail;
@@ -123,6 +124,46 @@ int sind_debug_dilate_planes(const unsigned long long* planes, int nplanes, int 
     SIND_TRY(sind::launch_dilate_planes(nullptr, a.p, b.p, nplanes, width, height, n));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, b.p, words * 8, hipMemcpyDeviceToHost));
+    return SIND_OK;
+}
+
+// parity-test access to the GPU region grow of the PEAC refinement (k_peac_grow): n depth frames (host, [n][height][width] u16) go through the block
+// statistics kernel and the host graph clustering (PeacFitter::part1); then ONE launch grows all frames on the GPU and the host statement of the same
+// FIFO grows them one by one.  member_* [n][height*width] int8 (plane or -1), pair_* [n][127*127] (row stride = the frame's plane count), status [n][4] =
+// kernel status, BFS levels, seeds processed, plane count.  A frame the kernel skips (capacities) reports status 4 and undefined GPU outputs.
+int sind_debug_peac_grow(const uint16_t* depth, int n, int width, int height, float fx, float fy, float cx, float cy, float depth_scale, int device,
+                         int8_t* member_gpu, int8_t* member_host, uint8_t* pair_gpu, uint8_t* pair_host, int* status) {
+    if (!depth || n < 1 || !member_gpu || !member_host || !pair_gpu || !pair_host || !status) { sind_set_error("sind_debug_peac_grow: bad arguments"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    const size_t N = (size_t)width * height, nblk = (size_t)(width / 16) * (height / 16), PP = (size_t)PEAC_GROW_MAX_PLANES * PEAC_GROW_MAX_PLANES;
+    DevBuf<uint16_t> dd; DevBuf<sind::PeacBlockStats> bd; SIND_TRY(dd.alloc(N * n)); SIND_TRY(bd.alloc(nblk * n));
+    HIP_TRY(hipMemcpy(dd.p, depth, N * n * 2, hipMemcpyHostToDevice));
+    SIND_TRY(sind::launch_peac_block_stats(nullptr, dd.p, width, height, 16, 16, fx, fy, cx, cy, depth_scale, bd.p, n));
+    std::vector<sind::PeacBlockStats> bh(nblk * n);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(bh.data(), bd.p, bh.size() * sizeof(sind::PeacBlockStats), hipMemcpyDeviceToHost));
+    sind::PeacGrowBatch batch; SIND_TRY(batch.init(width, height, fx, fy, cx, cy, depth_scale, n));
+    PinnedBuf<uint8_t> in_h, pair_h; PinnedBuf<int8_t> mem_h; PinnedBuf<int> st_h;
+    SIND_TRY(in_h.alloc((size_t)n * PG_IN_STRIDE)); SIND_TRY(pair_h.alloc(PP * n)); SIND_TRY(mem_h.alloc(N * n)); SIND_TRY(st_h.alloc((size_t)4 * n));
+    std::vector<std::unique_ptr<sind::PeacFitter>> fit(n);
+    for (int k = 0; k < n; k++) {
+        sind::PeacInput pin{bh.data() + nblk * k, depth + N * k, width, height, fx, fy, cx, cy, depth_scale};
+        fit[k].reset(new sind::PeacFitter(pin)); fit[k]->part1();
+        sind::peac_grow_pack(*fit[k], k, in_h.p + (size_t)k * PG_IN_STRIDE);
+    }
+    SIND_TRY(batch.run(nullptr, in_h.p, dd.p, n, mem_h.p, pair_h.p, st_h.p));
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t i = 0; i < N * n; i++) member_gpu[i] = mem_h.p[i] < 0 ? (int8_t)-1 : mem_h.p[i];       // the kernel keeps the number of failed tries in the negative values (-2 .. -6)
+    std::memcpy(pair_gpu, pair_h.p, PP * n);
+    for (int k = 0; k < n; k++) {
+        for (int q = 0; q < 3; q++) status[4 * k + q] = st_h.p[4 * k + q];
+        status[4 * k + 3] = fit[k]->n_planes();
+        std::vector<int8_t> m8; std::vector<int16_t> m16; std::vector<uint8_t> seen;
+        fit[k]->grow_host(m8, m16, seen);
+        std::memset(pair_host + PP * k, 0, PP);
+        if (!m8.empty()) { std::memcpy(member_host + N * k, m8.data(), N); std::memcpy(pair_host + PP * k, seen.data(), seen.size()); }
+        else std::memset(member_host + N * k, 0x80, N);       // more than 127 planes: no int8 map (and the kernel skipped the frame)
+    }
     return SIND_OK;
 }
 

@@ -2,10 +2,11 @@
 // (reference include/PEAC/AHCPlaneFitter.hpp:186-236 run, :881-1039 initGraph, :1050-1256 ahCluster,
 //  :274-400 refineDetails, :603-705 findBlockMembership, :546-594 floodFill; AHCPlaneSeg.hpp:103-134 PCA;
 //  AHCParamSet.hpp:48-148 thresholds; DisjointSet.hpp).
-// Split of work: the 1200 per-window second-order statistics come from the GPU (depth_kernels.hip
-// k_peac_block_stats); the graph (<= 1200 nodes, priority queue, disjoint sets) and the pixel-level region grow along
-// plane borders are serial and stay here.  Nodes live in an index pool; neighbour sets are ordered by node index
-// (= creation order; the reference orders by heap address, which only matters for exactly tied MSEs).
+// Split of work: the 1200 per-window second-order statistics come from the GPU (depth_kernels.hip k_peac_block_stats); the graph
+// (<= 1200 nodes, priority queue, disjoint sets) is serial and stays here (part1 / part2); the pixel-level region grow along the plane
+// borders (floodFill, :546-601) runs on the GPU as a level-synchronous ordered BFS (peac_kernels.hip k_peac_grow, same visiting order as
+// the FIFO), with grow_host as the statement of that FIFO for inputs beyond the kernel's fixed capacities and for the CPU tests.
+// Nodes live in an index pool; neighbour sets are ordered by node index (= creation order; the reference orders by heap address, which only matters for exactly tied MSEs).
 // Eigen's 3x3 self-adjoint solver is replaced by a cyclic Jacobi iteration (Eigen is not available).
 #include <cmath>
 #include <limits>
@@ -68,10 +69,13 @@ struct Seg {
 };
 
 struct Fitter {
-    const PeacInput& in; Params P; const int W, H; static constexpr int bw = 16, bh = 16, minSupport = 2000, maxStep = 100000;
+    const PeacInput in; Params P; const int W, H; static constexpr int bw = 16, bh = 16, minSupport = 2000, maxStep = 100000;
     std::vector<Seg> pool; std::vector<int> dsParent, dsSize; std::vector<int> extracted;
     const float invScale;
     explicit Fitter(const PeacInput& i) : in(i), W(i.w), H(i.h), invScale(1.0f / i.depthScale) {}
+    // state handed from part1 to the grow and to part2
+    int Nh = 0, Nw = 0, NB = 0; std::vector<int> planes; std::map<int, int> rid2pl; std::vector<int8_t> blk8; std::vector<int> blkMap; std::vector<char> valid;
+    struct Seed { uint16_t x, y; int pl; }; std::vector<Seed> seeds; std::vector<PeacGrowPlane> pc; std::vector<uint32_t> seedWords;
     struct QCmp { const std::vector<Seg>* pool; bool operator()(int a, int b) const { return (*pool)[b].mse < (*pool)[a].mse; } };
     typedef std::priority_queue<int, std::vector<int>, QCmp> Queue;
 
@@ -127,8 +131,9 @@ struct Fitter {
         return step;
     }
 
-    void run(BitImg& planeContours) {
-        const int Nh = H / bh, Nw = W / bw, NB = Nh * Nw;
+    // ---- part 1: initial graph, agglomerative clustering, plane list, block erosion, the region grow's seeds and per-plane constants
+    void part1() {
+        Nh = H / bh; Nw = W / bw; NB = Nh * Nw;
         dsParent.resize(NB); dsSize.assign(NB, 1); for (int i = 0; i < NB; i++) dsParent[i] = i;
         pool.reserve(NB * 16);
         std::vector<int> G(NB, -1);
@@ -160,13 +165,11 @@ struct Fitter {
             else --i;
         }
         cluster(q);
-        // ---- refineDetails: block erosion, seeds, region grow, last merge
-        std::vector<int> planes = extracted; extracted.clear();
-        std::map<int, int> rid2pl; for (int k = 0; k < (int)planes.size(); k++) rid2pl.insert({pool[planes[k]].rid, k});
-        // per-pixel plane index, or -1 - (number of failed tries), stops at -6; 16 bits keep the grow's working set small (at most W*H/minSupport planes)
-        std::vector<int16_t> member((size_t)W * H, -1); std::vector<int> blkMap(NB, -1); std::vector<char> valid(planes.size(), 0);
-        struct Seed { uint16_t x, y; int pl; };
-        std::vector<Seed> seeds; seeds.reserve((size_t)W * H);
+        // ---- refineDetails: block erosion, seeds
+        planes = extracted; extracted.clear();
+        for (int k = 0; k < (int)planes.size(); k++) rid2pl.insert({pool[planes[k]].rid, k});
+        blkMap.assign(NB, -1); valid.assign(planes.size(), 0);
+        seeds.reserve((size_t)W * H);
         auto seed_at = [&](int idx, int pl) { const int y = idx / W; seeds.push_back({(uint16_t)(idx - y * W), (uint16_t)y, pl}); };
         auto nb4 = [](int i, int j, int Hh, int Ww, int out[4]) { const int id = i * Ww + j; int c = 0; if (j > 0) out[c++] = id - 1; if (j < Ww - 1) out[c++] = id + 1; if (i > 0) out[c++] = id - Ww; if (i < Hh - 1) out[c++] = id + Ww; return c; };
         for (int i = 0, b = 0; i < Nh; ++i) for (int j = 0; j < Nw; ++j, ++b) {
@@ -175,7 +178,7 @@ struct Fitter {
                 int nb[4]; const int nn = nb4(i, j, Nh, Nw, nb); bool same = true;
                 for (int k = 0; k < nn; k++) if (find(nb[k]) != set) { same = false; break; }
                 const int pl = rid2pl[set];
-                if (same) { blkMap[b] = pl; valid[pl] = 1; for (int y = i * bh; y < (i + 1) * bh; y++) std::fill_n(&member[(size_t)y * W + j * bw], bw, (int16_t)pl); }
+                if (same) { blkMap[b] = pl; valid[pl] = 1; }
             }
             if (blkMap[b] < 0) {
                 if (i > 0 && blkMap[b - Nw] >= 0) { const int s = (i * bh - 1) * W + j * bw; for (int k = 1; k < bw; ++k) seed_at(s + k, blkMap[b - Nw]); }
@@ -186,15 +189,37 @@ struct Fitter {
                 if (j > 0 && blkMap[b - 1] != pl) { const int s = (i * bh) * W + j * bw; for (int k = 1; k < bh; ++k) seed_at(s + k * W, pl); }
             }
         }
-        // region grow along the plane borders (FIFO, order-defined).  Per plane: the distance test's constants; per plane pair: whether
-        // the refine link has been decided already (normals do not change here, so the first decision is final)
+        // per plane: the distance test's constants (normals do not change during the grow)
         const int nPl = (int)planes.size();
-        struct PlaneC { double n[3], c[3], thr; };
-        std::vector<PlaneC> pc(nPl);
-        for (int k = 0; k < nPl; k++) { const Seg& sg = pool[planes[k]]; for (int q = 0; q < 3; q++) { pc[k].n[q] = sg.normal[q]; pc[k].c[q] = sg.center[q]; } pc[k].thr = 9 * sg.mse + 1e-5; }
-        std::vector<char> linkSeen((size_t)nPl * nPl, 0);
+        pc.resize(nPl);
+        for (int k = 0; k < nPl; k++) { const Seg& sg = pool[planes[k]]; for (int q = 0; q < 3; q++) { pc[k].n[q] = sg.normal[q]; pc[k].c[q] = sg.center[q]; } pc[k].thr = 9 * sg.mse + 1e-5; pc[k].pad = 0; }
+    }
+    // what the GPU grow takes: the block map as bytes and the initial seeds as frontier words (peac_kernels.hip: count - 1 << 30 | index << 28 | plane << 20 | pixel)
+    bool pack_for_gpu() {
+        const int nPl = (int)planes.size();
+        if (nPl > PEAC_GROW_MAX_PLANES || (int)seeds.size() > PEAC_GROW_MAX_SEEDS0 || (size_t)W * H > (1u << 20)) return false;
+        blk8.resize(NB); for (int b = 0; b < NB; b++) blk8[b] = (int8_t)blkMap[b];
+        seedWords.resize(seeds.size());
+        std::map<int, int> cnt;                          // seeds that share a pixel (rare: borders of two eroded planes meeting)
+        for (const Seed& sd : seeds) cnt[sd.y * W + sd.x]++;
+        std::map<int, int> seen;
+        for (size_t k = 0; k < seeds.size(); k++) {
+            const int c = seeds[k].y * W + seeds[k].x, n = cnt[c], idx = seen[c]++;
+            if (n > PEAC_GROW_SLOTS) return false;
+            seedWords[k] = ((uint32_t)(n - 1) << 30) | ((uint32_t)idx << 28) | ((uint32_t)seeds[k].pl << 20) | (uint32_t)c;
+        }
+        return true;
+    }
+    // ---- the region grow along the plane borders (FIFO, order-defined), host statement.  member: plane index per pixel or -1 (nobody's);
+    // pairSeen[a * nPl + b] = 1: a seed of plane a passed the distance test on a pixel that plane b held
+    void grow_host(std::vector<int8_t>& member8, std::vector<int16_t>& member16, std::vector<uint8_t>& pairSeen) {
+        const int nPl = (int)planes.size();
+        // per-pixel plane index, or -1 - (number of failed tries), stops at -6; 16 bits keep the grow's working set small (at most W*H/minSupport planes)
+        std::vector<int16_t> member((size_t)W * H, -1);
+        for (int i = 0, b = 0; i < Nh; ++i) for (int j = 0; j < Nw; ++j, ++b) if (blkMap[b] >= 0) for (int y = i * bh; y < (i + 1) * bh; y++) std::fill_n(&member[(size_t)y * W + j * bw], bw, (int16_t)blkMap[b]);
+        pairSeen.assign((size_t)nPl * nPl, 0);
         std::vector<float> distMap((size_t)W * H, std::numeric_limits<float>::max());
-        auto visit = [&](int cx, int cy, int pl, const PlaneC& S) {
+        auto visit = [&](int cx, int cy, int pl, const PeacGrowPlane& S) {
             const int c = cy * W + cx; int16_t& trail = member[c];
             if (trail <= -6) return;
             if (trail == pl) return;
@@ -204,10 +229,7 @@ struct Fitter {
             const bool has_pt = point(cy, cx, pt);
             if (has_pt) cdist = (float)std::fabs(S.n[0] * (pt[0] - S.c[0]) + S.n[1] * (pt[1] - S.c[1]) + S.n[2] * (pt[2] - S.c[2]));
             if (has_pt && (double)cdist * (double)cdist < S.thr) {
-                if (trail >= 0 && !linkSeen[(size_t)pl * nPl + trail]) {
-                    linkSeen[(size_t)pl * nPl + trail] = linkSeen[(size_t)trail * nPl + pl] = 1;
-                    if (pool[planes[pl]].similarity(pool[planes[trail]]) >= P.simRefine) link(planes[trail], planes[pl]);
-                }
+                if (trail >= 0) pairSeen[(size_t)pl * nPl + trail] = 1;
                 float& od = distMap[c];
                 if (cdist < od) { trail = (int16_t)pl; od = cdist; seeds.push_back({(uint16_t)cx, (uint16_t)cy, pl}); }
                 else if (trail < 0) trail -= 1;
@@ -219,12 +241,20 @@ struct Fitter {
                 __builtin_prefetch(&member[c]); if (f.y > 0) __builtin_prefetch(&member[c - W]); if (f.y < H - 1) __builtin_prefetch(&member[c + W]);
                 __builtin_prefetch(&in.depth[c]); __builtin_prefetch(&distMap[c]);
             }
-            const Seed sd = seeds[k]; const int sx = sd.x, sy = sd.y; const PlaneC& S = pc[sd.pl];
+            const Seed sd = seeds[k]; const int sx = sd.x, sy = sd.y; const PeacGrowPlane& S = pc[sd.pl];
             if (sx > 0) visit(sx - 1, sy, sd.pl, S);
             if (sx < W - 1) visit(sx + 1, sy, sd.pl, S);
             if (sy > 0) visit(sx, sy - 1, sd.pl, S);
             if (sy < H - 1) visit(sx, sy + 1, sd.pl, S);
         }
+        if (nPl <= 127) { member8.resize(member.size()); for (size_t k = 0; k < member.size(); k++) member8[k] = (int8_t)std::max<int>(member[k], -1); member16.clear(); }
+        else { member16.swap(member); member8.clear(); }
+    }
+    // ---- part 2: refine links between the planes that met during the grow, last merge, plane masks -> closed -> external contours, thickness 2
+    template <class T> void part2(const T* member, const uint8_t* pairSeen, BitImg& planeContours) {
+        const int nPl = (int)planes.size();
+        for (int a = 0; a < nPl; a++) for (int b = a + 1; b < nPl; b++)          // the first meeting of two planes decides their link (order-free: a set of links)
+            if ((pairSeen[(size_t)a * nPl + b] | pairSeen[(size_t)b * nPl + a]) && pool[planes[a]].similarity(pool[planes[b]]) >= P.simRefine) link(planes[a], planes[b]);
         Queue q2(QCmp{&pool});
         for (int k = 0; k < (int)planes.size(); k++) if (valid[k]) q2.push(planes[k]);
         cluster(q2);
@@ -239,7 +269,7 @@ struct Fitter {
         std::vector<BitImg> masks(nOut); for (auto& m : masks) m.create(W, H);
         std::vector<int> yLo(nOut, H), yHi(nOut, -1);
         for (int y = 0; y < H; y++) {                                  // runs of equal membership -> bit ranges
-            const int16_t* m = &member[(size_t)y * W];
+            const T* m = &member[(size_t)y * W];
             for (int x = 0; x < W;) {
                 const int pl = m[x], x0 = x; while (x < W && m[x] == pl) x++;
                 if (pl < 0 || plmap[pl] < 0 || plmap[pl] >= nOut) continue;
@@ -259,9 +289,27 @@ struct Fitter {
 };
 }  // namespace
 
+PeacFitter::PeacFitter(const PeacInput& in) : f(new Fitter(in)) {}
+PeacFitter::~PeacFitter() { delete static_cast<Fitter*>(f); }
+#define FIT static_cast<Fitter*>(f)
+void PeacFitter::part1() { FIT->part1(); gpu_ok = FIT->pack_for_gpu(); }
+int PeacFitter::n_planes() const { return (int)FIT->planes.size(); }
+int PeacFitter::n_blocks() const { return FIT->NB; }
+const PeacGrowPlane* PeacFitter::planes() const { return FIT->pc.data(); }
+const int8_t* PeacFitter::block_map() const { return FIT->blk8.data(); }
+const std::vector<uint32_t>& PeacFitter::seed_words() const { return FIT->seedWords; }
+void PeacFitter::grow_host(std::vector<int8_t>& m8, std::vector<int16_t>& m16, std::vector<uint8_t>& pairSeen) { FIT->grow_host(m8, m16, pairSeen); }
+void PeacFitter::part2(const int8_t* m8, const int16_t* m16, const uint8_t* pairSeen, BitImg& planeContours) {
+    planeContours.create(FIT->W, FIT->H);
+    if (m8) FIT->part2(m8, pairSeen, planeContours); else FIT->part2(m16, pairSeen, planeContours);
+}
+#undef FIT
+
 void peac_plane_contours(const PeacInput& in, BitImg& planeContours) {
-    planeContours.create(in.w, in.h);
-    Fitter f(in); f.run(planeContours);
+    PeacFitter f(in); f.part1();
+    std::vector<int8_t> m8; std::vector<int16_t> m16; std::vector<uint8_t> seen;
+    f.grow_host(m8, m16, seen);
+    f.part2(m8.empty() ? nullptr : m8.data(), m16.empty() ? nullptr : m16.data(), seen.data(), planeContours);
 }
 
 }  // namespace sind

@@ -1,0 +1,67 @@
+"""GPU: the region grow of the PEAC plane refinement as a level-synchronous ordered BFS (k_peac_grow) against the host statement of the reference's FIFO
+(AHCPlaneFitter.hpp:546-601 floodFill): the membership map of every pixel and the set of plane pairs that met must be identical."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sindslam_amd._lib import check, lib, ptr
+from sindslam_amd.synth import D455, TUM3, SyntheticStream
+
+pytestmark = pytest.mark.gpu
+PP = 127 * 127
+
+
+def _grow(depth, intr):
+    n, h, w = depth.shape
+    mg = np.zeros((n, h * w), np.int8); mh = np.zeros((n, h * w), np.int8); pg = np.zeros((n, PP), np.uint8); ph = np.zeros((n, PP), np.uint8)
+    st = np.zeros((n, 4), np.int32)
+    check(lib().sind_debug_peac_grow(ptr(np.ascontiguousarray(depth, np.uint16)), n, w, h, C.c_float(intr["fx"]), C.c_float(intr["fy"]), C.c_float(intr["cx"]), C.c_float(intr["cy"]),
+                                     C.c_float(intr["depth_factor"]), 0, ptr(mg), ptr(mh), ptr(pg), ptr(ph), ptr(st)), "sind_debug_peac_grow")
+    return mg, mh, pg, ph, st
+
+
+def _same(mg, mh, pg, ph, st):
+    for k in range(len(st)):
+        assert st[k, 0] == 0, ("kernel status", k, st[k])
+        npl = st[k, 3]
+        assert np.array_equal(mg[k], mh[k]), (k, int((mg[k] != mh[k]).sum()), st[k])
+        assert np.array_equal(pg[k, :npl * npl], ph[k, :npl * npl]), (k, "pairs")
+
+
+def test_grow_equals_the_fifo_on_stream_frames(stream):
+    _, depth = stream.frames(0, 12)
+    mg, mh, pg, ph, st = _grow(depth, TUM3)
+    _same(mg, mh, pg, ph, st)
+    assert (st[:, 3] >= 3).all() and (st[:, 1] > 50).all() and (st[:, 2] > 50_000).all()           # planes found, a deep traversal, ~10^5 seeds per frame
+    assert (mg >= 0).mean() > 0.3
+
+
+def test_grow_on_a_second_scene_and_a_mirrored_one():
+    s = SyntheticStream(seed=777)
+    _, depth = s.frames(3, 6)
+    d2 = np.concatenate([depth, depth[:, :, ::-1], depth[:, ::-1]])
+    _same(*_grow(d2, TUM3))
+
+
+def test_grow_at_1280x720():
+    sc = 2.0; intr = dict(D455, fx=D455["fx"] * sc, fy=D455["fy"] * sc, cx=D455["cx"] * sc, cy=D455["cy"] * sc)
+    s = SyntheticStream(1280, 720, 4242, D455)
+    _, depth = s.frames(0, 3)
+    mg, mh, pg, ph, st = _grow(depth, intr)
+    _same(mg, mh, pg, ph, st)
+
+
+def test_degenerate_frames():
+    h, w = 480, 640
+    flat = np.full((1, h, w), 7500, np.uint16)                       # one fronto-parallel plane: every block eroded, nothing to grow
+    holes = flat.copy(); holes[0, ::7, ::5] = 0                       # invalid pixels sprinkled over it
+    empty = np.zeros((1, h, w), np.uint16)                            # no depth at all: no planes
+    rng = np.random.default_rng(5); noise = rng.integers(500, 30000, (1, h, w)).astype(np.uint16)
+    yy, xx = np.mgrid[0:h, 0:w]
+    two = np.where(xx < 300, 5000 + 6 * xx, 12000 - 3 * yy).astype(np.uint16)[None]      # two slanted planes meeting at a depth step
+    wedge = (6000 + 4 * np.abs(xx - 320) + 2 * yy).astype(np.uint16)[None]                # two planes meeting at a ridge: they DO meet during the grow
+    d = np.concatenate([flat, holes, empty, noise, two, wedge])
+    mg, mh, pg, ph, st = _grow(d, TUM3)
+    _same(mg, mh, pg, ph, st)
+    assert st[2, 3] == 0 and st[0, 3] == 1

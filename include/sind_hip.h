@@ -197,6 +197,12 @@ int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, do
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices);
 /* last sind_pipe_submit(_dev): time the call still waited for the previous step's tails after its own phase A had finished (0 = hidden) */
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms);
+/* Where the PEAC region grow of CalOccluded (AHCPlaneFitter.hpp:546-601) runs: `quarters` of every four frames on the GPU (k_peac_grow, one compute unit for
+ * a few ms per frame), the others on a host core; the results are bit-identical, the share only moves load between the GPU and the host.  -1 (default): the
+ * pipeline adapts the share step by step -- towards the GPU while a step waits for host work after its dense flow is done, towards the host while the host
+ * cores idle.  Environment SIND_GROW_GPU=0..4 fixes it at create. */
+int sind_pipe_set_grow_share(sind_pipe* p, int quarters);
+int sind_pipe_get_grow_share(sind_pipe* p, int* quarters);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Frame post-ORB steps: what the reference's RGB-D Frame constructor does with the extractor's output

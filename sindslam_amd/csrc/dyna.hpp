@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "depth.hpp"
 #include "flow.hpp"
+#include "peac_grow.hpp"
 #include "host/host.hpp"
 
 namespace sind {
@@ -38,6 +39,10 @@ struct DynaDebug {           // stage outputs of the last tail call (parity test
 
 struct OccResult { BitImg totalArea, occ1, occ2; bool ready = false; const float* gridFlow = nullptr;
                    uint8_t* occ2_dev = nullptr; uint8_t* depthN_dev = nullptr; hipEvent_t occ2_event = nullptr; };          // optional device slots the producer fills: plane-edge mask and 8-bit normalised depth for the RAG statistics     // state-free per-frame results computed ahead of the tail: CalOccluded outputs, flow at the 10-px sample grid (host)
+
+// state of a frame between the two host halves of CalOccluded (the PEAC region grow runs on the GPU in between)
+struct OccCtx { BitImg occ, totalArea; std::vector<PtI> endPoints; std::unique_ptr<PeacFitter> fit; bool grown_on_host = false;
+                std::vector<int8_t> m8; std::vector<int16_t> m16; std::vector<uint8_t> pairs; };
 
 // ---- GPU half of CalOccluded for a chunk of frames at once (state free: depth only).  Host-side results of one frame: OccGpuOut.
 struct OccGpuOut { const uint8_t* edge; const uint8_t* total; const PeacBlockStats* blocks;
@@ -95,6 +100,10 @@ public:
     // CalOccluded (DD:429-642) depends on the depth frame only: the pipeline runs it on this tail's stream while the dense flow
     // of the step is still on the GPU and the host cores are idle
     int compute_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, OccResult& out, const OccGpuOut* pre = nullptr);
+    // the same in two halves around a batched launch of the PEAC region grow (peac_grow.hpp): grow_block = the frame's page-locked input block
+    int compute_occluded_p1(const uint16_t* depth_host, const uint16_t* depth_dev, OccCtx& c, const OccGpuOut* pre, uint8_t* grow_block, int depth_index);
+    int compute_occluded_p2(OccCtx& c, const int8_t* member8, const uint8_t* pair_seen, const int* grow_status, OccResult& out, const OccGpuOut* pre);
+    long n_grow_fallback = 0;      // frames whose region grow overflowed a capacity of the kernel and ran on the host
     void reset();
     // Inter-frame state (reference DynaDetect.h:172-178, rolled at DynaDetect.cc:1660-1664) as one flat blob, so that a sequence can
     // continue on another handle / rank exactly where this one stopped ("phase B strictly in frame order"):
@@ -124,6 +133,11 @@ private:
     DevBuf<KmState> kstate; DevBuf<uint16_t> depth_fix; hipGraphExec_t kmGraph[2] = {nullptr, nullptr}; bool kmGraphBroken = false;
     int kmeans_enqueue(const uint16_t* depth0, bool prevLabels);
     int cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2, const OccGpuOut* pre = nullptr);
+    int cal_occluded_p1(const uint16_t* depth_host, const uint16_t* depth_dev, OccCtx& c, const OccGpuOut* pre, uint8_t* grow_block, int depth_index);
+    int cal_occluded_p2(OccCtx& c, const int8_t* member8, const uint8_t* pair_seen, const int* grow_status, BitImg& occ1, BitImg& occ2);
+    int finish_occluded(OccResult& out, const OccGpuOut* pre);
+    struct OwnGrow { PeacGrowBatch batch; PinnedBuf<uint8_t> in_h, pair_h; PinnedBuf<int8_t> member_h; PinnedBuf<int> status_h; };
+    std::unique_ptr<OwnGrow> own_grow;         // one-frame grow workspace, created on first use (single-frame API, unbatched pipeline steps)
     int seg_and_merge(const std::vector<BitImg>& allLabels, const BitImg& occ1, const BitImg& occ2, const BitImg& labelForSegEdge,
                       const uint16_t* depth_host, const uint16_t* depth_dev, std::vector<uint8_t>& labelNew, const OccResult* pre = nullptr);
 };

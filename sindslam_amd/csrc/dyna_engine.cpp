@@ -298,8 +298,10 @@ int KMeansBatch::run(const uint16_t* depth_base, size_t depth_stride, int B, con
     return SIND_OK;
 }
 
-// ---- DD:429-642: depth-gradient edges (GPU), end points, PEAC plane contours, plane-edge filtering (host)
-int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2, const OccGpuOut* pre) {
+// ---- DD:429-642: depth-gradient edges (GPU), end points, PEAC plane contours, plane-edge filtering (host).  Two host halves around the PEAC region grow, which runs
+// on the GPU (peac_kernels.hip): first half = GPU stencils (unless the batch produced them), packing, end points, PEAC graph clustering and the grow's input block;
+// second half = PEAC's last merge + plane contours, contour filter, closing.  grow_block == nullptr: the half grows on the host right away (no GPU grow wanted).
+int DynaTail::cal_occluded_p1(const uint16_t* depth_host, const uint16_t* depth_dev, OccCtx& c, const OccGpuOut* pre, uint8_t* grow_block, int depth_index) {
     double tf = tick_ms();
     #define FLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tf; tf = t_; }
     const uint8_t* edge_h = h_ab.p; const uint8_t* total_h = h_ab.p + N; const PeacBlockStats* blocks_h = h_blocks.data();
@@ -318,12 +320,14 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     HIP_TRY(sind_stream_wait(stream));
     }
     FLAP(0)
-    const BitImg occ = BitImg::from_u8(edge_h, W, H, W);
-    totalArea = BitImg::from_u8(total_h, W, H, W);
+    c.occ = BitImg::from_u8(edge_h, W, H, W);
+    c.totalArea = BitImg::from_u8(total_h, W, H, W);
+    if (keep_debug) dbg.gradEdge.assign(edge_h, edge_h + N);
     FLAP(1)
     // end points: edge pixels with at most 4 of the 12 radius-2 ring pixels set (DD:498-532), greedy NMS radius 6 in scan order
     static const int ring[12][2] = {{0,-2},{1,-2},{2,-1},{2,0},{2,1},{1,2},{0,2},{-1,2},{-2,1},{-2,0},{-2,-1},{-1,-2}};
-    std::vector<PtI> endPoints;
+    const BitImg& occ = c.occ;
+    std::vector<PtI>& endPoints = c.endPoints; endPoints.clear();
     for (int row = 3; row < H - 3; ++row) for (int col = 3; col < W - 3; ++col) {
         if (!occ.get(col, row)) continue;
         int s = 0; for (int i = 0; i < 12; i++) s += occ.get(col + ring[i][0], row + ring[i][1]);
@@ -331,20 +335,39 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     }
     { std::vector<PtI> sel; for (const PtI& e : endPoints) { bool ov = false; for (const PtI& q : sel) { const int dx = e.x - q.x, dy = e.y - q.y; if ((float)dx * dx + dy * dy < 6.0f * 6.0f) { ov = true; break; } } if (!ov) sel.push_back(e); } endPoints.swap(sel); }
     FLAP(2)
-    // PEAC plane contours (DD:558-593)
-    BitImg planeC; PeacInput pin{blocks_h, depth_host, W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale};
-    peac_plane_contours(pin, planeC);
+    // PEAC (DD:558-593), first part: graph clustering, planes, seeds of the region grow
+    PeacInput pin{blocks_h, depth_host, W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale};
+    c.fit.reset(new PeacFitter(pin)); c.fit->part1();
+    c.grown_on_host = false;
+    if (grow_block) peac_grow_pack(*c.fit, depth_index, grow_block);
+    if (!grow_block || !c.fit->gpu_ok) { c.fit->grow_host(c.m8, c.m16, c.pairs); c.grown_on_host = true; }      // beyond the kernel's capacities (or no GPU grow asked for)
     FLAP(3)
+    #undef FLAP
+    return SIND_OK;
+}
+int DynaTail::cal_occluded_p2(OccCtx& c, const int8_t* member8, const uint8_t* pair_seen, const int* grow_status, BitImg& occ1, BitImg& occ2) {
+    double tf = tick_ms();
+    #define FLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tf; tf = t_; }
+    BitImg planeC;
+    if (!c.grown_on_host && !(grow_status && grow_status[0] == PG_OK && member8 && pair_seen)) {
+        // the kernel reported a capacity overflow for this frame (status 1..3): the host statement of the same FIFO takes over
+        c.fit->grow_host(c.m8, c.m16, c.pairs); c.grown_on_host = true; n_grow_fallback++;
+    }
+    if (c.grown_on_host) c.fit->part2(c.m8.empty() ? nullptr : c.m8.data(), c.m16.empty() ? nullptr : c.m16.data(), c.pairs.data(), planeC);
+    else c.fit->part2(member8, nullptr, pair_seen, planeC);
+    c.fit.reset(); c.m8.clear(); c.m16.clear();
+    FLAP(3)
+    const BitImg& occ = c.occ;
     BitImg edgeByPlane = planeC; edgeByPlane.andnot(occ);                       // DD:599
     std::vector<Contour> contours; find_contours(edgeByPlane, contours, true);
     BitImg acc(W, H);
     const EllipseElem e10(10), e7(7), e3(3);
-    for (const Contour& c : contours) {
-        if (c.size() < 25) continue;
-        BitImg one(W, H); draw_thick2(one, c);
-        const Rect bb = contour_bbox(c);
+    for (const Contour& k : contours) {
+        if (k.size() < 25) continue;
+        BitImg one(W, H); draw_thick2(one, k);
+        const Rect bb = contour_bbox(k);
         one = one.dilated(e10, bb.y0 - 1, bb.y1 + 1);
-        bool isEnd = false; for (const PtI& e : endPoints) if (one.get(e.x, e.y)) { isEnd = true; break; }
+        bool isEnd = false; for (const PtI& e : c.endPoints) if (one.get(e.x, e.y)) { isEnd = true; break; }
         if (isEnd) acc |= one.eroded_rows(e7, bb.y0 - 7, bb.y1 + 7);
     }
     FLAP(4)
@@ -352,7 +375,26 @@ int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev
     BitImg u = occ; u |= acc; occ1 = u.closed(e3);
     FLAP(5)
     #undef FLAP
-    if (keep_debug) { dbg.gradEdge.assign(edge_h, edge_h + N); dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
+    if (keep_debug) { dbg.planeContours.resize(N); planeC.to_u8(dbg.planeContours.data(), W, 255); }
+    return SIND_OK;
+}
+// one frame on this tail's own stream: both halves with a one-frame launch of the grow kernel in between
+int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2, const OccGpuOut* pre) {
+    if (!own_grow) {
+        own_grow.reset(new OwnGrow());
+        SIND_TRY(own_grow->batch.init(W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale, 1));
+        SIND_TRY(own_grow->in_h.alloc(PG_IN_STRIDE)); SIND_TRY(own_grow->member_h.alloc(N)); SIND_TRY(own_grow->pair_h.alloc((size_t)PEAC_GROW_MAX_PLANES * PEAC_GROW_MAX_PLANES)); SIND_TRY(own_grow->status_h.alloc(4));
+    }
+    OccCtx c;
+    SIND_TRY(cal_occluded_p1(depth_host, depth_dev, c, pre, own_grow->in_h.p, 0));
+    if (!c.grown_on_host) {
+        const double t0 = tick_ms();
+        SIND_TRY(own_grow->batch.run(stream, own_grow->in_h.p, depth_dev, 1, own_grow->member_h.p, own_grow->pair_h.p, own_grow->status_h.p));
+        HIP_TRY(sind_stream_wait(stream));
+        t_fine[33] += tick_ms() - t0;
+    }
+    SIND_TRY(cal_occluded_p2(c, own_grow->member_h.p, own_grow->pair_h.p, own_grow->status_h.p, occ1, occ2));
+    totalArea = c.totalArea;
     return SIND_OK;
 }
 
@@ -561,6 +603,21 @@ int DynaTail::compute_occluded(const uint16_t* depth_host, const uint16_t* depth
     // the depth-only inputs of the RAG statistics go first so that they are finished by the time cal_occluded waits on the stream
     if (out.depthN_dev && !pre) { SIND_TRY(launch_max_u16(stream, depth_dev, N, umax_d.p + 1)); SIND_TRY(launch_depth_norm(stream, depth_dev, umax_d.p + 1, out.depthN_dev, N)); }
     SIND_TRY(cal_occluded(depth_host, depth_dev, out.totalArea, out.occ1, out.occ2, pre));
+    return finish_occluded(out, pre);
+}
+// batched pipeline: first half of a frame (the grow of its chunk is launched by whoever finishes the chunk's last first half) ...
+int DynaTail::compute_occluded_p1(const uint16_t* depth_host, const uint16_t* depth_dev, OccCtx& c, const OccGpuOut* pre, uint8_t* grow_block, int depth_index) {
+    HIP_TRY(hipSetDevice(cfg.device));
+    return cal_occluded_p1(depth_host, depth_dev, c, pre, grow_block, depth_index);
+}
+// ... and the second half once the chunk's grow results are on the host
+int DynaTail::compute_occluded_p2(OccCtx& c, const int8_t* member8, const uint8_t* pair_seen, const int* grow_status, OccResult& out, const OccGpuOut* pre) {
+    HIP_TRY(hipSetDevice(cfg.device));
+    SIND_TRY(cal_occluded_p2(c, member8, pair_seen, grow_status, out.occ1, out.occ2));
+    out.totalArea = c.totalArea;
+    return finish_occluded(out, pre);
+}
+int DynaTail::finish_occluded(OccResult& out, const OccGpuOut* pre) {
     if (out.occ2_dev && pre && pre->occ2_stage && pre->occ2_event) {      // batched path: page-locked staging of the frame's own, consumers wait on the event, not this thread
         out.occ2.to_u8(pre->occ2_stage, W, 255); HIP_TRY(hipMemcpyAsync(out.occ2_dev, pre->occ2_stage, N, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipEventRecord(pre->occ2_event, stream)); out.occ2_event = pre->occ2_event;

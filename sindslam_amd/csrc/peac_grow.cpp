@@ -8,8 +8,8 @@ int PeacGrowBatch::init(int W_, int H_, float fx_, float fy_, float cx_, float c
     W = W_; H = H_; fx = fx_; fy = fy_; cx = cx_; cy = cy_; inv_scale = 1.0f / depthScale; cap = cap_;
     if (W % 16 || H % 16 || (W / 16) * (H / 16) > PG_MAX_BLOCKS || (size_t)W * H > (1u << 20)) { sind_set_error("PeacGrowBatch: unsupported size %d x %d", W, H); return SIND_E_ARG; }
     const size_t N = (size_t)W * H, c = (size_t)cap;
-    SIND_TRY(in_d.alloc(c * PG_IN_STRIDE)); SIND_TRY(member_d.alloc(c * N)); SIND_TRY(dist_d.alloc(c * N)); SIND_TRY(tag_d.alloc(c * N)); SIND_TRY(ent_d.alloc(c * N * PEAC_GROW_SLOTS));
-    SIND_TRY(front_d.alloc(c * 2 * PG_FRONT_CAP)); SIND_TRY(payload_d.alloc(c * 4 * PG_FRONT_CAP)); SIND_TRY(pair_d.alloc(c * PEAC_GROW_MAX_PLANES * PEAC_GROW_MAX_PLANES));
+    SIND_TRY(in_d.alloc(c * PG_IN_STRIDE)); SIND_TRY(member_d.alloc(c * N)); SIND_TRY(dist_d.alloc(c * N)); SIND_TRY(slot_d.alloc(c * N)); SIND_TRY(ext_d.alloc(c * N * (PEAC_GROW_SLOTS - 1)));
+    SIND_TRY(front_d.alloc(c * 2 * PG_FRONT_CAP)); SIND_TRY(payload_d.alloc(c * 4 * PG_FRONT_CAP)); SIND_TRY(active_d.alloc(c * 4 * PG_FRONT_CAP)); SIND_TRY(pair_d.alloc(c * PEAC_GROW_MAX_PLANES * PEAC_GROW_MAX_PLANES));
     SIND_TRY(status_d.alloc(c * 4));
     return SIND_OK;
 }
@@ -18,7 +18,7 @@ int PeacGrowBatch::run(hipStream_t s, const uint8_t* in_h, const uint16_t* depth
     if (frames < 1 || frames > cap || !in_h || !depth_base || !member_h || !pair_h || !status_h) { sind_set_error("PeacGrowBatch::run: bad arguments (%d frames, capacity %d)", frames, cap); return SIND_E_ARG; }
     const size_t N = (size_t)W * H;
     HIP_TRY(hipMemcpyAsync(in_d.p, in_h, (size_t)frames * PG_IN_STRIDE, hipMemcpyHostToDevice, s));
-    PeacGrowArgs A{W, H, fx, fy, cx, cy, inv_scale, in_d.p, (size_t)PG_IN_STRIDE, depth_base, member_d.p, dist_d.p, tag_d.p, ent_d.p, front_d.p, payload_d.p, pair_d.p, status_d.p};
+    PeacGrowArgs A{W, H, fx, fy, cx, cy, inv_scale, (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W), in_d.p, (size_t)PG_IN_STRIDE, depth_base, member_d.p, dist_d.p, slot_d.p, ext_d.p, front_d.p, payload_d.p, active_d.p, pair_d.p, status_d.p};
     SIND_TRY(launch_peac_grow(s, A, frames));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(member_h, member_d.p, (size_t)frames * N, hipMemcpyDeviceToHost, s));

@@ -5,7 +5,7 @@
 
 namespace sind {
 
-#define PG_THREADS 1024
+#define PG_THREADS 512
 #define PG_FRONT_CAP 65536            /* seeds of one BFS level (measured: <= 7.2 k at 640 x 480) */
 #define PG_MAX_BLOCKS 3600            /* 16 x 16 blocks of a frame (1280 x 720) */
 #define PG_MAX_LEVELS 100000
@@ -20,10 +20,10 @@ struct PeacGrowHdr { int nPl, nSeeds, skip, depth_index; };
 static_assert(sizeof(PeacGrowPlane) == 64 && PG_OFF_BLOCKS % 16 == 0 && (PG_OFF_BLOCKS + PG_MAX_BLOCKS) % 16 == 0 && PG_IN_STRIDE % 16 == 0, "input block layout");
 
 struct PeacGrowArgs {
-    int W, H; float fx, fy, cx, cy, inv_scale;
+    int W, H; float fx, fy, cx, cy, inv_scale; unsigned w_magic;                  // w_magic = ceil(2^32 / W): pixel / W for pixel < 2^20 is one v_mul_hi
     const uint8_t* in; size_t in_stride;                // frames' input blocks
     const uint16_t* depth_base;                         // frame f reads depth_base + hdr.depth_index * W * H
-    int8_t* member; float* dist; unsigned *slot_tag, *slot_ent, *frontier, *payload; uint8_t* pair_seen; int* status;
+    int8_t* member; float* dist; unsigned long long* slot; unsigned *slot_ext, *frontier, *payload, *active; uint8_t* pair_seen; int* status;
 };
 int launch_peac_grow(hipStream_t s, const PeacGrowArgs& A, int frames);
 
@@ -38,7 +38,7 @@ public:
     int cap = 0;
 private:
     int W = 0, H = 0; float fx = 0, fy = 0, cx = 0, cy = 0, inv_scale = 0;
-    DevBuf<uint8_t> in_d, pair_d; DevBuf<int8_t> member_d; DevBuf<float> dist_d; DevBuf<unsigned> tag_d, ent_d, front_d, payload_d; DevBuf<int> status_d;
+    DevBuf<uint8_t> in_d, pair_d; DevBuf<int8_t> member_d; DevBuf<float> dist_d; DevBuf<unsigned long long> slot_d; DevBuf<unsigned> ext_d, front_d, payload_d, active_d; DevBuf<int> status_d;
 };
 // write one frame's input block from a fitter that finished part1 (skip = 1 when the frame does not fit the kernel's capacities: the caller grows it on the host)
 void peac_grow_pack(const PeacFitter& f, int depth_index, uint8_t* block);

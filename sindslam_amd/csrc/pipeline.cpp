@@ -73,6 +73,12 @@ struct sind_pipe {
     // GPU half of CalOccluded for all frames of a step, in chunks, on a stream of its own at the start of phase A (seven launches per chunk instead
     // of seven launches + a stream wait per frame); the runner tasks wait for their frame's chunk and do the host half
     OccBatch occb; hipStream_t occ_stream = nullptr; bool batch_occ = false; int occ_chunk = 64;
+    // PEAC region grow of CalOccluded on the GPU, one launch per chunk of frames (peac_grow.hpp): the runner that finishes the last first-half of a chunk enqueues it
+    PeacGrowBatch grow; hipStream_t grow_stream = nullptr; std::mutex grow_mu;
+    // Where a frame's region grow runs: grow_q of every 4 frames on the GPU (one CU for ~6 ms per frame), the others on the host (one core for ~5 ms); both give
+    // the same bits, so the share only moves load.  grow_q_fixed < 0: adapted step by step (grow_adapt) -- towards the GPU while the step waits for host work
+    // (CalOccluded or tails not done when the dense flow is), towards the host while the host cores idle.
+    int grow_q = 2, grow_q_fixed = -1, grow_idle_steps = 0; double cpu_ms_mark = 0, wall_ms_mark = 0; int cpu_share = 16;
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
     struct StepBuf {
@@ -80,6 +86,8 @@ struct sind_pipe {
         DevBuf<uint8_t> occ2_dev, depthN_dev;                  // per frame: plane-edge mask and normalised depth for the tails' RAG statistics (filled by the CalOccluded tasks)
         DevBuf<float> grid_dev; PinnedBuf<float> grid_h;       // flow at the 10-px sample grid of every frame (DD:1182-1204), gathered right after the dense flow
         std::atomic<int> occ_next{0};                          // next frame for the CalOccluded runner tasks
+        std::vector<OccCtx> occ_ctx; PinnedBuf<uint8_t> grow_in_h, grow_pair_h; PinnedBuf<int8_t> grow_member_h; PinnedBuf<int> grow_status_h;      // per frame: state between the halves, the grow's input block and results
+        std::vector<hipEvent_t> grow_ev; std::unique_ptr<std::atomic<int>[]> grow_left, grow_state; std::atomic<int> occ_next2{0}; int grow_q = 4;      // per chunk: first halves still out, 0 = not launched / 1 = launched / < 0 = failed
         PinnedBuf<uint8_t> occ_edge_h, occ_total_h; PinnedBuf<PeacBlockStats> occ_blocks_h; std::vector<hipEvent_t> occ_ev, occ2_ev;      // batched GPU half: per-frame host results, one event per chunk; one event per frame behind its occ2 upload
         // depth half of the tails (k-means, SegAndMerge) run ahead, underneath the dense flow (synchronous steps only): per-frame results,
         // and a gate per frame that opens when both its CalOccluded result and the stream's previous depth stage are there
@@ -101,6 +109,19 @@ struct sind_pipe {
     WorkerPool workers;          // declared last: joined first
 };
 
+static double process_cpu_ms() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static double now_ms();
+// One step of the grow-share controller (see sind_pipe::grow_q).  host_wait_ms: how long the step waited for host work after its GPU work was done;
+// step_ms: wall time of the step.  The host counts as idle below 70 % of its CPU share over the step; two idle steps in a row move a quarter back to the host.
+static void grow_adapt(sind_pipe* p, double host_wait_ms, double step_ms) {
+    const double cpu = process_cpu_ms(), wall = now_ms();
+    const double util = (p->wall_ms_mark > 0 && wall > p->wall_ms_mark) ? (cpu - p->cpu_ms_mark) / (wall - p->wall_ms_mark) / std::max(1, p->cpu_share) : 1.0;
+    p->cpu_ms_mark = cpu; p->wall_ms_mark = wall;
+    if (p->grow_q_fixed >= 0 || !p->batch_occ || step_ms <= 0) return;
+    if (host_wait_ms > 0.04 * step_ms) { p->grow_q = std::min(4, p->grow_q + 1); p->grow_idle_steps = 0; }
+    else if (util < 0.70) { if (++p->grow_idle_steps >= 2) { p->grow_q = std::max(0, p->grow_q - 1); p->grow_idle_steps = 0; } }
+    else p->grow_idle_steps = 0;
+}
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // max filter of the 0/125/255 image with the 15x15 ellipse = two binary dilations (>=125, ==255)
@@ -146,6 +167,8 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { long long q = 0, per = 0; if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) cpu_share = (int)std::max<long long>(1, std::min<long long>(cpu_share, q / per)); fclose(f); }
     if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int lw = atoi(e); if (lw > 1) cpu_share = std::max(2, cpu_share / lw); }      // ranks of one node (torch.distributed.run) share the quota
     cpu_share = std::min(cpu_share, 16);                                          // more host threads than this per GPU bring nothing (measured)
+    p->cpu_share = cpu_share;
+    if (const char* e = getenv("SIND_GROW_GPU")) { p->grow_q_fixed = std::max(0, std::min(4, atoi(e))); p->grow_q = p->grow_q_fixed; }
     const int nworkers = getenv("SIND_WORKERS") ? std::max(2, atoi(getenv("SIND_WORKERS"))) : cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 2);         // default: 2x the CPU share (workers sleep while they wait for the GPU)
     // A task leaves its stream idle (every GPU section ends in a wait), so the HIP streams belong to the workers, not to the camera
     // streams: their number does not grow with S.
@@ -182,7 +205,13 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
             for (int c = 0; c < nch; c++) HIP_TRY(hipEventCreateWithFlags(&p->sb[k].occ_ev[c], hipEventDisableTiming));
             p->sb[k].occ2_ev.assign(B, nullptr);
             for (int f = 0; f < B; f++) HIP_TRY(hipEventCreateWithFlags(&p->sb[k].occ2_ev[f], hipEventDisableTiming));
+            SIND_TRY(p->sb[k].grow_in_h.alloc((size_t)B * PG_IN_STRIDE)); SIND_TRY(p->sb[k].grow_member_h.alloc(np * B));
+            SIND_TRY(p->sb[k].grow_pair_h.alloc((size_t)B * PEAC_GROW_MAX_PLANES * PEAC_GROW_MAX_PLANES)); SIND_TRY(p->sb[k].grow_status_h.alloc((size_t)4 * B));
+            p->sb[k].grow_ev.assign(nch, nullptr); p->sb[k].grow_left.reset(new std::atomic<int>[nch]); p->sb[k].grow_state.reset(new std::atomic<int>[nch]);
+            for (int c = 0; c < nch; c++) HIP_TRY(hipEventCreateWithFlags(&p->sb[k].grow_ev[c], hipEventDisableTiming));
         }
+        SIND_TRY(make_stream(&p->grow_stream, !(getenv("SIND_OCC_PRIORITY") && atoi(getenv("SIND_OCC_PRIORITY")) == 0)));
+        SIND_TRY(p->grow.init(cfg->width, cfg->height, cfg->fx, cfg->fy, cfg->cx, cfg->cy, cfg->depth_scale, p->occ_chunk));
     }
     p->workers.start(nworkers, cfg->device, &p->gate);
     SIND_TRY(p->gray.alloc(np * std::max(B, 2)));          // sind_pipe_prime converts the two priming frames through this scratch, also when S * T == 1
@@ -221,8 +250,8 @@ int sind_pipe_destroy(sind_pipe* p) {
     (void)hipSetDevice(p->c.device);
     (void)hipDeviceSynchronize();
     if (p->round_thread.joinable()) p->round_thread.join();
-    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream); ss.push_back(p->km_stream); ss.push_back(p->occ_stream);
-    for (auto& b : p->sb) { for (hipEvent_t e : b.occ_ev) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : b.occ2_ev) if (e) (void)hipEventDestroy(e); }
+    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream); ss.push_back(p->km_stream); ss.push_back(p->occ_stream); ss.push_back(p->grow_stream);
+    for (auto& b : p->sb) { for (hipEvent_t e : b.occ_ev) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : b.occ2_ev) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : b.grow_ev) if (e) (void)hipEventDestroy(e); }
     for (size_t w = 0; w < p->worker_streams_lo.size(); w++) if (w >= p->worker_streams.size() || p->worker_streams_lo[w] != p->worker_streams[w]) ss.push_back(p->worker_streams_lo[w]); ss.push_back(p->orb_stream); ss.insert(ss.end(), p->extra_streams.begin(), p->extra_streams.end());
     if (p->ev_pool) (void)hipEventDestroy(p->ev_pool);
     if (p->ev_gray) (void)hipEventDestroy(p->ev_gray);
@@ -313,19 +342,55 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     // `occ_workers` runner tasks share the frames through a counter: CalOccluded is host-heavy (PEAC region grow), and more runnable
     // threads than the CPU quota of the box (cgroup cpu.max, 16 cores per GPU) only burn the quota early in a period and stall EVERY
     // thread of the process, the flow's launch threads included, until the period ends
-    sb.occ_next.store(0);
+    sb.occ_next.store(0); sb.occ_next2.store(0); sb.grow_q = p->grow_q;
+    if (p->batch_occ) {
+        sb.occ_ctx.clear(); sb.occ_ctx.resize(B);
+        const int nch = (B + p->occ_chunk - 1) / p->occ_chunk;
+        for (int c = 0; c < nch; c++) { sb.grow_left[c].store(std::min(p->occ_chunk, B - c * p->occ_chunk)); sb.grow_state[c].store(0); }
+    }
     auto push_occ = [&] { for (int r = 0; r < std::min(p->occ_workers, B); r++) p->workers.push(sb.occ_group, [p, &sb, B, np](int w) {
-        for (int k; (k = sb.occ_next.fetch_add(1)) < B;) {
-            int rc = SIND_OK;
-            if (p->batch_occ) {
-                const size_t nblk = (size_t)(p->c.width / 16) * (p->c.height / 16);
-                if (sind_event_wait(sb.occ_ev[k / p->occ_chunk]) != hipSuccess) { (void)hipGetLastError(); sind_set_error("batched CalOccluded stage failed"); rc = SIND_E_HIP; }
-                else { const OccGpuOut pre{sb.occ_edge_h.data() + np * k, sb.occ_total_h.data() + np * k, sb.occ_blocks_h.data() + nblk * k,
-                                           sb.occ_edge_h.data() + np * k /* the edge image has been packed by then */, sb.occ2_ev[k]};
-                       rc = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k], &pre); }
-            } else rc = p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]);
+        auto done = [&](int k, int rc) {          // frame k has its CalOccluded result (or its error): open the depth chain's gate
             if (rc != SIND_OK) { sb.occ_rc[k] = rc; sb.occ_err[k] = sind_last_error(); }
             if (sb.depth_ahead && sb.gate[k].fetch_add(1) == 1) { sind_pipe::StepBuf* sbp = &sb; p->workers.push(sb.depth_group, [p, sbp, k](int w2) { depth_task(p, sbp, k, w2); }); }
+        };
+        if (!p->batch_occ) {
+            for (int k; (k = sb.occ_next.fetch_add(1)) < B;) done(k, p->occ_tails[w]->compute_occluded(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ[k]));
+            return;
+        }
+        const size_t nblk = (size_t)(p->c.width / 16) * (p->c.height / 16), PP = (size_t)PEAC_GROW_MAX_PLANES * PEAC_GROW_MAX_PLANES;
+        auto pre_of = [&](int k) { return OccGpuOut{sb.occ_edge_h.data() + np * k, sb.occ_total_h.data() + np * k, sb.occ_blocks_h.data() + nblk * k,
+                                                    sb.occ_edge_h.data() + np * k /* the edge image has been packed by then */, sb.occ2_ev[k]}; };
+        // first halves: GPU stencil results of the frame's chunk -> end points, PEAC graph clustering, the grow's input block; the runner that completes a chunk
+        // enqueues its region grow (one launch for the chunk's frames; the launches share one device workspace, hence the lock around the enqueue)
+        for (int k; (k = sb.occ_next.fetch_add(1)) < B;) {
+            const int ch = k / p->occ_chunk; int rc = SIND_OK;
+            if (sind_event_wait(sb.occ_ev[ch]) != hipSuccess) { (void)hipGetLastError(); sind_set_error("batched CalOccluded stage failed"); rc = SIND_E_HIP; }
+            else {
+                const OccGpuOut pre = pre_of(k); uint8_t* block = sb.grow_in_h.p + (size_t)k * PG_IN_STRIDE;
+                const bool on_gpu = ((k + 1) * sb.grow_q) / 4 > (k * sb.grow_q) / 4;          // grow_q of every four frames
+                rc = p->occ_tails[w]->compute_occluded_p1(sb.depth_h.data() + np * k, sb.depth_dev.p + np * k, sb.occ_ctx[k], &pre, on_gpu ? block : nullptr, k);
+                if (!on_gpu) { const PeacGrowHdr skip{0, 0, 1, k}; std::memcpy(block, &skip, sizeof(skip)); }      // grown on the host in the first half: the kernel passes it over
+            }
+            if (rc != SIND_OK) { sb.occ_rc[k] = rc; sb.occ_err[k] = sind_last_error(); PeacGrowHdr skip{0, 0, 1, k}; std::memcpy(sb.grow_in_h.p + (size_t)k * PG_IN_STRIDE, &skip, sizeof(skip)); }
+            if (sb.grow_left[ch].fetch_sub(1) == 1) {
+                const int c0 = ch * p->occ_chunk, nb = std::min(p->occ_chunk, B - c0); int lrc;
+                { std::lock_guard<std::mutex> lk(p->grow_mu);
+                  lrc = p->grow.run(p->grow_stream, sb.grow_in_h.p + (size_t)c0 * PG_IN_STRIDE, sb.depth_dev.p, nb, sb.grow_member_h.p + np * c0, sb.grow_pair_h.p + PP * c0, sb.grow_status_h.p + 4 * c0);
+                  if (lrc == SIND_OK && hipEventRecord(sb.grow_ev[ch], p->grow_stream) != hipSuccess) lrc = SIND_E_HIP; }
+                sb.grow_state[ch].store(lrc == SIND_OK ? 1 : -1);
+            }
+        }
+        // second halves, in frame order: wait for the chunk's grow, then PEAC's last merge, plane contours, contour filter, closing
+        for (int k; (k = sb.occ_next2.fetch_add(1)) < B;) {
+            const int ch = k / p->occ_chunk; int rc = sb.occ_rc[k];
+            if (rc == SIND_OK) {
+                if (sb.grow_state[ch].load() == 0) { SindTokenPause pause; while (sb.grow_state[ch].load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(50)); }
+                if (sb.grow_state[ch].load() < 0 || sind_event_wait(sb.grow_ev[ch]) != hipSuccess) { (void)hipGetLastError(); sind_set_error("PEAC region grow (chunk %d) failed", ch); rc = SIND_E_HIP; }
+                else { const OccGpuOut pre = pre_of(k); rc = p->occ_tails[w]->compute_occluded_p2(sb.occ_ctx[k], sb.grow_member_h.p + np * k, sb.grow_pair_h.p + PP * k, sb.grow_status_h.p + 4 * k, sb.occ[k], &pre); }
+                if (rc != SIND_OK) { sb.occ_rc[k] = rc; sb.occ_err[k] = sind_last_error(); }
+            }
+            sb.occ_ctx[k] = OccCtx();
+            done(k, SIND_OK);              // (an error of this frame has been recorded above)
         } }); };
     t[1] = now_ms();
     // dense flow for every (n, n-2) pair, second pass for large-motion pairs, refinement, up-scale
@@ -483,6 +548,7 @@ int sind_pipe_process_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* 
     SIND_TRY(phase_b(p, p->sb[0], o));
     const double t4 = now_ms();
     p->stage_ms[0] = t[1] - t[0]; p->stage_ms[1] = t[2] - t[1]; p->stage_ms[2] = t[3] - t[2]; p->stage_ms[3] = 0; p->stage_ms[4] = t4 - t[3]; p->stage_ms[5] = t4 - t0;
+    grow_adapt(p, t[3] - t[2], t[3] - t0);             // synchronous step: phase A waits for CalOccluded only; its tails have the host to themselves afterwards
     return SIND_OK;
 }
 
@@ -512,6 +578,7 @@ int sind_pipe_submit_dev(sind_pipe* p, const uint8_t* bgr_dev, const uint16_t* d
     // tail_wait_ms: how long this call still waited for the previous step's tails after its own phase A was done (0 = the tails are hidden)
     p->stage_ms[0] = t[1] - t[0]; p->stage_ms[1] = t[2] - t[1]; p->stage_ms[2] = t[3] - t[2]; p->stage_ms[3] = 0; p->tail_wait_ms = has_prev ? t4 - ta1 : 0; p->stage_ms[4] = tb1 - tb0; p->stage_ms[5] = t4 - t0;
     p->cur ^= 1;
+    grow_adapt(p, (t[3] - t[2]) + p->tail_wait_ms, t4 - t0);
     return SIND_OK;
 }
 // drain: finish the last submitted step
@@ -588,6 +655,12 @@ int sind_pipe_set_state(sind_pipe* p, int s, const uint8_t* buf, size_t n) {
     return SIND_OK;
 }
 
+int sind_pipe_set_grow_share(sind_pipe* p, int quarters) {
+    if (!p || quarters > 4) { sind_set_error("sind_pipe_set_grow_share: quarters must be -1 (adaptive) or 0..4"); return SIND_E_ARG; }
+    p->grow_q_fixed = quarters < 0 ? -1 : quarters; if (quarters >= 0) p->grow_q = quarters;
+    return SIND_OK;
+}
+int sind_pipe_get_grow_share(sind_pipe* p, int* quarters) { if (!p || !quarters) return SIND_E_ARG; *quarters = p->grow_q; return SIND_OK; }
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms) { if (!p || !ms) return SIND_E_ARG; *ms = p->tail_wait_ms; return SIND_OK; }
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices) {
     if (!p) return SIND_E_ARG;

@@ -79,6 +79,13 @@ class Pipeline:
         """schedule of the synchronous step: depth half of the tails underneath the dense flow (same results)"""
         check(lib().sind_pipe_set_depth_ahead(self._h, int(bool(on))), "sind_pipe_set_depth_ahead")
 
+    def set_grow_share(self, quarters: int):
+        """PEAC region grow: `quarters` of every four frames on the GPU, the rest on the host (same results); -1 = adaptive (default)"""
+        check(lib().sind_pipe_set_grow_share(self._h, int(quarters)), "sind_pipe_set_grow_share")
+
+    def grow_share(self) -> int:
+        q = C.c_int(); check(lib().sind_pipe_get_grow_share(self._h, C.byref(q))); return q.value
+
     def get_state_bytes(self) -> int:
         return int(lib().sind_pipe_state_bytes(self._h))
 

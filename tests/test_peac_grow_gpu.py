@@ -31,8 +31,9 @@ def _same(mg, mh, pg, ph, st):
 
 def test_grow_equals_the_fifo_on_stream_frames(stream):
     _, depth = stream.frames(0, 12)
-    mg, mh, pg, ph, st = _grow(depth, TUM3)
-    _same(mg, mh, pg, ph, st)
+    for rep in range(4):                          # the kernel's phases race with each other if a barrier or an ownership rule is wrong: such bugs show up in SOME launches
+        mg, mh, pg, ph, st = _grow(depth, TUM3)
+        _same(mg, mh, pg, ph, st)
     assert (st[:, 3] >= 3).all() and (st[:, 1] > 50).all() and (st[:, 2] > 50_000).all()           # planes found, a deep traversal, ~10^5 seeds per frame
     assert (mg >= 0).mean() > 0.3
 

@@ -171,3 +171,30 @@ def test_batched_caloccluded_stage_equals_the_per_frame_chain(frames, monkeypatc
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
     assert (out["1"][1][0] == 255).any()
+
+
+def test_region_grow_share_does_not_change_the_results(frames):
+    """the PEAC region grow of CalOccluded on the GPU (k_peac_grow), on the host, or split frame by frame: same masks, labels and keypoints"""
+    from sindslam_amd.pipeline import Pipeline
+    bgr, depth = frames
+    S, T = 2, 2
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    sb = np.stack([bgr, bgr[:, :, ::-1]]); sd = np.stack([depth, depth[:, ::-1]])
+    outs = []
+    for q in (0, 4, 1, -1):
+        pipe = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5)
+        pipe.set_grow_share(q)
+        assert pipe.grow_share() == (q if q >= 0 else pipe.grow_share())
+        for s in range(S):
+            pipe.prime(s, sb[s, 1], sb[s, 0])
+        got = []
+        for step in range(2):
+            lo = 2 + step * T
+            pipe.process(sb[:, lo:lo + T], sd[:, lo:lo + T])
+            got.append((pipe.dyna.copy(), pipe.label.copy(), pipe.mask.copy(), pipe.nkp.copy(), pipe.kps.copy(), pipe.desc.copy()))
+        assert 0 <= pipe.grow_share() <= 4
+        pipe.close(); outs.append(got)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)

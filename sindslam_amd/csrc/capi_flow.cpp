@@ -122,7 +122,7 @@ int sind_debug_flow_thresholds(const int* hist, int n, int width, int height, in
 }
 int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h) {
     const int nt = tile_w * tile_h / 8;
-    if (mode < 0 || mode > 4 || fuse < 0 || fuse > 12 || tile_w < 16 || tile_w % 8 || tile_h < 8 || tile_h % 2 || nt % 128 || nt > 1024 || 4 * fuse >= tile_w || 4 * fuse >= tile_h ||
+    if (mode < 0 || mode > 5 || fuse < 0 || fuse > 12 || tile_w < 16 || tile_w % 8 || tile_h < 8 || tile_h % 2 || nt % 128 || nt > 1024 || 4 * fuse >= tile_w || 4 * fuse >= tile_h ||
         (mode == 3 && nt != 256 && nt != 384 && nt != 768)) {
         sind_set_error("sind_flow_set_sor_tiled: bad arguments (mode %d, fuse %d, tile %d x %d)", mode, fuse, tile_w, tile_h); return SIND_E_ARG;
     }

@@ -615,6 +615,162 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 }
 
 // tempW = W + dW (end of a fixed-point iteration); with commit != 0 also W = tempW (end of the level)
+
+// ---------------------------------------------------------------------------------------------------------
+// Third generation for the large levels: the solver STREAMS down the image instead of tiling it.
+// The tiled kernel above pays for its halo twice: a 64 x 64 tile with a 10-pixel halo computes (64 / 44)^2 = 2.1 x the pixel updates it keeps, and a
+// workgroup can neither load the next tile's coefficients nor store its result while it iterates (loads + write-back are 58 % of a tiled launch).
+// Here ONE workgroup owns one whole image (levels up to 408 pixels wide) and walks it top to bottom as a software pipeline in time:
+//   * half-sweep s (s = 0 .. 2 * iters - 1, red first) of image row y runs at step t = y + 2 s.  Row y then has rows y - 1 and y + 1 exactly after
+//     half-sweep s - 1 and before s + 1 -- what the sequential red-black order defines -- and the rows updated in one step (all of t's parity) never
+//     read each other: every pixel update is the same arithmetic on the same operands as in k_sor_color, so the result is bit-identical, with NO
+//     redundant update and every coefficient read from memory exactly once per launch;
+//   * a thread owns a 1 x 4 strip of TWO consecutive rows (2 p, 2 p + 1) for the 2 * SS_NQ steps they spend in the pipeline (even steps: its even row,
+//     odd steps: its odd row -- every thread has work at every step), keeps their system in registers, then takes the pair SS_NQ pairs further down;
+//   * du, dv and the smoothness weight live in LDS rings of SS_RING rows, split by column parity (the two pixels a strip updates in a half-sweep and
+//     their vertical neighbours are one 8-byte access per plane); threads are grouped by the parity of their pair slot (first half of the block even
+//     slots, second half odd) so that the active colour is wave-uniform;
+//   * the rows ahead of the pipeline are fetched by the same threads as a side job: every step each of 8 * SW threads issues ONE 16-byte load of the row
+//     SS_LEAD + 2 steps ahead and parks the piece loaded SS_LEAD steps ago in LDS (coefficients: staging ring, read once by the row's owner; du / dv / w:
+//     the rings).  The step barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so those loads stay in flight across steps;
+//   * a finished row goes straight from registers to global memory, in place (a row is read before it is written, by this workgroup only).
+#define SS_NQ 10           /* pair slots = rows in flight / 2 = half-sweeps per launch (5 iterations) */
+#define SS_RING 24         /* rows of du / dv / w resident in LDS: a row is needed from step y - 1 to y + 2 * SS_NQ - 1, written two steps before */
+#define SS_STG 4           /* rows of the coefficient staging ring */
+#define SS_LEAD 4          /* steps between a loader thread's global load and its LDS store */
+struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], du[4], dv[4]; float wl0; unsigned valid; };
+__device__ __forceinline__ void ss_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// MAXSW: widest row in strips the instance is laid out for.  The LDS layout is fixed at compile time (every plane at a constant offset: an access is one
+// base register per ring row plus an immediate), 102 strips = 408 pixels need 152 KB (one workgroup per CU), 51 strips 77 KB (two).
+template <int MAXSW>
+__global__ void __launch_bounds__(1024) k_sor_stream(int w, int h, int SW, int HT, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
+                                                     const float* __restrict__ gA22, const float* __restrict__ gB1, const float* __restrict__ gB2,
+                                                     const float* __restrict__ gW, float* __restrict__ gU, float* __restrict__ gV) {
+    extern __shared__ float4 lds4s[];
+    float* lds = reinterpret_cast<float*>(lds4s);
+    constexpr int HS = 2 * MAXSW + 4, EWS = 4 * MAXSW;            // floats per row: split plane (two guard floats on each side), staging
+    constexpr int PL = SS_RING * HS;                              // one parity plane of a ring
+    constexpr int O_DU = 2, O_DV = 2 * PL + 2, O_W = 4 * PL + 2, O_ST = 6 * PL, STP = SS_STG * EWS;      // float offsets (rings: + parity * PL + slot * HS + x / 2)
+    constexpr int total = 6 * PL + 5 * STP;
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * w * h;
+    for (int i = tid; i < total; i += blockDim.x) lds[i] = 0.f;   // guards, the row above the image, and everything not yet loaded read as zero
+    // compute role: slot group g (parity of the pair index), slot within the group, strip
+    const int g = tid >= HT ? 1 : 0, idx = g ? tid - HT : tid, qs = idx / SW, j = idx - qs * SW;
+    int p = qs < SS_NQ / 2 ? 2 * qs + g : (1 << 28);              // current row pair; the padding lanes of a half block never get one
+    const int k2 = 2 * j, x0 = 4 * j;
+    int slA = (2 * p) % SS_RING, slB = (2 * p + 1) % SS_RING;
+    // loader role: plane (0..4 coefficients, 5 weight, 6 du, 7 dv) and 4-pixel chunk of the incoming row
+    const bool loader = tid < 8 * SW; const int lpl = tid / SW, lch = tid - lpl * SW, lx = 4 * lch;
+    const float* lsrc = (lpl == 0 ? gA11 : lpl == 1 ? gA12 : lpl == 2 ? gA22 : lpl == 3 ? gB1 : lpl == 4 ? gB2 : lpl == 5 ? gW : lpl == 6 ? gU : gV) + base + lx;
+    const int ldst = lpl < 5 ? O_ST + lpl * STP + lx : (lpl == 5 ? O_W : lpl == 6 ? O_DU : O_DV) + 2 * lch;
+    float4 pf[SS_LEAD];
+    #pragma unroll
+    for (int i = 0; i < SS_LEAD; i++) pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    SsRow A, B;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) { A.a11[i] = A.a22[i] = B.a11[i] = B.a22[i] = 1.f; A.a12[i] = A.b1[i] = A.b2[i] = A.wp[i] = A.du[i] = A.dv[i] = 0.f; B.a12[i] = B.b1[i] = B.b2[i] = B.wp[i] = B.du[i] = B.dv[i] = 0.f; }
+    A.wl0 = B.wl0 = 0.f; A.valid = B.valid = 0u;
+    unsigned vmask = 0u;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) if (x0 + i < w) vmask |= 1u << i;
+    __syncthreads();
+
+    // row ROWY (ring slot SLOT) leaves LDS for registers (its owner, at the row's first step)
+    #define SS_LOAD(R, ROWY, SLOT)                                                                                                 \
+        {                                                                                                                          \
+            const float* st_ = lds + O_ST + ((ROWY) & (SS_STG - 1)) * EWS + x0; const float* rb_ = lds + (SLOT) * HS + k2;         \
+            const float4 c0 = *reinterpret_cast<const float4*>(st_), c1 = *reinterpret_cast<const float4*>(st_ + STP), c2 = *reinterpret_cast<const float4*>(st_ + 2 * STP); \
+            const float4 c3 = *reinterpret_cast<const float4*>(st_ + 3 * STP), c4 = *reinterpret_cast<const float4*>(st_ + 4 * STP); \
+            const float2 we = *reinterpret_cast<const float2*>(rb_ + O_W), wo = *reinterpret_cast<const float2*>(rb_ + O_W + PL); \
+            const float2 ue = *reinterpret_cast<const float2*>(rb_ + O_DU), uo = *reinterpret_cast<const float2*>(rb_ + O_DU + PL); \
+            const float2 ve = *reinterpret_cast<const float2*>(rb_ + O_DV), vo = *reinterpret_cast<const float2*>(rb_ + O_DV + PL); \
+            R.wl0 = rb_[O_W + PL - 1];                                                                                             \
+            R.a11[0] = c0.x; R.a11[1] = c0.y; R.a11[2] = c0.z; R.a11[3] = c0.w; R.a12[0] = c1.x; R.a12[1] = c1.y; R.a12[2] = c1.z; R.a12[3] = c1.w; \
+            R.a22[0] = c2.x; R.a22[1] = c2.y; R.a22[2] = c2.z; R.a22[3] = c2.w; R.b1[0] = c3.x; R.b1[1] = c3.y; R.b1[2] = c3.z; R.b1[3] = c3.w;     \
+            R.b2[0] = c4.x; R.b2[1] = c4.y; R.b2[2] = c4.z; R.b2[3] = c4.w;                                                        \
+            R.wp[0] = we.x; R.wp[2] = we.y; R.wp[1] = wo.x; R.wp[3] = wo.y; R.du[0] = ue.x; R.du[2] = ue.y; R.du[1] = uo.x; R.du[3] = uo.y; \
+            R.dv[0] = ve.x; R.dv[2] = ve.y; R.dv[1] = vo.x; R.dv[3] = vo.y;                                                        \
+            R.valid = vmask;                                                                                                       \
+        }
+    // one half-sweep of a row: the two strip pixels of column parity START (the strip starts at an even column)
+    #define SS_HALF(R, SLOT, START)                                                                                                \
+        {                                                                                                                          \
+            const float* rb_ = lds + (SLOT) * HS + k2 + (START) * PL;                                                              \
+            const float* ru_ = lds + ((SLOT) == 0 ? SS_RING - 1 : (SLOT) - 1) * HS + k2 + (START) * PL;                            \
+            const float* rd_ = lds + ((SLOT) == SS_RING - 1 ? 0 : (SLOT) + 1) * HS + k2 + (START) * PL;                            \
+            const float2 uu = *reinterpret_cast<const float2*>(ru_ + O_DU), ud = *reinterpret_cast<const float2*>(rd_ + O_DU);     \
+            const float2 vu = *reinterpret_cast<const float2*>(ru_ + O_DV), vd = *reinterpret_cast<const float2*>(rd_ + O_DV);     \
+            const float2 wu = *reinterpret_cast<const float2*>(ru_ + O_W);                                                         \
+            /* strip-edge horizontal neighbour: left of pixel 0 (an odd column) or right of pixel 3 (the next strip's first, even column) */ \
+            const float eu = (START) == 0 ? rb_[O_DU + PL - 1] : rb_[O_DU - PL + 2], ev = (START) == 0 ? rb_[O_DV + PL - 1] : rb_[O_DV - PL + 2]; \
+            const float uua[2] = {uu.x, uu.y}, uda[2] = {ud.x, ud.y}, vua[2] = {vu.x, vu.y}, vda[2] = {vd.x, vd.y}, wua[2] = {wu.x, wu.y}; \
+            _Pragma("unroll")                                                                                                      \
+            for (int k = 0; k < 2; k++) {                                                                                          \
+                const int i = (START) + 2 * k;                                                                                     \
+                const float wl = i == 0 ? R.wl0 : R.wp[i == 0 ? 0 : i - 1];                                                        \
+                const float ul = i == 0 ? eu : R.du[i == 0 ? 0 : i - 1], vl = i == 0 ? ev : R.dv[i == 0 ? 0 : i - 1];              \
+                const float ur = i == 3 ? eu : R.du[i == 3 ? 3 : i + 1], vr = i == 3 ? ev : R.dv[i == 3 ? 3 : i + 1];              \
+                const float sigmaU = wl * ul + R.wp[i] * ur + wua[k] * uua[k] + R.wp[i] * uda[k];                                  \
+                const float sigmaV = wl * vl + R.wp[i] * vr + wua[k] * vua[k] + R.wp[i] * vda[k];                                  \
+                float nu = R.du[i], nv = R.dv[i];                                                                                  \
+                nu += omega * (sor_div(sigmaU + R.b1[i] - nv * R.a12[i], R.a11[i], sor_rcp(R.a11[i])) - nu);                       \
+                nv += omega * (sor_div(sigmaV + R.b2[i] - nu * R.a12[i], R.a22[i], sor_rcp(R.a22[i])) - nv);                       \
+                const bool ok = (R.valid >> i) & 1u;                                                                               \
+                R.du[i] = ok ? nu : 0.f; R.dv[i] = ok ? nv : 0.f;                                                                  \
+            }                                                                                                                      \
+            *reinterpret_cast<float2*>(lds + (SLOT) * HS + k2 + (START) * PL + O_DU) = make_float2(R.du[START], R.du[(START) + 2]); \
+            *reinterpret_cast<float2*>(lds + (SLOT) * HS + k2 + (START) * PL + O_DV) = make_float2(R.dv[START], R.dv[(START) + 2]); \
+        }
+    #define SS_STORE(R, ROWY)                                                                                                      \
+        {                                                                                                                          \
+            const size_t go = base + (size_t)(ROWY) * w + x0;                                                                      \
+            if (R.valid == 0xfu) { *reinterpret_cast<F4u*>(gU + go) = F4u{R.du[0], R.du[1], R.du[2], R.du[3]}; *reinterpret_cast<F4u*>(gV + go) = F4u{R.dv[0], R.dv[1], R.dv[2], R.dv[3]}; } \
+            else { _Pragma("unroll") for (int i = 0; i < 4; i++) if ((R.valid >> i) & 1u) { gU[go + i] = R.du[i]; gV[go + i] = R.dv[i]; } } \
+        }
+
+    for (int t0 = -8; t0 < h + 2 * SS_NQ; t0 += 4) {
+        #pragma unroll
+        for (int tt = 0; tt < 4; tt++) {
+            const int t = t0 + tt;
+            // ---- side job: the piece loaded SS_LEAD steps ago (row t + 2) goes to LDS, the piece of row t + 2 + SS_LEAD is requested
+            if (loader) {
+                const int ys = t + 2, yl = ys + SS_LEAD;
+                if (ys >= 0 && ys <= h + 1) {
+                    const float4 v = ys < h ? pf[tt] : make_float4(0.f, 0.f, 0.f, 0.f);           // the two rows below the image read as zero
+                    if (lpl < 5) { if (ys < h) *reinterpret_cast<float4*>(lds + ldst + (ys & (SS_STG - 1)) * EWS) = v; }
+                    else {
+                        float* dst = lds + ldst + (ys % SS_RING) * HS;
+                        *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.z); *reinterpret_cast<float2*>(dst + PL) = make_float2(v.y, v.w);
+                    }
+                }
+                if (yl >= 0 && yl < h) {
+                    const float* q = lsrc + (size_t)yl * w;
+                    if (lx + 3 < w) { const F4u a = *reinterpret_cast<const F4u*>(q); pf[tt] = make_float4(a.x, a.y, a.z, a.w); }
+                    else pf[tt] = make_float4(q[0], lx + 1 < w ? q[1] : 0.f, lx + 2 < w ? q[2] : 0.f, 0.f);      // last chunk of a row whose width is not a multiple of 4
+                }
+            }
+            // ---- the pipeline step of this thread's row pair
+            int u = t - 2 * p;
+            if (u == 2 * SS_NQ) { p += SS_NQ; u = 0; slA = (slA + 2 * SS_NQ) % SS_RING; slB = (slB + 2 * SS_NQ) % SS_RING; }
+            const int yA = 2 * p, yB = yA + 1;
+            if ((tt & 1) == 0) {
+                if (u == 0 && yA < h) SS_LOAD(A, yA, slA)
+                if (u >= 0 && u < 2 * SS_NQ && yA < h) { if (g == 0) { if (tt == 0) SS_HALF(A, slA, 0) else SS_HALF(A, slA, 1) } else { if (tt == 0) SS_HALF(A, slA, 1) else SS_HALF(A, slA, 0) } }
+                if (u == 2 * SS_NQ - 2 && yA < h) SS_STORE(A, yA)
+            } else {
+                if (u == 1 && yB < h) SS_LOAD(B, yB, slB)
+                if (u >= 0 && u < 2 * SS_NQ && yB < h) { if (g == 0) { if (tt == 1) SS_HALF(B, slB, 1) else SS_HALF(B, slB, 0) } else { if (tt == 1) SS_HALF(B, slB, 0) else SS_HALF(B, slB, 1) } }
+                if (u == 2 * SS_NQ - 1 && yB < h) SS_STORE(B, yB)
+            }
+            ss_lds_barrier();
+        }
+    }
+    #undef SS_LOAD
+    #undef SS_HALF
+    #undef SS_STORE
+}
+
 __global__ void k_add_flow(const float* Wu, const float* Wv, const float* __restrict__ dWu,
                            const float* __restrict__ dWv, float* tWu, float* tWv, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1033,6 +1189,7 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 int g_sor_mode = 4;          // fused register-resident SOR with 1x8 strips: 4 = divisions through a reciprocal formed on the fly (hardware estimate + Newton step,
                              // then Markstein's correction; default, fastest), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in
                              // registers (three waves per SIMD); 2 = fused, 1x4 strips + reciprocal division; 0 = one launch per colour (A/B timing, cross-check)
+int g_sor_stream_min_b = 48; // mode 4: levels that are tiled go to the streaming kernel (one workgroup per image) from this many images per launch on; 5 = always
 int g_sor_fuse = 5;          // iterations per launch on the tiled levels; 0 = per-level plan (sor_fuse_plan: measured 1-2 % faster, 10 % more launches; not the default)
 double g_sor_plan_cost = 14; // prologue of a tile in iterations (sor_fuse_plan)
 int g_sor_xcd = 1;           // XCD-aware tile order of the fused kernel (0 = plain blockIdx order, for A/B timing)
@@ -1084,7 +1241,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         hipError_t attr_rc = hipSuccess;
         const void* fs[] = {(const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 512, 2, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>,
                             (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_fused<1, 384, 3, 0, 0>, (const void*)k_sor_fused<1, 768, 3, 0, 0>,
-                            (const void*)k_sor_fused<1, 256, 3, 0, 0>};
+                            (const void*)k_sor_fused<1, 256, 3, 0, 0>, (const void*)k_sor_stream<102>, (const void*)k_sor_stream<51>};
         for (const void* f : fs) if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         return attr_rc;
     }));
@@ -1097,10 +1254,26 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         if (shm > 150 * 1024) { sind_set_error("sor_iterations: a %d x %d level needs %zu bytes of LDS", w, h, shm); return SIND_E_ARG; }
         // <= 512 threads: two waves per SIMD, i.e. up to 256 registers -- room for the run-time tile sizes AND the reciprocal division without spills
         // (all 25 iterations run in this launch, so here the loop is the cost); larger blocks keep the four-waves-per-SIMD IEEE instance
-        auto kern1 = (nt <= 512 && g_sor_mode == 4) ? k_sor_fused<2, 512, 2, 0, 0> : k_sor_fused<0, 1024, 4, 0, 0>;
+        auto kern1 = (nt <= 512 && (g_sor_mode == 4 || g_sor_mode == 5)) ? k_sor_fused<2, 512, 2, 0, 0> : k_sor_fused<0, 1024, 4, 0, 0>;
         hipLaunchKernelGGL(kern1, dim3(1, B), dim3(nt), shm, s, w, h, EW, EH, EW, EH, 0, 0, 1, total, 0, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt,
                            P.r11, P.r22, P.dWu, P.dWv, P.dWu, P.dWv);
         *nlaunch += 1; return SIND_OK;
+    }
+    // large levels, enough images to fill the GPU with one workgroup each: the streaming kernel (no halo, loads and stores overlapped with the iterations)
+    {
+        const int SW = divup(w, 4), HT = divup(5 * SW, 64) * 64;
+        const bool fits = HT <= 512 && h >= 4 && total % (SS_NQ / 2) == 0;
+        if (fits && (g_sor_mode == 5 || (g_sor_mode == 4 && B >= g_sor_stream_min_b))) {
+            const int MS = SW <= 51 ? 51 : 102;               // layout instance: narrow levels leave room for two workgroups per CU
+            const size_t shm = ((size_t)6 * SS_RING * (2 * MS + 4) + (size_t)5 * SS_STG * 4 * MS) * sizeof(float);
+            auto kern = SW <= 51 ? k_sor_stream<51> : k_sor_stream<102>;
+            for (int done = 0; done < total; done += SS_NQ / 2) {
+                hipLaunchKernelGGL(kern, dim3(B), dim3(2 * HT), shm, s, w, h, SW, HT, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
+                *nlaunch += 1;
+            }
+            return SIND_OK;
+        }
+        if (g_sor_mode == 5 && !fits) { /* wider than one workgroup's strip: the tiled kernel below */ }
     }
     if (g_sor_mode == 2) {                             // 1x4 strips + reciprocal division (k_sor_fused4), 64 x 64 tiles, 1024 threads
         static SindPerDeviceInit attr4_init;
@@ -1130,7 +1303,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         const int k = std::min(plan[step++], total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
         const int ntx = divup(w, IW), nty = divup(h, IH);
         const bool t64 = EW == 64 && EH == 64 && nt == 512;           // the default tile has instances with compile-time sizes
-        auto kern = g_sor_mode == 4 ? (t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>) : !rcp ? (t64 ? k_sor_fused<0, 512, 4, 64, 64> : k_sor_fused<0, 1024, 4, 0, 0>)
+        auto kern = (g_sor_mode == 4 || g_sor_mode == 5) ? (t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>) : !rcp ? (t64 ? k_sor_fused<0, 512, 4, 64, 64> : k_sor_fused<0, 1024, 4, 0, 0>)
                     : nt == 384 ? k_sor_fused<1, 384, 3, 0, 0> : nt == 768 ? k_sor_fused<1, 768, 3, 0, 0> : k_sor_fused<1, 256, 3, 0, 0>;
         static const int dry = getenv("SIND_SOR_DRY") ? atoi(getenv("SIND_SOR_DRY")) : 0;       // timing experiment: 1 = no iterations (prologue + write-back only; results are wrong)
         hipLaunchKernelGGL(kern, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, dry ? 0 : k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,

@@ -633,19 +633,20 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 //   * the rows ahead of the pipeline are fetched by the same threads as a side job: every step each of 8 * SW threads issues ONE 16-byte load of the row
 //     SS_LEAD + 2 steps ahead and parks the piece loaded SS_LEAD steps ago in LDS (coefficients: staging ring, read once by the row's owner; du / dv / w:
 //     the rings).  The step barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so those loads stay in flight across steps;
-//   * a finished row goes straight from registers to global memory, in place (a row is read before it is written, by this workgroup only).
+//   * a finished row goes from LDS to the output planes (ping-pong with the input: neighbouring column strips read each other's halo columns).
 #define SS_NQ 10           /* pair slots = rows in flight / 2 = half-sweeps per launch (5 iterations) */
 #define SS_RING 24         /* rows of du / dv / w resident in LDS: a row is needed from step y - 1 to y + 2 * SS_NQ - 1, written two steps before */
 #define SS_STG 4           /* rows of the coefficient staging ring */
 #define SS_LEAD 4          /* steps between a loader thread's global load and its LDS store */
-struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], du[4], dv[4]; float wl0; unsigned valid; };
+struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4]; float wl0; };      // du / dv stay in the LDS rings (16 registers less: the kernel must fit 128 at 1024 threads)
 __device__ __forceinline__ void ss_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// MAXSW: widest row in strips the instance is laid out for.  The LDS layout is fixed at compile time (every plane at a constant offset: an access is one
-// base register per ring row plus an immediate), 102 strips = 408 pixels need 152 KB (one workgroup per CU), 51 strips 77 KB (two).
+// MAXSW: widest column strip (in 4-pixel strips) the instance is laid out for.  The LDS layout is fixed at compile time (every plane at a constant offset:
+// an access is one base register per ring row plus an immediate); 44 strips = 176 columns need 67 KB and 512 threads (7 compute waves + the loader):
+// two workgroups per CU.  Wider levels are cut into column strips (grid x), each with its own pipeline.
 template <int MAXSW>
-__global__ void __launch_bounds__(1024) k_sor_stream(int w, int h, int SW, int HT, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
+__global__ void __launch_bounds__(512) k_sor_stream(int w, int h, int SW, int HT, int IW, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
                                                      const float* __restrict__ gA22, const float* __restrict__ gB1, const float* __restrict__ gB2,
-                                                     const float* __restrict__ gW, float* __restrict__ gU, float* __restrict__ gV) {
+                                                     const float* __restrict__ gW, const float* __restrict__ gU, const float* __restrict__ gV, float* __restrict__ gUo, float* __restrict__ gVo) {
     extern __shared__ float4 lds4s[];
     float* lds = reinterpret_cast<float*>(lds4s);
     constexpr int HS = 2 * MAXSW + 4, EWS = 4 * MAXSW;            // floats per row: split plane (two guard floats on each side), staging
@@ -653,27 +654,35 @@ __global__ void __launch_bounds__(1024) k_sor_stream(int w, int h, int SW, int H
     constexpr int O_DU = 2, O_DV = 2 * PL + 2, O_W = 4 * PL + 2, O_ST = 6 * PL, STP = SS_STG * EWS;      // float offsets (rings: + parity * PL + slot * HS + x / 2)
     constexpr int total = 6 * PL + 5 * STP;
     const int tid = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * w * h;
+    const size_t base = (size_t)blockIdx.y * w * h;
+    // column strip of this workgroup: it keeps the columns [ix0, ix1) and works on [ex0, ex0 + 4 SW), 12 columns more on every side that is not an image
+    // border (a cut edge reads zeros from outside; what that falsifies creeps inwards one column per half-sweep, 10 columns in a launch; 12 keeps ex0 a multiple of 4)
+    const int ix0 = (int)blockIdx.x * IW, ix1 = min(ix0 + IW, w), ex0 = max(ix0 - 12, 0);
     for (int i = tid; i < total; i += blockDim.x) lds[i] = 0.f;   // guards, the row above the image, and everything not yet loaded read as zero
-    // compute role: slot group g (parity of the pair index), slot within the group, strip
+    // roles: threads [0, 10 SW) compute -- slot group g (parity of the pair index: first 5 SW threads even slots, next 5 SW odd), slot within the group, strip;
+    // the LAST wave of the block is the loader (its own 128 registers hold two rows of 16-byte pieces in flight; the compute waves hold none)
+    const int CT = (int)blockDim.x - 64;                          // compute threads (padded to whole waves)
+    const bool is_loader = tid >= CT;
     const int g = tid >= HT ? 1 : 0, idx = g ? tid - HT : tid, qs = idx / SW, j = idx - qs * SW;
-    int p = qs < SS_NQ / 2 ? 2 * qs + g : (1 << 28);              // current row pair; the padding lanes of a half block never get one
+    int p = (!is_loader && qs < SS_NQ / 2) ? 2 * qs + g : (1 << 28);      // current row pair; padding lanes and the loader never get one
     const int k2 = 2 * j, x0 = 4 * j;
     int slA = (2 * p) % SS_RING, slB = (2 * p + 1) % SS_RING;
-    // loader role: plane (0..4 coefficients, 5 weight, 6 du, 7 dv) and 4-pixel chunk of the incoming row
-    const bool loader = tid < 8 * SW; const int lpl = tid / SW, lch = tid - lpl * SW, lx = 4 * lch;
-    const float* lsrc = (lpl == 0 ? gA11 : lpl == 1 ? gA12 : lpl == 2 ? gA22 : lpl == 3 ? gB1 : lpl == 4 ? gB2 : lpl == 5 ? gW : lpl == 6 ? gU : gV) + base + lx;
-    const int ldst = lpl < 5 ? O_ST + lpl * STP + lx : (lpl == 5 ? O_W : lpl == 6 ? O_DU : O_DV) + 2 * lch;
-    float4 pf[SS_LEAD];
+    // loader: lane l takes the items l, l + 64, ... of a row's 8 SW pieces (plane 0..4 coefficients, 5 weight, 6 du, 7 dv; 4-pixel chunk)
+    const int llane = tid - CT, nitem = 8 * SW;
+    constexpr int SS_NC = (8 * MAXSW + 63) / 64;                  // pieces per loader lane and row
+    float4 pf[2][SS_NC];
     #pragma unroll
-    for (int i = 0; i < SS_LEAD; i++) pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < 2; a++) {
+        #pragma unroll
+        for (int c = 0; c < SS_NC; c++) pf[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     SsRow A, B;
     #pragma unroll
-    for (int i = 0; i < 4; i++) { A.a11[i] = A.a22[i] = B.a11[i] = B.a22[i] = 1.f; A.a12[i] = A.b1[i] = A.b2[i] = A.wp[i] = A.du[i] = A.dv[i] = 0.f; B.a12[i] = B.b1[i] = B.b2[i] = B.wp[i] = B.du[i] = B.dv[i] = 0.f; }
-    A.wl0 = B.wl0 = 0.f; A.valid = B.valid = 0u;
-    unsigned vmask = 0u;
+    for (int i = 0; i < 4; i++) { A.a11[i] = A.a22[i] = B.a11[i] = B.a22[i] = 1.f; A.a12[i] = A.b1[i] = A.b2[i] = A.wp[i] = 0.f; B.a12[i] = B.b1[i] = B.b2[i] = B.wp[i] = 0.f; }
+    A.wl0 = B.wl0 = 0.f;
+    unsigned vmask = 0u, smask = 0u;                             // strip pixels inside the image / inside the columns this workgroup keeps
     #pragma unroll
-    for (int i = 0; i < 4; i++) if (x0 + i < w) vmask |= 1u << i;
+    for (int i = 0; i < 4; i++) { if (ex0 + x0 + i < w) vmask |= 1u << i; if (ex0 + x0 + i >= ix0 && ex0 + x0 + i < ix1) smask |= 1u << i; }
     __syncthreads();
 
     // row ROWY (ring slot SLOT) leaves LDS for registers (its owner, at the row's first step)
@@ -683,73 +692,100 @@ __global__ void __launch_bounds__(1024) k_sor_stream(int w, int h, int SW, int H
             const float4 c0 = *reinterpret_cast<const float4*>(st_), c1 = *reinterpret_cast<const float4*>(st_ + STP), c2 = *reinterpret_cast<const float4*>(st_ + 2 * STP); \
             const float4 c3 = *reinterpret_cast<const float4*>(st_ + 3 * STP), c4 = *reinterpret_cast<const float4*>(st_ + 4 * STP); \
             const float2 we = *reinterpret_cast<const float2*>(rb_ + O_W), wo = *reinterpret_cast<const float2*>(rb_ + O_W + PL); \
-            const float2 ue = *reinterpret_cast<const float2*>(rb_ + O_DU), uo = *reinterpret_cast<const float2*>(rb_ + O_DU + PL); \
-            const float2 ve = *reinterpret_cast<const float2*>(rb_ + O_DV), vo = *reinterpret_cast<const float2*>(rb_ + O_DV + PL); \
             R.wl0 = rb_[O_W + PL - 1];                                                                                             \
             R.a11[0] = c0.x; R.a11[1] = c0.y; R.a11[2] = c0.z; R.a11[3] = c0.w; R.a12[0] = c1.x; R.a12[1] = c1.y; R.a12[2] = c1.z; R.a12[3] = c1.w; \
             R.a22[0] = c2.x; R.a22[1] = c2.y; R.a22[2] = c2.z; R.a22[3] = c2.w; R.b1[0] = c3.x; R.b1[1] = c3.y; R.b1[2] = c3.z; R.b1[3] = c3.w;     \
             R.b2[0] = c4.x; R.b2[1] = c4.y; R.b2[2] = c4.z; R.b2[3] = c4.w;                                                        \
-            R.wp[0] = we.x; R.wp[2] = we.y; R.wp[1] = wo.x; R.wp[3] = wo.y; R.du[0] = ue.x; R.du[2] = ue.y; R.du[1] = uo.x; R.du[3] = uo.y; \
-            R.dv[0] = ve.x; R.dv[2] = ve.y; R.dv[1] = vo.x; R.dv[3] = vo.y;                                                        \
-            R.valid = vmask;                                                                                                       \
+            R.wp[0] = we.x; R.wp[2] = we.y; R.wp[1] = wo.x; R.wp[3] = wo.y;                                                        \
         }
     // one half-sweep of a row: the two strip pixels of column parity START (the strip starts at an even column)
     #define SS_HALF(R, SLOT, START)                                                                                                \
         {                                                                                                                          \
-            const float* rb_ = lds + (SLOT) * HS + k2 + (START) * PL;                                                              \
+            float* rb_ = lds + (SLOT) * HS + k2 + (START) * PL;                                                                    \
             const float* ru_ = lds + ((SLOT) == 0 ? SS_RING - 1 : (SLOT) - 1) * HS + k2 + (START) * PL;                            \
             const float* rd_ = lds + ((SLOT) == SS_RING - 1 ? 0 : (SLOT) + 1) * HS + k2 + (START) * PL;                            \
             const float2 uu = *reinterpret_cast<const float2*>(ru_ + O_DU), ud = *reinterpret_cast<const float2*>(rd_ + O_DU);     \
             const float2 vu = *reinterpret_cast<const float2*>(ru_ + O_DV), vd = *reinterpret_cast<const float2*>(rd_ + O_DV);     \
             const float2 wu = *reinterpret_cast<const float2*>(ru_ + O_W);                                                         \
+            /* this row: the two pixels being updated (parity START) and the strip's two pixels of the other colour, their horizontal neighbours */ \
+            float2 cu = *reinterpret_cast<const float2*>(rb_ + O_DU), cv = *reinterpret_cast<const float2*>(rb_ + O_DV);           \
+            const float2 ou = *reinterpret_cast<const float2*>(rb_ + ((START) == 0 ? PL : -PL) + O_DU), ov = *reinterpret_cast<const float2*>(rb_ + ((START) == 0 ? PL : -PL) + O_DV); \
             /* strip-edge horizontal neighbour: left of pixel 0 (an odd column) or right of pixel 3 (the next strip's first, even column) */ \
             const float eu = (START) == 0 ? rb_[O_DU + PL - 1] : rb_[O_DU - PL + 2], ev = (START) == 0 ? rb_[O_DV + PL - 1] : rb_[O_DV - PL + 2]; \
             const float uua[2] = {uu.x, uu.y}, uda[2] = {ud.x, ud.y}, vua[2] = {vu.x, vu.y}, vda[2] = {vd.x, vd.y}, wua[2] = {wu.x, wu.y}; \
+            /* START 0: pixels 0, 2 between (edge, 1) and (1, 3); START 1: pixels 1, 3 between (0, 2) and (2, edge) */             \
+            const float ula[2] = {(START) == 0 ? eu : ou.x, (START) == 0 ? ou.x : ou.y}, ura[2] = {(START) == 0 ? ou.x : ou.y, (START) == 0 ? ou.y : eu}; \
+            const float vla[2] = {(START) == 0 ? ev : ov.x, (START) == 0 ? ov.x : ov.y}, vra[2] = {(START) == 0 ? ov.x : ov.y, (START) == 0 ? ov.y : ev}; \
+            float nua[2] = {cu.x, cu.y}, nva[2] = {cv.x, cv.y};                                                                    \
             _Pragma("unroll")                                                                                                      \
             for (int k = 0; k < 2; k++) {                                                                                          \
                 const int i = (START) + 2 * k;                                                                                     \
                 const float wl = i == 0 ? R.wl0 : R.wp[i == 0 ? 0 : i - 1];                                                        \
-                const float ul = i == 0 ? eu : R.du[i == 0 ? 0 : i - 1], vl = i == 0 ? ev : R.dv[i == 0 ? 0 : i - 1];              \
-                const float ur = i == 3 ? eu : R.du[i == 3 ? 3 : i + 1], vr = i == 3 ? ev : R.dv[i == 3 ? 3 : i + 1];              \
-                const float sigmaU = wl * ul + R.wp[i] * ur + wua[k] * uua[k] + R.wp[i] * uda[k];                                  \
-                const float sigmaV = wl * vl + R.wp[i] * vr + wua[k] * vua[k] + R.wp[i] * vda[k];                                  \
-                float nu = R.du[i], nv = R.dv[i];                                                                                  \
+                const float sigmaU = wl * ula[k] + R.wp[i] * ura[k] + wua[k] * uua[k] + R.wp[i] * uda[k];                          \
+                const float sigmaV = wl * vla[k] + R.wp[i] * vra[k] + wua[k] * vua[k] + R.wp[i] * vda[k];                          \
+                float nu = nua[k], nv = nva[k];                                                                                    \
                 nu += omega * (sor_div(sigmaU + R.b1[i] - nv * R.a12[i], R.a11[i], sor_rcp(R.a11[i])) - nu);                       \
                 nv += omega * (sor_div(sigmaV + R.b2[i] - nu * R.a12[i], R.a22[i], sor_rcp(R.a22[i])) - nv);                       \
-                const bool ok = (R.valid >> i) & 1u;                                                                               \
-                R.du[i] = ok ? nu : 0.f; R.dv[i] = ok ? nv : 0.f;                                                                  \
+                const bool ok = (vmask >> i) & 1u;                                                                                 \
+                nua[k] = ok ? nu : 0.f; nva[k] = ok ? nv : 0.f;                                                                    \
             }                                                                                                                      \
-            *reinterpret_cast<float2*>(lds + (SLOT) * HS + k2 + (START) * PL + O_DU) = make_float2(R.du[START], R.du[(START) + 2]); \
-            *reinterpret_cast<float2*>(lds + (SLOT) * HS + k2 + (START) * PL + O_DV) = make_float2(R.dv[START], R.dv[(START) + 2]); \
+            *reinterpret_cast<float2*>(rb_ + O_DU) = make_float2(nua[0], nua[1]); *reinterpret_cast<float2*>(rb_ + O_DV) = make_float2(nva[0], nva[1]); \
         }
-    #define SS_STORE(R, ROWY)                                                                                                      \
+    // a finished row: LDS (both column parities) -> global memory
+    #define SS_STORE(R, ROWY, SLOT)                                                                                                \
         {                                                                                                                          \
-            const size_t go = base + (size_t)(ROWY) * w + x0;                                                                      \
-            if (R.valid == 0xfu) { *reinterpret_cast<F4u*>(gU + go) = F4u{R.du[0], R.du[1], R.du[2], R.du[3]}; *reinterpret_cast<F4u*>(gV + go) = F4u{R.dv[0], R.dv[1], R.dv[2], R.dv[3]}; } \
-            else { _Pragma("unroll") for (int i = 0; i < 4; i++) if ((R.valid >> i) & 1u) { gU[go + i] = R.du[i]; gV[go + i] = R.dv[i]; } } \
+            const float* rb_ = lds + (SLOT) * HS + k2;                                                                             \
+            const float2 ue = *reinterpret_cast<const float2*>(rb_ + O_DU), uo = *reinterpret_cast<const float2*>(rb_ + O_DU + PL); \
+            const float2 ve = *reinterpret_cast<const float2*>(rb_ + O_DV), vo = *reinterpret_cast<const float2*>(rb_ + O_DV + PL); \
+            const float du_[4] = {ue.x, uo.x, ue.y, uo.y}, dv_[4] = {ve.x, vo.x, ve.y, vo.y};                                       \
+            const size_t go = base + (size_t)(ROWY) * w + ex0 + x0;                                                                \
+            if (smask == 0xfu) { *reinterpret_cast<F4u*>(gUo + go) = F4u{du_[0], du_[1], du_[2], du_[3]}; *reinterpret_cast<F4u*>(gVo + go) = F4u{dv_[0], dv_[1], dv_[2], dv_[3]}; } \
+            else { _Pragma("unroll") for (int i = 0; i < 4; i++) if ((smask >> i) & 1u) { gUo[go + i] = du_[i]; gVo[go + i] = dv_[i]; } } \
         }
 
+    // The loader wave and the compute waves run their own copy of the step loop (same number of steps, one barrier each): the register allocation of one
+    // role does not see the other's live values (two rows of pieces in flight there, two rows of coefficients here)
+    if (is_loader) {
+        // per piece, fixed for the launch: source pointer of row 0, LDS offset without the row part, kind (0 staging, 1 ring, -1 none), in-image mask of the 4 pixels
+        const float* psrc[SS_NC]; int pdst[SS_NC], pkind[SS_NC]; unsigned pmask[SS_NC];
+        #pragma unroll
+        for (int c = 0; c < SS_NC; c++) {
+            const int id = llane + 64 * c, lpl = id / SW, lch = id - lpl * SW, lx = 4 * lch, gx = ex0 + lx;
+            pkind[c] = id >= nitem ? -1 : lpl < 5 ? 0 : 1;
+            psrc[c] = (lpl == 0 ? gA11 : lpl == 1 ? gA12 : lpl == 2 ? gA22 : lpl == 3 ? gB1 : lpl == 4 ? gB2 : lpl == 5 ? gW : lpl == 6 ? gU : gV) + base + min(gx, w - 1);      // (a chunk wholly right of the image re-reads around the last pixel and is masked)
+            pdst[c] = lpl < 5 ? O_ST + lpl * STP + lx : (lpl == 5 ? O_W : lpl == 6 ? O_DU : O_DV) + 2 * lch;
+            pmask[c] = (gx < w ? 1u : 0u) | (gx + 1 < w ? 2u : 0u) | (gx + 2 < w ? 4u : 0u) | (gx + 3 < w ? 8u : 0u);
+        }
+        for (int t0 = -8; t0 < h + 2 * SS_NQ; t0 += 4) {
+            #pragma unroll
+            for (int tt = 0; tt < 4; tt++) {
+                // the pieces loaded two steps ago (row t + 2) go to LDS, the pieces of row t + 4 are requested.  Always a whole 16-byte load (a chunk that
+                // crosses the end of its row reads into the next row -- the planes are padded -- and is masked when it is parked)
+                const int t = t0 + tt, ys = t + 2, yl = ys + 2;
+                const bool park = ys >= 0 && ys <= h + 1, fetch = yl >= 0 && yl < h;
+                const unsigned rowm = ys < h ? 0xfu : 0u;                          // the two rows below the image read as zero
+                const int stg_off = (ys & (SS_STG - 1)) * EWS, ring_off = (((ys % SS_RING) + SS_RING) % SS_RING) * HS;
+                const size_t src_off = (size_t)(fetch ? yl : 0) * w;
+                #pragma unroll
+                for (int c = 0; c < SS_NC; c++) {
+                    if (pkind[c] < 0) continue;
+                    if (park) {
+                        const float4 q = pf[tt & 1][c]; const unsigned m = pmask[c] & rowm;
+                        const float4 v = make_float4((m & 1u) ? q.x : 0.f, (m & 2u) ? q.y : 0.f, (m & 4u) ? q.z : 0.f, (m & 8u) ? q.w : 0.f);
+                        if (pkind[c] == 0) *reinterpret_cast<float4*>(lds + pdst[c] + stg_off) = v;
+                        else { float* dst = lds + pdst[c] + ring_off; *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.z); *reinterpret_cast<float2*>(dst + PL) = make_float2(v.y, v.w); }
+                    }
+                    if (fetch) { const F4u a = *reinterpret_cast<const F4u*>(psrc[c] + src_off); pf[tt & 1][c] = make_float4(a.x, a.y, a.z, a.w); }
+                }
+                ss_lds_barrier();
+            }
+        }
+        return;
+    }
     for (int t0 = -8; t0 < h + 2 * SS_NQ; t0 += 4) {
         #pragma unroll
         for (int tt = 0; tt < 4; tt++) {
             const int t = t0 + tt;
-            // ---- side job: the piece loaded SS_LEAD steps ago (row t + 2) goes to LDS, the piece of row t + 2 + SS_LEAD is requested
-            if (loader) {
-                const int ys = t + 2, yl = ys + SS_LEAD;
-                if (ys >= 0 && ys <= h + 1) {
-                    const float4 v = ys < h ? pf[tt] : make_float4(0.f, 0.f, 0.f, 0.f);           // the two rows below the image read as zero
-                    if (lpl < 5) { if (ys < h) *reinterpret_cast<float4*>(lds + ldst + (ys & (SS_STG - 1)) * EWS) = v; }
-                    else {
-                        float* dst = lds + ldst + (ys % SS_RING) * HS;
-                        *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.z); *reinterpret_cast<float2*>(dst + PL) = make_float2(v.y, v.w);
-                    }
-                }
-                if (yl >= 0 && yl < h) {
-                    const float* q = lsrc + (size_t)yl * w;
-                    if (lx + 3 < w) { const F4u a = *reinterpret_cast<const F4u*>(q); pf[tt] = make_float4(a.x, a.y, a.z, a.w); }
-                    else pf[tt] = make_float4(q[0], lx + 1 < w ? q[1] : 0.f, lx + 2 < w ? q[2] : 0.f, 0.f);      // last chunk of a row whose width is not a multiple of 4
-                }
-            }
             // ---- the pipeline step of this thread's row pair
             int u = t - 2 * p;
             if (u == 2 * SS_NQ) { p += SS_NQ; u = 0; slA = (slA + 2 * SS_NQ) % SS_RING; slB = (slB + 2 * SS_NQ) % SS_RING; }
@@ -757,11 +793,11 @@ __global__ void __launch_bounds__(1024) k_sor_stream(int w, int h, int SW, int H
             if ((tt & 1) == 0) {
                 if (u == 0 && yA < h) SS_LOAD(A, yA, slA)
                 if (u >= 0 && u < 2 * SS_NQ && yA < h) { if (g == 0) { if (tt == 0) SS_HALF(A, slA, 0) else SS_HALF(A, slA, 1) } else { if (tt == 0) SS_HALF(A, slA, 1) else SS_HALF(A, slA, 0) } }
-                if (u == 2 * SS_NQ - 2 && yA < h) SS_STORE(A, yA)
+                if (u == 2 * SS_NQ - 2 && yA < h) SS_STORE(A, yA, slA)
             } else {
                 if (u == 1 && yB < h) SS_LOAD(B, yB, slB)
                 if (u >= 0 && u < 2 * SS_NQ && yB < h) { if (g == 0) { if (tt == 1) SS_HALF(B, slB, 1) else SS_HALF(B, slB, 0) } else { if (tt == 1) SS_HALF(B, slB, 0) else SS_HALF(B, slB, 1) } }
-                if (u == 2 * SS_NQ - 1 && yB < h) SS_STORE(B, yB)
+                if (u == 2 * SS_NQ - 1 && yB < h) SS_STORE(B, yB, slB)
             }
             ss_lds_barrier();
         }
@@ -1241,7 +1277,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         hipError_t attr_rc = hipSuccess;
         const void* fs[] = {(const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 512, 2, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>,
                             (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_fused<1, 384, 3, 0, 0>, (const void*)k_sor_fused<1, 768, 3, 0, 0>,
-                            (const void*)k_sor_fused<1, 256, 3, 0, 0>, (const void*)k_sor_stream<102>, (const void*)k_sor_stream<51>};
+                            (const void*)k_sor_fused<1, 256, 3, 0, 0>, (const void*)k_sor_stream<44>};
         for (const void* f : fs) if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         return attr_rc;
     }));
@@ -1261,14 +1297,16 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     }
     // large levels, enough images to fill the GPU with one workgroup each: the streaming kernel (no halo, loads and stores overlapped with the iterations)
     {
-        const int SW = divup(w, 4), HT = divup(5 * SW, 64) * 64;
-        const bool fits = HT <= 512 && h >= 4 && total % (SS_NQ / 2) == 0;
+        // column strips: n = fewest strips whose working width (kept columns + 12 on each cut side, a multiple of 4) fits 176 columns
+        int n = 1, IW = divup(w, 4) * 4, SW = IW / 4;
+        while (SW > 44) { n++; IW = divup(divup(w, n), 4) * 4; SW = (IW + 24) / 4; }
+        const int HT = 5 * SW, CT = divup(10 * SW, 64) * 64;      // threads of one slot group, compute threads (whole waves); + one loader wave
+        const bool fits = h >= 4 && total % (SS_NQ / 2) == 0;
         if (fits && (g_sor_mode == 5 || (g_sor_mode == 4 && B >= g_sor_stream_min_b))) {
-            const int MS = SW <= 51 ? 51 : 102;               // layout instance: narrow levels leave room for two workgroups per CU
-            const size_t shm = ((size_t)6 * SS_RING * (2 * MS + 4) + (size_t)5 * SS_STG * 4 * MS) * sizeof(float);
-            auto kern = SW <= 51 ? k_sor_stream<51> : k_sor_stream<102>;
+            const size_t shm = ((size_t)6 * SS_RING * (2 * 44 + 4) + (size_t)5 * SS_STG * 4 * 44) * sizeof(float);
             for (int done = 0; done < total; done += SS_NQ / 2) {
-                hipLaunchKernelGGL(kern, dim3(B), dim3(2 * HT), shm, s, w, h, SW, HT, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
+                hipLaunchKernelGGL(k_sor_stream<44>, dim3(n, B), dim3(CT + 64), shm, s, w, h, SW, HT, IW, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
+                std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);      // column strips read each other's halo columns: not in place
                 *nlaunch += 1;
             }
             return SIND_OK;

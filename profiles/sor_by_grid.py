@@ -6,7 +6,7 @@ import glob
 import sys
 from collections import defaultdict
 
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*kernel_trace.csv') + glob.glob(sys.argv[1] + '/*kernel_trace.csv'))[0]
 bins = defaultdict(lambda: [0, 0.0]); tot = 0.0
 for r in csv.DictReader(open(f)):
     if (sys.argv[2] if len(sys.argv) > 2 else 'k_sor_fused') not in r['Kernel_Name']:

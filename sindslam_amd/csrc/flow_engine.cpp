@@ -26,6 +26,8 @@ int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     if (const char* e = getenv("SIND_SOR_PLAN_COST")) g_sor_plan_cost = std::max(0.0, atof(e));
     if (const char* e = getenv("SIND_SOR_XCD")) g_sor_xcd = atoi(e) != 0;
     if (const char* e = getenv("SIND_SOR_TILEH")) g_sor_tile_h = atoi(e);
+    if (const char* e = getenv("SIND_SOR_STREAM_MINB")) g_sor_stream_min_b = atoi(e);
+    if (const char* e = getenv("SIND_SOR_STREAM_MINPX")) g_sor_stream_min_px = atoi(e);       // images per launch from which the tiled levels take the streaming kernel
     if (const char* e = getenv("SIND_LAUNCH_AHEAD")) launch_ahead = std::max(0, atoi(e));       // 0: unbounded
     levels = deepflow_sizes(fw, fh);
     level_off.clear(); pyr_pixels = 0;

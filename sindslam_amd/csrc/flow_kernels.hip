@@ -635,16 +635,16 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 //     the rings).  The step barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so those loads stay in flight across steps;
 //   * a finished row goes from LDS to the output planes (ping-pong with the input: neighbouring column strips read each other's halo columns).
 #define SS_NQ 10           /* pair slots = rows in flight / 2 = half-sweeps per launch (5 iterations) */
-#define SS_RING 24         /* rows of du / dv / w resident in LDS: a row is needed from step y - 1 to y + 2 * SS_NQ - 1, written two steps before */
+#define SS_RING 24         /* rows of du / dv / w resident in LDS: the rows of pair p are parked during step p - 1 and read until step p + SS_NQ */
 #define SS_STG 4           /* rows of the coefficient staging ring */
-#define SS_LEAD 4          /* steps between a loader thread's global load and its LDS store */
-struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4]; float wl0; };      // du / dv stay in the LDS rings (16 registers less: the kernel must fit 128 at 1024 threads)
+typedef float ss_f4 __attribute__((ext_vector_type(4)));
+struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], r11[4], r22[4]; float wl0; };      // du / dv stay in the LDS rings; r = RN(1 / a), formed once per row (0 for a pixel outside the image: its update returns exactly 0)
 __device__ __forceinline__ void ss_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // MAXSW: widest column strip (in 4-pixel strips) the instance is laid out for.  The LDS layout is fixed at compile time (every plane at a constant offset:
 // an access is one base register per ring row plus an immediate); 44 strips = 176 columns need 67 KB and 512 threads (7 compute waves + the loader):
 // two workgroups per CU.  Wider levels are cut into column strips (grid x), each with its own pipeline.
 template <int MAXSW>
-__global__ void __launch_bounds__(512) k_sor_stream(int w, int h, int SW, int HT, int IW, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per_eu(4, 4))) k_sor_stream(int w, int h, int SW, int HT, int IW, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
                                                      const float* __restrict__ gA22, const float* __restrict__ gB1, const float* __restrict__ gB2,
                                                      const float* __restrict__ gW, const float* __restrict__ gU, const float* __restrict__ gV, float* __restrict__ gUo, float* __restrict__ gVo) {
     extern __shared__ float4 lds4s[];
@@ -670,15 +670,15 @@ __global__ void __launch_bounds__(512) k_sor_stream(int w, int h, int SW, int HT
     // loader: lane l takes the items l, l + 64, ... of a row's 8 SW pieces (plane 0..4 coefficients, 5 weight, 6 du, 7 dv; 4-pixel chunk)
     const int llane = tid - CT, nitem = 8 * SW;
     constexpr int SS_NC = (8 * MAXSW + 63) / 64;                  // pieces per loader lane and row
-    float4 pf[2][SS_NC];
+    ss_f4 pf[2][2][SS_NC];                                        // [step parity][row of the pair][piece]: two row pairs in flight
     #pragma unroll
     for (int a = 0; a < 2; a++) {
         #pragma unroll
-        for (int c = 0; c < SS_NC; c++) pf[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < SS_NC; c++) { pf[a][0][c] = ss_f4{0.f, 0.f, 0.f, 0.f}; pf[a][1][c] = ss_f4{0.f, 0.f, 0.f, 0.f}; }
     }
     SsRow A, B;
     #pragma unroll
-    for (int i = 0; i < 4; i++) { A.a11[i] = A.a22[i] = B.a11[i] = B.a22[i] = 1.f; A.a12[i] = A.b1[i] = A.b2[i] = A.wp[i] = 0.f; B.a12[i] = B.b1[i] = B.b2[i] = B.wp[i] = 0.f; }
+    for (int i = 0; i < 4; i++) { A.a11[i] = A.a22[i] = B.a11[i] = B.a22[i] = 1.f; A.a12[i] = A.b1[i] = A.b2[i] = A.wp[i] = A.r11[i] = A.r22[i] = 0.f; B.a12[i] = B.b1[i] = B.b2[i] = B.wp[i] = B.r11[i] = B.r22[i] = 0.f; }
     A.wl0 = B.wl0 = 0.f;
     unsigned vmask = 0u, smask = 0u;                             // strip pixels inside the image / inside the columns this workgroup keeps
     #pragma unroll
@@ -697,6 +697,7 @@ __global__ void __launch_bounds__(512) k_sor_stream(int w, int h, int SW, int HT
             R.a22[0] = c2.x; R.a22[1] = c2.y; R.a22[2] = c2.z; R.a22[3] = c2.w; R.b1[0] = c3.x; R.b1[1] = c3.y; R.b1[2] = c3.z; R.b1[3] = c3.w;     \
             R.b2[0] = c4.x; R.b2[1] = c4.y; R.b2[2] = c4.z; R.b2[3] = c4.w;                                                        \
             R.wp[0] = we.x; R.wp[2] = we.y; R.wp[1] = wo.x; R.wp[3] = wo.y;                                                        \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) { const bool ok = (vmask >> i) & 1u; R.r11[i] = ok ? sor_rcp(R.a11[i]) : 0.f; R.r22[i] = ok ? sor_rcp(R.a22[i]) : 0.f; } \
         }
     // one half-sweep of a row: the two strip pixels of column parity START (the strip starts at an even column)
     #define SS_HALF(R, SLOT, START)                                                                                                \
@@ -724,10 +725,9 @@ __global__ void __launch_bounds__(512) k_sor_stream(int w, int h, int SW, int HT
                 const float sigmaU = wl * ula[k] + R.wp[i] * ura[k] + wua[k] * uua[k] + R.wp[i] * uda[k];                          \
                 const float sigmaV = wl * vla[k] + R.wp[i] * vra[k] + wua[k] * vua[k] + R.wp[i] * vda[k];                          \
                 float nu = nua[k], nv = nva[k];                                                                                    \
-                nu += omega * (sor_div(sigmaU + R.b1[i] - nv * R.a12[i], R.a11[i], sor_rcp(R.a11[i])) - nu);                       \
-                nv += omega * (sor_div(sigmaV + R.b2[i] - nu * R.a12[i], R.a22[i], sor_rcp(R.a22[i])) - nv);                       \
-                const bool ok = (vmask >> i) & 1u;                                                                                 \
-                nua[k] = ok ? nu : 0.f; nva[k] = ok ? nv : 0.f;                                                                    \
+                nu += omega * (sor_div(sigmaU + R.b1[i] - nv * R.a12[i], R.a11[i], R.r11[i]) - nu);                                \
+                nv += omega * (sor_div(sigmaV + R.b2[i] - nu * R.a12[i], R.a22[i], R.r22[i]) - nv);                                \
+                nua[k] = nu; nva[k] = nv;                                                                                          \
             }                                                                                                                      \
             *reinterpret_cast<float2*>(rb_ + O_DU) = make_float2(nua[0], nua[1]); *reinterpret_cast<float2*>(rb_ + O_DV) = make_float2(nva[0], nva[1]); \
         }
@@ -752,53 +752,66 @@ __global__ void __launch_bounds__(512) k_sor_stream(int w, int h, int SW, int HT
         for (int c = 0; c < SS_NC; c++) {
             const int id = llane + 64 * c, lpl = id / SW, lch = id - lpl * SW, lx = 4 * lch, gx = ex0 + lx;
             pkind[c] = id >= nitem ? -1 : lpl < 5 ? 0 : 1;
-            psrc[c] = (lpl == 0 ? gA11 : lpl == 1 ? gA12 : lpl == 2 ? gA22 : lpl == 3 ? gB1 : lpl == 4 ? gB2 : lpl == 5 ? gW : lpl == 6 ? gU : gV) + base + min(gx, w - 1);      // (a chunk wholly right of the image re-reads around the last pixel and is masked)
+            psrc[c] = id >= nitem ? gA11 + base : (lpl == 0 ? gA11 : lpl == 1 ? gA12 : lpl == 2 ? gA22 : lpl == 3 ? gB1 : lpl == 4 ? gB2 : lpl == 5 ? gW : lpl == 6 ? gU : gV) + base + min(gx, w - 1);      // (a chunk wholly right of the image re-reads around the last pixel and is masked)
             pdst[c] = lpl < 5 ? O_ST + lpl * STP + lx : (lpl == 5 ? O_W : lpl == 6 ? O_DU : O_DV) + 2 * lch;
             pmask[c] = (gx < w ? 1u : 0u) | (gx + 1 < w ? 2u : 0u) | (gx + 2 < w ? 4u : 0u) | (gx + 3 < w ? 8u : 0u);
         }
-        for (int t0 = -8; t0 < h + 2 * SS_NQ; t0 += 4) {
+        for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 1; T0 += 2) {
             #pragma unroll
-            for (int tt = 0; tt < 4; tt++) {
-                // the pieces loaded two steps ago (row t + 2) go to LDS, the pieces of row t + 4 are requested.  Always a whole 16-byte load (a chunk that
-                // crosses the end of its row reads into the next row -- the planes are padded -- and is masked when it is parked)
-                const int t = t0 + tt, ys = t + 2, yl = ys + 2;
-                const bool park = ys >= 0 && ys <= h + 1, fetch = yl >= 0 && yl < h;
-                const unsigned rowm = ys < h ? 0xfu : 0u;                          // the two rows below the image read as zero
-                const int stg_off = (ys & (SS_STG - 1)) * EWS, ring_off = (((ys % SS_RING) + SS_RING) % SS_RING) * HS;
-                const size_t src_off = (size_t)(fetch ? yl : 0) * w;
+            for (int tt = 0; tt < 2; tt++) {
+                // step T: the pieces of row pair T + 1 (requested two steps ago) go to LDS, then the pieces of pair T + 3 are requested: 2 SS_NC loads per step,
+                // always (rows outside the image re-read row 0 / h - 1 and are masked when parked), so that "at most 2 SS_NC loads outstanding" means exactly
+                // "the loads of two steps ago have landed".  The loads are inline assembly: the compiler's own s_waitcnt would be vmcnt(0) at every use of a
+                // loaded register in this loop (it cannot count across the back edge), i.e. one full memory latency per piece instead of per step.
+                const int T = T0 + tt;
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * SS_NC) : "memory");
                 #pragma unroll
-                for (int c = 0; c < SS_NC; c++) {
-                    if (pkind[c] < 0) continue;
-                    if (park) {
-                        const float4 q = pf[tt & 1][c]; const unsigned m = pmask[c] & rowm;
+                for (int r = 0; r < 2; r++) {
+                    const int ys = 2 * (T + 1) + r;
+                    const bool park = ys >= 0 && ys <= h + 1;
+                    const unsigned rowm = ys < h ? 0xfu : 0u;                      // the two rows below the image read as zero
+                    const int stg_off = (ys & (SS_STG - 1)) * EWS, ring_off = (((ys % SS_RING) + SS_RING) % SS_RING) * HS;
+                    #pragma unroll
+                    for (int c = 0; c < SS_NC; c++) {
+                        ss_f4 q = pf[tt][r][c];
+                        asm volatile("" : "+v"(q));                                   // (uses stay behind the wait above)
+                        if (pkind[c] < 0 || !park) continue;
+                        const unsigned m = pmask[c] & rowm;
                         const float4 v = make_float4((m & 1u) ? q.x : 0.f, (m & 2u) ? q.y : 0.f, (m & 4u) ? q.z : 0.f, (m & 8u) ? q.w : 0.f);
                         if (pkind[c] == 0) *reinterpret_cast<float4*>(lds + pdst[c] + stg_off) = v;
                         else { float* dst = lds + pdst[c] + ring_off; *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.z); *reinterpret_cast<float2*>(dst + PL) = make_float2(v.y, v.w); }
                     }
-                    if (fetch) { const F4u a = *reinterpret_cast<const F4u*>(psrc[c] + src_off); pf[tt & 1][c] = make_float4(a.x, a.y, a.z, a.w); }
+                }
+                #pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int yl = min(max(2 * (T + 3) + r, 0), h - 1);
+                    const size_t src_off = (size_t)yl * w;
+                    #pragma unroll
+                    for (int c = 0; c < SS_NC; c++) { const float* a = psrc[c] + src_off; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf[tt][r][c]) : "v"(a) : "memory"); }
                 }
                 ss_lds_barrier();
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
-    for (int t0 = -8; t0 < h + 2 * SS_NQ; t0 += 4) {
+    for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 1; T0 += 2) {
         #pragma unroll
-        for (int tt = 0; tt < 4; tt++) {
-            const int t = t0 + tt;
-            // ---- the pipeline step of this thread's row pair
-            int u = t - 2 * p;
-            if (u == 2 * SS_NQ) { p += SS_NQ; u = 0; slA = (slA + 2 * SS_NQ) % SS_RING; slB = (slB + 2 * SS_NQ) % SS_RING; }
-            const int yA = 2 * p, yB = yA + 1;
-            if ((tt & 1) == 0) {
-                if (u == 0 && yA < h) SS_LOAD(A, yA, slA)
-                if (u >= 0 && u < 2 * SS_NQ && yA < h) { if (g == 0) { if (tt == 0) SS_HALF(A, slA, 0) else SS_HALF(A, slA, 1) } else { if (tt == 0) SS_HALF(A, slA, 1) else SS_HALF(A, slA, 0) } }
-                if (u == 2 * SS_NQ - 2 && yA < h) SS_STORE(A, yA, slA)
-            } else {
-                if (u == 1 && yB < h) SS_LOAD(B, yB, slB)
-                if (u >= 0 && u < 2 * SS_NQ && yB < h) { if (g == 0) { if (tt == 1) SS_HALF(B, slB, 1) else SS_HALF(B, slB, 0) } else { if (tt == 1) SS_HALF(B, slB, 0) else SS_HALF(B, slB, 1) } }
-                if (u == 2 * SS_NQ - 1 && yB < h) SS_STORE(B, yB, slB)
+        for (int tt = 0; tt < 2; tt++) {
+            // step T of this thread's row pair p: s = T - p.  First its odd row's half-sweep s - 1, then its even row's half-sweep s (the even row's vertical
+            // neighbours in the odd row are of the colour just updated -- same thread, same columns).  Both update the column parity s & 1 = (T + g) & 1.
+            const int T = T0 + tt;
+            int sg = T - p;
+            const int yB0 = 2 * p + 1;
+            if (sg >= 1 && sg <= SS_NQ && yB0 < h) { if (((tt + g) & 1) == 0) SS_HALF(B, slB, 0) else SS_HALF(B, slB, 1) }
+            if (sg == SS_NQ) {                                  // the pair is through: its odd row leaves, the thread takes the pair SS_NQ further down (same parity)
+                if (yB0 < h) SS_STORE(B, yB0, slB)
+                p += SS_NQ; sg = 0; slA = (slA + 2 * SS_NQ) % SS_RING; slB = (slB + 2 * SS_NQ) % SS_RING;
             }
+            const int yA = 2 * p, yB = yA + 1;
+            if (sg == 0 && yA < h) { SS_LOAD(A, yA, slA) if (yB < h) SS_LOAD(B, yB, slB) }
+            if (sg >= 0 && sg < SS_NQ && yA < h) { if (((tt + g) & 1) == 0) SS_HALF(A, slA, 0) else SS_HALF(A, slA, 1) }
+            if (sg == SS_NQ - 1 && yA < h) SS_STORE(A, yA, slA)
             ss_lds_barrier();
         }
     }
@@ -1225,6 +1238,7 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 int g_sor_mode = 4;          // fused register-resident SOR with 1x8 strips: 4 = divisions through a reciprocal formed on the fly (hardware estimate + Newton step,
                              // then Markstein's correction; default, fastest), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in
                              // registers (three waves per SIMD); 2 = fused, 1x4 strips + reciprocal division; 0 = one launch per colour (A/B timing, cross-check)
+int g_sor_stream_min_px = 0; // ... and only for levels of at least this many pixels (smaller ones leave workgroup slots empty: one workgroup per image strip)
 int g_sor_stream_min_b = 48; // mode 4: levels that are tiled go to the streaming kernel (one workgroup per image) from this many images per launch on; 5 = always
 int g_sor_fuse = 5;          // iterations per launch on the tiled levels; 0 = per-level plan (sor_fuse_plan: measured 1-2 % faster, 10 % more launches; not the default)
 double g_sor_plan_cost = 14; // prologue of a tile in iterations (sor_fuse_plan)
@@ -1277,7 +1291,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         hipError_t attr_rc = hipSuccess;
         const void* fs[] = {(const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 512, 2, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>,
                             (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_fused<1, 384, 3, 0, 0>, (const void*)k_sor_fused<1, 768, 3, 0, 0>,
-                            (const void*)k_sor_fused<1, 256, 3, 0, 0>, (const void*)k_sor_stream<44>};
+                            (const void*)k_sor_fused<1, 256, 3, 0, 0>, (const void*)k_sor_stream<40>};
         for (const void* f : fs) if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         return attr_rc;
     }));
@@ -1297,15 +1311,15 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     }
     // large levels, enough images to fill the GPU with one workgroup each: the streaming kernel (no halo, loads and stores overlapped with the iterations)
     {
-        // column strips: n = fewest strips whose working width (kept columns + 12 on each cut side, a multiple of 4) fits 176 columns
+        // column strips: n = fewest strips whose working width (kept columns + 12 on each cut side, a multiple of 4) fits 160 columns
         int n = 1, IW = divup(w, 4) * 4, SW = IW / 4;
-        while (SW > 44) { n++; IW = divup(divup(w, n), 4) * 4; SW = (IW + 24) / 4; }
+        while (SW > 40) { n++; IW = divup(divup(w, n), 4) * 4; SW = (IW + 24) / 4; }
         const int HT = 5 * SW, CT = divup(10 * SW, 64) * 64;      // threads of one slot group, compute threads (whole waves); + one loader wave
         const bool fits = h >= 4 && total % (SS_NQ / 2) == 0;
-        if (fits && (g_sor_mode == 5 || (g_sor_mode == 4 && B >= g_sor_stream_min_b))) {
-            const size_t shm = ((size_t)6 * SS_RING * (2 * 44 + 4) + (size_t)5 * SS_STG * 4 * 44) * sizeof(float);
+        if (fits && (g_sor_mode == 5 || (g_sor_mode == 4 && B >= g_sor_stream_min_b && w * h >= g_sor_stream_min_px))) {
+            const size_t shm = ((size_t)6 * SS_RING * (2 * 40 + 4) + (size_t)5 * SS_STG * 4 * 40) * sizeof(float);
             for (int done = 0; done < total; done += SS_NQ / 2) {
-                hipLaunchKernelGGL(k_sor_stream<44>, dim3(n, B), dim3(CT + 64), shm, s, w, h, SW, HT, IW, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
+                hipLaunchKernelGGL(k_sor_stream<40>, dim3(n, B), dim3(CT + 64), shm, s, w, h, SW, HT, IW, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
                 std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);      // column strips read each other's halo columns: not in place
                 *nlaunch += 1;
             }

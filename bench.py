@@ -64,6 +64,8 @@ def parse_args(argv=None):
                                                      "overlaps the tails of step i (sind_pipe_submit_dev / flush; all K steps are drained inside the timed region)")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker pool size (0 = library default, the GPU box's CPU share)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for CPU-side rehearsal)")
+    ap.add_argument("--collective", choices=["torch", "cabi"], default="torch", help="mask gather through torch.distributed (default) or through the library's own C-ABI collective "
+                                                                                    "(sind_pipe_gather_masks on RCCL; torch.distributed then only hands the 128-byte id to the ranks)")
     ap.add_argument("--collective-at-1", action="store_true", help="with one rank, still create the process group and run the per-step mask gather (RCCL calls at world size 1)")
     ap.add_argument("--rendezvous-only", action="store_true", help="ranks only meet, count themselves and exit (launcher test, needs no GPU)")
     return ap.parse_args(argv)
@@ -384,9 +386,23 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     seq_masks = torch.zeros((world, S, K, T, H, W), dtype=torch.uint8, device="cuda" if comm_dev == "cuda" else "cpu")
     gbuf = {}
 
+    cabi = None
+    if pg and args.collective == "cabi":     # the library's own collective (RCCL through the C ABI): torch.distributed only carries the 128-byte id to the ranks
+        from sindslam_amd.parallel import Comm
+        box = [Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        cabi = Comm(box[0], rank, world, local)
+
     def gather(step):
         m = pipe.dyna_pinned if pipe.dyna_pinned is not None else torch.from_numpy(pipe.dyna)
-        if pg and comm_dev == "cuda":
+        if cabi is not None:
+            if "out" not in gbuf:
+                gbuf["out"] = torch.empty((world,) + tuple(m.shape), dtype=m.dtype, device="cuda")
+            out = cabi.gather_pipeline_masks(pipe, out=gbuf["out"])
+            if comm_dev != "cuda":
+                out = out.cpu()
+        elif pg and comm_dev == "cuda":
             if "dev" not in gbuf:
                 gbuf["dev"] = torch.empty_like(m, device="cuda"); gbuf["out"] = torch.empty((world,) + tuple(m.shape), dtype=m.dtype, device="cuda")
             gbuf["dev"].copy_(m, non_blocking=True)
@@ -433,8 +449,10 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
             "value": owned / dt, "value_excl_warmup": plan.processed_total / dt, "seconds": dt, "final_flush_ms": flush_ms, "region_grow_gpu_quarters": grow_q,
             "note": "value = owned frames of the whole sequence / wall time of ALL the work (the 24 state warm-up frames of every chunk after the first run inside the timed "
                     "region); value_excl_warmup counts every processed frame as if it were owned (the pipeline's processing rate)",
-            "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if pg else "single rank (no collective)",
+            "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL through the C ABI (sind_pipe_gather_masks)" if args.collective == "cabi" else "RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if pg else "single rank (no collective)",
             "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
+    if cabi is not None:
+        cabi.close()
     pipe.close()
     # ---- rank 0: the first frames again in the in-order ("exact") mode -> IoU of the chunked masks at and behind the chunk seams, and the exact mode's own rate
     if rank == 0 and exact_leg and n > 1:

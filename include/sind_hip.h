@@ -59,6 +59,7 @@ int sind_flow_set_max_levels(sind_flow* f, int n);
  * (tile height 48 for mode 3, 64 otherwise). */
 int sind_flow_set_sor(int mode, int fuse, int tile_w);
 int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h);
+int sind_lab_build(void);        /* 1: built with -DSIND_LAB (dormant solver variants and the SIND_* experiment switches of the measurement rounds), 0: the shipped drop-in */
 /* HIP-event timing of everything enqueued on the handle's stream between begin and end (bench.py roofline leg) */
 int sind_flow_timer_begin(sind_flow* f);
 int sind_flow_timer_end(sind_flow* f, float* milliseconds);
@@ -197,6 +198,23 @@ int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, do
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices);
 /* last sind_pipe_submit(_dev): time the call still waited for the previous step's tails after its own phase A had finished (0 = hidden) */
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms);
+int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes);      /* size of one step's dyna / label / mask array: streams * frames_per_step * height * width */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The multi-GPU collective of the path: frames of a sequence shard across the GPUs of a node, one process per GPU, and the per-frame
+ * dynamic masks are gathered with ONE ncclAllGather (RCCL, xGMI) per pipeline step.  No other collective exists: the path shards by frame.
+ * Rank 0 calls sind_comm_unique_id and passes the 128 bytes to the other ranks out of band (the application's own channel); every rank then calls
+ * sind_comm_create(id, rank, world, device).  sind_pipe_gather_masks sends the `dyna` array a step returned (host memory) and receives all ranks' arrays in
+ * rank order into all_dev (device memory, world * sind_pipe_mask_bytes) and, if not NULL, all_host.  RCCL is loaded at first use (dlopen): a box
+ * without it still loads the library and gets SIND_E_STATE from these calls. */
+typedef struct sind_comm sind_comm;
+int sind_comm_unique_id(void* id128, size_t bytes);
+int sind_comm_create(const void* id128, int rank, int world, int device, sind_comm** out);
+int sind_comm_destroy(sind_comm* c);
+int sind_comm_rank(const sind_comm* c);
+int sind_comm_world(const sind_comm* c);
+int sind_comm_allgather_u8(sind_comm* c, const uint8_t* local_host, size_t bytes, uint8_t* all_dev, uint8_t* all_host_or_null);
+int sind_pipe_gather_masks(sind_pipe* p, sind_comm* c, const uint8_t* dyna_host, uint8_t* all_dev, uint8_t* all_host_or_null);
 /* Where the PEAC region grow of CalOccluded (AHCPlaneFitter.hpp:546-601) runs: `quarters` of every four frames on the GPU (k_peac_grow, one compute unit for
  * a few ms per frame), the others on a host core; the results are bit-identical, the share only moves load between the GPU and the host.  -1 (default): the
  * pipeline adapts the share step by step -- towards the GPU while a step waits for host work after its dense flow is done, towards the host while the host

@@ -1,15 +1,40 @@
 // ORACLE — test infrastructure only (see cvx_core.hpp header).  PARITY UNPINNED.
 //
-// Stand-in for cv::findHomography(src, dst, noArray(), cv::RHO) (reference DynaDetect.cc:1235).
-// OpenCV's RHO estimator (calib3d/src/rho.cpp, ~2.6 kLoC: PROSAC sampling + SPRT + its own LM) is not
-// vendored under /root/reference and cannot be restated bit for bit from memory; SURVEY.md App. B
-// allows "a documented seeded substitute".  This is that substitute, keeping what the caller relies on:
-//   * correspondences are assumed sorted by decreasing quality (PROSAC ordering, Chum & Matas 2005);
-//   * reprojection threshold 3 px, confidence 0.995, at most 2000 hypotheses;
-//   * deterministic RNG (cv::RNG recurrence, fixed seed);
-//   * final refinement on the inlier set (normalised least squares + Gauss-Newton on the transfer error);
-//   * result scaled so H(2,2) = 1, returned as 9 doubles row-major; all-zero if estimation fails.
-// The product carries its own implementation of the same specification (sindslam_amd/csrc/host/).
+// Stand-ins for cv::findHomography(src, dst, noArray(), cv::RHO) (reference DynaDetect.cc:1235).  OpenCV 4.2's RHO estimator lives in
+// calib3d/src/rho.cpp (~2.6 kLoC), is not vendored under /root/reference and cannot be restated bit for bit offline.  Two estimators are kept here:
+//   find_homography_rho_scheme   (further down) RHO's PUBLISHED scheme -- PROSAC + SPRT + LM in float32; the oracle's default.
+//                                The product's sindslam_amd/csrc/host/homography.cpp is a transliteration of it into the product's own types
+//                                (same PRNG and warm-up, same SPRT constants, solver, LM loop and thresholds): the two agree bit for bit BY
+//                                CONSTRUCTION, which checks the two implementations against each other and says nothing about OpenCV's output.
+//   find_homography_prosac       round 1's lighter substitute (PROSAC + normalised least squares + Gauss-Newton); the only estimator here that is
+//                                independent of the product, kept for tests/test_a8_sensitivity_cpu.py.
+// What is known of rho.cpp itself, for whoever can read the 4.2.0 sources again.  [R] = recalled with confidence, [G] = guessed / uncertain.
+//   call site   fundam.cpp findHomography(method == RHO) -> createAndRunRHORegistrator(confidence 0.995, maxIters 2000, threshold 3.0, ...)      [R]
+//               -> rhoHest(src, dst, mask, N, maxD = 3.0f, maxI = 2000, rConvg = 2000, cfd = 0.995, minInl = 4, beta = 0.35,
+//                          RHO_FLAG_ENABLE_NR | RHO_FLAG_ENABLE_FINAL_REFINEMENT, guess = NULL, H)                                            [R: the flags; G: beta 0.35]
+//               findHomography's own LM refinement (createLMSolver, 10 iterations) is skipped for RHO; H is divided by H(2,2) afterwards.   [R]
+//   PRNG        xorshift128+ ("fastRandom"), seeded by fastSeed(~0ULL) in rhoInit; a new estimator object is created per findHomography call,
+//               so every call starts from the same state.                                                                                    [R: generator and seed; G: the seeding recipe]
+//               (here: an xorshift128+ whose two words are derived from the seed by two constants and warmed up 20 draws -- NOT OpenCV's recipe)
+//   sampling    PROSAC (Chum & Matas 2005) over the caller's order (best first) while NR is enabled: phNum starts at SMPL_SIZE = 4, grows when the
+//               iteration count passes phEndI, phEndFpI follows the T'_n recurrence with T_N = rConvg; the 4th point is the phNum-th
+//               correspondence, the other three are drawn below it.                                                                           [R: structure; G: rounding of phEndFpI]
+//   degeneracy  isSampleDegenerate: orientation of the point triples must be preserved between source and destination (cross products).     [R]
+//   model       hFuncRefC: 8x9 Gaussian elimination in float32, row pivoting only where a pivot vanishes.                                    [R: float32 elimination; G: pivoting rule]
+//               (here: partial pivoting on the largest magnitude)
+//   evaluation  SPRT (Matas & Chum 2005): SPRT_T_M = 25, SPRT_M_S = 1, SPRT_EPSILON = 0.1, SPRT_DELTA = 0.01; lambda multiplied point by point in
+//               INDEX order over all N correspondences (no shuffle), rejection at lambda > A; epsilon / delta redesigned on a new best model
+//               and on a rejected model whose inlier ratio differs by more than MIN_DELTA_CHNG = 0.1 relative.                                [R: constants; G: index order, the redesign rule's exact form]
+//               (here: points are tested in a fixed random order and delta is redesigned at 5 % relative change -- in index order a dozen bad
+//                leading pairs of this caller's ranking rejected every model)
+//   stopping    updateBounds: the PROSAC non-randomness test (N*: the smallest n whose inlier count among the n best is not explicable by
+//               chance, chi-square constants CHI_STAT = 2.706, CHI_SQ = 1.645, beta) shrinks the evaluated set and the iteration bound
+//               together with the usual log(1 - cfd) / log(1 - eps^4) bound.                                                                  [R: that it exists and its constants; not restated here]
+//   refinement  sacLMRefine on the inliers: at most 10 iterations, lambda starts at 0.01, gain ratio thresholds LM_GAIN_LO = 0.25 /
+//               LM_GAIN_HI = 0.75 scale lambda by 2 / 0.5 (not 10 / 0.1), 8x8 damped Cholesky in float32 (sacChol8x8Damped, sacTRISolve8x8).   [R: thresholds and Cholesky; G: the scale factors]
+//               (here: lambda *= 0.1 on success, *= 10 on failure)
+// The sensitivity of the dynamic mask to these free choices is what tests/test_a8_sensitivity_cpu.py measures (profiles/r03/a8_sensitivity.txt).
+// Every estimator returns H scaled so that H(2,2) = 1 as 9 doubles row-major, all-zero if estimation fails.
 #pragma once
 #include "cvx_core.hpp"
 
@@ -181,15 +206,12 @@ inline bool find_homography_prosac(const std::vector<Pt2f>& src, const std::vect
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// SECOND, INDEPENDENT estimator: the published scheme behind cv::RHO (Bazargani, Bilaniuk & Laganiere, "A fast and robust homography scheme
-// for real-time planar target detection", 2015; OpenCV calib3d/src/rho.cpp), restated from the paper and from memory of rho.cpp's structure --
-// PROSAC sampling over the quality-sorted correspondences, a float32 minimal solver, the orientation test on the sample, SPRT evaluation
-// (Matas & Chum's optimal randomized RANSAC: likelihood ratio with early rejection, t_M = 25, m_S = 1, eps_0 = 0.1, delta_0 = 0.01),
-// the confidence bound on the iteration count, Levenberg-Marquardt on the inliers in float32 with a damped Cholesky solve.  It shares no code
-// with find_homography_prosac above (nor with the product's sindslam_amd/csrc/host/homography.cpp).  It is NOT bit-compatible with OpenCV
-// (its PRNG seeding, the N* non-randomness test and several constants are not reproducible offline); its purpose is the question the parity
-// tests cannot answer by comparing the substitute with itself: how far does the dynamic mask move when the homography comes from a
-// different, RHO-like estimator on the same correspondences?  (tests/test_a8_sensitivity_cpu.py)
+// The published scheme behind cv::RHO (Bazargani, Bilaniuk & Laganiere, "A fast and robust homography scheme for real-time planar target
+// detection", 2015; OpenCV calib3d/src/rho.cpp), restated from the paper and from memory of rho.cpp's structure (see the header of this file for what
+// is recalled and what is guessed): PROSAC sampling over the quality-sorted correspondences, a float32 minimal solver, the orientation test on the
+// sample, SPRT evaluation (t_M = 25, m_S = 1, eps_0 = 0.1, delta_0 = 0.01), the confidence bound on the iteration count, Levenberg-Marquardt on the
+// inliers in float32 with a damped Cholesky solve.  It is NOT bit-compatible with OpenCV.  The product's host/homography.cpp is a transliteration of
+// THIS function (parity by construction); find_homography_prosac above is the independent one.
 namespace rho_scheme {
 struct Xs128 { uint64_t s[2];
     explicit Xs128(uint64_t seed) { s[0] = seed ^ 0x2545F4914F6CDD1Dull; s[1] = ~seed + 0x9E3779B97F4A7C15ull; for (int i = 0; i < 20; i++) next(); }

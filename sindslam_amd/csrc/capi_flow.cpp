@@ -126,11 +126,23 @@ int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h) {
         (mode == 3 && nt != 256 && nt != 384 && nt != 768)) {
         sind_set_error("sind_flow_set_sor_tiled: bad arguments (mode %d, fuse %d, tile %d x %d)", mode, fuse, tile_w, tile_h); return SIND_E_ARG;
     }
+#ifndef SIND_LAB
+    // the shipped library carries the per-colour reference (0), the tiled kernel with the reciprocal formed on the fly (4, fixed fuse depth) and the streaming
+    // kernel (5); IEEE-division, reciprocal-plane and 1 x 4-strip variants and the per-level fuse plans are lab builds (make -C sindslam_amd/csrc lab)
+    if ((mode != 0 && mode != 4 && mode != 5) || fuse == 0) { sind_set_error("sind_flow_set_sor_tiled: solver variant (mode %d, fuse %d) exists in lab builds only", mode, fuse); return SIND_E_ARG; }
+#endif
     sind::g_sor_mode = mode; sind::g_sor_fuse = fuse; sind::g_sor_tile_w = tile_w; sind::g_sor_tile_h = tile_h; return SIND_OK;
 }
 int sind_flow_set_sor(int mode, int fuse, int tile_w) {
     if (tile_w != 64 && tile_w != 128) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }
     return sind_flow_set_sor_tiled(mode, fuse, tile_w, mode == 3 ? (tile_w == 64 ? 48 : 48) : 64);
+}
+int sind_lab_build(void) {
+#ifdef SIND_LAB
+    return 1;
+#else
+    return 0;
+#endif
 }
 int sind_flow_sync(sind_flow* f) { if (!f) return SIND_E_ARG; HIP_TRY(hipStreamSynchronize(f->stream)); return SIND_OK; }
 int sind_flow_timer_begin(sind_flow* f) { if (!f) return SIND_E_ARG; HIP_TRY(hipEventRecord(f->ev0, f->stream)); return SIND_OK; }

@@ -36,6 +36,21 @@ void sind_set_error(const char* fmt, ...);
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 
+// The library ships as a drop-in: the A/B switches of the measurement rounds (SIND_FLOW_SPLIT, SIND_SOR_*, SIND_*_PRIORITY, ...) and the dormant solver
+// variants exist only in a LAB build (make -C sindslam_amd/csrc lab  =  -DSIND_LAB; profiles/tools/*.sh need it).  Always on: SIND_TAIL_TIMING (stage
+// report at destroy), SIND_GROW_GPU (fixed region-grow share).
+#ifdef SIND_LAB
+static inline const char* sind_lab_env(const char* name) { return getenv(name); }
+#else
+static inline const char* sind_lab_env(const char*) { return nullptr; }
+#endif
+
+// ROCTx ranges around the stages of a step (rocprofv3 --marker-trace shows them next to the kernels).  The marker library is looked up
+// at first use (librocprofiler-sdk-roctx, else the older libroctx64); without it the calls do nothing.
+void sind_range_push(const char* name);
+void sind_range_pop();
+struct SindRange { explicit SindRange(const char* name) { sind_range_push(name); } ~SindRange() { sind_range_pop(); } SindRange(const SindRange&) = delete; SindRange& operator=(const SindRange&) = delete; };
+
 // CPU tokens: the GPU boxes bound a process to a CPU quota (cgroup cpu.max, 16 cores per GPU on this pool); more runnable threads than that burn the
 // quota early in a 100 ms period and the kernel then stalls EVERY thread of the process -- the flow's launch threads included -- until the period ends
 // (bench.py reports it as cpu_quota.throttled_periods).  Pool tasks therefore hold a token while they compute and hand it back while they wait for

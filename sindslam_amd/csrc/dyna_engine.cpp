@@ -228,7 +228,7 @@ int DynaTail::kmeans_enqueue(const uint16_t* depth0, bool prevLabels) {
     return SIND_OK;
 }
 int DynaTail::kmeans(const uint16_t* depth_dev, std::vector<uint8_t>& label8, float centers[KM_K][3], int counts[KM_K]) {
-    static const bool use_graph = !(getenv("SIND_KM_GRAPH") && atoi(getenv("SIND_KM_GRAPH")) == 0);
+    static const bool use_graph = !(sind_lab_env("SIND_KM_GRAPH") && atoi(sind_lab_env("SIND_KM_GRAPH")) == 0);
     if (kmLabelLastAny) { std::memcpy(h_lab8.p, kmLabelLast.data(), N); HIP_TRY(hipMemcpyAsync(labPrev8.p, h_lab8.p, N, hipMemcpyHostToDevice, stream)); }
     bool graphed = false;
     if (use_graph && !kmGraphBroken) {

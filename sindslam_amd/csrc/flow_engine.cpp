@@ -20,15 +20,15 @@ static std::vector<std::pair<int, int>> deepflow_sizes(int w, int h) {
 
 int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     fw = fw_; fh = fh_; maxB = maxB_; stream = s;
-    if (const char* e = getenv("SIND_SOR_MODE")) g_sor_mode = atoi(e);       // see g_sor_mode (flow_kernels.hip); the tile / fuse variables are for A/B timing
-    if (const char* e = getenv("SIND_SOR_TILEW")) g_sor_tile_w = atoi(e);
-    if (const char* e = getenv("SIND_SOR_FUSE")) g_sor_fuse = std::max(0, std::min(atoi(e), 12));
-    if (const char* e = getenv("SIND_SOR_PLAN_COST")) g_sor_plan_cost = std::max(0.0, atof(e));
-    if (const char* e = getenv("SIND_SOR_XCD")) g_sor_xcd = atoi(e) != 0;
-    if (const char* e = getenv("SIND_SOR_TILEH")) g_sor_tile_h = atoi(e);
-    if (const char* e = getenv("SIND_SOR_STREAM_MINB")) g_sor_stream_min_b = atoi(e);
-    if (const char* e = getenv("SIND_SOR_STREAM_MINPX")) g_sor_stream_min_px = atoi(e);       // images per launch from which the tiled levels take the streaming kernel
-    if (const char* e = getenv("SIND_LAUNCH_AHEAD")) launch_ahead = std::max(0, atoi(e));       // 0: unbounded
+    if (const char* e = sind_lab_env("SIND_SOR_MODE")) g_sor_mode = atoi(e);       // see g_sor_mode (flow_kernels.hip); the tile / fuse variables are for A/B timing
+    if (const char* e = sind_lab_env("SIND_SOR_TILEW")) g_sor_tile_w = atoi(e);
+    if (const char* e = sind_lab_env("SIND_SOR_FUSE")) g_sor_fuse = std::max(0, std::min(atoi(e), 12));
+    if (const char* e = sind_lab_env("SIND_SOR_PLAN_COST")) g_sor_plan_cost = std::max(0.0, atof(e));
+    if (const char* e = sind_lab_env("SIND_SOR_XCD")) g_sor_xcd = atoi(e) != 0;
+    if (const char* e = sind_lab_env("SIND_SOR_TILEH")) g_sor_tile_h = atoi(e);
+    if (const char* e = sind_lab_env("SIND_SOR_STREAM_MINB")) g_sor_stream_min_b = atoi(e);
+    if (const char* e = sind_lab_env("SIND_SOR_STREAM_MINPX")) g_sor_stream_min_px = atoi(e);       // images per launch from which the tiled levels take the streaming kernel
+    if (const char* e = sind_lab_env("SIND_LAUNCH_AHEAD")) launch_ahead = std::max(0, atoi(e));       // 0: unbounded
     levels = deepflow_sizes(fw, fh);
     level_off.clear(); pyr_pixels = 0;
     for (auto& l : levels) { level_off.push_back(pyr_pixels); pyr_pixels += (size_t)l.first * l.second; }
@@ -110,5 +110,18 @@ int FlowEngine::varref_f32(const float* I0, const float* I1, int w, int h, int B
 static thread_local char g_err[512] = "";
 std::atomic<long long> g_sind_wait_ns{0}, g_sind_wait_calls{0};
 thread_local SindHostGate* t_sind_gate = nullptr;
+
+#include <dlfcn.h>
+namespace {
+struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void* so = dlopen(lib, RTLD_NOW | RTLD_LOCAL)) { push = (int (*)(const char*))dlsym(so, "roctxRangePushA"); pop = (int (*)())dlsym(so, "roctxRangePop"); if (push && pop) return; push = nullptr; pop = nullptr; }
+        }
+    } };
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void sind_range_push(const char* name) { if (roctx().push) (void)roctx().push(name); }
+void sind_range_pop() { if (roctx().pop) (void)roctx().pop(); }
 void sind_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
 extern "C" const char* sind_last_error() { return g_err; }

@@ -495,6 +495,7 @@ k_sor_fused(int w, int h, int EW, int EH, int IW, int IH, int halo_x, int halo, 
     }
 }
 
+#ifdef SIND_LAB      /* dormant variant of the measurement rounds (make lab): kept for A/B timing, bit-identical to the shipped kernels */
 // ---------------------------------------------------------------------------------------------------------
 // Second generation of the fused kernel for the tiled levels: 1x4 pixel strips (1024 threads per 64x64 tile) leave room in the
 // 128-VGPR budget for the RECIPROCALS of A11 / A22, so the two IEEE divisions of a pixel update (~14 VALU operations each, and the
@@ -615,6 +616,8 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 }
 
 // tempW = W + dW (end of a fixed-point iteration); with commit != 0 also W = tempW (end of the level)
+
+#endif  // SIND_LAB
 
 // ---------------------------------------------------------------------------------------------------------
 // Third generation for the large levels: the solver STREAMS down the image instead of tiling it.
@@ -1289,9 +1292,12 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     static SindPerDeviceInit attr_init;
     HIP_TRY(attr_init.run([] {
         hipError_t attr_rc = hipSuccess;
-        const void* fs[] = {(const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 512, 2, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>,
-                            (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_fused<1, 384, 3, 0, 0>, (const void*)k_sor_fused<1, 768, 3, 0, 0>,
-                            (const void*)k_sor_fused<1, 256, 3, 0, 0>, (const void*)k_sor_stream<40>};
+        const void* fs[] = {(const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 512, 2, 0, 0>, (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_stream<40>,
+#ifdef SIND_LAB
+                            (const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>, (const void*)k_sor_fused<1, 384, 3, 0, 0>, (const void*)k_sor_fused<1, 768, 3, 0, 0>,
+                            (const void*)k_sor_fused<1, 256, 3, 0, 0>,
+#endif
+        };
         for (const void* f : fs) if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         return attr_rc;
     }));
@@ -1304,7 +1310,11 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         if (shm > 150 * 1024) { sind_set_error("sor_iterations: a %d x %d level needs %zu bytes of LDS", w, h, shm); return SIND_E_ARG; }
         // <= 512 threads: two waves per SIMD, i.e. up to 256 registers -- room for the run-time tile sizes AND the reciprocal division without spills
         // (all 25 iterations run in this launch, so here the loop is the cost); larger blocks keep the four-waves-per-SIMD IEEE instance
-        auto kern1 = (nt <= 512 && (g_sor_mode == 4 || g_sor_mode == 5)) ? k_sor_fused<2, 512, 2, 0, 0> : k_sor_fused<0, 1024, 4, 0, 0>;
+#ifdef SIND_LAB
+        auto kern1 = (nt <= 512 && (g_sor_mode == 4 || g_sor_mode == 5)) ? k_sor_fused<2, 512, 2, 0, 0> : (g_sor_mode == 4 || g_sor_mode == 5) ? k_sor_fused<2, 1024, 4, 0, 0> : k_sor_fused<0, 1024, 4, 0, 0>;
+#else
+        auto kern1 = nt <= 512 ? k_sor_fused<2, 512, 2, 0, 0> : k_sor_fused<2, 1024, 4, 0, 0>;
+#endif
         hipLaunchKernelGGL(kern1, dim3(1, B), dim3(nt), shm, s, w, h, EW, EH, EW, EH, 0, 0, 1, total, 0, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt,
                            P.r11, P.r22, P.dWu, P.dWv, P.dWu, P.dWv);
         *nlaunch += 1; return SIND_OK;
@@ -1327,6 +1337,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         }
         if (g_sor_mode == 5 && !fits) { /* wider than one workgroup's strip: the tiled kernel below */ }
     }
+#ifdef SIND_LAB
     if (g_sor_mode == 2) {                             // 1x4 strips + reciprocal division (k_sor_fused4), 64 x 64 tiles, 1024 threads
         static SindPerDeviceInit attr4_init;
         HIP_TRY(attr4_init.run([] { return hipFuncSetAttribute((const void*)k_sor_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); }));
@@ -1342,6 +1353,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         }
         return SIND_OK;
     }
+#endif
     // tiled levels.  Reciprocal instance (default): EW x EH tiles of EW * EH / 8 threads at three waves per SIMD; IEEE-division instance: four waves per SIMD
     const int EW = g_sor_tile_w, EH = g_sor_tile_h, nt = threads_for(EW, EH);
     const bool rcp = g_sor_mode == 3;
@@ -1355,9 +1367,13 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         const int k = std::min(plan[step++], total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
         const int ntx = divup(w, IW), nty = divup(h, IH);
         const bool t64 = EW == 64 && EH == 64 && nt == 512;           // the default tile has instances with compile-time sizes
+#ifdef SIND_LAB
         auto kern = (g_sor_mode == 4 || g_sor_mode == 5) ? (t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>) : !rcp ? (t64 ? k_sor_fused<0, 512, 4, 64, 64> : k_sor_fused<0, 1024, 4, 0, 0>)
                     : nt == 384 ? k_sor_fused<1, 384, 3, 0, 0> : nt == 768 ? k_sor_fused<1, 768, 3, 0, 0> : k_sor_fused<1, 256, 3, 0, 0>;
-        static const int dry = getenv("SIND_SOR_DRY") ? atoi(getenv("SIND_SOR_DRY")) : 0;       // timing experiment: 1 = no iterations (prologue + write-back only; results are wrong)
+#else
+        auto kern = t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>;
+#endif
+        static const int dry = sind_lab_env("SIND_SOR_DRY") ? atoi(sind_lab_env("SIND_SOR_DRY")) : 0;       // timing experiment: 1 = no iterations (prologue + write-back only; results are wrong)
         hipLaunchKernelGGL(kern, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, dry ? 0 : k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
                            P.wgt, P.r11, P.r22, P.dWu, P.dWv, P.dWu2, P.dWv2);
         std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);

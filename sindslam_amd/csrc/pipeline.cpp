@@ -147,12 +147,12 @@ static int ensure_dtails(sind_pipe* p);
 static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     p->c = *cfg; p->S = cfg->streams; p->T = cfg->frames_per_step;
     p->dc.W = cfg->width; p->dc.H = cfg->height; p->dc.fx = cfg->fx; p->dc.fy = cfg->fy; p->dc.cx = cfg->cx; p->dc.cy = cfg->cy; p->dc.depthScale = cfg->depth_scale; p->dc.device = cfg->device;
-    const bool flow_hi = getenv("SIND_FLOW_PRIORITY") && atoi(getenv("SIND_FLOW_PRIORITY")) != 0;
+    const bool flow_hi = sind_lab_env("SIND_FLOW_PRIORITY") && atoi(sind_lab_env("SIND_FLOW_PRIORITY")) != 0;
     SIND_TRY(make_stream(&p->stream, flow_hi)); SIND_TRY(make_stream(&p->orb_stream, false)); HIP_TRY(hipEventCreateWithFlags(&p->ev_gray, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_depth, hipEventDisableTiming));
     const int B = p->S * p->T; const size_t np = (size_t)cfg->width * cfg->height;
     // dense-flow slices: three concurrent streams keep the GPU busy through the launch tails and the small pyramid levels of each other
     // (measured at B = 256: 270 -> 253 ms per step); small batches stay in one piece
-    const int nsplit = std::max(1, std::min(getenv("SIND_FLOW_SPLIT") ? atoi(getenv("SIND_FLOW_SPLIT")) : (B >= 96 ? 3 : B >= 48 ? 2 : 1), 4)), Bs = (B + nsplit - 1) / nsplit;
+    const int nsplit = std::max(1, std::min(sind_lab_env("SIND_FLOW_SPLIT") ? atoi(sind_lab_env("SIND_FLOW_SPLIT")) : (B >= 96 ? 3 : B >= 48 ? 2 : 1), 4)), Bs = (B + nsplit - 1) / nsplit;
     SIND_TRY(p->front.init(p->dc, nsplit > 1 ? std::max(Bs, 2) : B, p->stream));
     HIP_TRY(hipEventCreate(&p->ev_pool));                   // with timing: also the time base of the solver intervals
     for (int i = 1; i < nsplit; i++) {
@@ -169,7 +169,7 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     cpu_share = std::min(cpu_share, 16);                                          // more host threads than this per GPU bring nothing (measured)
     p->cpu_share = cpu_share;
     if (const char* e = getenv("SIND_GROW_GPU")) { p->grow_q_fixed = std::max(0, std::min(4, atoi(e))); p->grow_q = p->grow_q_fixed; }
-    const int nworkers = getenv("SIND_WORKERS") ? std::max(2, atoi(getenv("SIND_WORKERS"))) : cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 2);         // default: 2x the CPU share (workers sleep while they wait for the GPU)
+    const int nworkers = sind_lab_env("SIND_WORKERS") ? std::max(2, atoi(sind_lab_env("SIND_WORKERS"))) : cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 2);         // default: 2x the CPU share (workers sleep while they wait for the GPU)
     // A task leaves its stream idle (every GPU section ends in a wait), so the HIP streams belong to the workers, not to the camera
     // streams: their number does not grow with S.
     p->worker_streams.resize(nworkers); p->occ_tails.resize(nworkers); p->tails.resize(p->S);
@@ -178,26 +178,26 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     // workgroups (dense flow 230 -> 221 ms, but 65-90 ms of CalOccluded / depth-stage work is then left over when the flow ends); at high
     // priority they cost the solver about what they would cost alone.  Either way the small kernels of a step are worth ~90 ms of GPU time.
     p->worker_streams_lo.resize(nworkers);
-    const bool phase_a_hi = !(getenv("SIND_PHASEA_PRIORITY") && atoi(getenv("SIND_PHASEA_PRIORITY")) == 0);
+    const bool phase_a_hi = !(sind_lab_env("SIND_PHASEA_PRIORITY") && atoi(sind_lab_env("SIND_PHASEA_PRIORITY")) == 0);
     for (int w = 0; w < nworkers; w++) {
-        SIND_TRY(make_stream(&p->worker_streams[w], !(getenv("SIND_TAIL_PRIORITY") && atoi(getenv("SIND_TAIL_PRIORITY")) == 0)));
+        SIND_TRY(make_stream(&p->worker_streams[w], !(sind_lab_env("SIND_TAIL_PRIORITY") && atoi(sind_lab_env("SIND_TAIL_PRIORITY")) == 0)));
         if (phase_a_hi) p->worker_streams_lo[w] = p->worker_streams[w];      // same stream (extra streams would also change how the runtime spreads the workers' streams over its hardware queues)
         else SIND_TRY(make_stream(&p->worker_streams_lo[w], false));
         p->occ_tails[w].reset(new DynaTail()); SIND_TRY(p->occ_tails[w]->init(p->dc, p->worker_streams_lo[w]));
     }
     for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers]));
         if (p->S == 1) p->tails[s]->piece_threads = std::max(1, std::min(4, cpu_share / 3)); }       // one stream: the tails are two serial chains, host cores idle
-    p->cpu_tokens = getenv("SIND_CPU_TOKENS") ? std::max(1, atoi(getenv("SIND_CPU_TOKENS"))) : std::max(2, cpu_share - 1);       // one core stays with the flow launch threads, the ORB thread and the round driver (they mostly sleep)
+    p->cpu_tokens = sind_lab_env("SIND_CPU_TOKENS") ? std::max(1, atoi(sind_lab_env("SIND_CPU_TOKENS"))) : std::max(2, cpu_share - 1);       // one core stays with the flow launch threads, the ORB thread and the round driver (they mostly sleep)
     p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads
-    if (const char* e = getenv("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
-    p->depth_ahead = getenv("SIND_DEPTH_AHEAD") && atoi(getenv("SIND_DEPTH_AHEAD")) != 0;
+    if (const char* e = sind_lab_env("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
+    p->depth_ahead = sind_lab_env("SIND_DEPTH_AHEAD") && atoi(sind_lab_env("SIND_DEPTH_AHEAD")) != 0;
     if (p->depth_ahead) SIND_TRY(ensure_dtails(p));
-    p->batch_km = p->S >= 2 && !(getenv("SIND_KM_BATCH") && atoi(getenv("SIND_KM_BATCH")) == 0);
+    p->batch_km = p->S >= 2 && !(sind_lab_env("SIND_KM_BATCH") && atoi(sind_lab_env("SIND_KM_BATCH")) == 0);
     if (p->batch_km) { SIND_TRY(make_stream(&p->km_stream, true)); SIND_TRY(p->kmb.init(p->dc, p->S, p->km_stream)); }
-    p->batch_occ = B >= 4 && !(getenv("SIND_OCC_BATCH") && atoi(getenv("SIND_OCC_BATCH")) == 0);
+    p->batch_occ = B >= 4 && !(sind_lab_env("SIND_OCC_BATCH") && atoi(sind_lab_env("SIND_OCC_BATCH")) == 0);
     if (p->batch_occ) {
-        p->occ_chunk = std::min(B, std::max(1, getenv("SIND_OCC_CHUNK") ? atoi(getenv("SIND_OCC_CHUNK")) : 64));
-        SIND_TRY(make_stream(&p->occ_stream, !(getenv("SIND_OCC_PRIORITY") && atoi(getenv("SIND_OCC_PRIORITY")) == 0))); SIND_TRY(p->occb.init(p->dc, p->occ_chunk));
+        p->occ_chunk = std::min(B, std::max(1, sind_lab_env("SIND_OCC_CHUNK") ? atoi(sind_lab_env("SIND_OCC_CHUNK")) : 64));
+        SIND_TRY(make_stream(&p->occ_stream, !(sind_lab_env("SIND_OCC_PRIORITY") && atoi(sind_lab_env("SIND_OCC_PRIORITY")) == 0))); SIND_TRY(p->occb.init(p->dc, p->occ_chunk));
         const size_t nblk = (size_t)(cfg->width / 16) * (cfg->height / 16); const int nch = (B + p->occ_chunk - 1) / p->occ_chunk;
         for (int k = 0; k < 2; k++) {
             SIND_TRY(p->sb[k].occ_edge_h.alloc(np * B)); SIND_TRY(p->sb[k].occ_total_h.alloc(np * B)); SIND_TRY(p->sb[k].occ_blocks_h.alloc(nblk * B));
@@ -210,7 +210,7 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
             p->sb[k].grow_ev.assign(nch, nullptr); p->sb[k].grow_left.reset(new std::atomic<int>[nch]); p->sb[k].grow_state.reset(new std::atomic<int>[nch]);
             for (int c = 0; c < nch; c++) HIP_TRY(hipEventCreateWithFlags(&p->sb[k].grow_ev[c], hipEventDisableTiming));
         }
-        SIND_TRY(make_stream(&p->grow_stream, !(getenv("SIND_OCC_PRIORITY") && atoi(getenv("SIND_OCC_PRIORITY")) == 0)));
+        SIND_TRY(make_stream(&p->grow_stream, !(sind_lab_env("SIND_OCC_PRIORITY") && atoi(sind_lab_env("SIND_OCC_PRIORITY")) == 0)));
         SIND_TRY(p->grow.init(cfg->width, cfg->height, cfg->fx, cfg->fy, cfg->cx, cfg->cy, cfg->depth_scale, p->occ_chunk));
     }
     p->workers.start(nworkers, cfg->device, &p->gate);
@@ -292,6 +292,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     const int S = p->S, T = p->T, B = S * T, W = p->c.width, H = p->c.height;
     const size_t np = (size_t)W * H, fb = (size_t)p->fw * p->fh;
     t[0] = now_ms();
+    SindRange range_a("sind phase A (state-free: gray, dense flow, ORB front, CalOccluded)");
+    sind_range_push("sind front: gray + 0.6 resize");
     // gray for all frames, 0.6-scaled gray into the per-stream pools behind the two history slots
     SIND_TRY(launch_bgr2gray(p->stream, bgr_dev, p->gray.p, np * B, false));
     // frame t of stream s goes to pool slot s * (T + 2) + 2 + t: one launch, T frames per group, two history slots skipped between the groups
@@ -301,6 +303,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     // ORB front (pyramid, FAST, octree, orientation, blur, BRIEF) of all frames: independent of the flow, so it runs on its own HIP
     // stream and host thread underneath the dense flow instead of after it
     HIP_TRY(hipEventRecord(p->ev_gray, p->stream));
+    sind_range_pop();
     // private copies of the depth frames: device (tail kernels of this step run while the caller may reuse its buffer) and host.  They go
     // ahead of the ORB front on its stream (157 MB to the host, ~3 ms): the flow slices need not wait for them, only the CalOccluded tasks do
     HIP_TRY(hipMemcpyAsync(sb.depth_dev.p, depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToDevice, p->orb_stream));
@@ -311,7 +314,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         (void)pthread_setname_np(pthread_self(), "sind-orb");
         (void)hipSetDevice(p->c.device);
         if (hipStreamWaitEvent(p->orb_stream, p->ev_gray, 0) != hipSuccess) { orb_rc = SIND_E_HIP; orb_err = "hipStreamWaitEvent failed"; return; }
-        orb_rc = p->orb.extract_all(gray_for_orb, B, sb.orb);
+        { SindRange r("sind ORB front: pyramid, FAST, octree, orientation, BRIEF"); orb_rc = p->orb.extract_all(gray_for_orb, B, sb.orb); }
         if (orb_rc != SIND_OK) orb_err = sind_last_error();
         g_cpu_us_orb += (long long)(thread_cpu_ms() * 1e3); });
     struct OrbJoin { std::thread& t; ~OrbJoin() { if (t.joinable()) t.join(); } } orb_join{orb_thread};
@@ -363,6 +366,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         // first halves: GPU stencil results of the frame's chunk -> end points, PEAC graph clustering, the grow's input block; the runner that completes a chunk
         // enqueues its region grow (one launch for the chunk's frames; the launches share one device workspace, hence the lock around the enqueue)
         for (int k; (k = sb.occ_next.fetch_add(1)) < B;) {
+            SindRange r("sind CalOccluded, first half: end points, PEAC graph");
             const int ch = k / p->occ_chunk; int rc = SIND_OK;
             if (sind_event_wait(sb.occ_ev[ch]) != hipSuccess) { (void)hipGetLastError(); sind_set_error("batched CalOccluded stage failed"); rc = SIND_E_HIP; }
             else {
@@ -382,6 +386,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         }
         // second halves, in frame order: wait for the chunk's grow, then PEAC's last merge, plane contours, contour filter, closing
         for (int k; (k = sb.occ_next2.fetch_add(1)) < B;) {
+            SindRange r("sind CalOccluded, second half: plane contours, contour filter");
             const int ch = k / p->occ_chunk; int rc = sb.occ_rc[k];
             if (rc == SIND_OK) {
                 if (sb.grow_state[ch].load() == 0) { SindTokenPause pause; while (sb.grow_state[ch].load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(50)); }
@@ -407,6 +412,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         std::vector<double> slice_ms(nsl, 0.0); std::vector<std::vector<std::pair<double, double>>> slice_iv(nsl);
         auto run = [&](int i) {
             const int b0 = i * Bs, nb = std::min(Bs, B - b0); if (nb <= 0) return;
+            SindRange r("sind dense flow slice: DeepFlow, large-motion pass, refinement, up-scale");
             DynaFront& f = *fr[i]; f.flow.sor_timer.enabled = true; f.flow.sor_timer.reset();
             if (i > 0 && hipStreamWaitEvent(f.stream, p->ev_pool, 0) != hipSuccess) { rc[i] = SIND_E_HIP; er[i] = "hipStreamWaitEvent failed"; return; }
             rc[i] = f.dense_flow(p->pool.p, cur.data() + b0, p1.data() + b0, p2.data() + b0, nb, sb.U.p + np * b0, sb.V.p + np * b0, nullptr);
@@ -473,6 +479,7 @@ static void depth_task(sind_pipe* p, sind_pipe::StepBuf* sb, int k, int worker) 
     if (t + 1 < T && sb->gate[k + 1].fetch_add(1) == 1) p->workers.push(sb->depth_group, [p, sb, k](int w) { depth_task(p, sb, k + 1, w); });
 }
 static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker, const KmFrameResult* km = nullptr, bool chain = true) {
+    SindRange range_t("sind tail: flow masks, SegAndMerge, fusion, dilation, ORB mask filter");
     p->tails[s]->stream = p->worker_streams[worker];
     const int T = p->T, W = p->c.width, H = p->c.height; const size_t np = (size_t)W * H;
     static thread_local std::vector<uint8_t> dy, lb, dil;
@@ -510,7 +517,9 @@ static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o
             for (int t = 0; t < p->T; t++) {
                 for (int s = 0; s < S; s++) prev[s] = depth_half(p, s)->prev_km_labels();
                 const double tk = now_ms();
+                sind_range_push("sind round: batched k-means of frame t of every stream");
                 const int rc = p->kmb.run(sbp->depth_dev.p + np * t, np * p->T, S, prev.data());
+                sind_range_pop();
                 p->km_round_ms += now_ms() - tk; p->km_rounds++;
                 if (rc != SIND_OK) { const std::string e = sind_last_error(); for (int s = 0; s < S; s++) if (sbp->tail_rc[s] == SIND_OK) { sbp->tail_rc[s] = rc; sbp->tail_err[s] = "batched k-means: " + e; } return; }
                 for (int s = 0; s < S; s++) if (sbp->tail_rc[s] == SIND_OK) p->workers.push(sbp->tail_group, [p, sbp, o, s, t](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb.result(s), false); });
@@ -661,6 +670,7 @@ int sind_pipe_set_grow_share(sind_pipe* p, int quarters) {
     return SIND_OK;
 }
 int sind_pipe_get_grow_share(sind_pipe* p, int* quarters) { if (!p || !quarters) return SIND_E_ARG; *quarters = p->grow_q; return SIND_OK; }
+int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes) { if (!p || !bytes) { sind_set_error("sind_pipe_mask_bytes: null argument"); return SIND_E_ARG; } *bytes = (size_t)p->S * p->T * p->c.width * p->c.height; return SIND_OK; }
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms) { if (!p || !ms) return SIND_E_ARG; *ms = p->tail_wait_ms; return SIND_OK; }
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices) {
     if (!p) return SIND_E_ARG;

@@ -68,3 +68,51 @@ def gather_sequence_masks(masks, owned, group=None):
         if c:
             out[f:f + c] = blocks[r][:c].to(out.device)
     return out.numpy() if isinstance(masks, np.ndarray) else out
+
+
+class Comm:
+    """The C-ABI collective (include/sind_hip.h sind_comm_*): RCCL all-gather of byte blocks without torch.distributed -- what a C++ caller of
+    include/DynaDetect.h uses.  `uid` = the 128 bytes of Comm.unique_id() made on rank 0 and passed to the other ranks by the application."""
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int = 0):
+        import ctypes as C
+        from ._lib import check, lib
+        self._C, self._lib, self._check = C, lib(), check
+        self.rank, self.world, self.device = rank, world, device
+        h = C.c_void_p(); buf = (C.c_char * 128).from_buffer_copy(uid)
+        check(self._lib.sind_comm_create(buf, rank, world, device, C.byref(h)), "sind_comm_create")
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from ._lib import check, lib
+        buf = (C.c_char * 128)()
+        check(lib().sind_comm_unique_id(buf, 128), "sind_comm_unique_id")
+        return bytes(buf)
+
+    def allgather(self, local: np.ndarray, want_host: bool = True):
+        """local: contiguous u8 array (host) -> (device tensor [world, ...] as torch u8, host copy or None)"""
+        import torch
+        C = self._C
+        local = np.ascontiguousarray(local, np.uint8)
+        out = torch.empty((self.world,) + local.shape, dtype=torch.uint8, device=f"cuda:{self.device}")
+        host = np.empty((self.world,) + local.shape, np.uint8) if want_host else None
+        self._check(self._lib.sind_comm_allgather_u8(self._h, local.ctypes.data_as(C.c_void_p), C.c_size_t(local.size), C.c_void_p(out.data_ptr()),
+                                                     host.ctypes.data_as(C.c_void_p) if want_host else None), "sind_comm_allgather_u8")
+        return out, host
+
+    def gather_pipeline_masks(self, pipe, out=None):
+        """one step's dynamic masks of every rank: torch u8 [world, S, T, H, W] on the device"""
+        import torch
+        C = self._C
+        if out is None:
+            out = torch.empty((self.world,) + pipe.dyna.shape, dtype=torch.uint8, device=f"cuda:{self.device}")
+        self._check(self._lib.sind_pipe_gather_masks(pipe._h, self._h, pipe.dyna.ctypes.data_as(C.c_void_p), C.c_void_p(out.data_ptr()), None), "sind_pipe_gather_masks")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sind_comm_destroy(self._h); self._h = None
+
+    __del__ = close

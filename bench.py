@@ -503,6 +503,12 @@ def main():
         sys.exit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ONE JSON line on stdout: libraries write banners there (RCCL prints its version block when a communicator is created), so file descriptor 1 is
+    # pointed at stderr for the duration of the run and the line goes out through the saved descriptor
+    sys.stdout.flush(); real_stdout = os.dup(1); os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
     if args.rendezvous_only:                 # launcher test: meet, count, leave (no GPU needed)
         import torch
         import torch.distributed as dist
@@ -515,7 +521,7 @@ def main():
         else:
             seen = 1
         if rank == 0:
-            print(json.dumps({"ranks_seen": seen, "n_gpus": world, "gpus_arg": args.gpus, "warmup": args.warmup, "steps": args.steps, **host_load_fields(loads)}))
+            emit({"ranks_seen": seen, "n_gpus": world, "gpus_arg": args.gpus, "warmup": args.warmup, "steps": args.steps, **host_load_fields(loads)})
         return
 
     import numpy as np
@@ -674,7 +680,7 @@ def main():
             out["cpu_baseline"], out["parity"] = cpu_baseline(frames_of_stream, intr, cfg, min(T, 4), first_dyna, first_kps, threads=args.cpu_threads, n_streams=NPS)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        emit(out)
     if pg:
         dist.destroy_process_group()
 

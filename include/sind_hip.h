@@ -217,8 +217,8 @@ int sind_comm_allgather_u8(sind_comm* c, const uint8_t* local_host, size_t bytes
 int sind_pipe_gather_masks(sind_pipe* p, sind_comm* c, const uint8_t* dyna_host, uint8_t* all_dev, uint8_t* all_host_or_null);
 /* Where the PEAC region grow of CalOccluded (AHCPlaneFitter.hpp:546-601) runs: `quarters` of every four frames on the GPU (k_peac_grow, one compute unit for
  * a few ms per frame), the others on a host core; the results are bit-identical, the share only moves load between the GPU and the host.  -1 (default): the
- * pipeline adapts the share step by step -- towards the GPU while a step waits for host work after its dense flow is done, towards the host while the host
- * cores idle.  Environment SIND_GROW_GPU=0..4 fixes it at create. */
+ * pipeline adapts the share step by step -- towards the GPU while a step waits for host work after its dense flow is done, back towards the host while
+ * no step waits (the smallest GPU share the host keeps up with).  Environment SIND_GROW_GPU=0..4 fixes it at create. */
 int sind_pipe_set_grow_share(sind_pipe* p, int quarters);
 int sind_pipe_get_grow_share(sind_pipe* p, int* quarters);
 

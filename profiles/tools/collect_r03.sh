@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 evidence under gpurun_out/<tag>/ on the GPU box (copy what is to be judged into profiles/r03/ afterwards):
 #   bash profiles/tools/collect_r03.sh <tag> [part]
-# part 1: kernel trace + stats of the default bench command, the solver's per-level table, the two HBM PMC passes (FETCH_SIZE / WRITE_SIZE in separate
+# part 1: kernel trace + stats of the default bench command, the solver's per-level table;  part 1b: the two HBM PMC passes (FETCH_SIZE / WRITE_SIZE in separate
 #         runs, --kernel-trace only next to them), SQ counters of the solver alone;  part 2: the plain bench lines of every config.
 set -o pipefail
 tag=${1:-r03}; part=${2:-all}; R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/$tag; mkdir -p $O
@@ -11,6 +11,8 @@ if [ "$part" = all ] || [ "$part" = 1 ]; then
   cp $O/prof/*/*kernel_stats.csv $O/kernel_stats.csv
   python3 $R/profiles/sor_by_grid.py $O/prof k_sor_ > $O/sor_by_level.txt; python3 $R/profiles/kernel_duration_dist.py $O/prof > $O/tail_kernel_durations.txt; python3 $R/profiles/tail_gpu_busy.py $O/prof 4 > $O/tail_gpu_busy.txt
   rm -rf $O/prof
+fi
+if [ "$part" = all ] || [ "$part" = 1b ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sequence-leg > $O/pmc_$c.json 2> $O/pmc_$c.err || exit 1
     python3 $R/profiles/pmc_sum.py k_sor_stream $O/pmc_$c > $O/pmc_$c.txt; python3 $R/profiles/pmc_sum.py k_sor_fused $O/pmc_$c >> $O/pmc_$c.txt; python3 $R/profiles/pmc_sum.py k_peac_grow $O/pmc_$c >> $O/pmc_$c.txt; rm -rf $O/pmc_$c

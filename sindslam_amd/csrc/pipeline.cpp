@@ -77,8 +77,8 @@ struct sind_pipe {
     PeacGrowBatch grow; hipStream_t grow_stream = nullptr; std::mutex grow_mu;
     // Where a frame's region grow runs: grow_q of every 4 frames on the GPU (one CU for ~6 ms per frame), the others on the host (one core for ~5 ms); both give
     // the same bits, so the share only moves load.  grow_q_fixed < 0: adapted step by step (grow_adapt) -- towards the GPU while the step waits for host work
-    // (CalOccluded or tails not done when the dense flow is), towards the host while the host cores idle.
-    int grow_q = 2, grow_q_fixed = -1, grow_idle_steps = 0; double cpu_ms_mark = 0, wall_ms_mark = 0; int cpu_share = 16;
+    // (CalOccluded or tails not done when the dense flow is), back towards the host while no step waits.
+    int grow_q = 1, grow_q_fixed = -1, grow_idle_steps = 0; int cpu_share = 16;
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
     struct StepBuf {
@@ -109,17 +109,15 @@ struct sind_pipe {
     WorkerPool workers;          // declared last: joined first
 };
 
-static double process_cpu_ms() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static double now_ms();
 // One step of the grow-share controller (see sind_pipe::grow_q).  host_wait_ms: how long the step waited for host work after its GPU work was done;
-// step_ms: wall time of the step.  The host counts as idle below 70 % of its CPU share over the step; two idle steps in a row move a quarter back to the host.
+// step_ms: wall time of the step.  The GPU is the scarcer resource of the two (a frame's grow costs one compute unit ~6 ms against one core ~5 ms, and a
+// box has 256 of the one and 16 of the other -- but the solver wants all 256), so the share settles at the SMALLEST one the host keeps up with: a quarter
+// more to the GPU as soon as a step waits for the host (> 3 % of the step), a quarter back after three steps in a row without any wait (< 0.5 %).
 static void grow_adapt(sind_pipe* p, double host_wait_ms, double step_ms) {
-    const double cpu = process_cpu_ms(), wall = now_ms();
-    const double util = (p->wall_ms_mark > 0 && wall > p->wall_ms_mark) ? (cpu - p->cpu_ms_mark) / (wall - p->wall_ms_mark) / std::max(1, p->cpu_share) : 1.0;
-    p->cpu_ms_mark = cpu; p->wall_ms_mark = wall;
     if (p->grow_q_fixed >= 0 || !p->batch_occ || step_ms <= 0) return;
-    if (host_wait_ms > 0.04 * step_ms) { p->grow_q = std::min(4, p->grow_q + 1); p->grow_idle_steps = 0; }
-    else if (util < 0.70) { if (++p->grow_idle_steps >= 2) { p->grow_q = std::max(0, p->grow_q - 1); p->grow_idle_steps = 0; } }
+    if (host_wait_ms > 0.03 * step_ms) { p->grow_q = std::min(4, p->grow_q + 1); p->grow_idle_steps = 0; }
+    else if (host_wait_ms < 0.005 * step_ms) { if (++p->grow_idle_steps >= 3) { p->grow_q = std::max(0, p->grow_q - 1); p->grow_idle_steps = 0; } }
     else p->grow_idle_steps = 0;
 }
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

@@ -280,12 +280,12 @@ def roofline_of(acc, K, dt, pairs_per_launch, config_name):
     traffic = pmc["hbm_bytes_per_launch_per_pair"] * pairs_per_launch if pmc else None
     # bound: the contract's yardstick is the HBM roofline on the ALGORITHMIC bytes (44 B per pixel and iteration) and `frac` keeps that meaning;
     # the fused kernel moves ~0.18 of those bytes and its SQ counters show the VALU pipes as the busiest unit, so the binding resource is named here
-    roof = {"bound": "valu", "bound_note": "frac = algorithmic bytes (44 B per pixel update, SURVEY 8d) against the HBM peak, the yardstick of the metric; the fused solver keeps a tile's "
+    roof = {"bound": "valu", "bound_note": "frac = algorithmic bytes (44 B per pixel update, SURVEY 8d) against the HBM peak, the yardstick of the metric; the solver keeps a row pair's "
                                            "system in registers for five iterations and really moves hbm_frac_measured of the peak -- the busiest unit by the SQ counters is the VALU (valu_busy_measured)",
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "frac_wall": (acc.sor_bytes / dt / 1e9 / 8000.0) if dt > 0 else None, "traffic": traffic,
             "traffic_source": (pmc["file"] + " (committed rocprofv3 --pmc passes of this command, per pair x pairs per launch; not re-measured in this run)") if pmc else None,
-            "kernel": "k_sor_fused", "launches": acc.sor_launches, "avg_launch_us": (acc.sor_ms * 1e3 / acc.sor_launches) if acc.sor_launches else None,
+            "kernel": "k_sor_stream (levels above 8192 pixels, from 48 pairs per launch) + k_sor_fused (one-workgroup levels)", "launches": acc.sor_launches, "avg_launch_us": (acc.sor_ms * 1e3 / acc.sor_launches) if acc.sor_launches else None,
             "alg_bytes_per_launch": (acc.sor_bytes / acc.sor_launches) if acc.sor_launches else None,
             "concurrent_launches": acc.sor_slices, "achieved_per_launch": per_launch, "solver_busy_ms_per_step": acc.sor_union / K}
     if pmc and acc.sor_launches and acc.sor_union > 0:

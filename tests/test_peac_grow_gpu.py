@@ -66,3 +66,25 @@ def test_degenerate_frames():
     mg, mh, pg, ph, st = _grow(d, TUM3)
     _same(mg, mh, pg, ph, st)
     assert st[2, 3] == 0 and st[0, 3] == 1
+
+
+def test_more_planes_than_the_kernel_holds_go_to_the_host():
+    """130 small planes (a checkerboard of 48 x 48 facets tilted +-30 degrees in x and y -- three blocks a side, the smallest the fitter's two-apart
+    linking rule joins): beyond the kernel's 127, the frame is flagged `skipped` and the host statement of the
+    FIFO grows it -- end to end the detector still equals the oracle on such a frame"""
+    import oracle_lib as O
+    from sindslam_amd.dyna import DynaDetect
+    h, w = 480, 640
+    yy, xx = np.mgrid[0:h, 0:w]
+    ti, tj = yy // 48, xx // 48
+    sx = np.where(tj % 2 == 0, 1, -1); sy = np.where(ti % 2 == 0, 1, -1)
+    depth = (7500 + sx * 8 * (xx - tj * 48 - 24) + sy * 8 * (yy - ti * 48 - 24)).astype(np.uint16)
+    mg, mh, pg, ph, st = _grow(depth[None], TUM3)
+    assert st[0, 3] > 127 and st[0, 0] == 4, st
+    rng = np.random.default_rng(3)
+    bgr = rng.integers(0, 255, (3, h, w, 3), dtype=np.uint8)
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    gpu = DynaDetect(bgr[1], bgr[0], *K); ref = O.DynaDetect(bgr[1], bgr[0], *K)
+    gd, gl = gpu.DetectDynaArea(bgr[2], depth, 2); rd, rl = ref.detect(bgr[2], depth)
+    g, r = gpu.debug(), ref.debug()
+    assert np.array_equal(g["occ1"], r["occ1"]) and np.array_equal(g["occ2"], r["occ2"]) and np.array_equal(gd, rd) and np.array_equal(gl, rl)

@@ -11,7 +11,8 @@ namespace sind {
 
 struct KmState { float ctr[KM_K][3], old[KM_K][3], base[3]; int cnt[KM_K]; int iter, done, phase, fix_k, max_k, maxCount, overflow; double eps2; unsigned long long far; };
 struct MorphElem { int n, ax, ay; int j1[MORPH_MAX], j2[MORPH_MAX]; };
-struct PeacBlockStats { double sx, sy, sz, sxx, syy, szz, sxy, syz, sxz; int N, valid; };
+// moments of a 16 x 16 block + (fitted = 1: filled by k_peac_block_fit) its plane fit, so that the host's graph clustering starts from fitted nodes
+struct PeacBlockStats { double sx, sy, sz, sxx, syy, szz, sxy, syz, sxz; int N, valid; double mse, center[3], normal[3]; int fitted, pad; };
 
 MorphElem make_ellipse(int n);
 // k-means chain: every launcher takes a batch of B frames (default one) with per-frame plane strides in elements

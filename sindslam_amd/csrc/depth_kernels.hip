@@ -8,6 +8,7 @@
 #include <mutex>
 #include "common.hpp"
 #include "depth.hpp"
+#include "host/peac_fit.hpp"
 
 namespace sind {
 
@@ -586,6 +587,16 @@ __global__ void __launch_bounds__(256) k_peac_block_stats(const uint16_t* __rest
     if (lane == 0) { out[blk].N = valid ? PEAC_BW * PEAC_BW : 0; out[blk].valid = valid ? 1 : 0; }
     if (lane < 9 && !valid) { double* o = &out[blk].sx; o[lane] = 0; }
 }
+// Plane fit of every valid block (host/peac_fit.hpp, the host's own function): the 1200 (640 x 480) to 3600 (1280 x 720) initial nodes are a third of all the
+// fits of a frame's graph clustering (~1 us each on a host core: a 3 x 3 Jacobi iteration).  One thread per block.
+__global__ void k_peac_block_fit(PeacBlockStats* __restrict__ blocks, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PeacBlockStats& S = blocks[i];
+    int fitted = 0;
+    if (S.valid && S.N >= 4) { double c[3], nrm[3], mse; peac_fit(&S.sx, S.N, c, nrm, mse); S.mse = mse; for (int k = 0; k < 3; k++) { S.center[k] = c[k]; S.normal[k] = nrm[k]; } fitted = 1; }
+    S.fitted = fitted; S.pad = 0;
+}
 
 // ---------------------------------------------------------------- imgDepth/depth_max*255 -> 8U (DD:765-768): u16 * (float)((1/max)*255), cvRound, saturate
 __global__ void k_depth_norm(const uint16_t* __restrict__ depth, const unsigned* __restrict__ dmax, uint8_t* __restrict__ out, int n, int dmax_stride) {
@@ -767,7 +778,8 @@ int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, 
 int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out, int B) {
     if (bw != PEAC_BW || bh != PEAC_BW) { sind_set_error("peac_block_stats: %d x %d blocks (only %d x %d)", bw, bh, PEAC_BW, PEAC_BW); return SIND_E_ARG; }
     const int nb = (w / bw) * (h / bh);
-    hipLaunchKernelGGL(k_peac_block_stats, dim3(divup(nb, 4), B), dim3(256), 0, s, depth, w, h, w / bw, nb, fx, fy, cx, cy, depthScale, 0.04, 0.02 * 1000, out); return SIND_OK; }
+    hipLaunchKernelGGL(k_peac_block_stats, dim3(divup(nb, 4), B), dim3(256), 0, s, depth, w, h, w / bw, nb, fx, fy, cx, cy, depthScale, 0.04, 0.02 * 1000, out);
+    hipLaunchKernelGGL(k_peac_block_fit, dim3(divup(nb * B, 64)), dim3(64), 0, s, out, nb * B); return SIND_OK; }
 int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n, int B, int dmax_stride) {
     hipLaunchKernelGGL(k_depth_norm, dim3(divup(n, 256), B), dim3(256), 0, s, depth, dmax, out, n, dmax_stride); return SIND_OK; }
 int launch_rag_stats(hipStream_t s, const unsigned long long* planes, int C, int w, int h, int wpr, const uint8_t* occ2, const uint8_t* depthN,

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <iterator>
 #include "host.hpp"
+#include "peac_fit.hpp"
 
 namespace sind {
 namespace {
@@ -28,42 +29,11 @@ struct Params {   // AHCParamSet.hpp:48-56 — millimetre defaults applied to me
     double ang_init(double z) const { const double cz = std::min(std::max(z, z_near), z_far), f = (angle_far - angle_near) / (z_far - z_near); return std::cos(f * cz + angle_near - f * z_near); }
 };
 
-void jacobi3(const double K[3][3], double s[3], double V[3][3]) {
-    double A[3][3]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { A[i][j] = K[i][j]; V[i][j] = i == j; }
-    for (int sweep = 0; sweep < 60; sweep++) {
-        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
-        if (off <= 1e-32 * diag || off == 0) break;
-        for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
-            if (A[p][q] == 0) continue;
-            const double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
-            const double c = 1 / std::sqrt(t * t + 1), sn = t * c;
-            for (int k = 0; k < 3; k++) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - sn * b; A[k][q] = sn * a + c * b; }
-            for (int k = 0; k < 3; k++) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - sn * b; A[q][k] = sn * a + c * b; }
-            for (int k = 0; k < 3; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - sn * b; V[k][q] = sn * a + c * b; }
-        }
-    }
-    int o[3] = {0, 1, 2}; const double e[3] = {A[0][0], A[1][1], A[2][2]};
-    for (int i = 0; i < 3; i++) for (int j = i + 1; j < 3; j++) if (e[o[i]] > e[o[j]]) std::swap(o[i], o[j]);
-    double T[3][3]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[i][j] = V[i][o[j]];
-    for (int i = 0; i < 3; i++) { s[i] = e[o[i]]; for (int j = 0; j < 3; j++) V[i][j] = T[i][j]; }
-}
-
 struct Seg {
     double sx = 0, sy = 0, sz = 0, sxx = 0, syy = 0, szz = 0, sxy = 0, syz = 0, sxz = 0; int N = 0;
     int rid = 0; double mse = 0, center[3] = {0, 0, 0}, normal[3] = {0, 0, 0}; bool nouse = false;
     std::vector<int> nbs;                    // neighbour node indices, ascending (the iteration order of the candidate loop)
-    void fit() {
-        const double sc = 1.0 / N;
-        center[0] = sx * sc; center[1] = sy * sc; center[2] = sz * sc;
-        double K[3][3] = {{sxx - sx * sx * sc, sxy - sx * sy * sc, sxz - sx * sz * sc}, {0, syy - sy * sy * sc, syz - sy * sz * sc}, {0, 0, szz - sz * sz * sc}};
-        K[1][0] = K[0][1]; K[2][0] = K[0][2]; K[2][1] = K[1][2];
-        double sv[3], V[3][3]; jacobi3(K, sv, V);
-        const double sgn = (V[0][0] * center[0] + V[1][0] * center[1] + V[2][0] * center[2] <= 0) ? 1.0 : -1.0;
-        normal[0] = sgn * V[0][0]; normal[1] = sgn * V[1][0]; normal[2] = sgn * V[2][0];
-        mse = sv[0] * sc;
-    }
+    void fit() { const double m[9] = {sx, sy, sz, sxx, syy, szz, sxy, syz, sxz}; peac_fit(m, N, center, normal, mse); }
     double similarity(const Seg& o) const { return std::fabs(normal[0] * o.normal[0] + normal[1] * o.normal[1] + normal[2] * o.normal[2]); }
     double dist(const double p[3]) const { return normal[0] * (p[0] - center[0]) + normal[1] * (p[1] - center[1]) + normal[2] * (p[2] - center[2]); }
 };
@@ -141,7 +111,9 @@ struct Fitter {
         for (int b = 0; b < NB; b++) {
             const PeacBlockStats& S = in.blocks[b];
             if (!S.valid || S.N < 4) continue;
-            Seg s; s.sx = S.sx; s.sy = S.sy; s.sz = S.sz; s.sxx = S.sxx; s.syy = S.syy; s.szz = S.szz; s.sxy = S.sxy; s.syz = S.syz; s.sxz = S.sxz; s.N = S.N; s.rid = b; s.fit();
+            Seg s; s.sx = S.sx; s.sy = S.sy; s.sz = S.sz; s.sxx = S.sxx; s.syy = S.syy; s.szz = S.szz; s.sxy = S.sxy; s.syz = S.syz; s.sxz = S.sxz; s.N = S.N; s.rid = b;
+            if (S.fitted) { s.mse = S.mse; for (int k = 0; k < 3; k++) { s.center[k] = S.center[k]; s.normal[k] = S.normal[k]; } }      // fitted on the GPU (k_peac_block_fit: the same function)
+            else s.fit();
             if (!(s.mse < P.mse_init(s.center[2]))) continue;
             pool.push_back(s); G[b] = (int)pool.size() - 1;
         }

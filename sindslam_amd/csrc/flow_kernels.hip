@@ -691,14 +691,19 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
     // row ROWY (ring slot SLOT) leaves LDS for registers (its owner, at the row's first step)
     #define SS_LOAD(R, ROWY, SLOT)                                                                                                 \
         {                                                                                                                          \
-            const float* st_ = lds + O_ST + ((ROWY) & (SS_STG - 1)) * EWS + x0; const float* rb_ = lds + (SLOT) * HS + k2;         \
-            const float4 c0 = *reinterpret_cast<const float4*>(st_), c1 = *reinterpret_cast<const float4*>(st_ + STP), c2 = *reinterpret_cast<const float4*>(st_ + 2 * STP); \
-            const float4 c3 = *reinterpret_cast<const float4*>(st_ + 3 * STP), c4 = *reinterpret_cast<const float4*>(st_ + 4 * STP); \
+            const float* st_ = lds + O_ST + ((ROWY) & (SS_STG - 1)) * EWS + k2; const float* rb_ = lds + (SLOT) * HS + k2;         \
+            /* the staging rows are split by column parity like the rings: (pixel 0, pixel 2) and (pixel 1, pixel 3) arrive as the register pairs the    \
+               packed FP32 operations of a half-sweep take (a float4 per plane left the pairs to be rebuilt by moves in every half-sweep) */            \
+            const float2 e0 = *reinterpret_cast<const float2*>(st_), o0 = *reinterpret_cast<const float2*>(st_ + EWS / 2);                             \
+            const float2 e1 = *reinterpret_cast<const float2*>(st_ + STP), o1 = *reinterpret_cast<const float2*>(st_ + STP + EWS / 2);                 \
+            const float2 e2 = *reinterpret_cast<const float2*>(st_ + 2 * STP), o2 = *reinterpret_cast<const float2*>(st_ + 2 * STP + EWS / 2);         \
+            const float2 e3 = *reinterpret_cast<const float2*>(st_ + 3 * STP), o3 = *reinterpret_cast<const float2*>(st_ + 3 * STP + EWS / 2);         \
+            const float2 e4 = *reinterpret_cast<const float2*>(st_ + 4 * STP), o4 = *reinterpret_cast<const float2*>(st_ + 4 * STP + EWS / 2);         \
             const float2 we = *reinterpret_cast<const float2*>(rb_ + O_W), wo = *reinterpret_cast<const float2*>(rb_ + O_W + PL); \
             R.wl0 = rb_[O_W + PL - 1];                                                                                             \
-            R.a11[0] = c0.x; R.a11[1] = c0.y; R.a11[2] = c0.z; R.a11[3] = c0.w; R.a12[0] = c1.x; R.a12[1] = c1.y; R.a12[2] = c1.z; R.a12[3] = c1.w; \
-            R.a22[0] = c2.x; R.a22[1] = c2.y; R.a22[2] = c2.z; R.a22[3] = c2.w; R.b1[0] = c3.x; R.b1[1] = c3.y; R.b1[2] = c3.z; R.b1[3] = c3.w;     \
-            R.b2[0] = c4.x; R.b2[1] = c4.y; R.b2[2] = c4.z; R.b2[3] = c4.w;                                                        \
+            R.a11[0] = e0.x; R.a11[2] = e0.y; R.a11[1] = o0.x; R.a11[3] = o0.y; R.a12[0] = e1.x; R.a12[2] = e1.y; R.a12[1] = o1.x; R.a12[3] = o1.y; \
+            R.a22[0] = e2.x; R.a22[2] = e2.y; R.a22[1] = o2.x; R.a22[3] = o2.y; R.b1[0] = e3.x; R.b1[2] = e3.y; R.b1[1] = o3.x; R.b1[3] = o3.y;     \
+            R.b2[0] = e4.x; R.b2[2] = e4.y; R.b2[1] = o4.x; R.b2[3] = o4.y;                                                        \
             R.wp[0] = we.x; R.wp[2] = we.y; R.wp[1] = wo.x; R.wp[3] = wo.y;                                                        \
             _Pragma("unroll") for (int i = 0; i < 4; i++) { const bool ok = (vmask >> i) & 1u; R.r11[i] = ok ? sor_rcp(R.a11[i]) : 0.f; R.r22[i] = ok ? sor_rcp(R.a22[i]) : 0.f; } \
         }
@@ -756,7 +761,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
             const int id = llane + 64 * c, lpl = id / SW, lch = id - lpl * SW, lx = 4 * lch, gx = ex0 + lx;
             pkind[c] = id >= nitem ? -1 : lpl < 5 ? 0 : 1;
             psrc[c] = id >= nitem ? gA11 + base : (lpl == 0 ? gA11 : lpl == 1 ? gA12 : lpl == 2 ? gA22 : lpl == 3 ? gB1 : lpl == 4 ? gB2 : lpl == 5 ? gW : lpl == 6 ? gU : gV) + base + min(gx, w - 1);      // (a chunk wholly right of the image re-reads around the last pixel and is masked)
-            pdst[c] = lpl < 5 ? O_ST + lpl * STP + lx : (lpl == 5 ? O_W : lpl == 6 ? O_DU : O_DV) + 2 * lch;
+            pdst[c] = (lpl < 5 ? O_ST + lpl * STP : (lpl == 5 ? O_W : lpl == 6 ? O_DU : O_DV)) + 2 * lch;      // every plane split by column parity: even columns first
             pmask[c] = (gx < w ? 1u : 0u) | (gx + 1 < w ? 2u : 0u) | (gx + 2 < w ? 4u : 0u) | (gx + 3 < w ? 8u : 0u);
         }
         for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 1; T0 += 2) {
@@ -781,8 +786,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
                         if (pkind[c] < 0 || !park) continue;
                         const unsigned m = pmask[c] & rowm;
                         const float4 v = make_float4((m & 1u) ? q.x : 0.f, (m & 2u) ? q.y : 0.f, (m & 4u) ? q.z : 0.f, (m & 8u) ? q.w : 0.f);
-                        if (pkind[c] == 0) *reinterpret_cast<float4*>(lds + pdst[c] + stg_off) = v;
-                        else { float* dst = lds + pdst[c] + ring_off; *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.z); *reinterpret_cast<float2*>(dst + PL) = make_float2(v.y, v.w); }
+                        float* dst = lds + pdst[c] + (pkind[c] == 0 ? stg_off : ring_off); const int odd = pkind[c] == 0 ? EWS / 2 : PL;
+                        *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.z); *reinterpret_cast<float2*>(dst + odd) = make_float2(v.y, v.w);
                     }
                 }
                 #pragma unroll

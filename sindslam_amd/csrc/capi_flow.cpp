@@ -8,6 +8,10 @@ struct sind_flow {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+#ifdef SIND_LAB
+namespace sind { int debug_ss_profile(unsigned long long* out, int reset); }
+#endif
+
 extern "C" {
 
 int sind_flow_set_max_levels(sind_flow* f, int n) { if (!f || n < 0) return SIND_E_ARG; f->eng.max_levels = n; return SIND_OK; }
@@ -105,6 +109,10 @@ int sind_debug_rcp_scan(int device, int exp_lo, int exp_hi, unsigned long long o
     HIP_TRY(hipMemcpy(out, d.p, sizeof(init), hipMemcpyDeviceToHost));
     return SIND_OK;
 }
+#ifdef SIND_LAB
+int sind_lab_ss_profile(unsigned long long* out96, int reset) { return sind::debug_ss_profile(out96, reset); }      // lab builds only: k_sor_stream's per-wave step cycles
+#endif
+
 int sind_debug_flow_thresholds(const int* hist, int n, int width, int height, int variant, int device, int* res, double* mu1) {
     if (!hist || !res || n < 1 || variant < 0 || variant > 2 || width < 1 || height < 1) { sind_set_error("sind_debug_flow_thresholds: bad arguments"); return SIND_E_ARG; }
     HIP_TRY(hipSetDevice(device));

@@ -35,6 +35,7 @@ int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     const size_t n0 = (size_t)fw * fh * maxB;
     static_assert(sizeof(FlowPlanes) == 18 * sizeof(float*), "FlowPlanes is filled as an array of 18 plane pointers");
     SIND_TRY(plane_store.alloc(n0 * 18 + 16));           // + 16: the streaming solver's row loader reads whole 16-byte chunks (up to 3 floats past a row's end)
+    if (hipMemsetAsync(plane_store.p, 0, (n0 * 18 + 16) * sizeof(float), stream) != hipSuccess) { sind_set_error("hipMemset(plane store) failed"); return SIND_E_HIP; }     // (the loader's over-reads must find finite values)
     float** f = reinterpret_cast<float**>(&planes);
     for (int i = 0; i < 18; i++) f[i] = plane_store.p + n0 * i;
     SIND_TRY(pyr0.alloc(pyr_pixels * maxB));

@@ -640,11 +640,31 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 #define SS_NQ 10           /* pair slots = rows in flight / 2 = half-sweeps per launch (5 iterations) */
 #define SS_RING 24         /* rows of du / dv / w resident in LDS: the rows of pair p are parked during step p - 1 and read until step p + SS_NQ */
 #define SS_STG 4           /* rows of the coefficient staging ring */
+#define SS_MAXSW 38        /* widest column strip in 4-pixel strips: 6 compute waves + 2 loader waves = 512 threads, two workgroups per CU */
+#define SS_NST 7           /* staging planes: A11, A12, A22, b1, b2 and the reciprocals of A11 and A22 (formed by the loader wave) */
 typedef float ss_f4 __attribute__((ext_vector_type(4)));
-struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], r11[4], r22[4]; float wl0; };      // du / dv stay in the LDS rings; r = RN(1 / a), formed once per row (0 for a pixel outside the image: its update returns exactly 0)
 __device__ __forceinline__ void ss_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifdef SIND_LAB
+// lab builds: where a step's cycles go, per wave of the workgroups (0, y): [wave][0] cycles from the step's start to its barrier, [1] cycles in the barrier,
+// [2] steps, [3] / [4] the same two sums over the steps in which the wave holds threads changing row pairs; wave 15 = the loader
+__device__ unsigned long long g_ss_prof[16][6];
+#define SS_PROF_BEGIN unsigned long long pr_b = 0, pr_w = 0, pr_n = 0, pr_hb = 0, pr_hn = 0;
+#define SS_PROF_T0 const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
+#define SS_PROF_MARK { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pr_hb += __builtin_amdgcn_s_memtime() - pr_t0; pr_hn++; }     /* (loader: the wait for the loads of two steps ago) */
+#define SS_PROF_BARRIER(HEAVY) { const unsigned long long pr_t1 = __builtin_amdgcn_s_memtime(); ss_lds_barrier(); const unsigned long long pr_t2 = __builtin_amdgcn_s_memtime(); \
+        pr_b += pr_t1 - pr_t0; pr_w += pr_t2 - pr_t1; pr_n++; if (HEAVY) { pr_hb += pr_t1 - pr_t0; pr_hn++; } }
+#define SS_PROF_END(WAVE) if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { atomicAdd(&g_ss_prof[WAVE][0], pr_b); atomicAdd(&g_ss_prof[WAVE][1], pr_w); atomicAdd(&g_ss_prof[WAVE][2], pr_n); \
+        atomicAdd(&g_ss_prof[WAVE][3], pr_hb); atomicAdd(&g_ss_prof[WAVE][4], pr_hn); }
+#else
+#define SS_PROF_BEGIN
+#define SS_PROF_T0
+#define SS_PROF_MARK
+#define SS_PROF_BARRIER(HEAVY) ss_lds_barrier();
+#define SS_PROF_END(WAVE)
+#endif
+struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], r11[4], r22[4]; float wl0; };      // du / dv stay in the LDS rings; r = RN(1 / a), formed once per row by the loader wave (0 for a pixel outside the image: its update returns exactly 0)
 // MAXSW: widest column strip (in 4-pixel strips) the instance is laid out for.  The LDS layout is fixed at compile time (every plane at a constant offset:
-// an access is one base register per ring row plus an immediate); 44 strips = 176 columns need 67 KB and 512 threads (7 compute waves + the loader):
+// an access is one base register per ring row plus an immediate); 38 strips = 152 columns need 64 KB and 512 threads (6 compute waves + 2 loaders):
 // two workgroups per CU.  Wider levels are cut into column strips (grid x), each with its own pipeline.
 template <int MAXSW>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per_eu(4, 4))) k_sor_stream(int w, int h, int SW, int HT, int IW, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
@@ -655,7 +675,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
     constexpr int HS = 2 * MAXSW + 4, EWS = 4 * MAXSW;            // floats per row: split plane (two guard floats on each side), staging
     constexpr int PL = SS_RING * HS;                              // one parity plane of a ring
     constexpr int O_DU = 2, O_DV = 2 * PL + 2, O_W = 4 * PL + 2, O_ST = 6 * PL, STP = SS_STG * EWS;      // float offsets (rings: + parity * PL + slot * HS + x / 2)
-    constexpr int total = 6 * PL + 5 * STP;
+    constexpr int total = 6 * PL + SS_NST * STP;
     const int tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.y * w * h;
     // column strip of this workgroup: it keeps the columns [ix0, ix1) and works on [ex0, ex0 + 4 SW), 12 columns more on every side that is not an image
@@ -663,29 +683,31 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
     const int ix0 = (int)blockIdx.x * IW, ix1 = min(ix0 + IW, w), ex0 = max(ix0 - 12, 0);
     for (int i = tid; i < total; i += blockDim.x) lds[i] = 0.f;   // guards, the row above the image, and everything not yet loaded read as zero
     // roles: threads [0, 10 SW) compute -- slot group g (parity of the pair index: first 5 SW threads even slots, next 5 SW odd), slot within the group, strip;
-    // the LAST wave of the block is the loader (its own 128 registers hold two rows of 16-byte pieces in flight; the compute waves hold none)
-    const int CT = (int)blockDim.x - 64;                          // compute threads (padded to whole waves)
+    // the LAST TWO waves of the block are the loaders, one for the even and one for the odd row of every pair (their own registers hold two rows of 16-byte
+    // pieces in flight each; the compute waves hold none).  One loader wave for both rows ran ~3500 cycles a step against ~1900 of a compute wave and was
+    // the step time (s_memtime probes of the lab build, profiles/tools/ss_step_profile.py)
+    const int CT = (int)blockDim.x - 128;                         // compute threads (padded to whole waves)
     const bool is_loader = tid >= CT;
     const int g = tid >= HT ? 1 : 0, idx = g ? tid - HT : tid, qs = idx / SW, j = idx - qs * SW;
     int p = (!is_loader && qs < SS_NQ / 2) ? 2 * qs + g : (1 << 28);      // current row pair; padding lanes and the loader never get one
     const int k2 = 2 * j, x0 = 4 * j;
     int slA = (2 * p) % SS_RING, slB = (2 * p + 1) % SS_RING;
     // loader: lane l takes the items l, l + 64, ... of a row's 8 SW pieces (plane 0..4 coefficients, 5 weight, 6 du, 7 dv; 4-pixel chunk)
-    const int llane = tid - CT, nitem = 8 * SW;
+    const int llane = (tid - CT) & 63, lrow = (tid - CT) >> 6, nitem = 8 * SW;
     constexpr int SS_NC = (8 * MAXSW + 63) / 64;                  // pieces per loader lane and row
-    ss_f4 pf[2][2][SS_NC];                                        // [step parity][row of the pair][piece]: two row pairs in flight
+    ss_f4 pf[2][SS_NC];                                           // [step parity][piece]: this loader's row of two row pairs in flight
     #pragma unroll
     for (int a = 0; a < 2; a++) {
         #pragma unroll
-        for (int c = 0; c < SS_NC; c++) { pf[a][0][c] = ss_f4{0.f, 0.f, 0.f, 0.f}; pf[a][1][c] = ss_f4{0.f, 0.f, 0.f, 0.f}; }
+        for (int c = 0; c < SS_NC; c++) pf[a][c] = ss_f4{0.f, 0.f, 0.f, 0.f};
     }
     SsRow A, B;
     #pragma unroll
     for (int i = 0; i < 4; i++) { A.a11[i] = A.a22[i] = B.a11[i] = B.a22[i] = 1.f; A.a12[i] = A.b1[i] = A.b2[i] = A.wp[i] = A.r11[i] = A.r22[i] = 0.f; B.a12[i] = B.b1[i] = B.b2[i] = B.wp[i] = B.r11[i] = B.r22[i] = 0.f; }
     A.wl0 = B.wl0 = 0.f;
-    unsigned vmask = 0u, smask = 0u;                             // strip pixels inside the image / inside the columns this workgroup keeps
+    unsigned smask = 0u;                                         // strip pixels inside the columns this workgroup keeps
     #pragma unroll
-    for (int i = 0; i < 4; i++) { if (ex0 + x0 + i < w) vmask |= 1u << i; if (ex0 + x0 + i >= ix0 && ex0 + x0 + i < ix1) smask |= 1u << i; }
+    for (int i = 0; i < 4; i++) if (ex0 + x0 + i >= ix0 && ex0 + x0 + i < ix1) smask |= 1u << i;
     __syncthreads();
 
     // row ROWY (ring slot SLOT) leaves LDS for registers (its owner, at the row's first step)
@@ -699,13 +721,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
             const float2 e2 = *reinterpret_cast<const float2*>(st_ + 2 * STP), o2 = *reinterpret_cast<const float2*>(st_ + 2 * STP + EWS / 2);         \
             const float2 e3 = *reinterpret_cast<const float2*>(st_ + 3 * STP), o3 = *reinterpret_cast<const float2*>(st_ + 3 * STP + EWS / 2);         \
             const float2 e4 = *reinterpret_cast<const float2*>(st_ + 4 * STP), o4 = *reinterpret_cast<const float2*>(st_ + 4 * STP + EWS / 2);         \
+            const float2 e5 = *reinterpret_cast<const float2*>(st_ + 5 * STP), o5 = *reinterpret_cast<const float2*>(st_ + 5 * STP + EWS / 2);         \
+            const float2 e6 = *reinterpret_cast<const float2*>(st_ + 6 * STP), o6 = *reinterpret_cast<const float2*>(st_ + 6 * STP + EWS / 2);         \
             const float2 we = *reinterpret_cast<const float2*>(rb_ + O_W), wo = *reinterpret_cast<const float2*>(rb_ + O_W + PL); \
             R.wl0 = rb_[O_W + PL - 1];                                                                                             \
             R.a11[0] = e0.x; R.a11[2] = e0.y; R.a11[1] = o0.x; R.a11[3] = o0.y; R.a12[0] = e1.x; R.a12[2] = e1.y; R.a12[1] = o1.x; R.a12[3] = o1.y; \
             R.a22[0] = e2.x; R.a22[2] = e2.y; R.a22[1] = o2.x; R.a22[3] = o2.y; R.b1[0] = e3.x; R.b1[2] = e3.y; R.b1[1] = o3.x; R.b1[3] = o3.y;     \
             R.b2[0] = e4.x; R.b2[2] = e4.y; R.b2[1] = o4.x; R.b2[3] = o4.y;                                                        \
             R.wp[0] = we.x; R.wp[2] = we.y; R.wp[1] = wo.x; R.wp[3] = wo.y;                                                        \
-            _Pragma("unroll") for (int i = 0; i < 4; i++) { const bool ok = (vmask >> i) & 1u; R.r11[i] = ok ? sor_rcp(R.a11[i]) : 0.f; R.r22[i] = ok ? sor_rcp(R.a22[i]) : 0.f; } \
+            R.r11[0] = e5.x; R.r11[2] = e5.y; R.r11[1] = o5.x; R.r11[3] = o5.y; R.r22[0] = e6.x; R.r22[2] = e6.y; R.r22[1] = o6.x; R.r22[3] = o6.y; \
         }
     // one half-sweep of a row: the two strip pixels of column parity START (the strip starts at an even column)
     #define SS_HALF(R, SLOT, START)                                                                                                \
@@ -753,9 +777,14 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
 
     // The loader wave and the compute waves run their own copy of the step loop (same number of steps, one barrier each): the register allocation of one
     // role does not see the other's live values (two rows of pieces in flight there, two rows of coefficients here)
+    SS_PROF_BEGIN
     if (is_loader) {
         // per piece, fixed for the launch: source pointer of row 0, LDS offset without the row part, kind (0 staging, 1 ring, -1 none), in-image mask of the 4 pixels
-        const float* psrc[SS_NC]; int pdst[SS_NC], pkind[SS_NC]; unsigned pmask[SS_NC];
+        // an A11 / A22 piece also leaves its reciprocals in the staging planes 5 / 6 (prd: distance to that plane, 0 = none): the step's one heavy job of
+        // a compute thread -- taking over a new row pair -- is then LDS reads only.  (With the reciprocals formed by the row's owner the wave holding the
+        // threads that change pairs in a step ran ~2.8 x the instructions of the others, and every step has such a wave: the barrier made its path the step time.)
+        const float* psrc[SS_NC]; int pdst[SS_NC], pkind[SS_NC], prd[SS_NC]; unsigned pmask[SS_NC];
+        bool pslow[SS_NC], prcp[SS_NC];                           // wave-uniform: the piece holds du / dv chunks that stick out of the image; holds A11 / A22 chunks
         #pragma unroll
         for (int c = 0; c < SS_NC; c++) {
             const int id = llane + 64 * c, lpl = id / SW, lch = id - lpl * SW, lx = 4 * lch, gx = ex0 + lx;
@@ -763,44 +792,58 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
             psrc[c] = id >= nitem ? gA11 + base : (lpl == 0 ? gA11 : lpl == 1 ? gA12 : lpl == 2 ? gA22 : lpl == 3 ? gB1 : lpl == 4 ? gB2 : lpl == 5 ? gW : lpl == 6 ? gU : gV) + base + min(gx, w - 1);      // (a chunk wholly right of the image re-reads around the last pixel and is masked)
             pdst[c] = (lpl < 5 ? O_ST + lpl * STP : (lpl == 5 ? O_W : lpl == 6 ? O_DU : O_DV)) + 2 * lch;      // every plane split by column parity: even columns first
             pmask[c] = (gx < w ? 1u : 0u) | (gx + 1 < w ? 2u : 0u) | (gx + 2 < w ? 4u : 0u) | (gx + 3 < w ? 8u : 0u);
+            prd[c] = id >= nitem ? 0 : lpl == 0 ? 5 * STP : lpl == 2 ? 4 * STP : 0;
+            // what has to read as zero outside the image is du / dv (a neighbour's sum takes them) and the reciprocals (an outside pixel's update is then
+            // exactly 0 whatever finite coefficients it reads: the row's continuation in memory, or the zeroed padding behind the planes)
+            pslow[c] = __builtin_amdgcn_ballot_w64(id < nitem && lpl >= 6 && pmask[c] != 0xfu) != 0ull;
+            prcp[c] = __builtin_amdgcn_ballot_w64(prd[c] != 0) != 0ull;
         }
         for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 1; T0 += 2) {
             #pragma unroll
             for (int tt = 0; tt < 2; tt++) {
-                // step T: the pieces of row pair T + 1 (requested two steps ago) go to LDS, then the pieces of pair T + 3 are requested: 2 SS_NC loads per step,
-                // always (rows outside the image re-read row 0 / h - 1 and are masked when parked), so that "at most 2 SS_NC loads outstanding" means exactly
+                // step T: the pieces of row pair T + 1 (requested two steps ago) go to LDS, then the pieces of pair T + 3 are requested: SS_NC loads per step and loader,
+                // always (rows outside the image re-read row 0 / h - 1 and are masked when parked), so that "at most SS_NC loads outstanding" means exactly
                 // "the loads of two steps ago have landed".  The loads are inline assembly: the compiler's own s_waitcnt would be vmcnt(0) at every use of a
                 // loaded register in this loop (it cannot count across the back edge), i.e. one full memory latency per piece instead of per step.
                 const int T = T0 + tt;
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * SS_NC) : "memory");
-                #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const int ys = 2 * (T + 1) + r;
-                    const bool park = ys >= 0 && ys <= h + 1;
-                    const unsigned rowm = ys < h ? 0xfu : 0u;                      // the two rows below the image read as zero
+                SS_PROF_T0
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SS_NC) : "memory");
+                SS_PROF_MARK
+                {
+                    const int ys = 2 * (T + 1) + lrow;
+                    const bool park = ys >= 0 && ys <= h + 1, rowin = ys < h;       // the two rows below the image read as zero
                     const int stg_off = (ys & (SS_STG - 1)) * EWS, ring_off = (((ys % SS_RING) + SS_RING) % SS_RING) * HS;
                     #pragma unroll
                     for (int c = 0; c < SS_NC; c++) {
-                        ss_f4 q = pf[tt][r][c];
+                        ss_f4 q = pf[tt][c];
                         asm volatile("" : "+v"(q));                                   // (uses stay behind the wait above)
-                        if (pkind[c] < 0 || !park) continue;
-                        const unsigned m = pmask[c] & rowm;
-                        const float4 v = make_float4((m & 1u) ? q.x : 0.f, (m & 2u) ? q.y : 0.f, (m & 4u) ? q.z : 0.f, (m & 8u) ? q.w : 0.f);
+                        if (!park) continue;
                         float* dst = lds + pdst[c] + (pkind[c] == 0 ? stg_off : ring_off); const int odd = pkind[c] == 0 ? EWS / 2 : PL;
-                        *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.z); *reinterpret_cast<float2*>(dst + odd) = make_float2(v.y, v.w);
+                        if (pslow[c] || !rowin) {                                     // (uniform)
+                            const unsigned m = rowin ? ((pkind[c] == 1) ? pmask[c] : 0xfu) : 0u;
+                            if (pkind[c] >= 0) { *reinterpret_cast<float2*>(dst) = make_float2((m & 1u) ? q.x : 0.f, (m & 4u) ? q.z : 0.f); *reinterpret_cast<float2*>(dst + odd) = make_float2((m & 2u) ? q.y : 0.f, (m & 8u) ? q.w : 0.f); }
+                        } else if (pkind[c] >= 0) { *reinterpret_cast<float2*>(dst) = make_float2(q.x, q.z); *reinterpret_cast<float2*>(dst + odd) = make_float2(q.y, q.w); }
+                        if (c < (2 * MAXSW + MAXSW + 63) / 64 && prcp[c] && rowin) {   // (A11 / A22 chunks have the ids below 3 SW; uniform)
+                            const float r0 = sor_rcp(q.x), r1 = sor_rcp(q.y), r2 = sor_rcp(q.z), r3 = sor_rcp(q.w);
+                            const unsigned m = pmask[c];
+                            if (prd[c]) {
+                                *reinterpret_cast<float2*>(dst + prd[c]) = make_float2((m & 1u) ? r0 : 0.f, (m & 4u) ? r2 : 0.f);
+                                *reinterpret_cast<float2*>(dst + prd[c] + EWS / 2) = make_float2((m & 2u) ? r1 : 0.f, (m & 8u) ? r3 : 0.f);
+                            }
+                        }
                     }
                 }
-                #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const int yl = min(max(2 * (T + 3) + r, 0), h - 1);
+                {
+                    const int yl = min(max(2 * (T + 3) + lrow, 0), h - 1);
                     const size_t src_off = (size_t)yl * w;
                     #pragma unroll
-                    for (int c = 0; c < SS_NC; c++) { const float* a = psrc[c] + src_off; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf[tt][r][c]) : "v"(a) : "memory"); }
+                    for (int c = 0; c < SS_NC; c++) { const float* a = psrc[c] + src_off; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf[tt][c]) : "v"(a) : "memory"); }
                 }
-                ss_lds_barrier();
+                SS_PROF_BARRIER(false)
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SS_PROF_END(14 + lrow)
         return;
     }
     for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 1; T0 += 2) {
@@ -809,6 +852,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
             // step T of this thread's row pair p: s = T - p.  First its odd row's half-sweep s - 1, then its even row's half-sweep s (the even row's vertical
             // neighbours in the odd row are of the colour just updated -- same thread, same columns).  Both update the column parity s & 1 = (T + g) & 1.
             const int T = T0 + tt;
+            SS_PROF_T0
             int sg = T - p;
             const int yB0 = 2 * p + 1;
             if (sg >= 1 && sg <= SS_NQ && yB0 < h) { if (((tt + g) & 1) == 0) SS_HALF(B, slB, 0) else SS_HALF(B, slB, 1) }
@@ -820,13 +864,22 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
             if (sg == 0 && yA < h) { SS_LOAD(A, yA, slA) if (yB < h) SS_LOAD(B, yB, slB) }
             if (sg >= 0 && sg < SS_NQ && yA < h) { if (((tt + g) & 1) == 0) SS_HALF(A, slA, 0) else SS_HALF(A, slA, 1) }
             if (sg == SS_NQ - 1 && yA < h) SS_STORE(A, yA, slA)
-            ss_lds_barrier();
+            SS_PROF_BARRIER(__builtin_amdgcn_ballot_w64(sg == 0 && yA < h) != 0ull)
         }
     }
+    SS_PROF_END(tid >> 6)
     #undef SS_LOAD
     #undef SS_HALF
     #undef SS_STORE
 }
+
+#ifdef SIND_LAB
+int debug_ss_profile(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ss_prof), sizeof(g_ss_prof)) != hipSuccess) return SIND_E_HIP;
+    if (reset) { static const unsigned long long z[16][6] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ss_prof), z, sizeof(z)) != hipSuccess) return SIND_E_HIP; }
+    return SIND_OK;
+}
+#endif
 
 __global__ void k_add_flow(const float* Wu, const float* Wv, const float* __restrict__ dWu,
                            const float* __restrict__ dWv, float* tWu, float* tWv, size_t n) {
@@ -1297,7 +1350,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     static SindPerDeviceInit attr_init;
     HIP_TRY(attr_init.run([] {
         hipError_t attr_rc = hipSuccess;
-        const void* fs[] = {(const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 512, 2, 0, 0>, (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_stream<40>,
+        const void* fs[] = {(const void*)k_sor_fused<2, 1024, 4, 0, 0>, (const void*)k_sor_fused<2, 512, 2, 0, 0>, (const void*)k_sor_fused<2, 512, 4, 64, 64>, (const void*)k_sor_stream<SS_MAXSW>,
 #ifdef SIND_LAB
                             (const void*)k_sor_fused<0, 1024, 4, 0, 0>, (const void*)k_sor_fused<0, 512, 4, 64, 64>, (const void*)k_sor_fused<1, 384, 3, 0, 0>, (const void*)k_sor_fused<1, 768, 3, 0, 0>,
                             (const void*)k_sor_fused<1, 256, 3, 0, 0>,
@@ -1326,15 +1379,15 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     }
     // large levels, enough images to fill the GPU with one workgroup each: the streaming kernel (no halo, loads and stores overlapped with the iterations)
     {
-        // column strips: n = fewest strips whose working width (kept columns + 12 on each cut side, a multiple of 4) fits 160 columns
+        // column strips: n = fewest strips whose working width (kept columns + 12 on each cut side, a multiple of 4) fits 4 SS_MAXSW = 152 columns
         int n = 1, IW = divup(w, 4) * 4, SW = IW / 4;
-        while (SW > 40) { n++; IW = divup(divup(w, n), 4) * 4; SW = (IW + 24) / 4; }
-        const int HT = 5 * SW, CT = divup(10 * SW, 64) * 64;      // threads of one slot group, compute threads (whole waves); + one loader wave
+        while (SW > SS_MAXSW) { n++; IW = divup(divup(w, n), 4) * 4; SW = (IW + 24) / 4; }
+        const int HT = divup(5 * SW, 64) * 64, CT = 2 * HT;       // threads of one slot group (whole waves: a wave holding both groups would run both colours' code every step), compute threads; + two loader waves
         const bool fits = h >= 4 && total % (SS_NQ / 2) == 0;
         if (fits && (g_sor_mode == 5 || (g_sor_mode == 4 && B >= g_sor_stream_min_b && w * h >= g_sor_stream_min_px))) {
-            const size_t shm = ((size_t)6 * SS_RING * (2 * 40 + 4) + (size_t)5 * SS_STG * 4 * 40) * sizeof(float);
+            const size_t shm = ((size_t)6 * SS_RING * (2 * SS_MAXSW + 4) + (size_t)SS_NST * SS_STG * 4 * SS_MAXSW) * sizeof(float);
             for (int done = 0; done < total; done += SS_NQ / 2) {
-                hipLaunchKernelGGL(k_sor_stream<40>, dim3(n, B), dim3(CT + 64), shm, s, w, h, SW, HT, IW, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
+                hipLaunchKernelGGL(k_sor_stream<SS_MAXSW>, dim3(n, B), dim3(CT + 128), shm, s, w, h, SW, HT, IW, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
                 std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);      // column strips read each other's halo columns: not in place
                 *nlaunch += 1;
             }

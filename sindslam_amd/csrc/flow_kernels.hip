@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 //     the rings).  The step barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so those loads stay in flight across steps;
 //   * a finished row goes from LDS to the output planes (ping-pong with the input: neighbouring column strips read each other's halo columns).
 #define SS_NQ 10           /* pair slots = rows in flight / 2 = half-sweeps per launch (5 iterations) */
-#define SS_RING 24         /* rows of du / dv / w resident in LDS: the rows of pair p are parked during step p - 1 and read until step p + SS_NQ */
+#define SS_RING 28         /* rows of du / dv / w resident in LDS: the rows of pair p are parked during step p - 1 and read until step p + SS_NQ */
 #define SS_STG 4           /* rows of the coefficient staging ring */
 #define SS_MAXSW 38        /* widest column strip in 4-pixel strips: 6 compute waves + 2 loader waves = 512 threads, two workgroups per CU */
 #define SS_NST 7           /* staging planes: A11, A12, A22, b1, b2 and the reciprocals of A11 and A22 (formed by the loader wave) */
@@ -691,9 +691,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
     const int g = tid >= HT ? 1 : 0, idx = g ? tid - HT : tid, qs = idx / SW, j = idx - qs * SW;
     int p = (!is_loader && qs < SS_NQ / 2) ? 2 * qs + g : (1 << 28);      // current row pair; padding lanes and the loader never get one
     const int k2 = 2 * j, x0 = 4 * j;
-    int slA = (2 * p) % SS_RING, slB = (2 * p + 1) % SS_RING;
     // loader: lane l takes the items l, l + 64, ... of a row's 8 SW pieces (plane 0..4 coefficients, 5 weight, 6 du, 7 dv; 4-pixel chunk)
-    const int llane = (tid - CT) & 63, lrow = (tid - CT) >> 6, nitem = 8 * SW;
+    const int llane = (tid - CT) & 63, lrow = (tid - CT) >> 6;
     constexpr int SS_NC = (8 * MAXSW + 63) / 64;                  // pieces per loader lane and row
     ss_f4 pf[2][SS_NC];                                           // [step parity][piece]: this loader's row of two row pairs in flight
     #pragma unroll
@@ -711,9 +710,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
     __syncthreads();
 
     // row ROWY (ring slot SLOT) leaves LDS for registers (its owner, at the row's first step)
-    #define SS_LOAD(R, ROWY, SLOT)                                                                                                 \
+    #define SS_LOAD(R, ROWY, RB)                                                                                                   \
         {                                                                                                                          \
-            const float* st_ = lds + O_ST + ((ROWY) & (SS_STG - 1)) * EWS + k2; const float* rb_ = lds + (SLOT) * HS + k2;         \
+            const float* st_ = lds + O_ST + ((ROWY) & (SS_STG - 1)) * EWS + k2; const float* rb_ = (RB);                          \
             /* the staging rows are split by column parity like the rings: (pixel 0, pixel 2) and (pixel 1, pixel 3) arrive as the register pairs the    \
                packed FP32 operations of a half-sweep take (a float4 per plane left the pairs to be rebuilt by moves in every half-sweep) */            \
             const float2 e0 = *reinterpret_cast<const float2*>(st_), o0 = *reinterpret_cast<const float2*>(st_ + EWS / 2);                             \
@@ -732,11 +731,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
             R.r11[0] = e5.x; R.r11[2] = e5.y; R.r11[1] = o5.x; R.r11[3] = o5.y; R.r22[0] = e6.x; R.r22[2] = e6.y; R.r22[1] = o6.x; R.r22[3] = o6.y; \
         }
     // one half-sweep of a row: the two strip pixels of column parity START (the strip starts at an even column)
-    #define SS_HALF(R, SLOT, START)                                                                                                \
+    #define SS_HALF(R, RB, RU, RD, START)                                                                                          \
         {                                                                                                                          \
-            float* rb_ = lds + (SLOT) * HS + k2 + (START) * PL;                                                                    \
-            const float* ru_ = lds + ((SLOT) == 0 ? SS_RING - 1 : (SLOT) - 1) * HS + k2 + (START) * PL;                            \
-            const float* rd_ = lds + ((SLOT) == SS_RING - 1 ? 0 : (SLOT) + 1) * HS + k2 + (START) * PL;                            \
+            float* rb_ = (RB) + (START) * PL; const float* ru_ = (RU) + (START) * PL; const float* rd_ = (RD) + (START) * PL;       \
             const float2 uu = *reinterpret_cast<const float2*>(ru_ + O_DU), ud = *reinterpret_cast<const float2*>(rd_ + O_DU);     \
             const float2 vu = *reinterpret_cast<const float2*>(ru_ + O_DV), vd = *reinterpret_cast<const float2*>(rd_ + O_DV);     \
             const float2 wu = *reinterpret_cast<const float2*>(ru_ + O_W);                                                         \
@@ -764,9 +761,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
             *reinterpret_cast<float2*>(rb_ + O_DU) = make_float2(nua[0], nua[1]); *reinterpret_cast<float2*>(rb_ + O_DV) = make_float2(nva[0], nva[1]); \
         }
     // a finished row: LDS (both column parities) -> global memory
-    #define SS_STORE(R, ROWY, SLOT)                                                                                                \
+    #define SS_STORE(ROWY, RB)                                                                                                     \
         {                                                                                                                          \
-            const float* rb_ = lds + (SLOT) * HS + k2;                                                                             \
+            const float* rb_ = (RB);                                                                                               \
             const float2 ue = *reinterpret_cast<const float2*>(rb_ + O_DU), uo = *reinterpret_cast<const float2*>(rb_ + O_DU + PL); \
             const float2 ve = *reinterpret_cast<const float2*>(rb_ + O_DV), vo = *reinterpret_cast<const float2*>(rb_ + O_DV + PL); \
             const float du_[4] = {ue.x, uo.x, ue.y, uo.y}, dv_[4] = {ve.x, vo.x, ve.y, vo.y};                                       \
@@ -783,22 +780,31 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
         // an A11 / A22 piece also leaves its reciprocals in the staging planes 5 / 6 (prd: distance to that plane, 0 = none): the step's one heavy job of
         // a compute thread -- taking over a new row pair -- is then LDS reads only.  (With the reciprocals formed by the row's owner the wave holding the
         // threads that change pairs in a step ran ~2.8 x the instructions of the others, and every step has such a wave: the barrier made its path the step time.)
-        const float* psrc[SS_NC]; int pdst[SS_NC], pkind[SS_NC], prd[SS_NC]; unsigned pmask[SS_NC];
-        bool pslow[SS_NC], prcp[SS_NC];                           // wave-uniform: the piece holds du / dv chunks that stick out of the image; holds A11 / A22 chunks
+        // Pieces 0 .. NCS-1 hold the staging planes' chunks (A11, A22, A12, b1, b2 -- the two that need reciprocals first), the rest the ring planes' (w, du, dv):
+        // what a piece is, is known when the code is compiled, and everything that is the same for the whole wave is kept scalar (readfirstlane)
+        constexpr int NCS = (5 * MAXSW + 63) / 64, NCR = (3 * MAXSW + 63) / 64, NCRCP = (2 * MAXSW + 63) / 64;
+        static_assert(NCS + NCR == SS_NC, "k_sor_stream: pieces per loader lane");
+        const int srow = __builtin_amdgcn_readfirstlane(lrow);
+        const float* psrc[SS_NC]; int pdst[SS_NC], prd[SS_NC]; unsigned pmask[SS_NC]; bool pact[SS_NC];
+        int slowbits = 0, rcpbits = 0;                            // per piece: holds du / dv chunks that stick out of the image; holds A11 / A22 chunks
         #pragma unroll
         for (int c = 0; c < SS_NC; c++) {
-            const int id = llane + 64 * c, lpl = id / SW, lch = id - lpl * SW, lx = 4 * lch, gx = ex0 + lx;
-            pkind[c] = id >= nitem ? -1 : lpl < 5 ? 0 : 1;
-            psrc[c] = id >= nitem ? gA11 + base : (lpl == 0 ? gA11 : lpl == 1 ? gA12 : lpl == 2 ? gA22 : lpl == 3 ? gB1 : lpl == 4 ? gB2 : lpl == 5 ? gW : lpl == 6 ? gU : gV) + base + min(gx, w - 1);      // (a chunk wholly right of the image re-reads around the last pixel and is masked)
-            pdst[c] = (lpl < 5 ? O_ST + lpl * STP : (lpl == 5 ? O_W : lpl == 6 ? O_DU : O_DV)) + 2 * lch;      // every plane split by column parity: even columns first
+            const bool stg = c < NCS;
+            const int id = llane + 64 * (stg ? c : c - NCS), lp = id / SW, lch = id - lp * SW, gx = ex0 + 4 * lch;
+            pact[c] = id < (stg ? 5 : 3) * SW;
+            const float* plane = stg ? (lp == 0 ? gA11 : lp == 1 ? gA22 : lp == 2 ? gA12 : lp == 3 ? gB1 : gB2) : (lp == 0 ? gW : lp == 1 ? gU : gV);
+            psrc[c] = (pact[c] ? plane : gA11) + base + min(gx, w - 1);      // (a chunk wholly right of the image re-reads around the last pixel; inactive lanes read somewhere valid)
+            // staging planes in LDS: 0 A11, 1 A12, 2 A22, 3 b1, 4 b2, 5 1 / A11, 6 1 / A22; every plane split by column parity: even columns first
+            pdst[c] = (stg ? O_ST + (lp == 0 ? 0 : lp == 1 ? 2 : lp == 2 ? 1 : lp) * STP : (lp == 0 ? O_W : lp == 1 ? O_DU : O_DV)) + 2 * lch;
             pmask[c] = (gx < w ? 1u : 0u) | (gx + 1 < w ? 2u : 0u) | (gx + 2 < w ? 4u : 0u) | (gx + 3 < w ? 8u : 0u);
-            prd[c] = id >= nitem ? 0 : lpl == 0 ? 5 * STP : lpl == 2 ? 4 * STP : 0;
+            prd[c] = (stg && pact[c] && lp == 0) ? 5 * STP : (stg && pact[c] && lp == 1) ? 4 * STP : 0;
             // what has to read as zero outside the image is du / dv (a neighbour's sum takes them) and the reciprocals (an outside pixel's update is then
             // exactly 0 whatever finite coefficients it reads: the row's continuation in memory, or the zeroed padding behind the planes)
-            pslow[c] = __builtin_amdgcn_ballot_w64(id < nitem && lpl >= 6 && pmask[c] != 0xfu) != 0ull;
-            prcp[c] = __builtin_amdgcn_ballot_w64(prd[c] != 0) != 0ull;
+            if (__builtin_amdgcn_ballot_w64(!stg && pact[c] && lp >= 1 && pmask[c] != 0xfu) != 0ull) slowbits |= 1 << c;
+            if (__builtin_amdgcn_ballot_w64(prd[c] != 0) != 0ull) rcpbits |= 1 << c;
         }
-        for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 1; T0 += 2) {
+        slowbits = __builtin_amdgcn_readfirstlane(slowbits); rcpbits = __builtin_amdgcn_readfirstlane(rcpbits);
+        for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 2; T0 += 2) {
             #pragma unroll
             for (int tt = 0; tt < 2; tt++) {
                 // step T: the pieces of row pair T + 1 (requested two steps ago) go to LDS, then the pieces of pair T + 3 are requested: SS_NC loads per step and loader,
@@ -810,7 +816,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SS_NC) : "memory");
                 SS_PROF_MARK
                 {
-                    const int ys = 2 * (T + 1) + lrow;
+                    const int ys = 2 * (T + 1) + srow;
                     const bool park = ys >= 0 && ys <= h + 1, rowin = ys < h;       // the two rows below the image read as zero
                     const int stg_off = (ys & (SS_STG - 1)) * EWS, ring_off = (((ys % SS_RING) + SS_RING) % SS_RING) * HS;
                     #pragma unroll
@@ -818,23 +824,29 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
                         ss_f4 q = pf[tt][c];
                         asm volatile("" : "+v"(q));                                   // (uses stay behind the wait above)
                         if (!park) continue;
-                        float* dst = lds + pdst[c] + (pkind[c] == 0 ? stg_off : ring_off); const int odd = pkind[c] == 0 ? EWS / 2 : PL;
-                        if (pslow[c] || !rowin) {                                     // (uniform)
-                            const unsigned m = rowin ? ((pkind[c] == 1) ? pmask[c] : 0xfu) : 0u;
-                            if (pkind[c] >= 0) { *reinterpret_cast<float2*>(dst) = make_float2((m & 1u) ? q.x : 0.f, (m & 4u) ? q.z : 0.f); *reinterpret_cast<float2*>(dst + odd) = make_float2((m & 2u) ? q.y : 0.f, (m & 8u) ? q.w : 0.f); }
-                        } else if (pkind[c] >= 0) { *reinterpret_cast<float2*>(dst) = make_float2(q.x, q.z); *reinterpret_cast<float2*>(dst + odd) = make_float2(q.y, q.w); }
-                        if (c < (2 * MAXSW + MAXSW + 63) / 64 && prcp[c] && rowin) {   // (A11 / A22 chunks have the ids below 3 SW; uniform)
-                            const float r0 = sor_rcp(q.x), r1 = sor_rcp(q.y), r2 = sor_rcp(q.z), r3 = sor_rcp(q.w);
-                            const unsigned m = pmask[c];
-                            if (prd[c]) {
-                                *reinterpret_cast<float2*>(dst + prd[c]) = make_float2((m & 1u) ? r0 : 0.f, (m & 4u) ? r2 : 0.f);
-                                *reinterpret_cast<float2*>(dst + prd[c] + EWS / 2) = make_float2((m & 2u) ? r1 : 0.f, (m & 8u) ? r3 : 0.f);
+                        if (c < NCS) {
+                            if (!rowin) continue;                                     // (nobody takes over a row below the image)
+                            float* dst = lds + pdst[c] + stg_off;
+                            if (pact[c]) { *reinterpret_cast<float2*>(dst) = make_float2(q.x, q.z); *reinterpret_cast<float2*>(dst + EWS / 2) = make_float2(q.y, q.w); }
+                            if (c < NCRCP && ((rcpbits >> c) & 1)) {
+                                const float r0 = sor_rcp(q.x), r1 = sor_rcp(q.y), r2 = sor_rcp(q.z), r3 = sor_rcp(q.w);
+                                const unsigned m = pmask[c];
+                                if (prd[c]) {
+                                    *reinterpret_cast<float2*>(dst + prd[c]) = make_float2((m & 1u) ? r0 : 0.f, (m & 4u) ? r2 : 0.f);
+                                    *reinterpret_cast<float2*>(dst + prd[c] + EWS / 2) = make_float2((m & 2u) ? r1 : 0.f, (m & 8u) ? r3 : 0.f);
+                                }
                             }
+                        } else {
+                            float* dst = lds + pdst[c] + ring_off;
+                            if (((slowbits >> c) & 1) || !rowin) {
+                                const unsigned m = rowin ? pmask[c] : 0u;                // (a weight chunk is masked with its piece: nobody reads a weight outside the image)
+                                if (pact[c]) { *reinterpret_cast<float2*>(dst) = make_float2((m & 1u) ? q.x : 0.f, (m & 4u) ? q.z : 0.f); *reinterpret_cast<float2*>(dst + PL) = make_float2((m & 2u) ? q.y : 0.f, (m & 8u) ? q.w : 0.f); }
+                            } else if (pact[c]) { *reinterpret_cast<float2*>(dst) = make_float2(q.x, q.z); *reinterpret_cast<float2*>(dst + PL) = make_float2(q.y, q.w); }
                         }
                     }
                 }
                 {
-                    const int yl = min(max(2 * (T + 3) + lrow, 0), h - 1);
+                    const int yl = min(max(2 * (T + 3) + srow, 0), h - 1);
                     const size_t src_off = (size_t)yl * w;
                     #pragma unroll
                     for (int c = 0; c < SS_NC; c++) { const float* a = psrc[c] + src_off; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf[tt][c]) : "v"(a) : "memory"); }
@@ -846,27 +858,39 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
         SS_PROF_END(14 + lrow)
         return;
     }
-    for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 1; T0 += 2) {
+    // Per-thread pipeline state, touched only when the thread changes pairs (every SS_NQ steps): the ring rows of its pair (pA, pB), of the row above (pU)
+    // and below (pD), whether the pair's rows exist, and s = T - p counted up step by step
+    float *pA, *pB, *pU, *pD, *pS = lds; int yS = 0; bool okA, okB, stS = false;
+    #define SS_PAIR()                                                                                                              \
+        {                                                                                                                          \
+            const int sa_ = (2 * p) % SS_RING;                                                                                     \
+            pA = lds + sa_ * HS + k2; pB = lds + (sa_ + 1) * HS + k2;        /* (2 p is even and SS_RING is: the odd row never wraps) */ \
+            pU = lds + (sa_ == 0 ? SS_RING - 1 : sa_ - 1) * HS + k2; pD = lds + (sa_ + 2 == SS_RING ? 0 : sa_ + 2) * HS + k2;      \
+            okA = 2 * p < h; okB = 2 * p + 1 < h;                                                                                  \
+        }
+    SS_PAIR()
+    int sg = -4 - p;
+    for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 2; T0 += 2) {
         #pragma unroll
         for (int tt = 0; tt < 2; tt++) {
             // step T of this thread's row pair p: s = T - p.  First its odd row's half-sweep s - 1, then its even row's half-sweep s (the even row's vertical
             // neighbours in the odd row are of the colour just updated -- same thread, same columns).  Both update the column parity s & 1 = (T + g) & 1.
-            const int T = T0 + tt;
             SS_PROF_T0
-            int sg = T - p;
-            const int yB0 = 2 * p + 1;
-            if (sg >= 1 && sg <= SS_NQ && yB0 < h) { if (((tt + g) & 1) == 0) SS_HALF(B, slB, 0) else SS_HALF(B, slB, 1) }
-            if (sg == SS_NQ) {                                  // the pair is through: its odd row leaves, the thread takes the pair SS_NQ further down (same parity)
-                if (yB0 < h) SS_STORE(B, yB0, slB)
-                p += SS_NQ; sg = 0; slA = (slA + 2 * SS_NQ) % SS_RING; slB = (slB + 2 * SS_NQ) % SS_RING;
+            if (sg == 1 && stS) SS_STORE(yS, pS)               // the odd row of the pair left in the last step (the ring keeps a finished row for two steps)
+            if (sg >= 1 && okB) { if (((tt + g) & 1) == 0) SS_HALF(B, pB, pA, pD, 0) else SS_HALF(B, pB, pA, pD, 1) }
+            if (sg == SS_NQ) {                                  // the pair is through: the thread takes the pair SS_NQ further down (same parity)
+                pS = pB; yS = 2 * p + 1; stS = okB;
+                p += SS_NQ; sg = 0;
+                SS_PAIR()
             }
-            const int yA = 2 * p, yB = yA + 1;
-            if (sg == 0 && yA < h) { SS_LOAD(A, yA, slA) if (yB < h) SS_LOAD(B, yB, slB) }
-            if (sg >= 0 && sg < SS_NQ && yA < h) { if (((tt + g) & 1) == 0) SS_HALF(A, slA, 0) else SS_HALF(A, slA, 1) }
-            if (sg == SS_NQ - 1 && yA < h) SS_STORE(A, yA, slA)
-            SS_PROF_BARRIER(__builtin_amdgcn_ballot_w64(sg == 0 && yA < h) != 0ull)
+            if (sg == 0 && okA) { SS_LOAD(A, 2 * p, pA) if (okB) SS_LOAD(B, 2 * p + 1, pB) }
+            if (sg >= 0 && okA) { if (((tt + g) & 1) == 0) SS_HALF(A, pA, pU, pB, 0) else SS_HALF(A, pA, pU, pB, 1) }
+            if (sg == SS_NQ - 1 && okA) SS_STORE(2 * p, pA)
+            SS_PROF_BARRIER(__builtin_amdgcn_ballot_w64(sg == 0 && okA) != 0ull)
+            sg++;
         }
     }
+    #undef SS_PAIR
     SS_PROF_END(tid >> 6)
     #undef SS_LOAD
     #undef SS_HALF

@@ -328,10 +328,14 @@ int DynaTail::cal_occluded_p1(const uint16_t* depth_host, const uint16_t* depth_
     static const int ring[12][2] = {{0,-2},{1,-2},{2,-1},{2,0},{2,1},{1,2},{0,2},{-1,2},{-2,1},{-2,0},{-2,-1},{-1,-2}};
     const BitImg& occ = c.occ;
     std::vector<PtI>& endPoints = c.endPoints; endPoints.clear();
-    for (int row = 3; row < H - 3; ++row) for (int col = 3; col < W - 3; ++col) {
-        if (!occ.get(col, row)) continue;
-        int s = 0; for (int i = 0; i < 12; i++) s += occ.get(col + ring[i][0], row + ring[i][1]);
-        if (s <= 4) endPoints.push_back({col, row});
+    for (int row = 3; row < H - 3; ++row) {                                     // (edge pixels are sparse: walk the set bits of the row's words, in column order)
+        const uint64_t* r = occ.row(row);
+        for (int k = 0; k < occ.wpr; k++) for (uint64_t bits = r[k]; bits; bits &= bits - 1) {
+            const int col = (k << 6) + __builtin_ctzll(bits);
+            if (col < 3 || col >= W - 3) continue;
+            int s = 0; for (int i = 0; i < 12; i++) s += occ.get(col + ring[i][0], row + ring[i][1]);
+            if (s <= 4) endPoints.push_back({col, row});
+        }
     }
     { std::vector<PtI> sel; for (const PtI& e : endPoints) { bool ov = false; for (const PtI& q : sel) { const int dx = e.x - q.x, dy = e.y - q.y; if ((float)dx * dx + dy * dy < 6.0f * 6.0f) { ov = true; break; } } if (!ov) sel.push_back(e); } endPoints.swap(sel); }
     FLAP(2)

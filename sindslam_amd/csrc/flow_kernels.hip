@@ -662,7 +662,7 @@ __device__ unsigned long long g_ss_prof[16][6];
 #define SS_PROF_BARRIER(HEAVY) ss_lds_barrier();
 #define SS_PROF_END(WAVE)
 #endif
-struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], r11[4], r22[4]; float wl0; };      // du / dv stay in the LDS rings; r = RN(1 / a), formed once per row by the loader wave (0 for a pixel outside the image: its update returns exactly 0)
+struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], r11[4], r22[4], du[4], dv[4]; float wl0; };      // du / dv: the owner's copy (the rings hold the same values for the neighbours and the write-back); r = RN(1 / a), formed once per row by the loader wave (0 for a pixel outside the image: its update returns exactly 0)
 // MAXSW: widest column strip (in 4-pixel strips) the instance is laid out for.  The LDS layout is fixed at compile time (every plane at a constant offset:
 // an access is one base register per ring row plus an immediate); 38 strips = 152 columns need 64 KB and 512 threads (6 compute waves + 2 loaders):
 // two workgroups per CU.  Wider levels are cut into column strips (grid x), each with its own pipeline.
@@ -687,12 +687,14 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
     // pieces in flight each; the compute waves hold none).  One loader wave for both rows ran ~3500 cycles a step against ~1900 of a compute wave and was
     // the step time (s_memtime probes of the lab build, profiles/tools/ss_step_profile.py)
     const int CT = (int)blockDim.x - 128;                         // compute threads (padded to whole waves)
+    const int lw = (tid - CT) >> 6;                               // loader index (0, 1) if this wave loads
     const bool is_loader = tid >= CT;
-    const int g = tid >= HT ? 1 : 0, idx = g ? tid - HT : tid, qs = idx / SW, j = idx - qs * SW;
+    const int ct = tid;
+    const int g = ct >= HT ? 1 : 0, idx = g ? ct - HT : ct, qs = idx / SW, j = idx - qs * SW;
     int p = (!is_loader && qs < SS_NQ / 2) ? 2 * qs + g : (1 << 28);      // current row pair; padding lanes and the loader never get one
     const int k2 = 2 * j, x0 = 4 * j;
     // loader: lane l takes the items l, l + 64, ... of a row's 8 SW pieces (plane 0..4 coefficients, 5 weight, 6 du, 7 dv; 4-pixel chunk)
-    const int llane = (tid - CT) & 63, lrow = (tid - CT) >> 6;
+    const int llane = tid & 63, lrow = lw;
     constexpr int SS_NC = (8 * MAXSW + 63) / 64;                  // pieces per loader lane and row
     ss_f4 pf[2][SS_NC];                                           // [step parity][piece]: this loader's row of two row pairs in flight
     #pragma unroll
@@ -704,6 +706,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
     #pragma unroll
     for (int i = 0; i < 4; i++) { A.a11[i] = A.a22[i] = B.a11[i] = B.a22[i] = 1.f; A.a12[i] = A.b1[i] = A.b2[i] = A.wp[i] = A.r11[i] = A.r22[i] = 0.f; B.a12[i] = B.b1[i] = B.b2[i] = B.wp[i] = B.r11[i] = B.r22[i] = 0.f; }
     A.wl0 = B.wl0 = 0.f;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) A.du[i] = A.dv[i] = B.du[i] = B.dv[i] = 0.f;
     unsigned smask = 0u;                                         // strip pixels inside the columns this workgroup keeps
     #pragma unroll
     for (int i = 0; i < 4; i++) if (ex0 + x0 + i >= ix0 && ex0 + x0 + i < ix1) smask |= 1u << i;
@@ -724,41 +728,52 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
             const float2 e6 = *reinterpret_cast<const float2*>(st_ + 6 * STP), o6 = *reinterpret_cast<const float2*>(st_ + 6 * STP + EWS / 2);         \
             const float2 we = *reinterpret_cast<const float2*>(rb_ + O_W), wo = *reinterpret_cast<const float2*>(rb_ + O_W + PL); \
             R.wl0 = rb_[O_W + PL - 1];                                                                                             \
+            const float2 ue_ = *reinterpret_cast<const float2*>(rb_ + O_DU), uo_ = *reinterpret_cast<const float2*>(rb_ + O_DU + PL); \
+            const float2 ve_ = *reinterpret_cast<const float2*>(rb_ + O_DV), vo_ = *reinterpret_cast<const float2*>(rb_ + O_DV + PL); \
+            R.du[0] = ue_.x; R.du[2] = ue_.y; R.du[1] = uo_.x; R.du[3] = uo_.y; R.dv[0] = ve_.x; R.dv[2] = ve_.y; R.dv[1] = vo_.x; R.dv[3] = vo_.y; \
             R.a11[0] = e0.x; R.a11[2] = e0.y; R.a11[1] = o0.x; R.a11[3] = o0.y; R.a12[0] = e1.x; R.a12[2] = e1.y; R.a12[1] = o1.x; R.a12[3] = o1.y; \
             R.a22[0] = e2.x; R.a22[2] = e2.y; R.a22[1] = o2.x; R.a22[3] = o2.y; R.b1[0] = e3.x; R.b1[2] = e3.y; R.b1[1] = o3.x; R.b1[3] = o3.y;     \
             R.b2[0] = e4.x; R.b2[2] = e4.y; R.b2[1] = o4.x; R.b2[3] = o4.y;                                                        \
             R.wp[0] = we.x; R.wp[2] = we.y; R.wp[1] = wo.x; R.wp[3] = wo.y;                                                        \
             R.r11[0] = e5.x; R.r11[2] = e5.y; R.r11[1] = o5.x; R.r11[3] = o5.y; R.r22[0] = e6.x; R.r22[2] = e6.y; R.r22[1] = o6.x; R.r22[3] = o6.y; \
         }
-    // one half-sweep of a row: the two strip pixels of column parity START (the strip starts at an even column)
-    #define SS_HALF(R, RB, RU, RD, START)                                                                                          \
+    // one half-sweep of a row: the two strip pixels of column parity START (the strip starts at an even column).  The thread holds the values of its two rows
+    // in registers (the rings carry the same values for the neighbours): the odd row reads its upper neighbour and that row's weights from the even row's
+    // registers, the even row its lower neighbour from the odd row's; LDS gives only the row of the OTHER thread (above the even row, below the odd one) and
+    // the strip-edge neighbour.  UU / VU / WU, UD / VD: the vertical neighbours' values at the two updated columns.
+    #define SS_UPDATE(R, RB, START, UU0, UU1, VU0, VU1, WU0, WU1, UD0, UD1, VD0, VD1)                                              \
         {                                                                                                                          \
-            float* rb_ = (RB) + (START) * PL; const float* ru_ = (RU) + (START) * PL; const float* rd_ = (RD) + (START) * PL;       \
-            const float2 uu = *reinterpret_cast<const float2*>(ru_ + O_DU), ud = *reinterpret_cast<const float2*>(rd_ + O_DU);     \
-            const float2 vu = *reinterpret_cast<const float2*>(ru_ + O_DV), vd = *reinterpret_cast<const float2*>(rd_ + O_DV);     \
-            const float2 wu = *reinterpret_cast<const float2*>(ru_ + O_W);                                                         \
-            /* this row: the two pixels being updated (parity START) and the strip's two pixels of the other colour, their horizontal neighbours */ \
-            float2 cu = *reinterpret_cast<const float2*>(rb_ + O_DU), cv = *reinterpret_cast<const float2*>(rb_ + O_DV);           \
-            const float2 ou = *reinterpret_cast<const float2*>(rb_ + ((START) == 0 ? PL : -PL) + O_DU), ov = *reinterpret_cast<const float2*>(rb_ + ((START) == 0 ? PL : -PL) + O_DV); \
+            float* rb_ = (RB) + (START) * PL;                                                                                      \
             /* strip-edge horizontal neighbour: left of pixel 0 (an odd column) or right of pixel 3 (the next strip's first, even column) */ \
             const float eu = (START) == 0 ? rb_[O_DU + PL - 1] : rb_[O_DU - PL + 2], ev = (START) == 0 ? rb_[O_DV + PL - 1] : rb_[O_DV - PL + 2]; \
-            const float uua[2] = {uu.x, uu.y}, uda[2] = {ud.x, ud.y}, vua[2] = {vu.x, vu.y}, vda[2] = {vd.x, vd.y}, wua[2] = {wu.x, wu.y}; \
+            const float uua[2] = {UU0, UU1}, uda[2] = {UD0, UD1}, vua[2] = {VU0, VU1}, vda[2] = {VD0, VD1}, wua[2] = {WU0, WU1};     \
             /* START 0: pixels 0, 2 between (edge, 1) and (1, 3); START 1: pixels 1, 3 between (0, 2) and (2, edge) */             \
-            const float ula[2] = {(START) == 0 ? eu : ou.x, (START) == 0 ? ou.x : ou.y}, ura[2] = {(START) == 0 ? ou.x : ou.y, (START) == 0 ? ou.y : eu}; \
-            const float vla[2] = {(START) == 0 ? ev : ov.x, (START) == 0 ? ov.x : ov.y}, vra[2] = {(START) == 0 ? ov.x : ov.y, (START) == 0 ? ov.y : ev}; \
-            float nua[2] = {cu.x, cu.y}, nva[2] = {cv.x, cv.y};                                                                    \
+            const float ula[2] = {(START) == 0 ? eu : R.du[0], (START) == 0 ? R.du[1] : R.du[2]}, ura[2] = {(START) == 0 ? R.du[1] : R.du[2], (START) == 0 ? R.du[3] : eu}; \
+            const float vla[2] = {(START) == 0 ? ev : R.dv[0], (START) == 0 ? R.dv[1] : R.dv[2]}, vra[2] = {(START) == 0 ? R.dv[1] : R.dv[2], (START) == 0 ? R.dv[3] : ev}; \
             _Pragma("unroll")                                                                                                      \
             for (int k = 0; k < 2; k++) {                                                                                          \
                 const int i = (START) + 2 * k;                                                                                     \
                 const float wl = i == 0 ? R.wl0 : R.wp[i == 0 ? 0 : i - 1];                                                        \
                 const float sigmaU = wl * ula[k] + R.wp[i] * ura[k] + wua[k] * uua[k] + R.wp[i] * uda[k];                          \
                 const float sigmaV = wl * vla[k] + R.wp[i] * vra[k] + wua[k] * vua[k] + R.wp[i] * vda[k];                          \
-                float nu = nua[k], nv = nva[k];                                                                                    \
+                float nu = R.du[i], nv = R.dv[i];                                                                                  \
                 nu += omega * (sor_div(sigmaU + R.b1[i] - nv * R.a12[i], R.a11[i], R.r11[i]) - nu);                                \
                 nv += omega * (sor_div(sigmaV + R.b2[i] - nu * R.a12[i], R.a22[i], R.r22[i]) - nv);                                \
-                nua[k] = nu; nva[k] = nv;                                                                                          \
+                R.du[i] = nu; R.dv[i] = nv;                                                                                        \
             }                                                                                                                      \
-            *reinterpret_cast<float2*>(rb_ + O_DU) = make_float2(nua[0], nua[1]); *reinterpret_cast<float2*>(rb_ + O_DV) = make_float2(nva[0], nva[1]); \
+            *reinterpret_cast<float2*>(rb_ + O_DU) = make_float2(R.du[START], R.du[(START) + 2]); *reinterpret_cast<float2*>(rb_ + O_DV) = make_float2(R.dv[START], R.dv[(START) + 2]); \
+        }
+    #define SS_HALF_A(START)                                                                                                       \
+        {                                                                                                                          \
+            const float* ru_ = pU + (START) * PL;                                                                                  \
+            const float2 uu = *reinterpret_cast<const float2*>(ru_ + O_DU), vu = *reinterpret_cast<const float2*>(ru_ + O_DV), wu = *reinterpret_cast<const float2*>(ru_ + O_W); \
+            SS_UPDATE(A, pA, START, uu.x, uu.y, vu.x, vu.y, wu.x, wu.y, B.du[START], B.du[(START) + 2], B.dv[START], B.dv[(START) + 2]) \
+        }
+    #define SS_HALF_B(START)                                                                                                       \
+        {                                                                                                                          \
+            const float* rd_ = pD + (START) * PL;                                                                                  \
+            const float2 ud = *reinterpret_cast<const float2*>(rd_ + O_DU), vd = *reinterpret_cast<const float2*>(rd_ + O_DV);     \
+            SS_UPDATE(B, pB, START, A.du[START], A.du[(START) + 2], A.dv[START], A.dv[(START) + 2], A.wp[START], A.wp[(START) + 2], ud.x, ud.y, vd.x, vd.y) \
         }
     // a finished row: LDS (both column parities) -> global memory
     #define SS_STORE(ROWY, RB)                                                                                                     \
@@ -870,30 +885,38 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
         }
     SS_PAIR()
     int sg = -4 - p;
+    const int sgrp = __builtin_amdgcn_readfirstlane(g);        // (a slot group is whole waves: the colour of a step is a scalar)
     for (int T0 = -4; T0 < (h + 1) / 2 + SS_NQ + 2; T0 += 2) {
-        #pragma unroll
+        #pragma unroll 1
         for (int tt = 0; tt < 2; tt++) {
+            const int par = (tt + sgrp) & 1;
             // step T of this thread's row pair p: s = T - p.  First its odd row's half-sweep s - 1, then its even row's half-sweep s (the even row's vertical
             // neighbours in the odd row are of the colour just updated -- same thread, same columns).  Both update the column parity s & 1 = (T + g) & 1.
             SS_PROF_T0
             if (sg == 1 && stS) SS_STORE(yS, pS)               // the odd row of the pair left in the last step (the ring keeps a finished row for two steps)
-            if (sg >= 1 && okB) { if (((tt + g) & 1) == 0) SS_HALF(B, pB, pA, pD, 0) else SS_HALF(B, pB, pA, pD, 1) }
+            if (sg >= 1 && okB) { if (par == 0) SS_HALF_B(0) else SS_HALF_B(1) }
             if (sg == SS_NQ) {                                  // the pair is through: the thread takes the pair SS_NQ further down (same parity)
                 pS = pB; yS = 2 * p + 1; stS = okB;
                 p += SS_NQ; sg = 0;
                 SS_PAIR()
             }
-            if (sg == 0 && okA) { SS_LOAD(A, 2 * p, pA) if (okB) SS_LOAD(B, 2 * p + 1, pB) }
-            if (sg >= 0 && okA) { if (((tt + g) & 1) == 0) SS_HALF(A, pA, pU, pB, 0) else SS_HALF(A, pA, pU, pB, 1) }
+            if (sg == 0 && okA) {
+                SS_LOAD(A, 2 * p, pA)
+                if (okB) SS_LOAD(B, 2 * p + 1, pB)
+                else { _Pragma("unroll") for (int i = 0; i < 4; i++) B.du[i] = B.dv[i] = 0.f; }      // the row below the image reads as zero
+            }
+            if (sg >= 0 && okA) { if (par == 0) SS_HALF_A(0) else SS_HALF_A(1) }
             if (sg == SS_NQ - 1 && okA) SS_STORE(2 * p, pA)
             SS_PROF_BARRIER(__builtin_amdgcn_ballot_w64(sg == 0 && okA) != 0ull)
             sg++;
         }
     }
     #undef SS_PAIR
-    SS_PROF_END(tid >> 6)
+    SS_PROF_END(ct >> 6)
     #undef SS_LOAD
-    #undef SS_HALF
+    #undef SS_HALF_A
+    #undef SS_HALF_B
+    #undef SS_UPDATE
     #undef SS_STORE
 }
 

@@ -9,6 +9,7 @@
 // Nodes live in an index pool; neighbour sets are ordered by node index (= creation order; the reference orders by heap address, which only matters for exactly tied MSEs).
 // Eigen's 3x3 self-adjoint solver is replaced by a cyclic Jacobi iteration (Eigen is not available).
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <map>
 #include <queue>
@@ -32,7 +33,6 @@ struct Params {   // AHCParamSet.hpp:48-56 — millimetre defaults applied to me
 struct Seg {
     double sx = 0, sy = 0, sz = 0, sxx = 0, syy = 0, szz = 0, sxy = 0, syz = 0, sxz = 0; int N = 0;
     int rid = 0; double mse = 0, center[3] = {0, 0, 0}, normal[3] = {0, 0, 0}; bool nouse = false;
-    std::vector<int> nbs;                    // neighbour node indices, ascending (the iteration order of the candidate loop)
     void fit() { const double m[9] = {sx, sy, sz, sxx, syy, szz, sxy, syz, sxz}; peac_fit(m, N, center, normal, mse); }
     double similarity(const Seg& o) const { return std::fabs(normal[0] * o.normal[0] + normal[1] * o.normal[1] + normal[2] * o.normal[2]); }
     double dist(const double p[3]) const { return normal[0] * (p[0] - center[0]) + normal[1] * (p[1] - center[1]) + normal[2] * (p[2] - center[2]); }
@@ -41,6 +41,9 @@ struct Seg {
 struct Fitter {
     const PeacInput in; Params P; const int W, H; static constexpr int bw = 16, bh = 16, minSupport = 2000, maxStep = 100000;
     std::vector<Seg> pool; std::vector<int> dsParent, dsSize; std::vector<int> extracted;
+    std::vector<std::vector<int>> nbs;       // per node: neighbour node indices, ascending (the iteration order of the candidate loop); kept beside the
+                                             // statistics so that a candidate merge is plain data (no allocation per candidate)
+    int add_node(const Seg& s) { pool.push_back(s); nbs.emplace_back(); return (int)pool.size() - 1; }
     const float invScale;
     explicit Fitter(const PeacInput& i) : in(i), W(i.w), H(i.h), invScale(1.0f / i.depthScale) {}
     // state handed from part1 to the grow and to part2
@@ -53,8 +56,8 @@ struct Fitter {
     void unite(int x, int y) { int a = find(x), b = find(y); if (a == b) return; if (dsSize[a] < dsSize[b]) { dsParent[a] = b; dsSize[b] += dsSize[a]; } else { dsParent[b] = a; dsSize[a] += dsSize[b]; } }
     static void set_insert(std::vector<int>& v, int x) { auto it = std::lower_bound(v.begin(), v.end(), x); if (it == v.end() || *it != x) v.insert(it, x); }
     static void set_erase(std::vector<int>& v, int x) { auto it = std::lower_bound(v.begin(), v.end(), x); if (it != v.end() && *it == x) v.erase(it); }
-    void link(int a, int b) { set_insert(pool[a].nbs, b); set_insert(pool[b].nbs, a); }
-    void unlink_all(int a) { for (int nb : pool[a].nbs) set_erase(pool[nb].nbs, a); pool[a].nbs.clear(); }
+    void link(int a, int b) { set_insert(nbs[a], b); set_insert(nbs[b], a); }
+    void unlink_all(int a) { for (int nb : nbs[a]) set_erase(nbs[nb], a); nbs[a].clear(); }
     // point of the organised cloud (float arithmetic of the reference's cloud construction), computed where the region grow needs it:
     // the grow looks at ~2/3 of the pixels once, a materialised cloud would cost a pass over all of them plus 3.7 MB of traffic
     bool point(int row, int col, double p[3]) const {
@@ -65,30 +68,32 @@ struct Fitter {
         return true;
     }
 
-    std::vector<int> nbv;
+    std::vector<int> ubuf;
     int cluster(Queue& q) {
         int step = 0;
         while (!q.empty() && step <= maxStep) {
             const int p = q.top(); q.pop();
             if (pool[p].nouse) continue;
-            int cand = -1, cand_nb = -1;
-            nbv = pool[p].nbs;                                                      // pool may reallocate while candidates are appended
-            for (int nb : nbv) {
+            // the candidate with the smallest MSE (the first one among equals) becomes a node -- whether or not the merge then passes the threshold, as in the
+            // reference; the candidates that lose never enter the pool (node indices only order the neighbour sets, and only relatively)
+            int cand = -1, cand_nb = -1; bool have = false; Seg best;
+            for (int nb : nbs[p]) {
                 if (pool[p].similarity(pool[nb]) < P.simMerge) continue;
                 Seg m; const Seg &a = pool[p], &b = pool[nb];
                 m.sx = a.sx + b.sx; m.sy = a.sy + b.sy; m.sz = a.sz + b.sz; m.sxx = a.sxx + b.sxx; m.syy = a.syy + b.syy; m.szz = a.szz + b.szz;
                 m.sxy = a.sxy + b.sxy; m.syz = a.syz + b.syz; m.sxz = a.sxz + b.sxz; m.N = a.N + b.N; m.rid = a.N >= b.N ? a.rid : b.rid; m.fit();
-                if (cand < 0 || pool[cand].mse > m.mse) { pool.push_back(m); cand = (int)pool.size() - 1; cand_nb = nb; }
+                if (!have || best.mse > m.mse) { best = m; have = true; cand_nb = nb; }
             }
+            if (have) cand = add_node(best);
             if (cand >= 0 && pool[cand].mse < P.mse_merge(pool[cand].center[2])) {
                 q.push(cand);
                 unite(pool[p].rid, pool[cand_nb].rid);
-                std::vector<int> u; u.reserve(pool[p].nbs.size() + pool[cand_nb].nbs.size());
-                std::set_union(pool[p].nbs.begin(), pool[p].nbs.end(), pool[cand_nb].nbs.begin(), pool[cand_nb].nbs.end(), std::back_inserter(u));
+                std::vector<int>& u = ubuf; u.clear();
+                std::set_union(nbs[p].begin(), nbs[p].end(), nbs[cand_nb].begin(), nbs[cand_nb].end(), std::back_inserter(u));
                 set_erase(u, p); set_erase(u, cand_nb);
                 unlink_all(p); unlink_all(cand_nb);
-                for (int nb : u) set_insert(pool[nb].nbs, cand);
-                pool[cand].nbs.swap(u);
+                for (int nb : u) nbs[nb].push_back(cand);                            // (cand is the newest node: the largest index)
+                nbs[cand] = u;
                 pool[p].nouse = pool[cand_nb].nouse = true;
             } else {
                 if (pool[p].N >= minSupport) extracted.push_back(p);
@@ -105,7 +110,7 @@ struct Fitter {
     void part1() {
         Nh = H / bh; Nw = W / bw; NB = Nh * Nw;
         dsParent.resize(NB); dsSize.assign(NB, 1); for (int i = 0; i < NB; i++) dsParent[i] = i;
-        pool.reserve(NB * 16);
+        pool.reserve(NB * 3); nbs.reserve(NB * 3);
         std::vector<int> G(NB, -1);
         Queue q(QCmp{&pool});
         for (int b = 0; b < NB; b++) {
@@ -115,7 +120,7 @@ struct Fitter {
             if (S.fitted) { s.mse = S.mse; for (int k = 0; k < 3; k++) { s.center[k] = S.center[k]; s.normal[k] = S.normal[k]; } }      // fitted on the GPU (k_peac_block_fit: the same function)
             else s.fit();
             if (!(s.mse < P.mse_init(s.center[2]))) continue;
-            pool.push_back(s); G[b] = (int)pool.size() - 1;
+            G[b] = add_node(s);
         }
         for (int b = 0; b < NB; b++) if (G[b] >= 0) q.push(G[b]);
         for (int i = 0; i < Nh; ++i) for (int j = 1; j < Nw; j += 2) {           // row-direction links
@@ -141,7 +146,7 @@ struct Fitter {
         planes = extracted; extracted.clear();
         for (int k = 0; k < (int)planes.size(); k++) rid2pl.insert({pool[planes[k]].rid, k});
         blkMap.assign(NB, -1); valid.assign(planes.size(), 0);
-        seeds.reserve((size_t)W * H);
+        seeds.reserve(32768);
         auto seed_at = [&](int idx, int pl) { const int y = idx / W; seeds.push_back({(uint16_t)(idx - y * W), (uint16_t)y, pl}); };
         auto nb4 = [](int i, int j, int Hh, int Ww, int out[4]) { const int id = i * Ww + j; int c = 0; if (j > 0) out[c++] = id - 1; if (j < Ww - 1) out[c++] = id + 1; if (i > 0) out[c++] = id - Ww; if (i < Hh - 1) out[c++] = id + Ww; return c; };
         for (int i = 0, b = 0; i < Nh; ++i) for (int j = 0; j < Nw; ++j, ++b) {
@@ -172,14 +177,20 @@ struct Fitter {
         if (nPl > PEAC_GROW_MAX_PLANES || (int)seeds.size() > PEAC_GROW_MAX_SEEDS0 || (size_t)W * H > (1u << 20)) return false;
         blk8.resize(NB); for (int b = 0; b < NB; b++) blk8[b] = (int8_t)blkMap[b];
         seedWords.resize(seeds.size());
-        std::map<int, int> cnt;                          // seeds that share a pixel (rare: borders of two eroded planes meeting)
-        for (const Seed& sd : seeds) cnt[sd.y * W + sd.x]++;
-        std::map<int, int> seen;
-        for (size_t k = 0; k < seeds.size(); k++) {
-            const int c = seeds[k].y * W + seeds[k].x, n = cnt[c], idx = seen[c]++;
-            if (n > PEAC_GROW_SLOTS) return false;
+        // seeds that share a pixel (rare: borders of two eroded planes meeting): per pixel, low nibble = seeds on it, high nibble = seeds seen so far.
+        // (Two std::maps here cost 1.6 ms a frame -- more than the graph clustering.)
+        static thread_local std::vector<uint8_t> cnt;
+        if (cnt.size() < (size_t)W * H) cnt.assign((size_t)W * H, 0);
+        for (const Seed& sd : seeds) { uint8_t& c = cnt[(size_t)sd.y * W + sd.x]; if ((c & 15) < 15) c++; }
+        bool fits = true;
+        for (size_t k = 0; k < seeds.size() && fits; k++) {
+            const int c = seeds[k].y * W + seeds[k].x, n = cnt[c] & 15, idx = cnt[c] >> 4;
+            if (n > PEAC_GROW_SLOTS) { fits = false; break; }
+            cnt[c] += 16;
             seedWords[k] = ((uint32_t)(n - 1) << 30) | ((uint32_t)idx << 28) | ((uint32_t)seeds[k].pl << 20) | (uint32_t)c;
         }
+        for (const Seed& sd : seeds) cnt[(size_t)sd.y * W + sd.x] = 0;              // leave the scratch map clean for the thread's next frame
+        if (!fits) return false;
         return true;
     }
     // ---- the region grow along the plane borders (FIFO, order-defined), host statement.  member: plane index per pixel or -1 (nobody's);
@@ -243,7 +254,16 @@ struct Fitter {
         for (int y = 0; y < H; y++) {                                  // runs of equal membership -> bit ranges
             const T* m = &member[(size_t)y * W];
             for (int x = 0; x < W;) {
-                const int pl = m[x], x0 = x; while (x < W && m[x] == pl) x++;
+                const int pl = m[x], x0 = x;
+                if (sizeof(T) == 1) {                                   // eight pixels a step: first byte that differs from the run's value
+                    uint64_t bv; std::memset(&bv, (uint8_t)pl, 8);
+                    for (;;) {
+                        if (x + 8 > W) { while (x < W && m[x] == pl) x++; break; }
+                        uint64_t w8; std::memcpy(&w8, &m[x], 8); w8 ^= bv;
+                        if (w8) { x += __builtin_ctzll(w8) >> 3; break; }
+                        x += 8;
+                    }
+                } else while (x < W && m[x] == pl) x++;
                 if (pl < 0 || plmap[pl] < 0 || plmap[pl] >= nOut) continue;
                 const int o = plmap[pl]; uint64_t* r = masks[o].row(y); const int a = x0, b = x - 1, ka = a >> 6, kb = b >> 6;
                 for (int q = ka; q <= kb; q++) { uint64_t bits = ~0ull; if (q == ka) bits &= ~0ull << (a & 63); if (q == kb) bits &= (b & 63) == 63 ? ~0ull : ((1ull << ((b & 63) + 1)) - 1); r[q] |= bits; }

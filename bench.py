@@ -293,11 +293,13 @@ def roofline_of(acc, K, dt, pairs_per_launch, config_name):
         roof["hbm_frac_measured"] = traffic * acc.sor_launches / (acc.sor_union * 1e-3) / 8e12
     if pmc and pmc.get("valu_busy_measured") is not None:
         roof["valu_busy_measured"] = pmc["valu_busy_measured"]; roof["valu_busy_source"] = pmc.get("sq_counters")
-    # VALU floor: pixel updates (algorithmic bytes / 44 B) x VALU lane-operations per update (ISA count of the inner loop) x halo redundancy of the tiling,
+    # VALU share: pixel updates (algorithmic bytes / 44 B) x VALU lane-instructions per update (the committed SQ-counter figure of the PMC file, which already
+    # holds the halo columns and the loader waves; without that file: an ISA count of the tiled loop x its halo redundancy),
     # over the FP32 vector peak of 78.6e12 lane-operations/s (157.3 TFLOP/s / 2 flops per FMA lane; MI355X_MICROARCH.md)
     valu_ops_per_update = (pmc or {}).get("valu_ops_per_pixel_update", 44); halo = (pmc or {}).get("halo_redundancy", 2.1)
+    valu_peak = (pmc or {}).get("valu_peak_lane_instructions_per_s", 78.6e12)      # the measured figure counts a packed operation as one instruction: 39.3e12 lane-instructions/s
     if acc.sor_union > 0:
-        roof["valu_frac"] = (acc.sor_bytes / 44.0) * valu_ops_per_update * halo / 78.6e12 / (acc.sor_union * 1e-3)
+        roof["valu_frac"] = (acc.sor_bytes / 44.0) * valu_ops_per_update * halo / valu_peak / (acc.sor_union * 1e-3)
     return roof
 
 

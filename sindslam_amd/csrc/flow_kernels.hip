@@ -643,6 +643,7 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 #define SS_MAXSW 38        /* widest column strip in 4-pixel strips: 6 compute waves + 2 loader waves = 512 threads, two workgroups per CU */
 #define SS_NST 7           /* staging planes: A11, A12, A22, b1, b2 and the reciprocals of A11 and A22 (formed by the loader wave) */
 typedef float ss_f4 __attribute__((ext_vector_type(4)));
+typedef float ss_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void ss_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef SIND_LAB
 // lab builds: where a step's cycles go, per wave of the workgroups (0, y): [wave][0] cycles from the step's start to its barrier, [1] cycles in the barrier,
@@ -761,7 +762,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
                 nv += omega * (sor_div(sigmaV + R.b2[i] - nu * R.a12[i], R.a22[i], R.r22[i]) - nv);                                \
                 R.du[i] = nu; R.dv[i] = nv;                                                                                        \
             }                                                                                                                      \
-            *reinterpret_cast<float2*>(rb_ + O_DU) = make_float2(R.du[START], R.du[(START) + 2]); *reinterpret_cast<float2*>(rb_ + O_DV) = make_float2(R.dv[START], R.dv[(START) + 2]); \
+            /* (one 8-byte vector store each: as HIP float2 structs the stores were split into scalars, sunk below the two colours' code and came out as four ds_write_b32 with four address adds) */ \
+            *reinterpret_cast<ss_f2*>(rb_ + O_DU) = ss_f2{R.du[START], R.du[(START) + 2]}; *reinterpret_cast<ss_f2*>(rb_ + O_DV) = ss_f2{R.dv[START], R.dv[(START) + 2]}; \
         }
     #define SS_HALF_A(START)                                                                                                       \
         {                                                                                                                          \

@@ -623,19 +623,22 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 // Third generation for the large levels: the solver STREAMS down the image instead of tiling it.
 // The tiled kernel above pays for its halo twice: a 64 x 64 tile with a 10-pixel halo computes (64 / 44)^2 = 2.1 x the pixel updates it keeps, and a
 // workgroup can neither load the next tile's coefficients nor store its result while it iterates (loads + write-back are 58 % of a tiled launch).
-// Here ONE workgroup owns one whole image (levels up to 408 pixels wide) and walks it top to bottom as a software pipeline in time:
+// Here ONE workgroup owns one column strip of an image (up to 152 columns: 128 kept + 12 halo columns on each cut side) and walks it top to bottom as a
+// software pipeline in time:
 //   * half-sweep s (s = 0 .. 2 * iters - 1, red first) of image row y runs at step t = y + 2 s.  Row y then has rows y - 1 and y + 1 exactly after
 //     half-sweep s - 1 and before s + 1 -- what the sequential red-black order defines -- and the rows updated in one step (all of t's parity) never
 //     read each other: every pixel update is the same arithmetic on the same operands as in k_sor_color, so the result is bit-identical, with NO
 //     redundant update and every coefficient read from memory exactly once per launch;
-//   * a thread owns a 1 x 4 strip of TWO consecutive rows (2 p, 2 p + 1) for the 2 * SS_NQ steps they spend in the pipeline (even steps: its even row,
-//     odd steps: its odd row -- every thread has work at every step), keeps their system in registers, then takes the pair SS_NQ pairs further down;
-//   * du, dv and the smoothness weight live in LDS rings of SS_RING rows, split by column parity (the two pixels a strip updates in a half-sweep and
-//     their vertical neighbours are one 8-byte access per plane); threads are grouped by the parity of their pair slot (first half of the block even
-//     slots, second half odd) so that the active colour is wave-uniform;
-//   * the rows ahead of the pipeline are fetched by the same threads as a side job: every step each of 8 * SW threads issues ONE 16-byte load of the row
-//     SS_LEAD + 2 steps ahead and parks the piece loaded SS_LEAD steps ago in LDS (coefficients: staging ring, read once by the row's owner; du / dv / w:
-//     the rings).  The step barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so those loads stay in flight across steps;
+//   * a thread owns a 1 x 4 strip of TWO consecutive rows (2 p, 2 p + 1) for the SS_NQ steps they spend in the pipeline (every step: a half-sweep of its odd
+//     row, then one of its even row), keeps their system AND their du / dv in registers, then takes the pair SS_NQ pairs further down;
+//   * du, dv and the smoothness weight also live in LDS rings of SS_RING rows, split by column parity (the two pixels a strip updates in a half-sweep and
+//     their vertical neighbours are one 8-byte access per plane): a thread reads from them only what OTHER threads own -- the row above its even row, the
+//     row below its odd row and the strip-edge neighbours; threads are grouped by the parity of their pair slot (whole waves per group) so that the active
+//     colour is a scalar per wave;
+//   * the rows ahead of the pipeline are fetched by two LOADER waves (one per row of a pair): every step a loader parks the 16-byte pieces it requested two
+//     steps earlier in LDS (coefficients and the reciprocals of A11 / A22, which it forms: staging ring, read once by the row's next owner; du / dv / w:
+//     the rings) and requests the pieces of the pair three steps ahead.  The step barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so those
+//     loads stay in flight across steps.  (One loader wave for both rows was the step time: DESIGN 3.1-9, profiles/r03/v2_step_probes.txt);
 //   * a finished row goes from LDS to the output planes (ping-pong with the input: neighbouring column strips read each other's halo columns).
 #define SS_NQ 10           /* pair slots = rows in flight / 2 = half-sweeps per launch (5 iterations) */
 #define SS_RING 28         /* rows of du / dv / w resident in LDS: the rows of pair p are parked during step p - 1 and read until step p + SS_NQ */
@@ -647,7 +650,8 @@ typedef float ss_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void ss_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef SIND_LAB
 // lab builds: where a step's cycles go, per wave of the workgroups (0, y): [wave][0] cycles from the step's start to its barrier, [1] cycles in the barrier,
-// [2] steps, [3] / [4] the same two sums over the steps in which the wave holds threads changing row pairs; wave 15 = the loader
+// [2] steps, [3] / [4] the same two sums over the steps in which the wave holds threads changing row pairs; waves 14 / 15 = the loaders
+// ([3] there: the wait for the loads of two steps ago)
 __device__ unsigned long long g_ss_prof[16][6];
 #define SS_PROF_BEGIN unsigned long long pr_b = 0, pr_w = 0, pr_n = 0, pr_hb = 0, pr_hn = 0;
 #define SS_PROF_T0 const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
@@ -665,7 +669,7 @@ __device__ unsigned long long g_ss_prof[16][6];
 #endif
 struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], r11[4], r22[4], du[4], dv[4]; float wl0; };      // du / dv: the owner's copy (the rings hold the same values for the neighbours and the write-back); r = RN(1 / a), formed once per row by the loader wave (0 for a pixel outside the image: its update returns exactly 0)
 // MAXSW: widest column strip (in 4-pixel strips) the instance is laid out for.  The LDS layout is fixed at compile time (every plane at a constant offset:
-// an access is one base register per ring row plus an immediate); 38 strips = 152 columns need 64 KB and 512 threads (6 compute waves + 2 loaders):
+// an access is one base register per ring row plus an immediate); 38 strips = 152 columns need 69 KB and 512 threads (6 compute waves + 2 loaders):
 // two workgroups per CU.  Wider levels are cut into column strips (grid x), each with its own pipeline.
 template <int MAXSW>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per_eu(4, 4))) k_sor_stream(int w, int h, int SW, int HT, int IW, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,

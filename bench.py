@@ -443,12 +443,12 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     if pg:
         tt = torch.tensor([dt], device=comm_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     loads = gather_host_load(load, pg, comm_dev)
-    grow_q = pipe.grow_share()
+    grow_q = pipe.grow_share(); km_groups = pipe.kmeans_groups()
     owned = sum(c.last - c.first for c in plan.chunks)
     info = {"frames": plan.frames, "owned_frames": owned, "chunks": n, "chunks_per_gpu": S, "frames_per_step_per_chunk": T, "steps": K,
             "processed_frames_per_chunk": plan.processed, "state_warmup_frames": SEQ_WARMUP_FRAMES, "state_warmup_steps": -(-SEQ_WARMUP_FRAMES // T),
             "processed_frames": plan.processed_total, "warmup_overhead": plan.processed_total / owned - 1.0,
-            "value": owned / dt, "value_excl_warmup": plan.processed_total / dt, "seconds": dt, "final_flush_ms": flush_ms, "region_grow_gpu_quarters": grow_q,
+            "value": owned / dt, "value_excl_warmup": plan.processed_total / dt, "seconds": dt, "final_flush_ms": flush_ms, "region_grow_gpu_quarters": grow_q, "kmeans_groups": km_groups,
             "note": "value = owned frames of the whole sequence / wall time of ALL the work (the 24 state warm-up frames of every chunk after the first run inside the timed "
                     "region); value_excl_warmup counts every processed frame as if it were owned (the pipeline's processing rate)",
             "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL through the C ABI (sind_pipe_gather_masks)" if args.collective == "cabi" else "RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if pg else "single rank (no collective)",
@@ -646,7 +646,7 @@ def main():
                 print(f"[thread-cpu] {name:16s} {(th1[name] - th0.get(name, 0.0)) / K * 1e3:9.1f} core-ms per step", file=sys.stderr)
             live = sum(th1[n_] - th0.get(n_, 0.0) for n_ in th1)
             print(f"[thread-cpu] {'(exited threads)':16s} {(cpu_s - live) / K * 1e3:9.1f} core-ms per step   total {cpu_s / K * 1e3:.1f}", file=sys.stderr)
-        grow_q = pipe.grow_share()
+        grow_q = pipe.grow_share(); km_groups = pipe.kmeans_groups()
         pipe.close(); del dev_b, dev_d, pipe
         # ---- one GPU: the fixed-length sequence job as well (the N = 1 point of the curve that --gpus N > 1 reports as its headline)
         if seq_leg:
@@ -676,6 +676,8 @@ def main():
         out.update(host_load_fields(loads))
         # PEAC region grow of CalOccluded: share of the frames grown on the GPU at the end of the run, in quarters (adaptive by default; same results either way)
         out["region_grow_gpu_quarters"] = grow_q if not seq else seq_info.get("region_grow_gpu_quarters")
+        # groups of streams whose batched k-means rounds run as independent chains at the end of the run (2..4, same controller; same results)
+        out["kmeans_groups"] = km_groups if not seq else seq_info.get("kmeans_groups")
         if seq_info:
             out["sequence"] = seq_info
         if not args.no_cpu_baseline and world == 1 and first_dyna is not None:

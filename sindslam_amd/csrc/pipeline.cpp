@@ -67,7 +67,9 @@ struct sind_pipe {
     std::vector<std::unique_ptr<DynaTail>> dtails;
     // k-means of one frame of every stream as ONE batched kernel chain (phase B then runs frame t of all streams as a round: batched k-means,
     // then the S tails of that frame on the pool); used when there are several streams and the depth half is not run ahead
-    KMeansBatch kmb; hipStream_t km_stream = nullptr; bool batch_km = false; std::thread round_thread; double km_round_ms = 0; long km_rounds = 0;
+    static constexpr int KM_GROUPS = 4;
+    KMeansBatch kmb[KM_GROUPS]; int km_groups = 1, km_groups_max = 1, km_idle_steps = 0; hipStream_t km_stream = nullptr, km_streams[KM_GROUPS] = {nullptr}; bool batch_km = false;
+    std::vector<std::thread> round_threads; std::mutex km_stat_mu; double km_round_ms = 0; long km_rounds = 0;
     std::vector<std::unique_ptr<PinnedBuf<uint8_t>>> upload_stage;        // page-locked staging of sind_pipe_process (host-buffer entry point), two 4 MB buffers per uploading worker
     std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
     // GPU half of CalOccluded for all frames of a step, in chunks, on a stream of its own at the start of phase A (seven launches per chunk instead
@@ -93,7 +95,7 @@ struct sind_pipe {
         // and a gate per frame that opens when both its CalOccluded result and the stream's previous depth stage are there
         bool depth_ahead = false; std::vector<DepthStageOut> dout; std::unique_ptr<std::atomic<int>[]> gate; TaskGroup depth_group;
         std::vector<int> depth_rc; std::vector<std::string> depth_err;
-        TaskGroup occ_group, tail_group; std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
+        TaskGroup occ_group, tail_group, km_tails[4]; int km_groups = 1, km_first[5] = {0, 0, 0, 0, 0};       /* (4 = sind_pipe::KM_GROUPS) the step's own partition of the streams */ std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
     } sb[2];
     int cur = 0; int occ_workers = 24;
     // CPU tokens (common.hpp) for the software-pipelined steps, where CalOccluded runners and tails compete for the quota (measured: throttled periods 7 -> 2
@@ -116,9 +118,15 @@ static double now_ms();
 // more to the GPU as soon as a step waits for the host (> 3 % of the step), a quarter back after three steps in a row without any wait (< 0.5 %).
 static void grow_adapt(sind_pipe* p, double host_wait_ms, double step_ms) {
     if (p->grow_q_fixed >= 0 || !p->batch_occ || step_ms <= 0) return;
-    if (host_wait_ms > 0.03 * step_ms) { p->grow_q = std::min(4, p->grow_q + 1); p->grow_idle_steps = 0; }
-    else if (host_wait_ms < 0.005 * step_ms) { if (++p->grow_idle_steps >= 3) { p->grow_q = std::max(0, p->grow_q - 1); p->grow_idle_steps = 0; } }
-    else p->grow_idle_steps = 0;
+    if (host_wait_ms > 0.03 * step_ms) {
+        if (p->grow_q >= 4 && p->batch_km) p->km_groups = std::min(p->km_groups_max, p->km_groups + 1);      // every grow is on the GPU already: one more k-means chain
+        p->grow_q = std::min(4, p->grow_q + 1); p->grow_idle_steps = 0;
+    } else if (host_wait_ms < 0.005 * step_ms) {
+        if (++p->grow_idle_steps >= 3) {
+            if (p->batch_km && p->km_groups > std::min(2, p->km_groups_max)) p->km_groups--; else p->grow_q = std::max(0, p->grow_q - 1);
+            p->grow_idle_steps = 0;
+        }
+    } else p->grow_idle_steps = 0;
 }
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -191,7 +199,17 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     p->depth_ahead = sind_lab_env("SIND_DEPTH_AHEAD") && atoi(sind_lab_env("SIND_DEPTH_AHEAD")) != 0;
     if (p->depth_ahead) SIND_TRY(ensure_dtails(p));
     p->batch_km = p->S >= 2 && !(sind_lab_env("SIND_KM_BATCH") && atoi(sind_lab_env("SIND_KM_BATCH")) == 0);
-    if (p->batch_km) { SIND_TRY(make_stream(&p->km_stream, true)); SIND_TRY(p->kmb.init(p->dc, p->S, p->km_stream)); }
+    if (p->batch_km) {
+        // Two to four groups of streams, each with its own batched k-means chain, HIP stream and round thread: a round is ~60 dependent launches and takes
+        // ~20 ms next to the flow solver whatever the batch (24 or 128 frames), and while ONE batch for all streams ran, every tail worker was idle --
+        // 80 of a 280 ms tail phase at 1280x720.  The groups are independent (a stream's k-means needs only its own previous frame's merged labels), so
+        // one group's round overlaps the other groups' tails.  How many: more chains take more of the GPU from the flow solver (four instead of two cost
+        // 5 % at 640x480, where the GPU is the bottleneck, and bring 3 % at 1280x720, where the host is), so the count follows the same signal as the
+        // region grow's share (grow_adapt): two to begin with, one more when steps wait for the host although every grow already runs on the GPU.
+        p->km_groups_max = std::max(1, std::min((int)sind_pipe::KM_GROUPS, p->S / 8)); p->km_groups = std::min(2, p->km_groups_max);
+        const int per = p->km_groups_max >= 2 ? (p->S + 1) / 2 : p->S;        // the largest group any partition has
+        for (int g = 0; g < p->km_groups_max; g++) { SIND_TRY(make_stream(&p->km_streams[g], true)); SIND_TRY(p->kmb[g].init(p->dc, per, p->km_streams[g])); }
+    }
     p->batch_occ = B >= 4 && !(sind_lab_env("SIND_OCC_BATCH") && atoi(sind_lab_env("SIND_OCC_BATCH")) == 0);
     if (p->batch_occ) {
         p->occ_chunk = std::min(B, std::max(1, sind_lab_env("SIND_OCC_CHUNK") ? atoi(sind_lab_env("SIND_OCC_CHUNK")) : 64));
@@ -239,7 +257,7 @@ int sind_pipe_destroy(sind_pipe* p) {
         if (n) fprintf(stderr, "[sind] cal_occluded: gpu+d2h %.2f pack %.2f endpoints %.2f peac %.2f contour-filter %.2f close %.2f | seg_merge: pieces %.2f sort+paint+pack %.2f alloc %.2f h2d-enqueue %.2f rag %.2f merge %.2f\n", f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5] / n, f[6] / n, f[10] / n, f[11] / n, f[7] / n, f[8] / n, f[9] / n);
         if (n) fprintf(stderr, "[sind] pieces: open %.2f contours %.2f masks %.2f lianjie %.2f centre %.2f | flow_masks host: weights %.2f sort+wait %.2f homography %.2f pack %.2f | fusion: low %.2f clusters %.2f fill %.2f out+state %.2f\n",
                        f[12] / n, f[13] / n, f[14] / n, f[15] / n, f[16] / n, f[20] / n, f[21] / n, f[22] / n, f[23] / n, f[25] / n, f[26] / n, f[27] / n, f[28] / n);
-        if (p->km_rounds) fprintf(stderr, "[sind] batched k-means: %.2f ms per round of %d frames (%ld rounds)\n", p->km_round_ms / p->km_rounds, p->S, p->km_rounds);
+        if (p->km_rounds) fprintf(stderr, "[sind] batched k-means: %.2f ms per round of %d frames (%ld rounds)\n", p->km_round_ms / p->km_rounds, p->S / std::max(1, p->km_groups), p->km_rounds);
         if (n) fprintf(stderr, "[sind] after the tail: dilate15 %.2f output copies %.2f orb mask filter %.2f\n", f[30] / n, f[31] / n, f[32] / n);
         if (g_cpu_steps.load()) fprintf(stderr, "[sind] phase-A thread CPU per step: flow slices %.1f ms, ORB thread %.1f ms (octree threads not included)\n", g_cpu_us_flow.load() / 1e3 / g_cpu_steps.load(), g_cpu_us_orb.load() / 1e3 / g_cpu_steps.load());
         if (n) fprintf(stderr, "[sind] stream waits: %.2f ms and %.1f calls per frame (occ + tail + batch stream)\n", g_sind_wait_ns.load() / 1e6 / n, (double)g_sind_wait_calls.load() / n);
@@ -247,8 +265,8 @@ int sind_pipe_destroy(sind_pipe* p) {
     }
     (void)hipSetDevice(p->c.device);
     (void)hipDeviceSynchronize();
-    if (p->round_thread.joinable()) p->round_thread.join();
-    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream); ss.push_back(p->km_stream); ss.push_back(p->occ_stream); ss.push_back(p->grow_stream);
+    for (std::thread& t : p->round_threads) if (t.joinable()) t.join();
+    std::vector<hipStream_t> ss = p->worker_streams; ss.push_back(p->stream); ss.push_back(p->km_stream); for (hipStream_t k : p->km_streams) ss.push_back(k); ss.push_back(p->occ_stream); ss.push_back(p->grow_stream);
     for (auto& b : p->sb) { for (hipEvent_t e : b.occ_ev) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : b.occ2_ev) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : b.grow_ev) if (e) (void)hipEventDestroy(e); }
     for (size_t w = 0; w < p->worker_streams_lo.size(); w++) if (w >= p->worker_streams.size() || p->worker_streams_lo[w] != p->worker_streams[w]) ss.push_back(p->worker_streams_lo[w]); ss.push_back(p->orb_stream); ss.insert(ss.end(), p->extra_streams.begin(), p->extra_streams.end());
     if (p->ev_pool) (void)hipEventDestroy(p->ev_pool);
@@ -509,27 +527,30 @@ static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o
     sind_pipe::StepBuf* sbp = &sb;
     if (p->batch_km && !sb.depth_ahead) {
         // rounds: frame t of every stream -- the batched k-means chain on its own stream, then the S tails of that frame on the pool
-        p->round_thread = std::thread([p, sbp, o, S] {
+        sbp->km_groups = p->km_groups; for (int g = 0; g <= sbp->km_groups; g++) sbp->km_first[g] = (int)((long long)S * g / sbp->km_groups);
+        for (int g = 0; g < sbp->km_groups; g++) p->round_threads.emplace_back([p, sbp, o, g] {
             (void)pthread_setname_np(pthread_self(), "sind-rounds"); (void)hipSetDevice(p->c.device);
-            const size_t np = (size_t)p->c.width * p->c.height; std::vector<const uint8_t*> prev(S);
+            const size_t np = (size_t)p->c.width * p->c.height;
+            const int s0 = sbp->km_first[g], ns = sbp->km_first[g + 1] - s0; std::vector<const uint8_t*> prev(ns);
             for (int t = 0; t < p->T; t++) {
-                for (int s = 0; s < S; s++) prev[s] = depth_half(p, s)->prev_km_labels();
+                if (t > 0) WorkerPool::wait(sbp->km_tails[g]);           // this group's tails of frame t - 1 (their merged labels start this round's k-means)
+                for (int s = 0; s < ns; s++) prev[s] = depth_half(p, s0 + s)->prev_km_labels();
                 const double tk = now_ms();
-                sind_range_push("sind round: batched k-means of frame t of every stream");
-                const int rc = p->kmb.run(sbp->depth_dev.p + np * t, np * p->T, S, prev.data());
+                sind_range_push("sind round: batched k-means of frame t of one group of streams");
+                const int rc = p->kmb[g].run(sbp->depth_dev.p + np * ((size_t)s0 * p->T + t), np * p->T, ns, prev.data());
                 sind_range_pop();
-                p->km_round_ms += now_ms() - tk; p->km_rounds++;
-                if (rc != SIND_OK) { const std::string e = sind_last_error(); for (int s = 0; s < S; s++) if (sbp->tail_rc[s] == SIND_OK) { sbp->tail_rc[s] = rc; sbp->tail_err[s] = "batched k-means: " + e; } return; }
-                for (int s = 0; s < S; s++) if (sbp->tail_rc[s] == SIND_OK) p->workers.push(sbp->tail_group, [p, sbp, o, s, t](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb.result(s), false); });
-                WorkerPool::wait(sbp->tail_group);
+                { std::lock_guard<std::mutex> lk(p->km_stat_mu); p->km_round_ms += now_ms() - tk; p->km_rounds++; }
+                if (rc != SIND_OK) { const std::string e = sind_last_error(); for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK) { sbp->tail_rc[s] = rc; sbp->tail_err[s] = "batched k-means: " + e; } return; }
+                for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK) p->workers.push(sbp->km_tails[g], [p, sbp, o, s, t, g, s0](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb[g].result(s - s0), false); });
             } });
         return;
     }
     for (int s = 0; s < S; s++) p->workers.push(sb.tail_group, [p, sbp, o, s](int w) { tail_task(p, sbp, o, s, 0, w); });
 }
 static int phase_b_finish(sind_pipe* p, sind_pipe::StepBuf& sb) {
-    if (p->round_thread.joinable()) p->round_thread.join();
-    WorkerPool::wait(sb.tail_group);
+    for (std::thread& t : p->round_threads) if (t.joinable()) t.join();
+    p->round_threads.clear();
+    WorkerPool::wait(sb.tail_group); for (TaskGroup& g : sb.km_tails) WorkerPool::wait(g);
     sb.pending = false;
     for (int s = 0; s < p->S; s++) if (sb.tail_rc[s] != SIND_OK) { sind_set_error("stream %d: %s", s, sb.tail_err[s].c_str()); return sb.tail_rc[s]; }
     return SIND_OK;
@@ -668,6 +689,7 @@ int sind_pipe_set_grow_share(sind_pipe* p, int quarters) {
     return SIND_OK;
 }
 int sind_pipe_get_grow_share(sind_pipe* p, int* quarters) { if (!p || !quarters) return SIND_E_ARG; *quarters = p->grow_q; return SIND_OK; }
+int sind_pipe_get_kmeans_groups(sind_pipe* p, int* groups) { if (!p || !groups) { sind_set_error("sind_pipe_get_kmeans_groups: null argument"); return SIND_E_ARG; } *groups = p->batch_km ? p->km_groups : 0; return SIND_OK; }
 int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes) { if (!p || !bytes) { sind_set_error("sind_pipe_mask_bytes: null argument"); return SIND_E_ARG; } *bytes = (size_t)p->S * p->T * p->c.width * p->c.height; return SIND_OK; }
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms) { if (!p || !ms) return SIND_E_ARG; *ms = p->tail_wait_ms; return SIND_OK; }
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices) {

@@ -86,6 +86,10 @@ class Pipeline:
     def grow_share(self) -> int:
         q = C.c_int(); check(lib().sind_pipe_get_grow_share(self._h, C.byref(q))); return q.value
 
+    def kmeans_groups(self) -> int:
+        """groups of streams whose batched k-means rounds run as independent chains right now (0: no batched k-means)"""
+        q = C.c_int(); check(lib().sind_pipe_get_kmeans_groups(self._h, C.byref(q)), "sind_pipe_get_kmeans_groups"); return q.value
+
     def get_state_bytes(self) -> int:
         return int(lib().sind_pipe_state_bytes(self._h))
 

@@ -198,3 +198,36 @@ def test_region_grow_share_does_not_change_the_results(frames):
         for a, b in zip(outs[0], other):
             for x, y in zip(a, b):
                 assert np.array_equal(x, y)
+
+
+def test_kmeans_stream_groups_do_not_change_the_results(frames):
+    """from 16 streams on the batched k-means rounds run as independent chains per group of streams: the 16-stream pipeline (two groups) equals two
+    8-stream pipelines (one group each) on the same streams"""
+    from sindslam_amd.pipeline import Pipeline
+    bgr, depth = frames
+    T = 2
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    vb = [bgr, bgr[:, :, ::-1], bgr[:, ::-1], bgr[:, ::-1, ::-1]]; vd = [depth, depth[:, :, ::-1], depth[:, ::-1], depth[:, ::-1, ::-1]]
+    gain = [1.0, 0.9, 0.8, 0.7]
+    sb = np.stack([np.ascontiguousarray((vb[s % 4] * gain[s // 4]).astype(np.uint8)) for s in range(16)])
+    sd = np.stack([np.ascontiguousarray(vd[s % 4]) for s in range(16)])
+
+    def run(streams):
+        pipe = Pipeline(len(streams), T, 640, 480, *K, 1500, 1.2, 8, 15, 5)
+        for i, s in enumerate(streams):
+            pipe.prime(i, sb[s, 1], sb[s, 0])
+        got = []
+        for step in range(2):
+            lo = 2 + step * T
+            pipe.process(sb[streams, lo:lo + T], sd[streams, lo:lo + T])
+            got.append([np.asarray(a).reshape((len(streams), T, -1)).copy() for a in (pipe.dyna, pipe.label, pipe.mask, pipe.nkp)])      # frame k = stream * T + t
+        groups = pipe.kmeans_groups()
+        pipe.close()
+        return got, groups
+
+    whole, g16 = run(list(range(16)))
+    lo8, g8 = run(list(range(8))); hi8, _ = run(list(range(8, 16)))
+    assert g16 == 2 and g8 == 1
+    for step in range(2):
+        for k in range(4):
+            assert np.array_equal(whole[step][k][:8], lo8[step][k]) and np.array_equal(whole[step][k][8:], hi8[step][k])

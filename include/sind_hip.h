@@ -221,8 +221,9 @@ int sind_pipe_gather_masks(sind_pipe* p, sind_comm* c, const uint8_t* dyna_host,
  * no step waits (the smallest GPU share the host keeps up with).  Environment SIND_GROW_GPU=0..4 fixes it at create. */
 int sind_pipe_set_grow_share(sind_pipe* p, int quarters);
 int sind_pipe_get_grow_share(sind_pipe* p, int* quarters);
-/* How many groups of streams run their batched k-means rounds (reference DynaDetect.cc:315-420) as independent chains at the moment: 1 below 16 streams, else 2..4
+/* How many groups of streams run their batched k-means rounds (reference DynaDetect.cc:315-420) as independent chains at the moment: 1..4 (at most streams / 8)
  * chosen by the same controller (one more while steps wait for the host although every region grow already runs on the GPU).  Results do not depend on it. */
+int sind_pipe_set_kmeans_groups(sind_pipe* p, int groups);      /* 1 .. min(4, streams / 8), or -1 = adaptive (default); takes effect with the next step */
 int sind_pipe_get_kmeans_groups(sind_pipe* p, int* groups);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -68,7 +68,7 @@ struct sind_pipe {
     // k-means of one frame of every stream as ONE batched kernel chain (phase B then runs frame t of all streams as a round: batched k-means,
     // then the S tails of that frame on the pool); used when there are several streams and the depth half is not run ahead
     static constexpr int KM_GROUPS = 4;
-    KMeansBatch kmb[KM_GROUPS]; int km_groups = 1, km_groups_max = 1, km_idle_steps = 0; hipStream_t km_stream = nullptr, km_streams[KM_GROUPS] = {nullptr}; bool batch_km = false;
+    KMeansBatch kmb[KM_GROUPS]; int km_groups = 1, km_groups_max = 1, km_groups_fixed = -1; hipStream_t km_stream = nullptr, km_streams[KM_GROUPS] = {nullptr}; bool batch_km = false;
     std::vector<std::thread> round_threads; std::mutex km_stat_mu; double km_round_ms = 0; long km_rounds = 0;
     std::vector<std::unique_ptr<PinnedBuf<uint8_t>>> upload_stage;        // page-locked staging of sind_pipe_process (host-buffer entry point), two 4 MB buffers per uploading worker
     std::vector<std::unique_ptr<DynaTail>> occ_tails;     // CalOccluded workspaces, one per pool worker (state free)
@@ -119,11 +119,11 @@ static double now_ms();
 static void grow_adapt(sind_pipe* p, double host_wait_ms, double step_ms) {
     if (p->grow_q_fixed >= 0 || !p->batch_occ || step_ms <= 0) return;
     if (host_wait_ms > 0.03 * step_ms) {
-        if (p->grow_q >= 4 && p->batch_km) p->km_groups = std::min(p->km_groups_max, p->km_groups + 1);      // every grow is on the GPU already: one more k-means chain
+        if ((p->grow_q >= 4 || host_wait_ms > 0.15 * step_ms) && p->batch_km && p->km_groups_fixed < 0) p->km_groups = std::min(p->km_groups_max, p->km_groups + 1);      // every grow is on the GPU already (or the wait is long): one more k-means chain
         p->grow_q = std::min(4, p->grow_q + 1); p->grow_idle_steps = 0;
     } else if (host_wait_ms < 0.005 * step_ms) {
         if (++p->grow_idle_steps >= 3) {
-            if (p->batch_km && p->km_groups > std::min(2, p->km_groups_max)) p->km_groups--; else p->grow_q = std::max(0, p->grow_q - 1);
+            if (p->batch_km && p->km_groups > 1 && p->km_groups_fixed < 0) p->km_groups--; else p->grow_q = std::max(0, p->grow_q - 1);
             p->grow_idle_steps = 0;
         }
     } else p->grow_idle_steps = 0;
@@ -205,10 +205,10 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
         // 80 of a 280 ms tail phase at 1280x720.  The groups are independent (a stream's k-means needs only its own previous frame's merged labels), so
         // one group's round overlaps the other groups' tails.  How many: more chains take more of the GPU from the flow solver (four instead of two cost
         // 5 % at 640x480, where the GPU is the bottleneck, and bring 3 % at 1280x720, where the host is), so the count follows the same signal as the
-        // region grow's share (grow_adapt): two to begin with, one more when steps wait for the host although every grow already runs on the GPU.
-        p->km_groups_max = std::max(1, std::min((int)sind_pipe::KM_GROUPS, p->S / 8)); p->km_groups = std::min(2, p->km_groups_max);
-        const int per = p->km_groups_max >= 2 ? (p->S + 1) / 2 : p->S;        // the largest group any partition has
-        for (int g = 0; g < p->km_groups_max; g++) { SIND_TRY(make_stream(&p->km_streams[g], true)); SIND_TRY(p->kmb[g].init(p->dc, per, p->km_streams[g])); }
+        // region grow's share (grow_adapt): one to begin with, one more when steps wait for the host although every grow already runs on the GPU.
+        p->km_groups_max = std::max(1, std::min((int)sind_pipe::KM_GROUPS, p->S / 8)); p->km_groups = 1;
+        for (int g = 0; g < p->km_groups_max; g++) {                          // group 0 may hold all streams, the others at most half of them
+            SIND_TRY(make_stream(&p->km_streams[g], true)); SIND_TRY(p->kmb[g].init(p->dc, g == 0 ? p->S : (p->S + 1) / 2, p->km_streams[g])); }
     }
     p->batch_occ = B >= 4 && !(sind_lab_env("SIND_OCC_BATCH") && atoi(sind_lab_env("SIND_OCC_BATCH")) == 0);
     if (p->batch_occ) {
@@ -689,6 +689,10 @@ int sind_pipe_set_grow_share(sind_pipe* p, int quarters) {
     return SIND_OK;
 }
 int sind_pipe_get_grow_share(sind_pipe* p, int* quarters) { if (!p || !quarters) return SIND_E_ARG; *quarters = p->grow_q; return SIND_OK; }
+int sind_pipe_set_kmeans_groups(sind_pipe* p, int groups) {
+    if (!p || groups < -1 || groups == 0 || groups > p->km_groups_max) { sind_set_error("sind_pipe_set_kmeans_groups: -1 (adaptive) or 1..%d groups for this handle", p ? p->km_groups_max : 0); return SIND_E_ARG; }
+    p->km_groups_fixed = groups; if (groups > 0) p->km_groups = groups; return SIND_OK;
+}
 int sind_pipe_get_kmeans_groups(sind_pipe* p, int* groups) { if (!p || !groups) { sind_set_error("sind_pipe_get_kmeans_groups: null argument"); return SIND_E_ARG; } *groups = p->batch_km ? p->km_groups : 0; return SIND_OK; }
 int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes) { if (!p || !bytes) { sind_set_error("sind_pipe_mask_bytes: null argument"); return SIND_E_ARG; } *bytes = (size_t)p->S * p->T * p->c.width * p->c.height; return SIND_OK; }
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms) { if (!p || !ms) return SIND_E_ARG; *ms = p->tail_wait_ms; return SIND_OK; }

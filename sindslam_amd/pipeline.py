@@ -86,6 +86,10 @@ class Pipeline:
     def grow_share(self) -> int:
         q = C.c_int(); check(lib().sind_pipe_get_grow_share(self._h, C.byref(q))); return q.value
 
+    def set_kmeans_groups(self, groups: int):
+        """batched k-means rounds as `groups` independent chains over groups of streams (1 .. min(4, streams // 8)); -1 = adaptive (default); same results"""
+        check(lib().sind_pipe_set_kmeans_groups(self._h, int(groups)), "sind_pipe_set_kmeans_groups")
+
     def kmeans_groups(self) -> int:
         """groups of streams whose batched k-means rounds run as independent chains right now (0: no batched k-means)"""
         q = C.c_int(); check(lib().sind_pipe_get_kmeans_groups(self._h, C.byref(q)), "sind_pipe_get_kmeans_groups"); return q.value

@@ -212,8 +212,10 @@ def test_kmeans_stream_groups_do_not_change_the_results(frames):
     sb = np.stack([np.ascontiguousarray((vb[s % 4] * gain[s // 4]).astype(np.uint8)) for s in range(16)])
     sd = np.stack([np.ascontiguousarray(vd[s % 4]) for s in range(16)])
 
-    def run(streams):
+    def run(streams, groups=-1):
         pipe = Pipeline(len(streams), T, 640, 480, *K, 1500, 1.2, 8, 15, 5)
+        if groups > 0:
+            pipe.set_kmeans_groups(groups)
         for i, s in enumerate(streams):
             pipe.prime(i, sb[s, 1], sb[s, 0])
         got = []
@@ -225,7 +227,7 @@ def test_kmeans_stream_groups_do_not_change_the_results(frames):
         pipe.close()
         return got, groups
 
-    whole, g16 = run(list(range(16)))
+    whole, g16 = run(list(range(16)), 2)
     lo8, g8 = run(list(range(8))); hi8, _ = run(list(range(8, 16)))
     assert g16 == 2 and g8 == 1
     for step in range(2):

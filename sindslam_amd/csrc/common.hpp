@@ -77,14 +77,14 @@ struct SindTokenPause {        // scope in which a token holder does not need it
 extern std::atomic<long long> g_sind_wait_ns, g_sind_wait_calls;      // statistics of sind_stream_wait (SIND_TAIL_TIMING report)
 // (Tried in round 3: a per-thread hipEventBlockingSync event + hipEventSynchronize instead of the loop below -- on this ROCm it does not sleep either: host cores busy
 // 11.5 -> 14.7, CPU-quota throttling in 37 of 51 periods.)  The sleep grows with the wait: a waiter that has slept 0.2 ms is behind a queue of kernels and is
-// woken every 50, later every 100 us -- a wake-up costs 5-10 us of CPU, at 20 us a waiting thread kept a third of a core.
+// woken every 50, then 100, after ~3 ms every 250 us -- a wake-up costs 5-10 us of CPU, at 20 us a waiting thread kept a third of a core.
 static inline hipError_t sind_stream_wait(hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipErrorNotReady;
     for (int i = 0; i < 8 && e == hipErrorNotReady; i++) e = hipStreamQuery(s);
     if (e == hipErrorNotReady) {
         SindTokenPause pause;
-        for (int i = 0; e == hipErrorNotReady; i++) { std::this_thread::sleep_for(std::chrono::microseconds(i < 10 ? 20 : i < 20 ? 50 : 100)); e = hipStreamQuery(s); }
+        for (int i = 0; e == hipErrorNotReady; i++) { std::this_thread::sleep_for(std::chrono::microseconds(i < 10 ? 20 : i < 20 ? 50 : i < 40 ? 100 : 250)); e = hipStreamQuery(s); }
     }
     g_sind_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
     g_sind_wait_calls.fetch_add(1, std::memory_order_relaxed);

@@ -78,10 +78,14 @@ extern std::atomic<long long> g_sind_wait_ns, g_sind_wait_calls;      // statist
 // (Tried in round 3: a per-thread hipEventBlockingSync event + hipEventSynchronize instead of the loop below -- on this ROCm it does not sleep either: host cores busy
 // 11.5 -> 14.7, CPU-quota throttling in 37 of 51 periods.)  The sleep grows with the wait: a waiter that has slept 0.2 ms is behind a queue of kernels and is
 // woken every 50, then 100, after ~3 ms every 250 us -- a wake-up costs 5-10 us of CPU, at 20 us a waiting thread kept a third of a core.
+// A one-stream pipeline (the in-order sequence mode) is a chain of short dependent GPU steps with most of the host idle: its workers poll without sleeping for
+// t_sind_spin_us first (a sleep costs 50-70 us of wake-up latency, three to four times per frame of a 3.3 ms chain).
+extern thread_local int t_sind_spin_us;
 static inline hipError_t sind_stream_wait(hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipErrorNotReady;
     for (int i = 0; i < 8 && e == hipErrorNotReady; i++) e = hipStreamQuery(s);
+    if (t_sind_spin_us > 0) while (e == hipErrorNotReady && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < t_sind_spin_us) e = hipStreamQuery(s);
     if (e == hipErrorNotReady) {
         SindTokenPause pause;
         for (int i = 0; e == hipErrorNotReady; i++) { std::this_thread::sleep_for(std::chrono::microseconds(i < 10 ? 20 : i < 20 ? 50 : i < 40 ? 100 : 250)); e = hipStreamQuery(s); }

@@ -111,6 +111,7 @@ int FlowEngine::varref_f32(const float* I0, const float* I1, int w, int h, int B
 static thread_local char g_err[512] = "";
 std::atomic<long long> g_sind_wait_ns{0}, g_sind_wait_calls{0};
 thread_local SindHostGate* t_sind_gate = nullptr;
+thread_local int t_sind_spin_us = 0;
 
 #include <dlfcn.h>
 namespace {

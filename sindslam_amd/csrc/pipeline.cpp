@@ -32,10 +32,11 @@ static std::atomic<long long> g_cpu_us_flow{0}, g_cpu_us_orb{0}, g_cpu_steps{0};
 struct TaskGroup { std::mutex m; std::condition_variable cv; int left = 0; };
 class WorkerPool {
 public:
-    void start(int n, int device, SindHostGate* gate) {
-        for (int i = 0; i < n; i++) th.emplace_back([this, i, device, gate] {
+    void start(int n, int device, SindHostGate* gate, int spin_us = 0) {
+        for (int i = 0; i < n; i++) th.emplace_back([this, i, device, gate, spin_us] {
             (void)pthread_setname_np(pthread_self(), "sind-worker");      // names show up in /proc/<pid>/task/*/comm (bench.py --thread-cpu)
             (void)hipSetDevice(device);
+            t_sind_spin_us = spin_us;
             for (;;) {
                 std::pair<std::function<void(int)>, TaskGroup*> job;
                 { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return stop || !q.empty(); }); if (q.empty()) return; job = std::move(q.front()); q.pop_front(); }
@@ -229,7 +230,7 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
         SIND_TRY(make_stream(&p->grow_stream, !(sind_lab_env("SIND_OCC_PRIORITY") && atoi(sind_lab_env("SIND_OCC_PRIORITY")) == 0)));
         SIND_TRY(p->grow.init(cfg->width, cfg->height, cfg->fx, cfg->fy, cfg->cx, cfg->cy, cfg->depth_scale, p->occ_chunk));
     }
-    p->workers.start(nworkers, cfg->device, &p->gate);
+    p->workers.start(nworkers, cfg->device, &p->gate, p->S == 1 ? 400 : 0);        // one stream: serial chains, idle host -- poll before sleeping (common.hpp)
     SIND_TRY(p->gray.alloc(np * std::max(B, 2)));          // sind_pipe_prime converts the two priming frames through this scratch, also when S * T == 1
     SIND_TRY(p->pool.alloc((size_t)p->fw * p->fh * p->S * (p->T + 2)));
     if (cfg->orb_gray_rgb_order) SIND_TRY(p->gray_orb.alloc(np * B));
@@ -488,13 +489,17 @@ struct PipeOut { uint8_t *dyna, *label, *mask; sind_keypoint* kps; int cap; int*
 // Depth half of frame k = (stream s, frame t) of a synchronous step: runs while the dense flow is on the GPU, in frame order per stream
 // (the k-means warm labels are the previous frame's merged labels).  It opens the gate of the stream's next frame when it is done.
 static void depth_task(sind_pipe* p, sind_pipe::StepBuf* sb, int k, int worker) {
-    const int T = p->T, s = k / T, t = k % T; const size_t np = (size_t)p->c.width * p->c.height;
-    DynaTail* dt = depth_half(p, s); dt->stream = p->worker_streams_lo[worker];
-    const int r = dt->depth_stage(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, &sb->occ[k], sb->dout[k]);
-    if (r != SIND_OK) { sb->depth_rc[k] = r; sb->depth_err[k] = sind_last_error(); }
-    if (t + 1 < T && sb->gate[k + 1].fetch_add(1) == 1) p->workers.push(sb->depth_group, [p, sb, k](int w) { depth_task(p, sb, k + 1, w); });
+    for (;;) {
+        const int T = p->T, s = k / T, t = k % T; const size_t np = (size_t)p->c.width * p->c.height;
+        DynaTail* dt = depth_half(p, s); dt->stream = p->worker_streams_lo[worker];
+        const int r = dt->depth_stage(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, &sb->occ[k], sb->dout[k]);
+        if (r != SIND_OK) { sb->depth_rc[k] = r; sb->depth_err[k] = sind_last_error(); }
+        if (!(t + 1 < T && sb->gate[k + 1].fetch_add(1) == 1)) return;
+        if (p->S == 1) { k++; continue; }                    // one stream: the next frame's chain link right here (no hand-over to another worker)
+        p->workers.push(sb->depth_group, [p, sb, k](int w) { depth_task(p, sb, k + 1, w); }); return;
+    }
 }
-static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker, const KmFrameResult* km = nullptr, bool chain = true) {
+static bool tail_one(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker, const KmFrameResult* km) {
     SindRange range_t("sind tail: flow masks, SegAndMerge, fusion, dilation, ORB mask filter");
     p->tails[s]->stream = p->worker_streams[worker];
     const int T = p->T, W = p->c.width, H = p->c.height; const size_t np = (size_t)W * H;
@@ -504,7 +509,7 @@ static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, in
     int r = sb->depth_ahead ? p->tails[s]->flow_stage(sb->U.p + np * k, sb->V.p + np * k, sb->dout[k], dy.data(), lb.data(), sb->occ[k].gridFlow)
                             : p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k],
                                                    p->dtails.empty() ? nullptr : (p->dtails[s]->stream = p->worker_streams[worker], p->dtails[s].get()), km);
-    if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return; }
+    if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return false; }
     double* tf = p->tails[s]->t_fine; double t0 = now_ms();
     dilate15_codes(dy.data(), W, H, dil.data());
     { const double t1 = now_ms(); tf[30] += t1 - t0; t0 = t1; }
@@ -515,11 +520,18 @@ static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, in
     std::vector<OrbKeyPoint> kk; std::vector<uint8_t> dd;
     p->orb.finish(sb->orb[k], dil.data(), W, kk, dd);
     { const double t1 = now_ms(); tf[32] += t1 - t0; t0 = t1; }
-    if ((int)kk.size() > o.cap && (o.kps || o.desc)) { sb->tail_rc[s] = SIND_E_CAPACITY; sb->tail_err[s] = "keypoint capacity exceeded"; return; }
+    if ((int)kk.size() > o.cap && (o.kps || o.desc)) { sb->tail_rc[s] = SIND_E_CAPACITY; sb->tail_err[s] = "keypoint capacity exceeded"; return false; }
     if (o.nkp) o.nkp[k] = (int)kk.size();
     if (o.kps) std::memcpy(o.kps + (size_t)k * o.cap, kk.data(), kk.size() * sizeof(sind_keypoint));
     if (o.desc) std::memcpy(o.desc + (size_t)k * o.cap * 32, dd.data(), dd.size());
-    if (chain && t + 1 < T) p->workers.push(sb->tail_group, [p, sb, o, s, t](int w) { tail_task(p, sb, o, s, t + 1, w); });
+    return true;
+}
+static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker, const KmFrameResult* km = nullptr, bool chain = true) {
+    for (;;) {
+        if (!tail_one(p, sb, o, s, t, worker, km) || !chain || t + 1 >= p->T) return;
+        if (p->S == 1) { t++; km = nullptr; continue; }      // one stream: the next frame's chain link right here (no hand-over to another worker)
+        p->workers.push(sb->tail_group, [p, sb, o, s, t](int w) { tail_task(p, sb, o, s, t + 1, w); }); return;
+    }
 }
 static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
     const int S = p->S;

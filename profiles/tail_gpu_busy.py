@@ -5,7 +5,7 @@ import csv
 import glob
 import sys
 
-FLOW = ("k_sor_fused", "k_coef", "k_add_flow", "k_resize_f32", "k_warp_avg_iz", "k_resize_u8", "k_u8_to_f32_blur3", "k_bgr2gray", "k_mag_max", "k_scale")
+FLOW = ("k_sor_stream", "k_sor_fused", "k_sor_color", "k_coef", "k_add_flow", "k_resize_f32", "k_warp_avg_iz", "k_resize_u8", "k_u8_to_f32_blur3", "k_bgr2gray", "k_mag_max", "k_scale")
 ORB = ("k_fast_cells", "k_pad_reflect101", "k_blur7", "k_ic_angle", "k_brief", "k_compact_cells", "k_copy_into_slab")
 f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]; steps = int(sys.argv[2])
 iv = {"flow": [], "tail": []}

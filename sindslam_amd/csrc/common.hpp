@@ -58,8 +58,10 @@ struct SindRange { explicit SindRange(const char* name) { sind_range_push(name);
 #include <condition_variable>
 #include <mutex>
 struct SindHostGate {
-    std::mutex m; std::condition_variable cv; int free_tokens = 1 << 20;
-    void set_capacity(int n) { std::lock_guard<std::mutex> lk(m); free_tokens = n; cv.notify_all(); }
+    std::mutex m; std::condition_variable cv; int free_tokens = 1 << 20, capacity = 1 << 20;
+    // (relative to the tokens that are out: a submit re-sizes the gate while the previous step's tails still hold theirs -- setting the free count itself
+    // handed out up to twice the capacity and brought the quota throttling back)
+    void set_capacity(int n) { std::lock_guard<std::mutex> lk(m); free_tokens += n - capacity; capacity = n; cv.notify_all(); }
     void acquire() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return free_tokens > 0; }); free_tokens--; }
     void release() { { std::lock_guard<std::mutex> lk(m); free_tokens++; } cv.notify_one(); }
 };

@@ -101,7 +101,7 @@ struct sind_pipe {
     int cur = 0; int occ_workers = 24;
     // CPU tokens (common.hpp) for the software-pipelined steps, where CalOccluded runners and tails compete for the quota (measured: throttled periods 7 -> 2
     // of 22, +1 %); synchronous steps run ungated -- there the hand-over of tokens at every GPU wait costs more than the throttling (tails 145 -> 173 ms)
-    int cpu_tokens = 15;
+    int cpu_tokens = 15, cpu_tokens_min = 13, cpu_tokens_max = 15; bool cpu_tokens_fixed = false;
     // Optional schedule of the synchronous step: run the depth half of the tails (k-means, SegAndMerge) underneath the dense flow.
     // Parity-tested, off by default: the tails phase shrinks from ~75 to ~23 ms, but the solver loses as much to the ~13 k extra small
     // launches it then shares the GPU with (dense flow 232 -> 287 ms at high stream priority; at normal priority the chains starve).
@@ -122,7 +122,9 @@ static void grow_adapt(sind_pipe* p, double host_wait_ms, double step_ms) {
     if (host_wait_ms > 0.03 * step_ms) {
         if ((p->grow_q >= 4 || host_wait_ms > 0.15 * step_ms) && p->batch_km && p->km_groups_fixed < 0) p->km_groups = std::min(p->km_groups_max, p->km_groups + 1);      // every grow is on the GPU already (or the wait is long): one more k-means chain
         p->grow_q = std::min(4, p->grow_q + 1); p->grow_idle_steps = 0;
+        if (!p->cpu_tokens_fixed && host_wait_ms > 0.10 * step_ms) p->cpu_tokens = p->cpu_tokens_max;      // clearly host-bound: every core of the share
     } else if (host_wait_ms < 0.005 * step_ms) {
+        if (!p->cpu_tokens_fixed) p->cpu_tokens = std::max(p->cpu_tokens_min, p->cpu_tokens - 1);
         if (++p->grow_idle_steps >= 3) {
             if (p->batch_km && p->km_groups > 1 && p->km_groups_fixed < 0) p->km_groups--; else p->grow_q = std::max(0, p->grow_q - 1);
             p->grow_idle_steps = 0;
@@ -194,7 +196,11 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     }
     for (int s = 0; s < p->S; s++) { p->tails[s].reset(new DynaTail()); SIND_TRY(p->tails[s]->init(p->dc, p->worker_streams[s % nworkers]));
         if (p->S == 1) p->tails[s]->piece_threads = std::max(1, std::min(4, cpu_share / 3)); }       // one stream: the tails are two serial chains, host cores idle
-    p->cpu_tokens = sind_lab_env("SIND_CPU_TOKENS") ? std::max(1, atoi(sind_lab_env("SIND_CPU_TOKENS"))) : std::max(2, cpu_share - 1);       // one core stays with the flow launch threads, the ORB thread and the round driver (they mostly sleep)
+    // CPU tokens of the pool tasks: the flow's three launch threads, the ORB thread and the round drivers run beside them and are not gated, so share - 1 tokens
+    // overshoot the quota in bursts (10-17 of 77 periods throttled) and share - 3 do not (0 periods, -1 % at 640x480 where the GPU is the bottleneck); a
+    // host-bound configuration wants every core it can get.  The controller below moves between the two on the same signal as the region grow's share.
+    p->cpu_tokens_max = std::max(2, cpu_share - 1); p->cpu_tokens_min = std::max(2, cpu_share - 3); p->cpu_tokens = p->cpu_tokens_min;
+    if (sind_lab_env("SIND_CPU_TOKENS")) { p->cpu_tokens = std::max(1, atoi(sind_lab_env("SIND_CPU_TOKENS"))); p->cpu_tokens_fixed = true; }
     p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads
     if (const char* e = sind_lab_env("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
     p->depth_ahead = sind_lab_env("SIND_DEPTH_AHEAD") && atoi(sind_lab_env("SIND_DEPTH_AHEAD")) != 0;

@@ -33,6 +33,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SEQ_BASE_FRAMES = 50            # generated frames of the sequence workload, walked forth and back
+SEQ_WARMUP_FRAMES = 16          # state warm-up frames of a chunk: most rebuilt states equal the sequential one after ~16 frames; the others are found by the seam verification and repaired
+
 # BASELINE.json configs that fit one GPU; `tum3` is the one the metric is quoted on
 CONFIGS = {
     "tum3": dict(width=640, height=480, intr="TUM3", rgb=1, flow_max_levels=0, streams=128,
@@ -56,6 +59,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the first cpu_baseline setting (the reference pins its OpenMP loops to 8)")
     ap.add_argument("--sequence-frames", type=int, default=4000, help="sequence workload: length of the ONE sequence (BASELINE.json configs[3]: 4000 frames); fixed as --gpus grows = strong scaling")
+    ap.add_argument("--seq-warmup-frames", type=int, default=SEQ_WARMUP_FRAMES, help="sequence workload: frames every chunk after the first starts early to rebuild the inter-frame state (speculation; the seams are verified and repaired)")
+    ap.add_argument("--repair-streams", type=int, default=0, help="sequence workload: runners of the repair pipeline (0 = half the chunks of a GPU, 2..16)")
+    ap.add_argument("--repair-frames-per-step", type=int, default=4)
+    ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
+    ap.add_argument("--exact-leg-frames", type=int, default=480, help="sequence workload: frames of the in-order re-run the chunked masks are compared with")
+    ap.add_argument("--no-n1-leg", action="store_true", help="sequence workload on N > 1 ranks: skip the one-rank run of the same job on rank 0 after the timed region (sequence.n1_value)")
     ap.add_argument("--no-sequence-leg", action="store_true", help="streams workload on one GPU: skip the fixed-length sequence job that is run after the timed region (line field `sequence`)")
     ap.add_argument("--no-exact-leg", action="store_true", help="sequence workload: skip the in-order re-run of the first chunks (seam IoU, exact-mode rate)")
     ap.add_argument("--host-input", action="store_true", help="hand over HOST buffers each step (sind_pipe_process, PCIe-inclusive rate; DESIGN.md 6) instead of HBM-resident inputs")
@@ -333,53 +342,81 @@ def make_pipeline(cfg, intr, S, T, local, host_threads=0):
                     orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=host_threads, flow_max_levels=cfg["flow_max_levels"])
 
 
-SEQ_BASE_FRAMES = 50            # generated frames of the sequence workload, walked forth and back
-
-
-def sequence_streams(world, frames, cfg_streams, steps):
+def sequence_streams(world, frames, cfg_streams, steps, warm=None):
     """chunks per GPU of the fixed-length sequence when --streams is not given.  Every chunk after the first re-processes 24 state warm-up frames, so the
     chunk count trades batch size and tail parallelism (one tail chain per chunk) against warm-up work: start from the power of two that keeps the warm-up at
     about a quarter of the sequence (>= 4 chunks per GPU), then take the count near it whose lock-step plan processes the fewest frames in `steps` steps."""
     from sindslam_amd.sequence import plan_lockstep
+    warm = SEQ_WARMUP_FRAMES if warm is None else warm
     s0 = 4
-    while s0 * 2 <= cfg_streams and s0 * 2 * world * 4 * SEQ_WARMUP_FRAMES <= frames:
+    while s0 * 2 <= cfg_streams and s0 * 2 * world * 4 * max(warm, 8) <= frames:
         s0 *= 2
     best = None
     for s in range(max(4, (3 * s0) // 4), 2 * s0):
-        tot = plan_lockstep(frames, world * s, steps, SEQ_WARMUP_FRAMES).processed_total
+        tot = plan_lockstep(frames, world * s, steps, warm).processed_total
         if best is None or tot <= best[0]:
             best = (tot, s)
     return best[1]
 
 
-SEQ_WARMUP_FRAMES = 24          # a rebuilt tail state re-synchronises with the sequential run within ~16-24 frames (profiles/r02/seam_iou_by_warmup.txt)
+
+
+class BenchFrames:
+    """frame source of the sequence workload (sindslam_amd.sequence): the generated base frames live in HBM, sequence position q (0 = first processed frame; -1, -2 =
+    the two priming frames of chunk 0) shows generated frame pingpong(q + 2) -- an arbitrarily long sequence whose consecutive frames stay neighbours"""
+
+    def __init__(self, base_b, base_d):
+        import numpy as np
+        import torch
+        self.base_b = base_b; self.P = base_b.shape[0]
+        self.bb = torch.from_numpy(base_b).cuda(); self.bd = torch.from_numpy(base_d.view(np.int16)).cuda()
+
+    def fidx(self, q):
+        return pingpong(int(q) + 2, self.P)
+
+    def host_frame(self, q):
+        return self.base_b[self.fidx(q)]
+
+    def device_batch(self, pos):
+        import torch
+        idx = torch.tensor([[self.fidx(q) for q in row] for row in pos], device="cuda")
+        b = self.bb[idx].contiguous(); d = self.bd[idx].contiguous(); torch.cuda.current_stream().synchronize()
+        return b.data_ptr(), d.data_ptr(), (b, d)
 
 
 def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_dev, S, K, Wm, exact_leg):
     """BASELINE.json configs[3]: ONE synthetic RGB-D sequence of --sequence-frames frames, sharded by frame into world * S lock-step chunks (chunk g = stream
     g % S of rank g // S; sindslam_amd.sequence.plan_lockstep).  Wm untimed steps warm the process up (their state is thrown away: every stream is primed
-    again), then the K timed steps process the WHOLE job -- the state warm-up frames of every chunk after the first included -- software-pipelined, with one
-    all_gather of the step's dynamic masks per step (RCCL over xGMI with --backend nccl) into the sequence-ordered mask array every rank holds.
+    again), then the timed region is the WHOLE job: the K lock-step steps -- the state warm-up frames of every chunk after the first included --
+    software-pipelined, with one all_gather of the step's dynamic masks per step (RCCL over xGMI with --backend nccl) into the sequence-ordered mask array
+    every rank holds, THEN the verification of every chunk seam by state fingerprints and the repair of the chunks whose rebuilt state is not the sequential
+    one (sindslam_amd.sequence.VerifiedChunks; their corrected masks are exchanged once per round), so that the masks equal the sequential loop's.
     Returns (seconds [max over ranks], StepAcc, info dict, host load of every rank)."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from sindslam_amd.parallel import gather_masks
-    from sindslam_amd.sequence import plan_lockstep
-    H, W = cfg["height"], cfg["width"]; P50 = base_b.shape[0]
-    plan = plan_lockstep(args.sequence_frames, world * S, K, SEQ_WARMUP_FRAMES); T = plan.T; n = world * S
+    from sindslam_amd.sequence import VerifiedChunks, plan_lockstep
+    H, W = cfg["height"], cfg["width"]
+    SW = args.seq_warmup_frames
+    plan = plan_lockstep(args.sequence_frames, world * S, K, SW); T = plan.T; n = world * S
     if S * T > 4096:
         raise SystemExit(f"sequence workload: {S} chunks x {T} frames per step is more than one step should hold; use more --steps, fewer --streams or a shorter --sequence-frames")
-    mine = plan.chunks[rank * S:(rank + 1) * S]
-    # sequence position q (0 = first processed frame) shows generated frame pingpong(q + 2): positions -2, -1 are the two priming frames of chunk 0
-    fidx = lambda q: pingpong(q + 2, P50)
+    src = BenchFrames(base_b, base_d); bb, bd = src.bb, src.bd; fidx = src.fidx
     pipe = make_pipeline(cfg, intr, S, T, local, args.host_threads)
+    # the runners that repair mismatching chunks: a second, small pipeline (created and warmed before the clock starts, like the main one)
+    R = args.repair_streams or max(2, min(16, (S + 1) // 2)); Tr = max(1, args.repair_frames_per_step)
+    rp = make_pipeline(cfg, intr, R, Tr, local, args.host_threads) if (n > 1 and not args.no_verify) else None
+    vc = VerifiedChunks(plan, S, pipe, rp, src, rank, world)
+    mine = vc.mine
 
     def prime_all():
-        for s, c in enumerate(mine):
-            pipe.prime(s, base_b[fidx(c.start - 1)], base_b[fidx(c.start - 2)])
+        vc.prime()
+        if rp is not None:
+            for j in range(R):
+                rp.prime(j, src.host_frame(-1), src.host_frame(-2))
+            rp.set_state_hashing(True)
     prime_all()
-    bb = torch.from_numpy(base_b).cuda(); bd = torch.from_numpy(base_d.view(np.int16)).cuda()
     dev_b, dev_d = [], []
     for i in range(K):
         idx = torch.tensor([[fidx(c.start + i * T + t) for t in range(T)] for c in mine], device="cuda")
@@ -416,26 +453,55 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
             out = m[None]
         if step is not None:
             seq_masks[:, :, step].copy_(out)
+            if cabi is not None and out.is_cuda:
+                torch.cuda.current_stream().synchronize()        # the comm's own stream rewrites gbuf["out"] at the next step: the copy out of it must be done by then
 
     for i in range(Wm):                     # untimed: the first steps of the job, results and state dropped afterwards
         pipe.process_dev(dev_b[i % K].data_ptr(), dev_d[i % K].data_ptr()); gather(None)
-    if Wm:
+    if rp is not None:                      # one untimed step of the repair pipeline as well (first-use allocations)
+        inp = src.device_batch(np.tile(np.arange(Tr), (R, 1))); rp.process_dev(inp[0], inp[1]); del inp
+    if Wm or rp is not None:
         prime_all()                         # priming resets a stream's tail state: the timed region starts the job from scratch
     if pg:
         dist.barrier()
     torch.cuda.synchronize()
     thr0 = cgroup_throttle(); t0 = time.perf_counter(); c0 = time.process_time()
-    acc = StepAcc(); pending = None
-    for i in range(K):
-        ts = time.perf_counter(); have = pipe.submit_dev(dev_b[i].data_ptr(), dev_d[i].data_ptr()); acc.submit_wall += time.perf_counter() - ts
-        if have:
-            gather(pending)
-        pending = i
-        acc.add(pipe.stats(), True)
-    tf0 = time.perf_counter()
-    if pipe.flush():
-        gather(pending)
-    flush_ms = (time.perf_counter() - tf0) * 1e3
+    acc = StepAcc()
+
+    def after_submit(i, seconds):
+        acc.submit_wall += seconds; acc.add(pipe.stats(), True)
+    vc.run_main(on_step=lambda i, p_: gather(i), inputs=lambda i: (dev_b[i].data_ptr(), dev_d[i].data_ptr()), after_submit=after_submit)
+    flush_ms = vc.flush_seconds * 1e3
+    t_main = time.perf_counter() - t0
+    # ---- verify the chunk seams, repair the mismatching chunks (inside the clock); corrected masks replace the speculative ones on every rank
+    fixes = []                              # (global chunk, position, mask) of this round
+
+    def on_frame(s_, q, p_, j, t_):
+        g = rank * S + s_; c = mine[s_]; i = q - c.start
+        if world == 1:
+            seq_masks[0, s_, i // T, i % T].copy_(torch.from_numpy(p_.dyna[j, t_]))
+        else:
+            fixes.append((g, i, p_.dyna[j, t_].copy()))
+
+    def on_round():
+        if world == 1:
+            return
+        cnt = torch.tensor([len(fixes)], dtype=torch.int64, device=comm_dev); cnts = [torch.empty_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        m = max(int(c_.item()) for c_ in cnts)
+        if m:
+            ids = torch.full((m, 2), -1, dtype=torch.int64); blk = torch.zeros((m, H, W), dtype=torch.uint8)
+            for k_, (g, i, mk) in enumerate(fixes):
+                ids[k_, 0] = g; ids[k_, 1] = i; blk[k_] = torch.from_numpy(mk)
+            ids = ids.to(comm_dev); blk = blk.to(comm_dev)
+            all_ids = [torch.empty_like(ids) for _ in range(world)]; dist.all_gather(all_ids, ids)
+            all_blk = gather_masks(blk)
+            for r_ in range(world):
+                for k_ in range(int(cnts[r_].item())):
+                    g, i = int(all_ids[r_][k_, 0]), int(all_ids[r_][k_, 1])
+                    seq_masks[g // S, g % S, i // T, i % T].copy_(all_blk[r_][k_])
+        fixes.clear()
+    vstats = vc.verify_and_repair(on_frame=on_frame, on_round=on_round) if rp is not None else dict(vc.stats)
     torch.cuda.synchronize()
     if pg:
         dist.barrier()
@@ -446,21 +512,31 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     grow_q = pipe.grow_share(); km_groups = pipe.kmeans_groups()
     owned = sum(c.last - c.first for c in plan.chunks)
     info = {"frames": plan.frames, "owned_frames": owned, "chunks": n, "chunks_per_gpu": S, "frames_per_step_per_chunk": T, "steps": K,
-            "processed_frames_per_chunk": plan.processed, "state_warmup_frames": SEQ_WARMUP_FRAMES, "state_warmup_steps": -(-SEQ_WARMUP_FRAMES // T),
+            "processed_frames_per_chunk": plan.processed, "state_warmup_frames": SW, "state_warmup_steps": -(-SW // T),
             "processed_frames": plan.processed_total, "warmup_overhead": plan.processed_total / owned - 1.0,
             "value": owned / dt, "value_excl_warmup": plan.processed_total / dt, "seconds": dt, "final_flush_ms": flush_ms, "region_grow_gpu_quarters": grow_q, "kmeans_groups": km_groups,
-            "note": "value = owned frames of the whole sequence / wall time of ALL the work (the 24 state warm-up frames of every chunk after the first run inside the timed "
-                    "region); value_excl_warmup counts every processed frame as if it were owned (the pipeline's processing rate)",
+            "exact": rp is not None or n == 1,
+            "verify": {"seams": vstats["seams"], "mismatched_seams": vstats["mismatched_seams"], "rounds": vstats["rounds"], "repaired_chunks": vstats["repaired_chunks"],
+                       "repair_frames": vstats["repair_frames"], "repair_steps": vstats["repair_steps"], "runners_to_chunk_end": vstats["runners_to_chunk_end"],
+                       "max_frames_to_converge": vstats["max_frames_to_converge"], "repair_seconds": vstats["repair_seconds"], "lockstep_seconds": t_main,
+                       "repair_pipeline": f"{R} runners x {Tr} frames per step" if rp is not None else None,
+                       "note": "every chunk seam is verified by comparing 128-bit fingerprints of the inter-frame state (the chunk's rebuilt state vs the predecessor's true end state); "
+                               "a mismatching chunk is re-run from the true state until its state equals the speculative one of the same frame -- all inside the timed region"},
+            "repaired_chunks": vstats["repaired_chunks"], "repair_frames": vstats["repair_frames"],
+            "note": "value = owned frames of the whole sequence / wall time of ALL the work (the state warm-up frames of every chunk after the first, the seam verification "
+                    "and the repair runs are inside the timed region); value_excl_warmup counts every processed frame as if it were owned (the pipeline's processing rate)",
             "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL through the C ABI (sind_pipe_gather_masks)" if args.collective == "cabi" else "RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if pg else "single rank (no collective)",
             "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
     if cabi is not None:
         cabi.close()
     pipe.close()
+    if rp is not None:
+        rp.close()
     # ---- rank 0: the first frames again in the in-order ("exact") mode -> IoU of the chunked masks at and behind the chunk seams, and the exact mode's own rate
     if rank == 0 and exact_leg and n > 1:
         from sindslam_amd.pipeline import Pipeline
         P = plan.processed
-        E = min(max(320, P + 2 * (P - SEQ_WARMUP_FRAMES)), plan.frames, 480)      # chunk 0, chunks 1-2 and what else fits: long enough for a steady-state rate
+        E = min(max(320, P + 2 * (P - SW)), plan.frames, args.exact_leg_frames)      # chunk 0, chunks 1-2 and what else fits: long enough for a steady-state rate
         Te = 32 if E >= 64 else 16
         nst = -(-E // Te); E = nst * Te
         ex = make_pipeline(cfg, intr, 1, Te, local)
@@ -476,20 +552,21 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
             exact[prev * Te:(prev + 1) * Te] = ex.dyna[0]
         te = time.perf_counter() - te0; ex.close()
         sm = seq_masks.reshape(n, P, H, W)
-        ious = []; seam = []; inter_sum = union_sum = 0
+        ious = []; seam = []; inter_sum = union_sum = 0; equal_frames = 0
         for g, c in enumerate(plan.chunks):
             if g == 0:
                 continue                                          # chunk 0 starts like the sequential run: identical by construction
             for q in range(c.first, min(c.last, E)):
-                a_ = sm[g, q - c.start].cpu().numpy() == 255; b_ = exact[q] == 255; u = np.logical_or(a_, b_).sum()
+                raw_ = sm[g, q - c.start].cpu().numpy(); equal_frames += int(np.array_equal(raw_, exact[q]))
+                a_ = raw_ == 255; b_ = exact[q] == 255; u = np.logical_or(a_, b_).sum()
                 it_ = np.logical_and(a_, b_).sum(); inter_sum += int(it_); union_sum += int(u)
                 v = 1.0 if u == 0 else float(it_ / u); ious.append(v)
                 if q == c.first: seam.append(v)
         info.update({"seam_iou_mean": float(np.mean(ious)) if ious else None, "seam_iou_min": float(np.min(ious)) if ious else None,
                      "seam_iou_pooled": (inter_sum / union_sum) if union_sum else None, "seam_iou_below_0.99": int(sum(v < 0.99 for v in ious)),
-                     "seam_iou_first_frames": seam[:8], "seam_frames_compared": len(ious),
-                     "seam_note": "chunked (throughput) mode vs the in-order run on the same GPU code, owned frames of the chunks after the first; the chunked mode rebuilds the tail "
-                                  "state in the warm-up frames and returns valid but not identical masks -- parity (IoU >= 0.99 vs the oracle) holds for the in-order mode",
+                     "seam_iou_first_frames": seam[:8], "seam_frames_compared": len(ious), "seam_masks_equal": equal_frames,
+                     "seam_note": "chunked mode vs the in-order run on the same GPU code, owned frames of the chunks after the first: seam_masks_equal counts the frames whose "
+                                  "imgDyna is byte-identical (with verification: all of them)",
                      "exact_mode": {"frames": E, "frames_per_step": Te, "fps": E / te,
                                     "bound": "1 / per-frame latency of the slower tail chain (depth chain: k-means warm labels; flow chain: weights, previous high mask); "
                                              "host + launch latency bound, does not grow with the number of GPUs"}})
@@ -529,7 +606,7 @@ def main():
     import numpy as np
     cfg = dict(CONFIGS[args.config]); workload = args.workload if args.workload != "auto" else ("sequence" if world > 1 else "streams")
     T, K, Wm = args.frames_per_step, args.steps, args.warmup
-    S = args.streams or (cfg["streams"] if workload == "streams" else sequence_streams(world, args.sequence_frames, cfg["streams"], K))
+    S = args.streams or (cfg["streams"] if workload == "streams" else sequence_streams(world, args.sequence_frames, cfg["streams"], K, args.seq_warmup_frames))
     seq_leg = workload == "streams" and world == 1 and not args.no_sequence_leg and not args.host_input       # N = 1 point of the sequence curve next to the streams headline
     import sindslam_amd.synth as SY
     intr0 = getattr(SY, cfg["intr"]); sc = cfg["width"] / 640.0
@@ -566,6 +643,16 @@ def main():
     if workload == "sequence":
         dt, acc, seq_info, loads = sequence_job(args, cfg, intr, seq_b, seq_d, rank, world, local, pg, comm_dev, S, K, Wm, not args.no_exact_leg)
         T = seq_info["frames_per_step_per_chunk"]; pairs = seq_info["owned_frames"]; flush_ms = seq_info["final_flush_ms"]; loop_ms = sync_ms = None
+        if world > 1 and not args.no_n1_leg:
+            # the N = 1 point of the strong-scaling curve in the same line: rank 0 runs the SAME job alone on its GPU after the timed region, the others wait
+            if rank == 0:
+                torch.cuda.empty_cache()
+                S1 = sequence_streams(1, args.sequence_frames, cfg["streams"], K, args.seq_warmup_frames)
+                d1, _, i1, _ = sequence_job(args, cfg, intr, seq_b, seq_d, 0, 1, local, False, "cpu", S1, K, min(Wm, 2), False)
+                seq_info["n1_value"] = i1["value"]; seq_info["n1_seconds"] = d1; seq_info["n1_chunks"] = i1["chunks"]; seq_info["n1_verify"] = i1["verify"]
+                seq_info["speedup_vs_n1"] = seq_info["value"] / i1["value"]; seq_info["scaling_efficiency"] = seq_info["value"] / (world * i1["value"])
+                seq_info["n1_note"] = "the same fixed-length job on rank 0's GPU alone, run after the timed region of the N-rank job (same code path as --gpus 1's `sequence` leg)"
+            dist.barrier()
         ranks_seen = 1
         if pg:
             rs = torch.ones(1, device=comm_dev); dist.all_reduce(rs); ranks_seen = int(rs.item())
@@ -651,7 +738,7 @@ def main():
         # ---- one GPU: the fixed-length sequence job as well (the N = 1 point of the curve that --gpus N > 1 reports as its headline)
         if seq_leg:
             torch.cuda.empty_cache()
-            Ss = sequence_streams(1, args.sequence_frames, cfg["streams"], max(K, 10))
+            Ss = sequence_streams(1, args.sequence_frames, cfg["streams"], max(K, 10), args.seq_warmup_frames)
             sdt, sacc, seq_info, _ = sequence_job(args, cfg, intr, seq_b, seq_d, 0, 1, local, False, "cpu", Ss, max(K, 10), min(Wm, 2), not args.no_exact_leg)
             seq_info["solver_busy_ms_per_step"] = sacc.sor_union / max(K, 10); seq_info["ms_per_step"] = sdt / max(K, 10) * 1e3
             seq_info["leg_note"] = "same job as the headline of --gpus N > 1 (strong scaling over the ranks), run here after the timed region of the streams workload"

@@ -188,6 +188,19 @@ int sind_pipe_set_depth_ahead(sind_pipe* p, int on);
 size_t sind_pipe_state_bytes(sind_pipe* p);
 int sind_pipe_get_state(sind_pipe* p, int stream, uint8_t* buf, size_t n);
 int sind_pipe_set_state(sind_pipe* p, int stream, const uint8_t* buf, size_t n);
+/* Chunked sequences (one long sequence cut into contiguous chunks, one per stream; driver: sindslam_amd/sequence.py).  A chunk that starts in
+ * the middle of the sequence rebuilds the inter-frame state in a few warm-up frames; whether the rebuilt state IS the state the sequential loop
+ * (rgbd_tum_noros.cc:110-170) would have carried there is decided by comparing fingerprints: every output of a frame is a deterministic function of the
+ * input frames and the state before it, so equal states after frame q mean equal results on every later frame.
+ *   sind_pipe_set_state_hashing(on): every tail leaves a 128-bit fingerprint of its rolled state (DynaDetect.cc:1660-1664) per frame.
+ *   sind_pipe_get_state_hashes: the fingerprints of the step whose results were returned last, [streams][frames_per_step][2] (0, 0 = frame not processed).
+ *   sind_pipe_set_active_frames(n[streams]): in the NEXT step only, the stateful tail of stream s runs for its first n[s] frames (0..frames_per_step); the
+ *     state of the stream then is the state after frame n[s] - 1 -- a chunk can end, and its state be taken with sind_pipe_get_state, in the middle of a
+ *     step.  Outputs of the skipped frames are not written.  The state-free work still covers all frames, and the stream's gray history ends up at the
+ *     step's last frame: prime the stream again before it processes anything else.  NULL = all frames.  Not available with depth-ahead. */
+int sind_pipe_set_state_hashing(sind_pipe* p, int on);
+int sind_pipe_get_state_hashes(sind_pipe* p, uint64_t* out, size_t count);
+int sind_pipe_set_active_frames(sind_pipe* p, const int* frames_per_stream);
 /* per-stage wall times of the last step in milliseconds: {front_gray, dense_flow, orb_front, host_upload (sind_pipe_process only, else 0), tails, total},
  * plus HIP-event statistics of the flow solver: sor_launches, sor_ms (sum of event-bracketed SOR launch groups),
  * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */

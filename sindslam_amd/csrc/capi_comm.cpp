@@ -21,12 +21,15 @@ struct Rccl {
     bool load() {
         static std::once_flag once;
         std::call_once(once, [this] {
-            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { so = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (so) break; }
-            if (!so) { err = dlerror() ? dlerror() : "librccl.so.1 not found"; return; }
+            // SIND_RCCL_LIB: one explicit library name / path instead of the default search list (tests point it at a missing file)
+            const char* forced = getenv("SIND_RCCL_LIB");
+            if (forced) so = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            else for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { so = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (so) break; }
+            if (!so) { const char* e = dlerror(); err = e ? e : "librccl.so.1 not found"; return; }       // (dlerror() clears the message: one call)
             GetUniqueId = (decltype(GetUniqueId))dlsym(so, "ncclGetUniqueId"); CommInitRank = (decltype(CommInitRank))dlsym(so, "ncclCommInitRank");
             CommDestroy = (decltype(CommDestroy))dlsym(so, "ncclCommDestroy"); AllGather = (decltype(AllGather))dlsym(so, "ncclAllGather");
             GetErrorString = (decltype(GetErrorString))dlsym(so, "ncclGetErrorString");
-            if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) { err = "librccl lacks an expected symbol"; so = nullptr; }
+            if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) { err = "librccl lacks an expected symbol"; (void)dlclose(so); so = nullptr; }
         });
         return so != nullptr;
     }

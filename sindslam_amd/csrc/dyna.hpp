@@ -112,6 +112,9 @@ public:
     size_t state_bytes() const { return (size_t)4 * N + 2 * 256 * sizeof(int) + sizeof(int); }
     void save_state(uint8_t* buf, bool flow_half = true, bool depth_half = true) const;
     void load_state(const uint8_t* buf, bool flow_half = true, bool depth_half = true);
+    // hash_state: leave a 128-bit fingerprint of the rolled state (host/statehash.hpp) in state_hash after every frame -- what the chunked sequence mode
+    // compares at the chunk seams (sind_pipe_set_state_hashing).  It covers everything the blob carries: the blob's other fields are functions of these images.
+    bool hash_state = false; uint64_t state_hash[2] = {0, 0};
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; long n_frames = 0;
     double t_fine[40] = {0};       // cal_occluded: gpu+d2h, pack, endpoints, peac, contour filter, close | seg_merge: pieces, planes+h2d, rag gpu, merge    // flow masks, k-means, label prep, CalOccluded, SegAndMerge, fusion (ms, SIND_TAIL_TIMING=1)
 private:

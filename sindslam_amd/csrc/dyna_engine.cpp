@@ -11,6 +11,7 @@
 #include <atomic>
 #include <thread>
 #include "dyna.hpp"
+#include "host/statehash.hpp"
 #include <chrono>
 #include "host/rng.hpp"
 
@@ -353,6 +354,7 @@ int DynaTail::cal_occluded_p2(OccCtx& c, const int8_t* member8, const uint8_t* p
     double tf = tick_ms();
     #define FLAP(i) { const double t_ = tick_ms(); t_fine[i] += t_ - tf; tf = t_; }
     BitImg planeC;
+    if (!c.fit) { sind_set_error("CalOccluded, second half: the frame has no first half (its PEAC fitter is missing)"); return SIND_E_STATE; }
     if (!c.grown_on_host && !(grow_status && grow_status[0] == PG_OK && member8 && pair_seen)) {
         // the kernel reported a capacity overflow for this frame (status 1..3): the host statement of the same FIFO takes over
         c.fit->grow_host(c.m8, c.m16, c.pairs); c.grown_on_host = true; n_grow_fallback++;
@@ -384,20 +386,23 @@ int DynaTail::cal_occluded_p2(OccCtx& c, const int8_t* member8, const uint8_t* p
 }
 // one frame on this tail's own stream: both halves with a one-frame launch of the grow kernel in between
 int DynaTail::cal_occluded(const uint16_t* depth_host, const uint16_t* depth_dev, BitImg& totalArea, BitImg& occ1, BitImg& occ2, const OccGpuOut* pre) {
-    if (!own_grow) {
-        own_grow.reset(new OwnGrow());
-        SIND_TRY(own_grow->batch.init(W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale, 1));
-        SIND_TRY(own_grow->in_h.alloc(PG_IN_STRIDE)); SIND_TRY(own_grow->member_h.alloc(N)); SIND_TRY(own_grow->pair_h.alloc((size_t)PEAC_GROW_MAX_PLANES * PEAC_GROW_MAX_PLANES)); SIND_TRY(own_grow->status_h.alloc(4));
+    // sizes the grow kernel does not take (PeacGrowBatch::supports) are grown on the host in the first half, like before the kernel existed
+    const bool gpu_grow = PeacGrowBatch::supports(W, H);
+    if (gpu_grow && !own_grow) {
+        std::unique_ptr<OwnGrow> g(new OwnGrow());             // assigned only when every piece exists: a failed init must not leave a half-built workspace behind
+        SIND_TRY(g->batch.init(W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale, 1));
+        SIND_TRY(g->in_h.alloc(PG_IN_STRIDE)); SIND_TRY(g->member_h.alloc(N)); SIND_TRY(g->pair_h.alloc((size_t)PEAC_GROW_MAX_PLANES * PEAC_GROW_MAX_PLANES)); SIND_TRY(g->status_h.alloc(4));
+        own_grow = std::move(g);
     }
     OccCtx c;
-    SIND_TRY(cal_occluded_p1(depth_host, depth_dev, c, pre, own_grow->in_h.p, 0));
+    SIND_TRY(cal_occluded_p1(depth_host, depth_dev, c, pre, gpu_grow ? own_grow->in_h.p : nullptr, 0));
     if (!c.grown_on_host) {
         const double t0 = tick_ms();
         SIND_TRY(own_grow->batch.run(stream, own_grow->in_h.p, depth_dev, 1, own_grow->member_h.p, own_grow->pair_h.p, own_grow->status_h.p));
         HIP_TRY(sind_stream_wait(stream));
         t_fine[33] += tick_ms() - t0;
     }
-    SIND_TRY(cal_occluded_p2(c, own_grow->member_h.p, own_grow->pair_h.p, own_grow->status_h.p, occ1, occ2));
+    SIND_TRY(cal_occluded_p2(c, gpu_grow ? own_grow->member_h.p : nullptr, gpu_grow ? own_grow->pair_h.p : nullptr, gpu_grow ? own_grow->status_h.p : nullptr, occ1, occ2));
     totalArea = c.totalArea;
     return SIND_OK;
 }
@@ -730,6 +735,13 @@ int DynaTail::fuse(const BitImg& maskLow, const BitImg& maskHigh, const DepthSta
     std::memcpy(dynaLast.data(), dyna_out, N); labelLast = label3; highLast = maskHigh;
     std::memset(lastCnt, 0, sizeof(lastCnt)); std::memset(lastDyn, 0, sizeof(lastDyn));       // per-label pixel / dynamic-pixel counts for the next frame's sample weights
     for (int n = 1; n <= maxNum && n < 256; n++) { lastCnt[n] = clusters[n].count(); lastDyn[n] = BitImg::and_count(clusters[n], dyna); }
+    if (hash_state) {
+        // imgDynaLast = 255 on `dyna`, 125 on totalArea - dyna, else 0: hashed as those two bit images (canonical: equal byte images give equal words)
+        StateHash hs;
+        for (size_t i = 0; i < dyna.d.size(); i++) { hs.word(dyna.d[i]); hs.word(totalArea.d[i] & ~dyna.d[i]); hs.word(maskHigh.d[i]); }
+        hs.bytes(label3.data(), N); hs.bytes(lastCnt, sizeof(lastCnt)); hs.bytes(lastDyn, sizeof(lastDyn)); hs.word(maxNum > 0 ? 1 : 0);
+        hs.finish(state_hash);
+    }
     QLAP(28)
     #undef QLAP
     LAP(5)

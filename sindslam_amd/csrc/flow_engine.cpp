@@ -114,11 +114,25 @@ thread_local SindHostGate* t_sind_gate = nullptr;
 thread_local int t_sind_spin_us = 0;
 
 #include <dlfcn.h>
+#include <cstring>
+#include <cstdlib>
 namespace {
 struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    // The marker library is only looked for when a profiler is attached (rocprofv3 preloads librocprofiler-sdk-tool / sets ROCP_TOOL_LIBRARIES) or SIND_ROCTX=1
+    // asks for it: a production process does not dlopen profiler libraries.
+    static bool wanted() {
+        if (const char* e = getenv("SIND_ROCTX")) return atoi(e) != 0;
+        for (const char* v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH"}) if (getenv(v)) return true;
+        const char* pre = getenv("LD_PRELOAD"); return pre && strstr(pre, "rocprofiler");
+    }
     Roctx() {
+        if (!wanted()) return;
         for (const char* lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
-            if (void* so = dlopen(lib, RTLD_NOW | RTLD_LOCAL)) { push = (int (*)(const char*))dlsym(so, "roctxRangePushA"); pop = (int (*)())dlsym(so, "roctxRangePop"); if (push && pop) return; push = nullptr; pop = nullptr; }
+            if (void* so = dlopen(lib, RTLD_NOW | RTLD_LOCAL)) {
+                push = (int (*)(const char*))dlsym(so, "roctxRangePushA"); pop = (int (*)())dlsym(so, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr; (void)dlclose(so);
+            }
         }
     } };
 Roctx& roctx() { static Roctx r; return r; }

@@ -6,7 +6,7 @@ namespace sind {
 
 int PeacGrowBatch::init(int W_, int H_, float fx_, float fy_, float cx_, float cy_, float depthScale, int cap_) {
     W = W_; H = H_; fx = fx_; fy = fy_; cx = cx_; cy = cy_; inv_scale = 1.0f / depthScale; cap = cap_;
-    if (W % 16 || H % 16 || (W / 16) * (H / 16) > PG_MAX_BLOCKS || (size_t)W * H > (1u << 20)) { sind_set_error("PeacGrowBatch: unsupported size %d x %d", W, H); return SIND_E_ARG; }
+    if (!supports(W, H)) { sind_set_error("PeacGrowBatch: unsupported size %d x %d", W, H); return SIND_E_ARG; }
     const size_t N = (size_t)W * H, c = (size_t)cap;
     SIND_TRY(in_d.alloc(c * PG_IN_STRIDE)); SIND_TRY(member_d.alloc(c * N)); SIND_TRY(dist_d.alloc(c * N)); SIND_TRY(slot_d.alloc(c * N)); SIND_TRY(ext_d.alloc(c * N * (PEAC_GROW_SLOTS - 1)));
     SIND_TRY(front_d.alloc(c * 2 * PG_FRONT_CAP)); SIND_TRY(payload_d.alloc(c * 4 * PG_FRONT_CAP)); SIND_TRY(active_d.alloc(c * 4 * PG_FRONT_CAP)); SIND_TRY(pair_d.alloc(c * PEAC_GROW_MAX_PLANES * PEAC_GROW_MAX_PLANES));

@@ -31,6 +31,9 @@ int launch_peac_grow(hipStream_t s, const PeacGrowArgs& A, int frames);
 // results (membership map as int8, pair matrix, status) land in page-locked memory of the caller.
 class PeacGrowBatch {
 public:
+    // sizes the kernel handles (whole 16 x 16 blocks, at most PG_MAX_BLOCKS of them, pixel index below 2^20); frames of any other size are grown by the
+    // host statement of the same FIFO (PeacFitter::grow_host) -- callers ask before they create a workspace
+    static bool supports(int W, int H) { return W > 0 && H > 0 && W % 16 == 0 && H % 16 == 0 && (W / 16) * (H / 16) <= PG_MAX_BLOCKS && (size_t)W * H <= (1u << 20); }
     int init(int W, int H, float fx, float fy, float cx, float cy, float depthScale, int cap);
     // in_h: `frames` consecutive input blocks (page-locked); member_h: frames x W*H int8, pair_h: frames x 127^2, status_h: frames x 4 ints (all page-locked).
     // Enqueues copy-in, kernel and copies back on s; the caller records / waits.

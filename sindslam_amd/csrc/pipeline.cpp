@@ -77,7 +77,7 @@ struct sind_pipe {
     // of seven launches + a stream wait per frame); the runner tasks wait for their frame's chunk and do the host half
     OccBatch occb; hipStream_t occ_stream = nullptr; bool batch_occ = false; int occ_chunk = 64;
     // PEAC region grow of CalOccluded on the GPU, one launch per chunk of frames (peac_grow.hpp): the runner that finishes the last first-half of a chunk enqueues it
-    PeacGrowBatch grow; hipStream_t grow_stream = nullptr; std::mutex grow_mu;
+    PeacGrowBatch grow; hipStream_t grow_stream = nullptr; std::mutex grow_mu; bool grow_ok = false;       // grow_ok: the frame size fits the kernel (else every frame grows on the host)
     // Where a frame's region grow runs: grow_q of every 4 frames on the GPU (one CU for ~6 ms per frame), the others on the host (one core for ~5 ms); both give
     // the same bits, so the share only moves load.  grow_q_fixed < 0: adapted step by step (grow_adapt) -- towards the GPU while the step waits for host work
     // (CalOccluded or tails not done when the dense flow is), back towards the host while no step waits.
@@ -97,6 +97,7 @@ struct sind_pipe {
         bool depth_ahead = false; std::vector<DepthStageOut> dout; std::unique_ptr<std::atomic<int>[]> gate; TaskGroup depth_group;
         std::vector<int> depth_rc; std::vector<std::string> depth_err;
         TaskGroup occ_group, tail_group, km_tails[4]; int km_groups = 1, km_first[5] = {0, 0, 0, 0, 0};       /* (4 = sind_pipe::KM_GROUPS) the step's own partition of the streams */ std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
+        std::vector<int> active; std::vector<uint64_t> state_hash;      // tails of stream s run for t < active[s] (empty: all T); per-frame state fingerprints [S][T][2]
     } sb[2];
     int cur = 0; int occ_workers = 24;
     // CPU tokens (common.hpp) for the software-pipelined steps, where CalOccluded runners and tails compete for the quota (measured: throttled periods 7 -> 2
@@ -107,6 +108,9 @@ struct sind_pipe {
     // launches it then shares the GPU with (dense flow 232 -> 287 ms at high stream priority; at normal priority the chains starve).
     bool depth_ahead = false;
     std::vector<char> primed;
+    // Chunked sequences (sindslam_amd/sequence.py): hashing = every tail leaves the fingerprint of its rolled state per frame (last_hash: the step whose results
+    // were returned last, [S][T][2]); active_next = per-stream number of frames whose TAILS run in the next step (one step only; empty = all T)
+    bool hashing = false; std::vector<uint64_t> last_hash; std::vector<int> active_next;
     double stage_ms[6] = {0}; double tail_wait_ms = 0; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;
     SindHostGate gate;           // CPU tokens of this handle's pool tasks (common.hpp)
     WorkerPool workers;          // declared last: joined first
@@ -234,7 +238,8 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
             for (int c = 0; c < nch; c++) HIP_TRY(hipEventCreateWithFlags(&p->sb[k].grow_ev[c], hipEventDisableTiming));
         }
         SIND_TRY(make_stream(&p->grow_stream, !(sind_lab_env("SIND_OCC_PRIORITY") && atoi(sind_lab_env("SIND_OCC_PRIORITY")) == 0)));
-        SIND_TRY(p->grow.init(cfg->width, cfg->height, cfg->fx, cfg->fy, cfg->cx, cfg->cy, cfg->depth_scale, p->occ_chunk));
+        p->grow_ok = PeacGrowBatch::supports(cfg->width, cfg->height);
+        if (p->grow_ok) SIND_TRY(p->grow.init(cfg->width, cfg->height, cfg->fx, cfg->fy, cfg->cx, cfg->cy, cfg->depth_scale, p->occ_chunk));
     }
     p->workers.start(nworkers, cfg->device, &p->gate, p->S == 1 ? 400 : 0);        // one stream: serial chains, idle host -- poll before sleeping (common.hpp)
     SIND_TRY(p->gray.alloc(np * std::max(B, 2)));          // sind_pipe_prime converts the two priming frames through this scratch, also when S * T == 1
@@ -316,17 +321,18 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     const size_t np = (size_t)W * H, fb = (size_t)p->fw * p->fh;
     t[0] = now_ms();
     SindRange range_a("sind phase A (state-free: gray, dense flow, ORB front, CalOccluded)");
-    sind_range_push("sind front: gray + 0.6 resize");
+    const uint8_t* gray_for_orb = p->gray.p;
+    {
+    SindRange range_front("sind front: gray + 0.6 resize");
     // gray for all frames, 0.6-scaled gray into the per-stream pools behind the two history slots
     SIND_TRY(launch_bgr2gray(p->stream, bgr_dev, p->gray.p, np * B, false));
     // frame t of stream s goes to pool slot s * (T + 2) + 2 + t: one launch, T frames per group, two history slots skipped between the groups
     SIND_TRY(launch_resize_u8(p->stream, p->gray.p, p->pool.p + fb * 2, W, H, p->fw, p->fh, B, W, p->fw, np, fb, T, 2));
-    const uint8_t* gray_for_orb = p->gray.p;
     if (p->c.orb_gray_rgb_order) { SIND_TRY(launch_bgr2gray(p->stream, bgr_dev, p->gray_orb.p, np * B, true)); gray_for_orb = p->gray_orb.p; }
     // ORB front (pyramid, FAST, octree, orientation, blur, BRIEF) of all frames: independent of the flow, so it runs on its own HIP
     // stream and host thread underneath the dense flow instead of after it
     HIP_TRY(hipEventRecord(p->ev_gray, p->stream));
-    sind_range_pop();
+    }
     // private copies of the depth frames: device (tail kernels of this step run while the caller may reuse its buffer) and host.  They go
     // ahead of the ORB front on its stream (157 MB to the host, ~3 ms): the flow slices need not wait for them, only the CalOccluded tasks do
     HIP_TRY(hipMemcpyAsync(sb.depth_dev.p, depth_dev, np * B * sizeof(uint16_t), hipMemcpyDeviceToDevice, p->orb_stream));
@@ -368,7 +374,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     // `occ_workers` runner tasks share the frames through a counter: CalOccluded is host-heavy (PEAC region grow), and more runnable
     // threads than the CPU quota of the box (cgroup cpu.max, 16 cores per GPU) only burn the quota early in a period and stall EVERY
     // thread of the process, the flow's launch threads included, until the period ends
-    sb.occ_next.store(0); sb.occ_next2.store(0); sb.grow_q = p->grow_q;
+    sb.occ_next.store(0); sb.occ_next2.store(0); sb.grow_q = p->grow_ok ? p->grow_q : 0;
     if (p->batch_occ) {
         sb.occ_ctx.clear(); sb.occ_ctx.resize(B);
         const int nch = (B + p->occ_chunk - 1) / p->occ_chunk;
@@ -400,7 +406,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
             }
             if (rc != SIND_OK) { sb.occ_rc[k] = rc; sb.occ_err[k] = sind_last_error(); PeacGrowHdr skip{0, 0, 1, k}; std::memcpy(sb.grow_in_h.p + (size_t)k * PG_IN_STRIDE, &skip, sizeof(skip)); }
             if (sb.grow_left[ch].fetch_sub(1) == 1) {
-                const int c0 = ch * p->occ_chunk, nb = std::min(p->occ_chunk, B - c0); int lrc;
+                const int c0 = ch * p->occ_chunk, nb = std::min(p->occ_chunk, B - c0); int lrc = SIND_OK;
+                if (sb.grow_q == 0) { sb.grow_state[ch].store(2); continue; }         // every frame of the chunk grew on the host: nothing to launch (state 2)
                 { std::lock_guard<std::mutex> lk(p->grow_mu);
                   lrc = p->grow.run(p->grow_stream, sb.grow_in_h.p + (size_t)c0 * PG_IN_STRIDE, sb.depth_dev.p, nb, sb.grow_member_h.p + np * c0, sb.grow_pair_h.p + PP * c0, sb.grow_status_h.p + 4 * c0);
                   if (lrc == SIND_OK && hipEventRecord(sb.grow_ev[ch], p->grow_stream) != hipSuccess) lrc = SIND_E_HIP; }
@@ -410,10 +417,13 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         // second halves, in frame order: wait for the chunk's grow, then PEAC's last merge, plane contours, contour filter, closing
         for (int k; (k = sb.occ_next2.fetch_add(1)) < B;) {
             SindRange r("sind CalOccluded, second half: plane contours, contour filter");
-            const int ch = k / p->occ_chunk; int rc = sb.occ_rc[k];
+            const int ch = k / p->occ_chunk;
+            // grow_state[ch] is set behind EVERY first half of the chunk (grow_left): only after this wait is frame k's occ_rc final
+            if (sb.grow_state[ch].load() == 0) { SindTokenPause pause; while (sb.grow_state[ch].load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(50)); }
+            int rc = sb.occ_rc[k];
             if (rc == SIND_OK) {
-                if (sb.grow_state[ch].load() == 0) { SindTokenPause pause; while (sb.grow_state[ch].load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(50)); }
-                if (sb.grow_state[ch].load() < 0 || sind_event_wait(sb.grow_ev[ch]) != hipSuccess) { (void)hipGetLastError(); sind_set_error("PEAC region grow (chunk %d) failed", ch); rc = SIND_E_HIP; }
+                const int gs = sb.grow_state[ch].load();
+                if (gs < 0 || (gs == 1 && sind_event_wait(sb.grow_ev[ch]) != hipSuccess)) { (void)hipGetLastError(); sind_set_error("PEAC region grow (chunk %d) failed", ch); rc = SIND_E_HIP; }
                 else { const OccGpuOut pre = pre_of(k); rc = p->occ_tails[w]->compute_occluded_p2(sb.occ_ctx[k], sb.grow_member_h.p + np * k, sb.grow_pair_h.p + PP * k, sb.grow_status_h.p + 4 * k, sb.occ[k], &pre); }
                 if (rc != SIND_OK) { sb.occ_rc[k] = rc; sb.occ_err[k] = sind_last_error(); }
             }
@@ -483,6 +493,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     for (int k = 0; k < B; k++) if (sb.occ_rc[k] != SIND_OK) { sind_set_error("stream %d (CalOccluded): %s", k / T, sb.occ_err[k].c_str()); return sb.occ_rc[k]; }
     if (depth_ahead) for (int k = 0; k < B; k++) if (sb.depth_rc[k] != SIND_OK) { sind_set_error("stream %d (depth stage): %s", k / T, sb.depth_err[k].c_str()); return sb.depth_rc[k]; }
     t[3] = now_ms();
+    sb.active.swap(p->active_next); p->active_next.clear();           // applies to this step only
+    sb.state_hash.assign((size_t)2 * B, 0);
     sb.pending = true;
     return SIND_OK;
 }
@@ -516,6 +528,7 @@ static bool tail_one(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int
                             : p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k],
                                                    p->dtails.empty() ? nullptr : (p->dtails[s]->stream = p->worker_streams[worker], p->dtails[s].get()), km);
     if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return false; }
+    if (p->hashing) { sb->state_hash[2 * (size_t)k] = p->tails[s]->state_hash[0]; sb->state_hash[2 * (size_t)k + 1] = p->tails[s]->state_hash[1]; }
     double* tf = p->tails[s]->t_fine; double t0 = now_ms();
     dilate15_codes(dy.data(), W, H, dil.data());
     { const double t1 = now_ms(); tf[30] += t1 - t0; t0 = t1; }
@@ -534,7 +547,7 @@ static bool tail_one(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int
 }
 static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker, const KmFrameResult* km = nullptr, bool chain = true) {
     for (;;) {
-        if (!tail_one(p, sb, o, s, t, worker, km) || !chain || t + 1 >= p->T) return;
+        if (!tail_one(p, sb, o, s, t, worker, km) || !chain || t + 1 >= (sb->active.empty() ? p->T : std::min(p->T, sb->active[s]))) return;
         if (p->S == 1) { t++; km = nullptr; continue; }      // one stream: the next frame's chain link right here (no hand-over to another worker)
         p->workers.push(sb->tail_group, [p, sb, o, s, t](int w) { tail_task(p, sb, o, s, t + 1, w); }); return;
     }
@@ -554,22 +567,23 @@ static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o
                 if (t > 0) WorkerPool::wait(sbp->km_tails[g]);           // this group's tails of frame t - 1 (their merged labels start this round's k-means)
                 for (int s = 0; s < ns; s++) prev[s] = depth_half(p, s0 + s)->prev_km_labels();
                 const double tk = now_ms();
-                sind_range_push("sind round: batched k-means of frame t of one group of streams");
-                const int rc = p->kmb[g].run(sbp->depth_dev.p + np * ((size_t)s0 * p->T + t), np * p->T, ns, prev.data());
-                sind_range_pop();
+                int rc;
+                { SindRange range_km("sind round: batched k-means of frame t of one group of streams");
+                  rc = p->kmb[g].run(sbp->depth_dev.p + np * ((size_t)s0 * p->T + t), np * p->T, ns, prev.data()); }
                 { std::lock_guard<std::mutex> lk(p->km_stat_mu); p->km_round_ms += now_ms() - tk; p->km_rounds++; }
                 if (rc != SIND_OK) { const std::string e = sind_last_error(); for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK) { sbp->tail_rc[s] = rc; sbp->tail_err[s] = "batched k-means: " + e; } return; }
-                for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK) p->workers.push(sbp->km_tails[g], [p, sbp, o, s, t, g, s0](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb[g].result(s - s0), false); });
+                for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK && (sbp->active.empty() || t < sbp->active[s])) p->workers.push(sbp->km_tails[g], [p, sbp, o, s, t, g, s0](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb[g].result(s - s0), false); });
             } });
         return;
     }
-    for (int s = 0; s < S; s++) p->workers.push(sb.tail_group, [p, sbp, o, s](int w) { tail_task(p, sbp, o, s, 0, w); });
+    for (int s = 0; s < S; s++) if (sb.active.empty() || sb.active[s] > 0) p->workers.push(sb.tail_group, [p, sbp, o, s](int w) { tail_task(p, sbp, o, s, 0, w); });
 }
 static int phase_b_finish(sind_pipe* p, sind_pipe::StepBuf& sb) {
     for (std::thread& t : p->round_threads) if (t.joinable()) t.join();
     p->round_threads.clear();
     WorkerPool::wait(sb.tail_group); for (TaskGroup& g : sb.km_tails) WorkerPool::wait(g);
     sb.pending = false;
+    p->last_hash = sb.state_hash;
     for (int s = 0; s < p->S; s++) if (sb.tail_rc[s] != SIND_OK) { sind_set_error("stream %d: %s", s, sb.tail_err[s].c_str()); return sb.tail_rc[s]; }
     return SIND_OK;
 }
@@ -679,6 +693,7 @@ int sind_pipe_set_depth_ahead(sind_pipe* p, int on) {
     if (!p) return SIND_E_ARG;
     if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_set_depth_ahead: a submitted step is still pending"); return SIND_E_STATE; }
     HIP_TRY(hipSetDevice(p->c.device));
+    if (on && !p->active_next.empty()) { sind_set_error("sind_pipe_set_depth_ahead: a ragged step is pending (sind_pipe_set_active_frames)"); return SIND_E_STATE; }
     if (on) SIND_TRY(ensure_dtails(p));
     p->depth_ahead = on != 0; return SIND_OK;
 }
@@ -698,6 +713,28 @@ int sind_pipe_set_state(sind_pipe* p, int s, const uint8_t* buf, size_t n) {
     // unless its depth chain already ran ahead on the old warm labels
     for (int k = 0; k < 2; k++) if (p->sb[k].pending && p->sb[k].depth_ahead) { sind_set_error("sind_pipe_set_state: the depth chain of the pending step already ran (depth-ahead); set the state before submitting"); return SIND_E_STATE; }
     p->tails[s]->load_state(buf, true, false); depth_half(p, s)->load_state(buf, false, true);
+    return SIND_OK;
+}
+
+// ---- chunked sequences: per-frame state fingerprints and ragged steps
+int sind_pipe_set_state_hashing(sind_pipe* p, int on) {
+    if (!p) { sind_set_error("sind_pipe_set_state_hashing: null handle"); return SIND_E_ARG; }
+    if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_set_state_hashing: a submitted step is still pending"); return SIND_E_STATE; }
+    p->hashing = on != 0;
+    for (auto& t : p->tails) t->hash_state = p->hashing;
+    return SIND_OK;
+}
+int sind_pipe_get_state_hashes(sind_pipe* p, uint64_t* out, size_t count) {
+    if (!p || !out || count < (size_t)2 * p->S * p->T) { sind_set_error("sind_pipe_get_state_hashes: need room for 2 x streams x frames_per_step values"); return SIND_E_ARG; }
+    if (!p->hashing || p->last_hash.size() != (size_t)2 * p->S * p->T) { sind_set_error("sind_pipe_get_state_hashes: state hashing is off or no step has finished yet"); return SIND_E_STATE; }
+    std::memcpy(out, p->last_hash.data(), p->last_hash.size() * sizeof(uint64_t)); return SIND_OK;
+}
+int sind_pipe_set_active_frames(sind_pipe* p, const int* frames_per_stream) {
+    if (!p) { sind_set_error("sind_pipe_set_active_frames: null handle"); return SIND_E_ARG; }
+    if (!frames_per_stream) { p->active_next.clear(); return SIND_OK; }
+    if (p->depth_ahead) { sind_set_error("sind_pipe_set_active_frames: not available with depth-ahead (the depth chain runs ahead of the flow chain)"); return SIND_E_STATE; }
+    for (int s = 0; s < p->S; s++) if (frames_per_stream[s] < 0 || frames_per_stream[s] > p->T) { sind_set_error("sind_pipe_set_active_frames: stream %d: %d is not in 0..%d", s, frames_per_stream[s], p->T); return SIND_E_ARG; }
+    p->active_next.assign(frames_per_stream, frames_per_stream + p->S);
     return SIND_OK;
 }
 

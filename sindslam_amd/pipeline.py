@@ -112,6 +112,23 @@ class Pipeline:
         blob = np.ascontiguousarray(blob, np.uint8)
         check(lib().sind_pipe_set_state(self._h, stream, ptr(blob), C.c_size_t(blob.size)), "sind_pipe_set_state")
 
+    def set_state_hashing(self, on: bool = True):
+        """every tail leaves a 128-bit fingerprint of its rolled inter-frame state per frame (read with state_hashes())"""
+        check(lib().sind_pipe_set_state_hashing(self._h, int(bool(on))), "sind_pipe_set_state_hashing")
+
+    def state_hashes(self) -> np.ndarray:
+        """fingerprints of the step whose results were returned last: u64 [S, T, 2] ((0, 0) = the frame's tail did not run)"""
+        out = np.zeros((self.S, self.T, 2), np.uint64)
+        check(lib().sind_pipe_get_state_hashes(self._h, ptr(out), C.c_size_t(out.size)), "sind_pipe_get_state_hashes")
+        return out
+
+    def set_active_frames(self, frames_per_stream):
+        """next step only: the stateful tail of stream s runs for its first frames_per_stream[s] frames (None = all)"""
+        if frames_per_stream is None:
+            check(lib().sind_pipe_set_active_frames(self._h, None), "sind_pipe_set_active_frames"); return
+        a = np.ascontiguousarray(frames_per_stream, np.int32); assert a.shape == (self.S,)
+        check(lib().sind_pipe_set_active_frames(self._h, ptr(a)), "sind_pipe_set_active_frames")
+
     def keypoints(self, s: int, t: int):
         k = s * self.T + t; n = self.nkp[k]; return self.kps[k, :n], self.desc[k, :n]
 

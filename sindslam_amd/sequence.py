@@ -91,45 +91,260 @@ def plan_lockstep(frames: int, n_chunks: int, steps: int, warmup: int = 24) -> L
     return LockstepPlan(frames, n_chunks, steps, T, warmup, chunks)
 
 
-def process_sequence(bgr: np.ndarray, depth: np.ndarray, intr: dict, streams: int = 8, frames_per_step: int = 4, warmup: int = 24,
+# ---------------------------------------------------------------------------------------------------------------- verified chunks
+class HostFrames:
+    """Frame source over host arrays bgr u8 [N, H, W, 3] / depth u16 [N, H, W]: sequence POSITION q (0 = the first frame DetectDynaArea processes) is array
+    frame q + 1; positions -1 and -2 (the two priming frames of the sequential loop, rgbd_tum_noros.cc:103-107) are both frame 0; positions past the end
+    repeat the last frame (lock-step padding, results unowned)."""
+
+    def __init__(self, bgr: np.ndarray, depth: np.ndarray, device: int = 0):
+        self.bgr, self.depth, self.device = bgr, depth, device
+
+    def index(self, q):
+        return np.clip(np.asarray(q) + 1, 0, len(self.bgr) - 1)
+
+    def host_frame(self, q: int) -> np.ndarray:
+        return self.bgr[int(self.index(q))]
+
+    def device_batch(self, pos: np.ndarray):
+        import torch
+        idx = self.index(pos)
+        b = torch.from_numpy(np.ascontiguousarray(self.bgr[idx])).to(f"cuda:{self.device}")
+        d = torch.from_numpy(np.ascontiguousarray(self.depth[idx]).view(np.int16)).to(f"cuda:{self.device}")
+        torch.cuda.synchronize(self.device)
+        return b.data_ptr(), d.data_ptr(), (b, d)
+
+
+NO_HASH = np.array([np.iinfo(np.uint64).max, np.iinfo(np.uint64).max], np.uint64)      # "no such state": never equal to a fingerprint
+
+
+class VerifiedChunks:
+    """One sequence on n = world * S lock-step chunks whose results EQUAL the sequential frame loop (speculate -> verify -> repair).
+
+    Every output of a frame is a deterministic function of (input frames n, n-1, n-2, depth n, state before the frame); the state is the three images the
+    reference rolls at DynaDetect.cc:1660-1664 (consumed at :374-395, :1169-1219, :1560).  Chunk g > 0 SPECULATES: it starts `warmup` frames early from an
+    empty state and so reaches its first owned frame with some state; chunk g - 1 reaches the same frame with the TRUE state.  The pipeline leaves a 128-bit
+    fingerprint of the rolled state per frame (sind_pipe_set_state_hashing), so after the K lock-step steps:
+      verify   chunk g is the sequential result iff its state at position first_g - 1 equals the end state of chunk g - 1 (chunk 0 is the sequential loop).
+      repair   otherwise a RUNNER re-processes chunk g from the true state, frame by frame on a small second pipeline, until its state equals the
+               speculative state of the same frame -- from there on the speculative results are the sequential ones -- or the chunk ends.  A runner that
+               reaches the end of its chunk changes the chunk's end state, and the successor is verified again (next round).  The first unverified chunk
+               of a round always has a true predecessor, so the loop ends after at most n rounds; measured, a runner converges within ~13 frames.
+    With several ranks (chunk g lives on rank g // S) a round costs one all_gather of 32 bytes per chunk, plus one send / recv of the 1.2 MB state blob for
+    a seam between ranks that needs a runner.  There is no other cross-rank dependency: the path shards by frame.
+
+    pipe / repair: Pipeline-like objects (S x T and R x Tr); source: positions -> inputs (HostFrames or the bench's device-resident source)."""
+
+    def __init__(self, plan: LockstepPlan, S: int, pipe, repair, source, rank: int = 0, world: int = 1, group=None):
+        assert plan.n_chunks == S * world and pipe.S == S and pipe.T == plan.T
+        self.plan, self.S, self.pipe, self.repair, self.src, self.rank, self.world, self.group = plan, S, pipe, repair, source, rank, world, group
+        self.mine = plan.chunks[rank * S:(rank + 1) * S]
+        self.H = np.zeros((S, plan.processed, 2), np.uint64)             # fingerprint of the state after every processed frame of my chunks (current best chain)
+        self.end_blob = {}                                               # local chunk -> end-state blob when a runner changed it
+        self.stats = dict(seams=0, mismatched_seams=0, rounds=0, runners=0, repaired_chunks=0, repair_frames=0, repair_steps=0, overridden_frames=0,
+                          runners_to_chunk_end=0, repair_seconds=0.0, max_frames_to_converge=0)
+
+    # ---- the K lock-step steps
+    def prime(self):
+        for s, c in enumerate(self.mine):
+            self.pipe.prime(s, self.src.host_frame(c.start - 1), self.src.host_frame(c.start - 2))
+        self.pipe.set_state_hashing(True)
+
+    def positions(self, step: int) -> np.ndarray:
+        T = self.plan.T
+        return np.array([[c.start + step * T + t for t in range(T)] for c in self.mine], np.int64)
+
+    def run_main(self, on_step=None, inputs=None, after_submit=None):
+        """on_step(step, pipe): the results of `step` are in pipe.dyna / label / mask / kps.  inputs(step) -> (bgr_ptr, depth_ptr[, keep]) overrides the source
+        (the bench builds its K input blocks before the clock starts).  after_submit(step, seconds): the submit call of `step` has returned."""
+        import time
+        K, T = self.plan.steps, self.plan.T; pending = None
+
+        def collect(i):
+            self.H[:, i * T:(i + 1) * T] = self.pipe.state_hashes()
+            if on_step is not None:
+                on_step(i, self.pipe)
+        for i in range(K):
+            inp = inputs(i) if inputs is not None else self.src.device_batch(self.positions(i))
+            t0 = time.perf_counter(); have = self.pipe.submit_dev(inp[0], inp[1]); dt = time.perf_counter() - t0
+            if have:
+                collect(pending)
+            pending = i
+            if after_submit is not None:
+                after_submit(i, dt)
+        t0 = time.perf_counter()
+        if self.pipe.flush():
+            collect(pending)
+        self.flush_seconds = time.perf_counter() - t0
+
+    # ---- verify / repair
+    def _owns(self, g):
+        c = self.plan.chunks[g]; return c.last > c.first
+
+    def _hash_at(self, s, q):
+        c = self.mine[s]
+        return self.H[s, q - c.start] if c.start <= q < c.start + self.plan.processed else NO_HASH
+
+    def _gather(self, local: np.ndarray) -> np.ndarray:
+        """[S, k] u64 of every rank -> [world * S, k]"""
+        if self.world == 1:
+            return local
+        import torch
+        import torch.distributed as dist
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.from_numpy(local.view(np.int64).copy()).to(dev); parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t, group=self.group)
+        return np.concatenate([p.cpu().numpy() for p in parts]).view(np.uint64)
+
+    def _exchange_blobs(self, need):
+        """the end-state blob of the last chunk of rank r - 1 for every needed seam between ranks; returns {local chunk 0: blob} when this rank receives one"""
+        got = {}
+        if self.world == 1:
+            return got
+        import torch
+        import torch.distributed as dist
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        reqs = []; recv_t = None
+        if self.rank + 1 < self.world and need[(self.rank + 1) * self.S]:
+            blob = torch.from_numpy(self._end_blob(self.S - 1).copy()).to(dev); reqs.append(dist.isend(blob, dst=self.rank + 1, group=self.group))
+        if self.rank > 0 and need[self.rank * self.S]:
+            recv_t = torch.empty(self.pipe.get_state_bytes(), dtype=torch.uint8, device=dev); reqs.append(dist.irecv(recv_t, src=self.rank - 1, group=self.group))
+        for r in reqs:
+            r.wait()
+        if recv_t is not None:
+            got[0] = recv_t.cpu().numpy()
+        return got
+
+    def _end_blob(self, s):
+        return self.end_blob[s] if s in self.end_blob else self.pipe.get_state(s)
+
+    def verify_and_repair(self, on_frame=None, on_round=None):
+        """on_frame(s, q, repair_pipe, slot, t): frame q of my chunk s has been re-processed from the true state, its results are in repair_pipe.dyna[slot, t] ...
+        (called in frame order per chunk; the last call of a converged runner is the frame whose state matched).
+        on_round(): end of a round, called on every rank (collective hook of the bench's mask exchange)."""
+        import time
+        t0 = time.perf_counter()
+        S, n, P = self.S, self.plan.n_chunks, self.plan.processed
+        start_h = np.stack([self._hash_at(s, c.first - 1) if (self.rank * S + s) > 0 else np.zeros(2, np.uint64) for s, c in enumerate(self.mine)])
+        end_h = np.stack([self._hash_at(s, c.last - 1) for s, c in enumerate(self.mine)])
+        first = True
+        while True:
+            allh = self._gather(np.concatenate([start_h, end_h], axis=1))                    # [n, 4]
+            need = [g > 0 and self._owns(g) and not np.array_equal(allh[g, 0:2], allh[g - 1, 2:4]) for g in range(n)]
+            if first:
+                self.stats["seams"] = sum(1 for g in range(1, n) if self._owns(g)); self.stats["mismatched_seams"] = sum(need); first = False
+            if not any(need):
+                break
+            self.stats["rounds"] += 1
+            got = self._exchange_blobs(need)
+            local = [s for s in range(S) if need[self.rank * S + s]]
+            R = self.repair.S
+            for b0 in range(0, len(local), R):
+                self._run_runners(local[b0:b0 + R], got, allh, start_h, end_h, on_frame)
+            if on_round is not None:
+                on_round()
+        self.stats["repair_seconds"] += time.perf_counter() - t0
+        return self.stats
+
+    def _run_runners(self, batch, got, allh, start_h, end_h, on_frame):
+        rp, Tr, S = self.repair, self.repair.T, self.S
+        for j, s in enumerate(batch):
+            c = self.mine[s]
+            rp.prime(j, self.src.host_frame(c.first - 1), self.src.host_frame(c.first - 2))
+            rp.set_state(j, got[0] if (s == 0 and 0 in got) else self._end_blob(s - 1))
+            # the state this chunk's chain now starts from: a local predecessor may have got a new end state from an earlier batch of this round
+            start_h[s] = end_h[s - 1] if s > 0 else allh[self.rank * S - 1, 2:4]
+        live = {j: s for j, s in enumerate(batch)}; k = 0; self.stats["runners"] += len(batch)
+        while live:
+            pos = np.zeros((rp.S, Tr), np.int64); act = np.zeros(rp.S, np.int32)
+            for j in range(rp.S):
+                if j in live:
+                    c = self.mine[live[j]]; base = c.first + k * Tr
+                    act[j] = min(Tr, c.last - base); pos[j] = base + np.arange(Tr)
+                else:
+                    pos[j] = np.arange(Tr)                                   # idle slot: any valid frames, no tail runs
+            rp.set_active_frames(act)
+            inp = self.src.device_batch(pos)
+            rp.process_dev(inp[0], inp[1])
+            hh = rp.state_hashes(); self.stats["repair_steps"] += 1; self.stats["repair_frames"] += int(act.sum())
+            for j, s in list(live.items()):
+                c = self.mine[s]; done = False
+                for t in range(int(act[j])):
+                    q = int(pos[j, t]); i = q - c.start
+                    if on_frame is not None:
+                        on_frame(s, q, rp, j, t)
+                    self.stats["overridden_frames"] += 1
+                    if np.array_equal(hh[j, t], self.H[s, i]):               # same state as the chain that is already there: the rest of it stands
+                        self.stats["max_frames_to_converge"] = max(self.stats["max_frames_to_converge"], q - c.first + 1)
+                        done = True; break
+                    self.H[s, i] = hh[j, t]
+                if not done and int(pos[j, 0]) + int(act[j]) >= c.last:      # the runner IS the chunk now: new end state, the successor is verified again
+                    end_h[s] = self.H[s, c.last - 1 - c.start]; self.end_blob[s] = rp.get_state(j)
+                    self.stats["runners_to_chunk_end"] += 1; done = True
+                if done:
+                    del live[j]; self.stats["repaired_chunks"] += 1
+            k += 1
+
+
+def lockstep_for(frames: int, n_chunks: int, frames_per_step: int, warmup: int) -> LockstepPlan:
+    """the lock-step plan whose steps hold at most `frames_per_step` frames per chunk"""
+    need = -(-(frames + warmup * (n_chunks - 1)) // n_chunks)
+    if n_chunks > 1:
+        need = max(need, warmup + 1)
+    return plan_lockstep(frames, n_chunks, -(-need // max(1, frames_per_step)), warmup)
+
+
+def process_sequence(bgr: np.ndarray, depth: np.ndarray, intr: dict, streams: int = 8, frames_per_step: int = 4, warmup: int = 16,
                      nfeatures: int = 1500, scale_factor: float = 1.2, nlevels: int = 8, orb_gray_rgb_order: int = 1, device: int = 0,
-                     rank: int = 0, world: int = 1, want_keypoints: bool = True):
-    """bgr u8 [N, H, W, 3], depth u16 [N, H, W] (host) -> dict with dyna / label / mask u8 [N, H, W] (frame 0 stays zero, like the
-    reference's first frame) and, if asked, per-frame keypoint / descriptor lists, for the frames this rank owns (`owned` = sorted
-    frame indices).  All ranks must pass the same sequence and parameters."""
+                     rank: int = 0, world: int = 1, want_keypoints: bool = True, group=None, repair_streams: int = 0, repair_frames_per_step: int = 4,
+                     verify: bool = True, stats: dict | None = None, pipeline_factory=None, source=None):
+    """bgr u8 [N, H, W, 3], depth u16 [N, H, W] (host) -> dict with dyna / label / mask u8 [N, H, W] (frame 0 stays zero, like the reference's first frame)
+    and, if asked, per-frame keypoint / descriptor lists, for the frames this rank owns (`owned` = sorted frame indices).  All ranks must pass the same
+    sequence and parameters.  The sequence runs on streams * world lock-step chunks (VerifiedChunks): with verify (default) every owned frame equals the
+    sequential loop (rgbd_tum_noros.cc:110-170) bit for bit; verify=False keeps the speculative results of the chunks (round-3 behaviour: valid masks,
+    not identical near the seams).  With several ranks pass the process group (seam fingerprints and, for a mismatching seam between ranks, the state blob
+    travel over it); the caller assembles the masks with parallel.gather_sequence_masks."""
     from .pipeline import Pipeline
     n, h, w, _ = bgr.shape
-    chunks = plan_chunks(n, streams * world, warmup)[rank * streams:(rank + 1) * streams]
-    S, T = streams, frames_per_step
-    pipe = Pipeline(S, T, w, h, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], nfeatures, scale_factor, nlevels,
-                    intr["ini_th"], intr["min_th"], orb_gray_rgb_order=orb_gray_rgb_order, device=device)
+    plan = lockstep_for(n - 1, streams * world, frames_per_step, warmup)
+    mk = pipeline_factory or (lambda S_, T_: Pipeline(S_, T_, w, h, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], nfeatures, scale_factor, nlevels,
+                                                      intr["ini_th"], intr["min_th"], orb_gray_rgb_order=orb_gray_rgb_order, device=device))
+    src = source or HostFrames(bgr, depth, device)
+    pipe = mk(streams, plan.T); rp = None
     out = dict(dyna=np.zeros((n, h, w), np.uint8), label=np.zeros((n, h, w), np.uint8), mask=np.zeros((n, h, w), np.uint8), owned=[],
                keypoints=[None] * n, descriptors=[None] * n)
     try:
-        for s, c in enumerate(chunks):
-            a = min(c.start, n - 1)                     # an empty chunk still needs a primed stream; it processes repeats of a valid frame
-            pipe.prime(s, bgr[a - 1], bgr[max(a - 2, 0)])
-        steps = max((c.processed + T - 1) // T for c in chunks) if chunks else 0
-        sb = np.empty((S, T, h, w, 3), np.uint8); sd = np.empty((S, T, h, w), np.uint16)
-        for step in range(steps):
-            idx = np.empty((S, T), np.int64)
-            for s, c in enumerate(chunks):
-                for t in range(T):
-                    f = c.start + step * T + t
-                    idx[s, t] = f if f < c.last else -1
-                    g = min(max(f if f < c.last else c.last - 1, 1), n - 1)          # past the end of a chunk: repeat its last frame, outputs dropped
-                    sb[s, t] = bgr[g]; sd[s, t] = depth[g]
-            pipe.process(sb, sd)
-            for s, c in enumerate(chunks):
-                for t in range(T):
-                    f = int(idx[s, t])
-                    if f < c.first:                    # -1 (padding) or a warm-up frame
-                        continue
-                    out["dyna"][f] = pipe.dyna[s, t]; out["label"][f] = pipe.label[s, t]; out["mask"][f] = pipe.mask[s, t]; out["owned"].append(f)
-                    if want_keypoints:
-                        k, d = pipe.keypoints(s, t); out["keypoints"][f] = k.copy(); out["descriptors"][f] = d.copy()
+        if verify and plan.n_chunks > 1:
+            rp = mk(repair_streams or max(1, min(streams, 8)), max(1, repair_frames_per_step))
+            for j in range(rp.S):
+                rp.prime(j, src.host_frame(-1), src.host_frame(-2))
+            rp.set_state_hashing(True)
+        vc = VerifiedChunks(plan, streams, pipe, rp, src, rank, world, group)
+        vc.prime()
+
+        def take(p, s_, t_, q):
+            f = q + 1
+            out["dyna"][f] = p.dyna[s_, t_]; out["label"][f] = p.label[s_, t_]; out["mask"][f] = p.mask[s_, t_]
+            if want_keypoints:
+                k, d = p.keypoints(s_, t_); out["keypoints"][f] = k.copy(); out["descriptors"][f] = d.copy()
+
+        def on_step(i, p):
+            for s_, c in enumerate(vc.mine):
+                for t_ in range(plan.T):
+                    q = c.start + i * plan.T + t_
+                    if c.first <= q < c.last:
+                        take(p, s_, t_, q)
+        vc.run_main(on_step)
+        if rp is not None:
+            vc.verify_and_repair(on_frame=lambda s_, q, p, j, t_: take(p, j, t_, q))
+        for c in vc.mine:
+            out["owned"] += [q + 1 for q in range(c.first, c.last)]
+        if stats is not None:
+            stats.update(vc.stats); stats["plan"] = plan
     finally:
         pipe.close()
+        if rp is not None:
+            rp.close()
     out["owned"].sort()
     return out
 

@@ -288,3 +288,32 @@ def generate_point_cloud(cam5, bgr, depth, depth_last, dyna, dyna_last, label, p
     occ = np.zeros(12, np.float64); cnt = np.zeros(12, np.int32); kept = np.zeros(12, np.uint8)
     n = lib().orc_generate_point_cloud(_p(cam), *[_p(x) for x in a], w, h, _p(pr), _p(tw), _p(pts), cap, _p(occ), _p(cnt), _p(kept))
     return dict(points=pts[:n].copy(), occlusion=occ.astype(np.int32), label_count=cnt, kept=kept.astype(np.int32))
+
+
+def sequence_run(bgr, depth, intr, threads=8, swap_rb_orb=True, nfeatures=1500, want_orb=True):
+    """The reference's sequential frame loop (rgbd_tum_noros.cc:110-170) on the oracle over a whole sequence: frame 0 primes twice, frames 1.. go through
+    DetectDynaArea -> 15x15 dilate -> ORBextractor.  The dense flow of a frame is state free (frames n, n-1, n-2 only), so it is computed for all frames on
+    `threads` host threads first (one primed scalar detector per frame; ctypes calls release the GIL) and the stateful part then runs strictly in order with
+    detect_with_flow -- same results as detect() frame by frame (tests/test_oracle_sequence_cpu.py), in a fraction of the time.
+    Returns lists indexed by frame (entry 0 is None): dyna, label, mask, keypoints, descriptors."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(bgr); K = (intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"])
+    lib()
+
+    def flow_of(f):
+        d = DynaDetect(bgr[f - 1], bgr[max(f - 2, 0)], *K); return d.flow_only(bgr[f])[0]
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        flows = [None] + list(ex.map(flow_of, range(1, n)))
+    det = DynaDetect(bgr[0], bgr[0].copy(), *K)
+    orb = ORBextractor(nfeatures, 1.2, 8, intr["ini_th"], intr["min_th"]) if want_orb else None
+    out = dict(dyna=[None], label=[None], mask=[None], keypoints=[None], descriptors=[None])
+    for f in range(1, n):
+        dy, lb = det.detect_with_flow(bgr[f], depth[f], flows[f]); flows[f] = None
+        mk = dilate15(dy)
+        out["dyna"].append(dy); out["label"].append(lb); out["mask"].append(mk)
+        if want_orb:
+            k, dsc = orb.extract(bgr2gray(bgr[f], swap_rb=swap_rb_orb), mk)
+            out["keypoints"].append(k); out["descriptors"].append(dsc)
+        else:
+            out["keypoints"].append(None); out["descriptors"].append(None)
+    return out

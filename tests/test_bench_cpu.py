@@ -75,5 +75,5 @@ def test_sequence_chunk_count_heuristic():
     got = {n: bench.sequence_streams(n, 4000, 128, 20) for n in (1, 2, 4, 8)}
     assert got[1] > got[2] > got[4] > got[8] >= 4
     for n, s in got.items():
-        p = plan_lockstep(4000, n * s, 20)
+        p = plan_lockstep(4000, n * s, 20, bench.SEQ_WARMUP_FRAMES)
         assert p.processed_total <= 1.3 * 4000 and sum(c.last - c.first for c in p.chunks) == 4000

@@ -26,16 +26,20 @@ def test_two_ranks_frame_sharded_sequence_line():
     d = json.loads(lines[0]); s = d["sequence"]
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["mode"] == "sequence" and d["config"]["parallelism"] == "frame-sharded x2"
     assert d["warmup"] == 1 and d["steps"] == 4 and d["scaling"] == "strong"
-    # 200 frames on 4 chunks in 4 steps: P >= (200 + 3 * 24) / 4 = 68 -> T = 17, every chunk processes 68 frames, chunks 1.. own 44 each
-    assert s["chunks"] == 4 and s["frames_per_step_per_chunk"] == 17 and s["processed_frames_per_chunk"] == 68 and s["owned_frames"] == 200 and s["processed_frames"] == 272
-    assert s["state_warmup_frames"] == 24 and s["state_warmup_steps"] == 2
+    # 200 frames on 4 chunks in 4 steps: P >= (200 + 3 * 16) / 4 = 62 -> T = 16, every chunk processes 64 frames, chunks 1.. own 48 each
+    assert s["chunks"] == 4 and s["frames_per_step_per_chunk"] == 16 and s["processed_frames_per_chunk"] == 64 and s["owned_frames"] == 200 and s["processed_frames"] == 256
+    assert s["state_warmup_frames"] == 16 and s["state_warmup_steps"] == 1
     assert d["value"] > 0 and abs(d["value"] - s["value"]) < 1e-6 * d["value"] and s["value"] <= s["value_excl_warmup"]
-    assert abs(s["value_excl_warmup"] / s["value"] - 272 / 200) < 1e-6
+    assert abs(s["value_excl_warmup"] / s["value"] - 256 / 200) < 1e-6
     assert d["roofline"]["launches"] > 0 and d["roofline"]["frac_wall"] <= d["roofline"]["frac"] * 1.001
     assert len(d["host_by_rank"]) == 2 and all(h["host_cores_busy"] > 0 for h in d["host_by_rank"])
     # chunked masks vs the in-order run of the same frames (owned frames of chunks 1..3 inside the first E frames)
-    assert s["seam_frames_compared"] >= 100 and s["exact_mode"]["fps"] > 0
-    assert s["seam_iou_min"] >= 0.97 and s["seam_iou_mean"] >= 0.99 and s["seam_iou_below_0.99"] <= 0.02 * s["seam_frames_compared"] + 1
+    # verified chunks: every compared frame is byte-identical to the in-order run, whatever the seams needed (verification and repairs are inside the clock)
+    assert s["seam_frames_compared"] >= 100 and s["exact_mode"]["fps"] > 0 and s["exact"] is True
+    assert s["seam_masks_equal"] == s["seam_frames_compared"] and s["seam_iou_min"] == 1.0 and s["seam_iou_below_0.99"] == 0
+    v = s["verify"]; assert v["seams"] == 3 and 0 <= v["mismatched_seams"] <= 3 and (v["repair_frames"] > 0) == (v["mismatched_seams"] > 0)
+    # the line carries its own N = 1 point (same job on rank 0 alone, after the timed region)
+    assert s["n1_value"] > 0 and abs(s["speedup_vs_n1"] - s["value"] / s["n1_value"]) < 1e-9 and abs(s["scaling_efficiency"] - s["speedup_vs_n1"] / 2) < 1e-9
 
 
 @pytest.mark.timeout(900)
@@ -49,3 +53,18 @@ def test_one_gpu_line_carries_the_sequence_leg():
     assert d["config"]["mode"] == "streams" and d["scaling"] == "weak" and d["warmup"] == 1 and d["steps"] == 2 and d["config"]["frame_pairs_per_step"] == 32
     assert s["frames"] == 300 and s["owned_frames"] == 300 and s["steps"] == 10 and 0 < s["value"] <= s["value_excl_warmup"]
     assert d["roofline"]["bound"] == "valu" and d["roofline"]["frac_wall"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_sequence_at_the_drivers_chunk_count_every_seam_equal():
+    """the sequence workload with the chunk count of the driver's one-GPU run (26 chunks, 20 steps) on a shorter sequence, and the in-order re-run over the WHOLE
+    sequence: all 25 seams are covered, every owned frame of every later chunk is byte-identical to the in-order run"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "sequence", "--steps", "20", "--warmup", "1", "--streams", "26", "--sequence-frames", "1000",
+                        "--exact-leg-frames", "1000", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0]); s = d["sequence"]; v = s["verify"]
+    print({k: s[k] for k in ("value", "value_excl_warmup", "chunks", "frames_per_step_per_chunk", "seam_frames_compared", "seam_masks_equal", "seam_iou_min")}, v)
+    assert s["chunks"] == 26 and s["steps"] == 20 and v["seams"] == 25 and s["exact"] is True
+    assert s["seam_frames_compared"] >= 900 and s["seam_masks_equal"] == s["seam_frames_compared"] and s["seam_iou_min"] == 1.0
+    assert v["repaired_chunks"] >= v["mismatched_seams"] and v["repair_seconds"] < s["seconds"]

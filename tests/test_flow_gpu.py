@@ -90,6 +90,66 @@ def test_sor_variants_agree_bitwise(fs, frames):
         set_sor_variant()
 
 
+@pytest.fixture(scope="module")
+def fs_big():
+    from sindslam_amd.flow import FlowStage
+    f = FlowStage(768, 432, max_batch=2)
+    yield f
+    f.close()
+
+
+def _textured_pair(w, h, seed):
+    """a band-limited random texture and a copy shifted / warped by a few pixels (u8 values as float32, like DeepFlow's level images)"""
+    rng = np.random.default_rng(seed)
+    base = rng.normal(0, 1, (h + 16, w + 16)).astype(np.float32)
+    for _ in range(3):
+        base = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, (1, 1), (0, 1))) * np.float32(0.25)
+    base = (base - base.min()) / (base.max() - base.min()) * np.float32(255)
+    i0 = np.rint(base[8:8 + h, 8:8 + w]).astype(np.float32); i1 = np.rint(base[6:6 + h, 11:11 + w]).astype(np.float32)
+    return i0, i1
+
+
+# widths that cut into 1, 2, 3 and 6 column strips of the streaming kernel (a strip holds at most 152 columns), last strips whose width is not a multiple of
+# four (w % 4 = 1, 2, 3), odd and even heights; every size is beyond the one-workgroup kernel, so mode 5 runs k_sor_stream on it
+STREAM_SHAPES = [(129, 67), (152, 65), (153, 99), (155, 70), (300, 101), (302, 73), (303, 65), (384, 287), (385, 288), (768, 431), (767, 432), (612, 99)]
+
+
+@pytest.mark.parametrize("w,h", STREAM_SHAPES)
+def test_streaming_solver_equals_the_oracle_on_strip_cuts(fs_big, w, h):
+    """the kernel the bench runs (k_sor_stream, solver mode 5 = streaming on every level it fits) against the ORACLE's VariationalRefinement directly, at widths
+    that exercise every column-strip cut and heights that are odd: 5 fixed-point iterations x 25 SOR iterations with DeepFlow's level parameters"""
+    from sindslam_amd.flow import set_sor_variant
+    i0, i1 = _textured_pair(w, h, 7 * w + h)
+    rng = np.random.default_rng(w + 1000 * h)
+    u0 = rng.normal(0, 1.0, (h, w)).astype(np.float32); v0 = rng.normal(0, 1.0, (h, w)).astype(np.float32)
+    a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
+    ou, ov = O.varref(i0, i1, u0, v0, 5, 25, a, d, g, 1.6)
+    try:
+        set_sor_variant(5, 5, 64, 64)
+        gu, gv = fs_big.varref_f32(np.stack([i0, i0]), np.stack([i1, i1]), np.stack([u0, u0]), np.stack([v0, v0]), 5, 25, a, d, g, 1.6)
+    finally:
+        set_sor_variant()
+    for b in range(2):
+        assert np.array_equal(gu[b].view(np.uint32), ou.view(np.uint32)), (w, h, b, float(np.abs(gu[b] - ou).max()))
+        assert np.array_equal(gv[b].view(np.uint32), ov.view(np.uint32)), (w, h, b, float(np.abs(gv[b] - ov).max()))
+
+
+def test_streaming_solver_on_the_768x432_pyramid(fs_big):
+    """DeepFlow on the 1280 x 720 configuration's flow grid (768 x 432, 57 levels, six column strips of 128 on the top level): streaming (mode 5) ==
+    one launch per colour (mode 0) on every pixel of both pairs"""
+    from sindslam_amd.flow import set_sor_variant
+    assert len(fs_big.levels()) == 57 and fs_big.levels()[0] == (768, 432)
+    a0, a1 = _textured_pair(768, 432, 5); b0, b1 = _textured_pair(768, 432, 6)
+    i0 = np.stack([a0, b1]).astype(np.uint8); i1 = np.stack([a1, b0]).astype(np.uint8)
+    try:
+        set_sor_variant(0, 5, 64, 64); ru, rv = fs_big.deepflow(i0, i1)
+        set_sor_variant(5, 5, 64, 64); u, v = fs_big.deepflow(i0, i1)
+    finally:
+        set_sor_variant()
+    assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32))
+    assert np.abs(ru).max() > 0.5                   # a real flow field, not zeros
+
+
 def test_division_through_the_reciprocal_is_exact():
     """the solver's division (hardware reciprocal + one Newton step, then Markstein's correction) against the IEEE division: every one of the 2^23
     float significands, binary exponents -24..24 (the step is scale invariant; the system's diagonal lies in [0.01, 1e4]), 16 numerators per divisor,

@@ -233,3 +233,70 @@ def test_kmeans_stream_groups_do_not_change_the_results(frames):
     for step in range(2):
         for k in range(4):
             assert np.array_equal(whole[step][k][:8], lo8[step][k]) and np.array_equal(whole[step][k][8:], hi8[step][k])
+
+
+@pytest.mark.timeout(1200)
+def test_pipeline_in_the_shape_the_bench_runs_streaming_solver_and_ragged_step(frames):
+    """48 streams x 3 frames = 144 pairs per step: the dense flow runs as three slices of 48 pairs, i.e. on the STREAMING solver (k_sor_stream, the bench's
+    kernel; smaller test pipelines run the tiled one).  Four sampled streams against the ORACLE: imgDyna / imgLabel / mask / keypoints / descriptors of every
+    frame are equal.  Then a ragged step (sind_pipe_set_active_frames): the sampled streams stop after 0, 1, 2 and 3 frames -- their state fingerprints and state
+    blobs are exactly those of the oracle-checked prefix."""
+    from sindslam_amd.pipeline import Pipeline
+    bgr, depth = frames                       # 6 frames
+    S, T = 48, 3
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+
+    def variant(s):
+        b, d = bgr, depth
+        if s & 1: b, d = b[:, :, ::-1], d[:, :, ::-1]
+        if s & 2: b, d = b[:, ::-1], d[:, ::-1]
+        g = 1.0 - 0.03 * ((s >> 2) % 12)
+        return (np.clip(b.astype(np.float32) * g, 0, 255).astype(np.uint8) if g != 1.0 else np.ascontiguousarray(b)), np.ascontiguousarray(d)
+    sb = np.empty((S, 6) + bgr.shape[1:], np.uint8); sd = np.empty((S, 6) + depth.shape[1:], np.uint16)
+    for s in range(S):
+        sb[s], sd[s] = variant(s)
+    pipe = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5, orb_gray_rgb_order=1)
+    pipe.set_state_hashing(True)
+    for s in range(S):
+        pipe.prime(s, sb[s, 1], sb[s, 0])
+    pipe.process(sb[:, 2:5], sd[:, 2:5])
+    st = pipe.stats(); assert st["sor_slices"] == 3
+    sample = [0, 7, 22, 47]
+    orb_ref = O.ORBextractor(1500, 1.2, 8, 15, 5)
+    h_full = pipe.state_hashes(); assert (h_full != 0).any(axis=2).all()
+    for s in sample:
+        ref = O.DynaDetect(np.ascontiguousarray(sb[s, 1]), np.ascontiguousarray(sb[s, 0]), *K)
+        for t in range(T):
+            rd, rl = ref.detect(np.ascontiguousarray(sb[s, 2 + t]), np.ascontiguousarray(sd[s, 2 + t]))
+            assert np.array_equal(pipe.dyna[s, t], rd) and np.array_equal(pipe.label[s, t], rl), (s, t)
+            assert np.array_equal(pipe.mask[s, t], O.dilate15(rd))
+            rk, rdesc = orb_ref.extract(O.bgr2gray(np.ascontiguousarray(sb[s, 2 + t]), swap_rb=True), pipe.mask[s, t])
+            k, d = pipe.keypoints(s, t)
+            assert k.tobytes() == rk.tobytes() and np.array_equal(d, rdesc), (s, t)
+    blobs_full = {s: pipe.get_state(s) for s in sample}
+    # ragged step on the same inputs: stream sample[i] runs i frames
+    for s in range(S):
+        pipe.prime(s, sb[s, 1], sb[s, 0])
+    act = np.full(S, T, np.int32)
+    for i, s in enumerate(sample):
+        act[s] = i
+    pipe.set_active_frames(act)
+    keep_dyna = pipe.dyna.copy()
+    pipe.process(sb[:, 2:5], sd[:, 2:5])
+    h_rag = pipe.state_hashes()
+    for i, s in enumerate(sample):
+        assert np.array_equal(h_rag[s, :i], h_full[s, :i]) and (h_rag[s, i:] == 0).all(), (s, i)
+        assert np.array_equal(pipe.dyna[s, :i], keep_dyna[s, :i])
+    assert np.array_equal(h_rag[1], h_full[1]) and np.array_equal(pipe.dyna[1], keep_dyna[1])           # the other streams are not affected
+    assert np.array_equal(pipe.get_state(sample[3]), blobs_full[sample[3]])                              # 3 of 3 frames: the full step's state
+    # the state after i frames continues to the same results: stream sample[2] (2 frames done) processes frame 3 in a one-stream pipeline
+    s2 = sample[2]; one = Pipeline(1, 1, 640, 480, *K, 1500, 1.2, 8, 15, 5, orb_gray_rgb_order=1)
+    one.prime(0, sb[s2, 3], sb[s2, 2]); one.set_state(0, pipe.get_state(s2)); one.set_state_hashing(True)
+    one.process(sb[s2:s2 + 1, 4:5], sd[s2:s2 + 1, 4:5])
+    assert np.array_equal(one.dyna[0, 0], keep_dyna[s2, 2]) and np.array_equal(one.state_hashes()[0, 0], h_full[s2, 2])
+    # the call after a ragged step is a full step again
+    for s in range(S):
+        pipe.prime(s, sb[s, 1], sb[s, 0])
+    pipe.process(sb[:, 2:5], sd[:, 2:5])
+    assert np.array_equal(pipe.state_hashes(), h_full) and np.array_equal(pipe.dyna, keep_dyna)
+    one.close(); pipe.close()

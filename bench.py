@@ -60,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the first cpu_baseline setting (the reference pins its OpenMP loops to 8)")
     ap.add_argument("--sequence-frames", type=int, default=4000, help="sequence workload: length of the ONE sequence (BASELINE.json configs[3]: 4000 frames); fixed as --gpus grows = strong scaling")
     ap.add_argument("--seq-warmup-frames", type=int, default=SEQ_WARMUP_FRAMES, help="sequence workload: frames every chunk after the first starts early to rebuild the inter-frame state (speculation; the seams are verified and repaired)")
+    ap.add_argument("--retain-frames", type=int, default=64, help="sequence workload: the steps holding the first N owned frames of every chunk keep their phase-A outputs, so that a repair run "
+                                                                  "re-runs only the stateful tails of those frames (sind_pipe_replay); 0 = repair runs re-process whole frames")
     ap.add_argument("--repair-streams", type=int, default=0, help="sequence workload: runners of the repair pipeline (0 = half the chunks of a GPU, 2..16)")
     ap.add_argument("--repair-frames-per-step", type=int, default=4)
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
@@ -330,10 +332,18 @@ def gather_host_load(mine, pg, comm_dev):
     return [[float(x) for x in p.cpu()] for p in parts]
 
 
+def host_info_list(pipe):
+    """the pipeline's own sizing of its host side (sind_pipe_host_info) as floats, appended to a rank's host_load vector"""
+    h = pipe.host_info()
+    return [float(h["cpu_share"]), float(h["workers"]), float(h["cores_usable"]), float(-1 if h["cgroup_quota_cores"] is None else h["cgroup_quota_cores"]), float(h["local_world"])]
+
+
 def host_load_fields(loads):
     quota = lambda l: None if l[1] < 0 else {"periods": int(l[1]), "throttled_periods": int(l[2]), "throttled_ms": l[3]}
+    sizing = lambda l: None if len(l) < 9 else {"cpu_share": int(l[4]), "pool_workers": int(l[5]), "cores_usable": int(l[6]), "cgroup_quota_cores": None if l[7] < 0 else int(l[7]), "ranks_on_node": int(l[8]),
+                                                "rule": "share = min(cores usable, cgroup quota) / ranks on the node, at least 4, at most 16"}
     return {"host_cores_busy": loads[0][0], "cpu_quota": quota(loads[0]),
-            "host_by_rank": [{"rank": r, "host_cores_busy": l[0], "cpu_quota": quota(l)} for r, l in enumerate(loads)]}
+            "host_by_rank": [{"rank": r, "host_cores_busy": l[0], "cpu_quota": quota(l), "sizing": sizing(l)} for r, l in enumerate(loads)]}
 
 
 def make_pipeline(cfg, intr, S, T, local, host_threads=0):
@@ -407,7 +417,7 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     # the runners that repair mismatching chunks: a second, small pipeline (created and warmed before the clock starts, like the main one)
     R = args.repair_streams or max(2, min(16, (S + 1) // 2)); Tr = max(1, args.repair_frames_per_step)
     rp = make_pipeline(cfg, intr, R, Tr, local, args.host_threads) if (n > 1 and not args.no_verify) else None
-    vc = VerifiedChunks(plan, S, pipe, rp, src, rank, world)
+    vc = VerifiedChunks(plan, S, pipe, rp, src, rank, world, retain_frames=args.retain_frames if rp is not None else 0)
     mine = vc.mine
 
     def prime_all():
@@ -505,7 +515,7 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     torch.cuda.synchronize()
     if pg:
         dist.barrier()
-    load = host_load(c0, t0, thr0); dt = time.perf_counter() - t0
+    load = host_load(c0, t0, thr0) + host_info_list(pipe); dt = time.perf_counter() - t0
     if pg:
         tt = torch.tensor([dt], device=comm_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     loads = gather_host_load(load, pg, comm_dev)
@@ -518,11 +528,13 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
             "exact": rp is not None or n == 1,
             "verify": {"seams": vstats["seams"], "mismatched_seams": vstats["mismatched_seams"], "rounds": vstats["rounds"], "repaired_chunks": vstats["repaired_chunks"],
                        "repair_frames": vstats["repair_frames"], "repair_steps": vstats["repair_steps"], "runners_to_chunk_end": vstats["runners_to_chunk_end"],
+                       "replay_frames": vstats["replay_frames"], "replay_calls": vstats["replay_calls"], "runners_past_replay": vstats["runners_past_replay"], "retained_steps": len(vc.retained),
                        "max_frames_to_converge": vstats["max_frames_to_converge"], "repair_seconds": vstats["repair_seconds"], "lockstep_seconds": t_main,
                        "repair_pipeline": f"{R} runners x {Tr} frames per step" if rp is not None else None,
                        "note": "every chunk seam is verified by comparing 128-bit fingerprints of the inter-frame state (the chunk's rebuilt state vs the predecessor's true end state); "
-                               "a mismatching chunk is re-run from the true state until its state equals the speculative one of the same frame -- all inside the timed region"},
-            "repaired_chunks": vstats["repaired_chunks"], "repair_frames": vstats["repair_frames"],
+                               "a mismatching chunk is re-run from the true state until its state equals the speculative one of the same frame -- all inside the timed region; "
+                               "replay_frames were re-run as tails only on retained phase-A outputs, repair_frames as whole frames on the repair pipeline"},
+            "repaired_chunks": vstats["repaired_chunks"], "repair_frames": vstats["repair_frames"] + vstats["replay_frames"],
             "note": "value = owned frames of the whole sequence / wall time of ALL the work (the state warm-up frames of every chunk after the first, the seam verification "
                     "and the repair runs are inside the timed region); value_excl_warmup counts every processed frame as if it were owned (the pipeline's processing rate)",
             "mask_gather": ("%s all_gather per step, %.1f MB per rank" % ("RCCL through the C ABI (sind_pipe_gather_masks)" if args.collective == "cabi" else "RCCL" if args.backend == "nccl" else args.backend, S * T * H * W / 1e6)) if pg else "single rank (no collective)",
@@ -720,7 +732,7 @@ def main():
         if pg:
             dist.barrier()
         th1 = thread_cpu_seconds() if args.thread_cpu else None
-        load = host_load(c0, t0, thr0); dt = time.perf_counter() - t0
+        load = host_load(c0, t0, thr0) + host_info_list(pipe); dt = time.perf_counter() - t0
         ranks_seen = 1
         if pg:
             tt = torch.tensor([dt], device=comm_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())

@@ -201,6 +201,18 @@ int sind_pipe_set_state(sind_pipe* p, int stream, const uint8_t* buf, size_t n);
 int sind_pipe_set_state_hashing(sind_pipe* p, int on);
 int sind_pipe_get_state_hashes(sind_pipe* p, uint64_t* out, size_t count);
 int sind_pipe_set_active_frames(sind_pipe* p, const int* frames_per_stream);
+/* Retained steps: the repair runs of the chunked mode re-run only the stateful 1 % of a frame.  sind_pipe_reserve_retained(n) sets buffers for n steps aside
+ * (device: flow, depth, plane-edge mask, normalised depth; page-locked host: depth, sample-grid flow); sind_pipe_retain_next(tag) keeps the phase-A outputs
+ * (dense flow, depth copies, ORB front results, CalOccluded results; reference DynaDetect.cc:1023-1147, :429-642, ORBextractor.cc:1043-1151) of the NEXT
+ * submitted step under `tag` once its tails have run; sind_pipe_replay(tag, first, last, outputs) runs the tails (DynaDetect.cc:315-420, 653-1018, 1163-1367,
+ * 1553-1664 + dilation + mask filter of the keypoints) of frames [first[s], last[s]) of that step again for every stream, from the state the stream holds now
+ * (sind_pipe_set_state) -- nothing may be pending; outputs in the step layout, only the frames that ran are written; sind_pipe_release_retained(tag) hands the
+ * buffers back (tag < 0: all).  Not available with depth-ahead. */
+int sind_pipe_reserve_retained(sind_pipe* p, int steps);
+int sind_pipe_retain_next(sind_pipe* p, int tag);
+int sind_pipe_replay(sind_pipe* p, int tag, const int* first, const int* last, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated,
+                     sind_keypoint* kps, int cap, int* nkp, uint8_t* desc);
+int sind_pipe_release_retained(sind_pipe* p, int tag);
 /* per-stage wall times of the last step in milliseconds: {front_gray, dense_flow, orb_front, host_upload (sind_pipe_process only, else 0), tails, total},
  * plus HIP-event statistics of the flow solver: sor_launches, sor_ms (sum of event-bracketed SOR launch groups),
  * sor_alg_bytes (algorithmic bytes those launches cover: 44 B per pixel per red+black iteration) */
@@ -211,6 +223,9 @@ int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, do
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices);
 /* last sind_pipe_submit(_dev): time the call still waited for the previous step's tails after its own phase A had finished (0 = hidden) */
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms);
+/* how the handle sized its host side: {CPU share of this process (cores), pool workers, CPU tokens (max), cores the process may run on, cgroup cpu.max quota in
+ * cores or -1, ranks sharing the node (LOCAL_WORLD_SIZE)}.  share = min(cores, quota) / ranks, at least 4, at most 16. */
+int sind_pipe_host_info(sind_pipe* p, int* out6);
 int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes);      /* size of one step's dyna / label / mask array: streams * frames_per_step * height * width */
 
 /* ------------------------------------------------------------------------------------------------------------

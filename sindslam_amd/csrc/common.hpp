@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <thread>
+#include <utility>
 #include <vector>
 
 // error codes returned across the C ABI (include/sind_hip.h)
@@ -133,6 +134,7 @@ struct DevBuf {
         n = count; return SIND_OK;
     }
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
     ~DevBuf() { release(); }
     DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
 };
@@ -149,6 +151,7 @@ struct PinnedBuf {
         n = count; return SIND_OK;
     }
     void release() { if (p) { (void)hipHostFree(p); p = nullptr; n = 0; } }
+    void swap(PinnedBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
     T* data() { return p; } const T* data() const { return p; }
     ~PinnedBuf() { release(); }
     PinnedBuf() = default; PinnedBuf(const PinnedBuf&) = delete; PinnedBuf& operator=(const PinnedBuf&) = delete;

@@ -14,6 +14,7 @@
 #include <string>
 #include <thread>
 #include <pthread.h>
+#include <sched.h>
 #include <ctime>
 #include <cstdio>
 #include "../../include/sind_hip.h"
@@ -81,7 +82,7 @@ struct sind_pipe {
     // Where a frame's region grow runs: grow_q of every 4 frames on the GPU (one CU for ~6 ms per frame), the others on the host (one core for ~5 ms); both give
     // the same bits, so the share only moves load.  grow_q_fixed < 0: adapted step by step (grow_adapt) -- towards the GPU while the step waits for host work
     // (CalOccluded or tails not done when the dense flow is), back towards the host while no step waits.
-    int grow_q = 1, grow_q_fixed = -1, grow_idle_steps = 0; int cpu_share = 16;
+    int grow_q = 1, grow_q_fixed = -1, grow_idle_steps = 0; int cpu_share = 16; int host_info[6] = {0, 0, 0, 0, -1, 1};      // host_info: share, workers, tokens, cores usable, cgroup quota (-1 none), ranks of the node
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
     struct StepBuf {
@@ -97,8 +98,15 @@ struct sind_pipe {
         bool depth_ahead = false; std::vector<DepthStageOut> dout; std::unique_ptr<std::atomic<int>[]> gate; TaskGroup depth_group;
         std::vector<int> depth_rc; std::vector<std::string> depth_err;
         TaskGroup occ_group, tail_group, km_tails[4]; int km_groups = 1, km_first[5] = {0, 0, 0, 0, 0};       /* (4 = sind_pipe::KM_GROUPS) the step's own partition of the streams */ std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
-        std::vector<int> active; std::vector<uint64_t> state_hash;      // tails of stream s run for t < active[s] (empty: all T); per-frame state fingerprints [S][T][2]
+        std::vector<int> active, first; std::vector<uint64_t> state_hash;      // tails of stream s run for first[s] <= t < active[s] (empty: 0 / all T); per-frame state fingerprints [S][T][2]
+        int retain_tag = -1;                                           // >= 0: the phase-A outputs of this step are kept under this tag when its tails are done
     } sb[2];
+    // Phase-A outputs of a step kept beyond the step (sind_pipe_retain_next): everything the tails read -- dense flow, depth copies, ORB front results,
+    // CalOccluded results, sample-grid flow -- so that sind_pipe_replay can run the stateful tails of those frames again from another state without
+    // computing the state-free 99 % of the frame again (the repair runs of the chunked sequence mode).  Buffers come from a reserve made up front.
+    struct Retained { DevBuf<float> U, V, grid_dev; DevBuf<uint16_t> depth_dev; PinnedBuf<uint16_t> depth_h; PinnedBuf<float> grid_h; DevBuf<uint8_t> occ2_dev, depthN_dev;
+                      std::vector<OrbFrameResult> orb; std::vector<OccResult> occ; int tag = -1; };
+    std::vector<std::unique_ptr<Retained>> spare, kept; int retain_tag_next = -1;
     int cur = 0; int occ_workers = 24;
     // CPU tokens (common.hpp) for the software-pipelined steps, where CalOccluded runners and tails compete for the quota (measured: throttled periods 7 -> 2
     // of 22, +1 %); synchronous steps run ungated -- there the hand-over of tokens at every GPU wait costs more than the throttling (tails 145 -> 173 ms)
@@ -175,11 +183,16 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     p->front.flow.max_levels = std::max(0, cfg->flow_max_levels); for (auto& f : p->extra_fronts) f->flow.max_levels = p->front.flow.max_levels;
     p->fw = p->front.fw; p->fh = p->front.fh;
     SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->orb_stream));
-    // CPU share of this process: the container's quota (cgroup v2 cpu.max, 16 cores per GPU on the MI355X boxes), else the machine's cores
-    int cpu_share = (int)std::thread::hardware_concurrency(); if (cpu_share <= 0) cpu_share = 16;
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { long long q = 0, per = 0; if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) cpu_share = (int)std::max<long long>(1, std::min<long long>(cpu_share, q / per)); fclose(f); }
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int lw = atoi(e); if (lw > 1) cpu_share = std::max(2, cpu_share / lw); }      // ranks of one node (torch.distributed.run) share the quota
+    // CPU share of this process: the cores it may run on (affinity), bounded by the container's quota (cgroup v2 cpu.max: 16 cores per GPU on the MI355X
+    // boxes) and divided among the ranks of the node when a launcher started several in this container (LOCAL_WORLD_SIZE: they share cores and quota) --
+    // never below 4, so that a rank keeps a working pool on a lease whose quota was not scaled with the GPU count.  sind_pipe_host_info reports the decision.
+    int nproc = (int)std::thread::hardware_concurrency(); if (nproc <= 0) nproc = 16;
+    { cpu_set_t set; CPU_ZERO(&set); if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) nproc = std::min(nproc, a); } }
+    int cpu_share = nproc, quota = -1, lw = 1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { long long q = 0, per = 0; if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) { quota = (int)std::max<long long>(1, q / per); cpu_share = std::min(cpu_share, quota); } fclose(f); }
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { lw = std::max(1, atoi(e)); if (lw > 1) cpu_share = std::max(std::min(4, cpu_share), cpu_share / lw); }
     cpu_share = std::min(cpu_share, 16);                                          // more host threads than this per GPU bring nothing (measured)
+    p->host_info[0] = cpu_share; p->host_info[3] = nproc; p->host_info[4] = quota; p->host_info[5] = lw;
     p->cpu_share = cpu_share;
     if (const char* e = getenv("SIND_GROW_GPU")) { p->grow_q_fixed = std::max(0, std::min(4, atoi(e))); p->grow_q = p->grow_q_fixed; }
     const int nworkers = sind_lab_env("SIND_WORKERS") ? std::max(2, atoi(sind_lab_env("SIND_WORKERS"))) : cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 2);         // default: 2x the CPU share (workers sleep while they wait for the GPU)
@@ -205,6 +218,7 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     // host-bound configuration wants every core it can get.  The controller below moves between the two on the same signal as the region grow's share.
     p->cpu_tokens_max = std::max(2, cpu_share - 1); p->cpu_tokens_min = std::max(2, cpu_share - 3); p->cpu_tokens = p->cpu_tokens_min;
     if (sind_lab_env("SIND_CPU_TOKENS")) { p->cpu_tokens = std::max(1, atoi(sind_lab_env("SIND_CPU_TOKENS"))); p->cpu_tokens_fixed = true; }
+    p->host_info[1] = nworkers; p->host_info[2] = p->cpu_tokens_max;
     p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads
     if (const char* e = sind_lab_env("SIND_OCC_WORKERS")) p->occ_workers = std::max(1, std::min(atoi(e), nworkers));
     p->depth_ahead = sind_lab_env("SIND_DEPTH_AHEAD") && atoi(sind_lab_env("SIND_DEPTH_AHEAD")) != 0;
@@ -493,7 +507,8 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
     for (int k = 0; k < B; k++) if (sb.occ_rc[k] != SIND_OK) { sind_set_error("stream %d (CalOccluded): %s", k / T, sb.occ_err[k].c_str()); return sb.occ_rc[k]; }
     if (depth_ahead) for (int k = 0; k < B; k++) if (sb.depth_rc[k] != SIND_OK) { sind_set_error("stream %d (depth stage): %s", k / T, sb.depth_err[k].c_str()); return sb.depth_rc[k]; }
     t[3] = now_ms();
-    sb.active.swap(p->active_next); p->active_next.clear();           // applies to this step only
+    sb.active.swap(p->active_next); p->active_next.clear(); sb.first.clear();           // applies to this step only
+    sb.retain_tag = p->retain_tag_next; p->retain_tag_next = -1;
     sb.state_hash.assign((size_t)2 * B, 0);
     sb.pending = true;
     return SIND_OK;
@@ -564,6 +579,9 @@ static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o
             const size_t np = (size_t)p->c.width * p->c.height;
             const int s0 = sbp->km_first[g], ns = sbp->km_first[g + 1] - s0; std::vector<const uint8_t*> prev(ns);
             for (int t = 0; t < p->T; t++) {
+                bool any = false;                                        // ragged / replayed steps: rounds in which no stream of the group has a frame are passed over
+                for (int s = s0; s < s0 + ns && !any; s++) any = (sbp->first.empty() || t >= sbp->first[s]) && (sbp->active.empty() || t < sbp->active[s]);
+                if (!any) continue;
                 if (t > 0) WorkerPool::wait(sbp->km_tails[g]);           // this group's tails of frame t - 1 (their merged labels start this round's k-means)
                 for (int s = 0; s < ns; s++) prev[s] = depth_half(p, s0 + s)->prev_km_labels();
                 const double tk = now_ms();
@@ -572,11 +590,18 @@ static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o
                   rc = p->kmb[g].run(sbp->depth_dev.p + np * ((size_t)s0 * p->T + t), np * p->T, ns, prev.data()); }
                 { std::lock_guard<std::mutex> lk(p->km_stat_mu); p->km_round_ms += now_ms() - tk; p->km_rounds++; }
                 if (rc != SIND_OK) { const std::string e = sind_last_error(); for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK) { sbp->tail_rc[s] = rc; sbp->tail_err[s] = "batched k-means: " + e; } return; }
-                for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK && (sbp->active.empty() || t < sbp->active[s])) p->workers.push(sbp->km_tails[g], [p, sbp, o, s, t, g, s0](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb[g].result(s - s0), false); });
+                for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK && (sbp->first.empty() || t >= sbp->first[s]) && (sbp->active.empty() || t < sbp->active[s])) p->workers.push(sbp->km_tails[g], [p, sbp, o, s, t, g, s0](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb[g].result(s - s0), false); });
             } });
         return;
     }
-    for (int s = 0; s < S; s++) if (sb.active.empty() || sb.active[s] > 0) p->workers.push(sb.tail_group, [p, sbp, o, s](int w) { tail_task(p, sbp, o, s, 0, w); });
+    for (int s = 0; s < S; s++) {
+        const int t0 = sb.first.empty() ? 0 : sb.first[s], t1 = sb.active.empty() ? p->T : sb.active[s];
+        if (t0 < t1) p->workers.push(sb.tail_group, [p, sbp, o, s, t0](int w) { tail_task(p, sbp, o, s, t0, w); });
+    }
+}
+static void swap_phase_a_outputs(sind_pipe::StepBuf& sb, sind_pipe::Retained& r) {
+    sb.U.swap(r.U); sb.V.swap(r.V); sb.grid_dev.swap(r.grid_dev); sb.depth_dev.swap(r.depth_dev); sb.depth_h.swap(r.depth_h); sb.grid_h.swap(r.grid_h);
+    sb.occ2_dev.swap(r.occ2_dev); sb.depthN_dev.swap(r.depthN_dev); sb.orb.swap(r.orb); sb.occ.swap(r.occ);
 }
 static int phase_b_finish(sind_pipe* p, sind_pipe::StepBuf& sb) {
     for (std::thread& t : p->round_threads) if (t.joinable()) t.join();
@@ -584,6 +609,13 @@ static int phase_b_finish(sind_pipe* p, sind_pipe::StepBuf& sb) {
     WorkerPool::wait(sb.tail_group); for (TaskGroup& g : sb.km_tails) WorkerPool::wait(g);
     sb.pending = false;
     p->last_hash = sb.state_hash;
+    if (sb.retain_tag >= 0) {                       // keep this step's phase-A outputs: they change places with a reserve set of the same sizes
+        if (p->spare.empty()) { sind_set_error("sind_pipe: no reserve left to retain step %d (sind_pipe_reserve_retained)", sb.retain_tag); sb.retain_tag = -1; return SIND_E_STATE; }
+        std::unique_ptr<sind_pipe::Retained> r = std::move(p->spare.back()); p->spare.pop_back();
+        swap_phase_a_outputs(sb, *r); r->tag = sb.retain_tag; sb.retain_tag = -1;
+        for (OccResult& o : r->occ) o.occ2_event = nullptr;            // the uploads behind these events are long done; the events belong to the step buffer and are recorded again
+        p->kept.push_back(std::move(r));
+    }
     for (int s = 0; s < p->S; s++) if (sb.tail_rc[s] != SIND_OK) { sind_set_error("stream %d: %s", s, sb.tail_err[s].c_str()); return sb.tail_rc[s]; }
     return SIND_OK;
 }
@@ -738,6 +770,55 @@ int sind_pipe_set_active_frames(sind_pipe* p, const int* frames_per_stream) {
     return SIND_OK;
 }
 
+// ---- retained steps: phase-A outputs kept for a later replay of the stateful tails
+int sind_pipe_reserve_retained(sind_pipe* p, int steps) {
+    if (!p || steps < 0 || steps > 64) { sind_set_error("sind_pipe_reserve_retained: 0..64 steps"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(p->c.device));
+    const size_t np = (size_t)p->c.width * p->c.height, B = (size_t)p->S * p->T, gsz = (size_t)2 * ((p->c.width - 1) / 10) * ((p->c.height - 1) / 10);
+    while ((int)(p->spare.size() + p->kept.size()) < steps) {
+        std::unique_ptr<sind_pipe::Retained> r(new sind_pipe::Retained());
+        SIND_TRY(r->U.alloc(np * B)); SIND_TRY(r->V.alloc(np * B)); SIND_TRY(r->grid_dev.alloc(gsz * B)); SIND_TRY(r->depth_dev.alloc(np * B)); SIND_TRY(r->depth_h.alloc(np * B));
+        SIND_TRY(r->grid_h.alloc(gsz * B)); SIND_TRY(r->occ2_dev.alloc(np * B)); SIND_TRY(r->depthN_dev.alloc(np * B));
+        p->spare.push_back(std::move(r));
+    }
+    return SIND_OK;
+}
+int sind_pipe_retain_next(sind_pipe* p, int tag) {
+    if (!p || tag < 0) { sind_set_error("sind_pipe_retain_next: tag must be >= 0"); return SIND_E_ARG; }
+    if (p->depth_ahead) { sind_set_error("sind_pipe_retain_next: not available with depth-ahead"); return SIND_E_STATE; }
+    for (auto& r : p->kept) if (r->tag == tag) { sind_set_error("sind_pipe_retain_next: tag %d is in use", tag); return SIND_E_STATE; }
+    if (p->spare.empty()) { sind_set_error("sind_pipe_retain_next: no reserve left (sind_pipe_reserve_retained)"); return SIND_E_STATE; }
+    p->retain_tag_next = tag; return SIND_OK;
+}
+int sind_pipe_release_retained(sind_pipe* p, int tag) {
+    if (!p) return SIND_E_ARG;
+    for (size_t i = 0; i < p->kept.size();) if (tag < 0 || p->kept[i]->tag == tag) { p->kept[i]->tag = -1; p->spare.push_back(std::move(p->kept[i])); p->kept.erase(p->kept.begin() + i); } else i++;
+    return SIND_OK;
+}
+// The stateful tails of a retained step again: stream s runs frames [first[s], last[s]) of that step from whatever state it holds now (sind_pipe_set_state).
+// Outputs as in sind_pipe_process ([S][T] layout, only the frames that ran are written); fingerprints through sind_pipe_get_state_hashes.
+int sind_pipe_replay(sind_pipe* p, int tag, const int* first, const int* last, uint8_t* dyna, uint8_t* label, uint8_t* mask_dil, sind_keypoint* kps, int cap, int* nkp, uint8_t* desc) {
+    if (!p || !first || !last) { sind_set_error("sind_pipe_replay: null argument"); return SIND_E_ARG; }
+    if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_replay: a submitted step is still pending, call sind_pipe_flush first"); return SIND_E_STATE; }
+    if (p->depth_ahead) { sind_set_error("sind_pipe_replay: not available with depth-ahead"); return SIND_E_STATE; }
+    sind_pipe::Retained* r = nullptr; for (auto& k : p->kept) if (k->tag == tag) r = k.get();
+    if (!r) { sind_set_error("sind_pipe_replay: no retained step with tag %d", tag); return SIND_E_ARG; }
+    for (int s = 0; s < p->S; s++) if (first[s] < 0 || last[s] > p->T || (last[s] > first[s] && !p->primed[s])) { sind_set_error("sind_pipe_replay: stream %d: bad frame range %d..%d", s, first[s], last[s]); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(p->c.device));
+    p->gate.set_capacity(1 << 20);
+    sind_pipe::StepBuf& sb = p->sb[0];
+    swap_phase_a_outputs(sb, *r);
+    sb.first.assign(first, first + p->S); sb.active.assign(last, last + p->S); sb.depth_ahead = false; sb.retain_tag = -1;
+    sb.state_hash.assign((size_t)2 * p->S * p->T, 0);
+    const PipeOut o{dyna, label, mask_dil, kps, cap, nkp, desc};
+    const double t0 = now_ms();
+    const int rc = phase_b(p, sb, o);
+    p->stage_ms[4] = now_ms() - t0;
+    sb.first.clear(); sb.active.clear();
+    swap_phase_a_outputs(sb, *r);
+    return rc;
+}
+
 int sind_pipe_set_grow_share(sind_pipe* p, int quarters) {
     if (!p || quarters > 4) { sind_set_error("sind_pipe_set_grow_share: quarters must be -1 (adaptive) or 0..4"); return SIND_E_ARG; }
     p->grow_q_fixed = quarters < 0 ? -1 : quarters; if (quarters >= 0) p->grow_q = quarters;
@@ -749,6 +830,7 @@ int sind_pipe_set_kmeans_groups(sind_pipe* p, int groups) {
     p->km_groups_fixed = groups; if (groups > 0) p->km_groups = groups; return SIND_OK;
 }
 int sind_pipe_get_kmeans_groups(sind_pipe* p, int* groups) { if (!p || !groups) { sind_set_error("sind_pipe_get_kmeans_groups: null argument"); return SIND_E_ARG; } *groups = p->batch_km ? p->km_groups : 0; return SIND_OK; }
+int sind_pipe_host_info(sind_pipe* p, int* out6) { if (!p || !out6) { sind_set_error("sind_pipe_host_info: null argument"); return SIND_E_ARG; } std::memcpy(out6, p->host_info, sizeof(p->host_info)); return SIND_OK; }
 int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes) { if (!p || !bytes) { sind_set_error("sind_pipe_mask_bytes: null argument"); return SIND_E_ARG; } *bytes = (size_t)p->S * p->T * p->c.width * p->c.height; return SIND_OK; }
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms) { if (!p || !ms) return SIND_E_ARG; *ms = p->tail_wait_ms; return SIND_OK; }
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices) {

@@ -94,6 +94,10 @@ class Pipeline:
         """groups of streams whose batched k-means rounds run as independent chains right now (0: no batched k-means)"""
         q = C.c_int(); check(lib().sind_pipe_get_kmeans_groups(self._h, C.byref(q)), "sind_pipe_get_kmeans_groups"); return q.value
 
+    def host_info(self) -> dict:
+        a = np.zeros(6, np.int32); check(lib().sind_pipe_host_info(self._h, ptr(a)), "sind_pipe_host_info")
+        return dict(cpu_share=int(a[0]), workers=int(a[1]), cpu_tokens_max=int(a[2]), cores_usable=int(a[3]), cgroup_quota_cores=(int(a[4]) if a[4] >= 0 else None), local_world=int(a[5]))
+
     def get_state_bytes(self) -> int:
         return int(lib().sind_pipe_state_bytes(self._h))
 
@@ -128,6 +132,23 @@ class Pipeline:
             check(lib().sind_pipe_set_active_frames(self._h, None), "sind_pipe_set_active_frames"); return
         a = np.ascontiguousarray(frames_per_stream, np.int32); assert a.shape == (self.S,)
         check(lib().sind_pipe_set_active_frames(self._h, ptr(a)), "sind_pipe_set_active_frames")
+
+    def reserve_retained(self, steps: int):
+        """set buffers aside for `steps` retained steps (retain_next / replay)"""
+        check(lib().sind_pipe_reserve_retained(self._h, int(steps)), "sind_pipe_reserve_retained")
+
+    def retain_next(self, tag: int):
+        """keep the phase-A outputs of the next submitted step under `tag` (for replay)"""
+        check(lib().sind_pipe_retain_next(self._h, int(tag)), "sind_pipe_retain_next")
+
+    def replay(self, tag: int, first, last):
+        """the stateful tails of frames [first[s], last[s]) of the retained step `tag` again, from the streams' current states; results in self.dyna / ... (step layout)"""
+        a = np.ascontiguousarray(first, np.int32); b = np.ascontiguousarray(last, np.int32); assert a.shape == (self.S,) and b.shape == (self.S,)
+        check(lib().sind_pipe_replay(self._h, int(tag), ptr(a), ptr(b), ptr(self.dyna), ptr(self.label), ptr(self.mask), ptr(self.kps), self.cap, ptr(self.nkp), ptr(self.desc)),
+              "sind_pipe_replay")
+
+    def release_retained(self, tag: int = -1):
+        check(lib().sind_pipe_release_retained(self._h, int(tag)), "sind_pipe_release_retained")
 
     def keypoints(self, s: int, t: int):
         k = s * self.T + t; n = self.nkp[k]; return self.kps[k, :n], self.desc[k, :n]

@@ -135,20 +135,28 @@ class VerifiedChunks:
 
     pipe / repair: Pipeline-like objects (S x T and R x Tr); source: positions -> inputs (HostFrames or the bench's device-resident source)."""
 
-    def __init__(self, plan: LockstepPlan, S: int, pipe, repair, source, rank: int = 0, world: int = 1, group=None):
+    def __init__(self, plan: LockstepPlan, S: int, pipe, repair, source, rank: int = 0, world: int = 1, group=None, retain_frames: int = 0):
         assert plan.n_chunks == S * world and pipe.S == S and pipe.T == plan.T
         self.plan, self.S, self.pipe, self.repair, self.src, self.rank, self.world, self.group = plan, S, pipe, repair, source, rank, world, group
+        # REPLAY: the steps that hold the first `retain_frames` owned frames of the chunks after the first (processed frames warmup .. warmup + retain_frames of every
+        # such chunk: the chunks run in lock-step, so these are the same few steps for all of them) keep their phase-A outputs (sind_pipe_retain_next), and a
+        # runner re-runs only the stateful tails of those frames on the chunk's own stream (sind_pipe_replay) -- the state-free 99 % of a frame (dense flow, ORB
+        # front, CalOccluded) is not computed again.  A runner that is still not through after the retained frames continues on the repair pipeline.
+        T = plan.T
+        self.retained = list(range(plan.warmup // T, min(plan.steps, (plan.warmup + retain_frames - 1) // T + 1))) if (retain_frames > 0 and plan.n_chunks > 1) else []
         self.mine = plan.chunks[rank * S:(rank + 1) * S]
         self.H = np.zeros((S, plan.processed, 2), np.uint64)             # fingerprint of the state after every processed frame of my chunks (current best chain)
         self.end_blob = {}                                               # local chunk -> end-state blob when a runner changed it
         self.stats = dict(seams=0, mismatched_seams=0, rounds=0, runners=0, repaired_chunks=0, repair_frames=0, repair_steps=0, overridden_frames=0,
-                          runners_to_chunk_end=0, repair_seconds=0.0, max_frames_to_converge=0)
+                          runners_to_chunk_end=0, repair_seconds=0.0, max_frames_to_converge=0, replay_frames=0, replay_calls=0, runners_past_replay=0)
 
     # ---- the K lock-step steps
     def prime(self):
         for s, c in enumerate(self.mine):
             self.pipe.prime(s, self.src.host_frame(c.start - 1), self.src.host_frame(c.start - 2))
         self.pipe.set_state_hashing(True)
+        if self.retained:
+            self.pipe.release_retained(-1); self.pipe.reserve_retained(len(self.retained))
 
     def positions(self, step: int) -> np.ndarray:
         T = self.plan.T
@@ -166,6 +174,8 @@ class VerifiedChunks:
                 on_step(i, self.pipe)
         for i in range(K):
             inp = inputs(i) if inputs is not None else self.src.device_batch(self.positions(i))
+            if i in self.retained:
+                self.pipe.retain_next(i)
             t0 = time.perf_counter(); have = self.pipe.submit_dev(inp[0], inp[1]); dt = time.perf_counter() - t0
             if have:
                 collect(pending)
@@ -227,7 +237,7 @@ class VerifiedChunks:
         S, n, P = self.S, self.plan.n_chunks, self.plan.processed
         start_h = np.stack([self._hash_at(s, c.first - 1) if (self.rank * S + s) > 0 else np.zeros(2, np.uint64) for s, c in enumerate(self.mine)])
         end_h = np.stack([self._hash_at(s, c.last - 1) for s, c in enumerate(self.mine)])
-        first = True
+        first = True; saved = False
         while True:
             allh = self._gather(np.concatenate([start_h, end_h], axis=1))                    # [n, 4]
             need = [g > 0 and self._owns(g) and not np.array_equal(allh[g, 0:2], allh[g - 1, 2:4]) for g in range(n)]
@@ -236,54 +246,106 @@ class VerifiedChunks:
             if not any(need):
                 break
             self.stats["rounds"] += 1
+            if self.retained and not saved:          # the replay runs use the chunks' own streams: take every chunk's end state out first
+                for s in range(S):
+                    self.end_blob.setdefault(s, self.pipe.get_state(s))
+                saved = True
             got = self._exchange_blobs(need)
             local = [s for s in range(S) if need[self.rank * S + s]]
-            R = self.repair.S
-            for b0 in range(0, len(local), R):
-                self._run_runners(local[b0:b0 + R], got, allh, start_h, end_h, on_frame)
+            starts = {}                              # runner of chunk s: (first position to process, state blob before it)
+            for s in local:
+                starts[s] = (self.mine[s].first, got[0] if (s == 0 and 0 in got) else self._end_blob(s - 1))
+                # the state this chunk's chain now starts from (the gathered value; a local predecessor that gets a new end state in this round re-opens the seam)
+                start_h[s] = allh[self.rank * S + s - 1, 2:4]
+            self.stats["runners"] += len(local)
+            if self.retained:
+                starts = self._replay_runners(starts, end_h, on_frame)
+            if starts:
+                if self.repair is None:
+                    raise RuntimeError("VerifiedChunks: a chunk needs more repair than the retained frames hold and there is no repair pipeline")
+                order = sorted(starts); R = self.repair.S
+                for b0 in range(0, len(order), R):
+                    batch = {}
+                    for s in order[b0:b0 + R]:
+                        q0, blob = starts[s]
+                        if q0 == self.mine[s].first and s > 0 and s - 1 in self.end_blob:
+                            # a runner that has not started yet takes its LOCAL predecessor's newest end state: batches run in chunk order, so an earlier batch
+                            # of this round may just have made it true (saves the round that would otherwise re-open this seam)
+                            blob = self.end_blob[s - 1]; start_h[s] = end_h[s - 1]
+                        batch[s] = (q0, blob)
+                    self._run_runners(batch, end_h, on_frame)
             if on_round is not None:
                 on_round()
         self.stats["repair_seconds"] += time.perf_counter() - t0
         return self.stats
 
-    def _run_runners(self, batch, got, allh, start_h, end_h, on_frame):
-        rp, Tr, S = self.repair, self.repair.T, self.S
-        for j, s in enumerate(batch):
-            c = self.mine[s]
-            rp.prime(j, self.src.host_frame(c.first - 1), self.src.host_frame(c.first - 2))
-            rp.set_state(j, got[0] if (s == 0 and 0 in got) else self._end_blob(s - 1))
-            # the state this chunk's chain now starts from: a local predecessor may have got a new end state from an earlier batch of this round
-            start_h[s] = end_h[s - 1] if s > 0 else allh[self.rank * S - 1, 2:4]
-        live = {j: s for j, s in enumerate(batch)}; k = 0; self.stats["runners"] += len(batch)
-        while live:
+    def _take(self, s, q, hh, pipe_obj, slot, t, end_h, on_frame):
+        """frame q of my chunk s has been re-processed from the true state (fingerprint hh): hand the results on, then decide -- True: the runner is done"""
+        c = self.mine[s]; i = q - c.start
+        if on_frame is not None:
+            on_frame(s, q, pipe_obj, slot, t)
+        self.stats["overridden_frames"] += 1
+        if np.array_equal(hh, self.H[s, i]):                     # same state as the chain that is already there: the rest of it stands
+            self.stats["max_frames_to_converge"] = max(self.stats["max_frames_to_converge"], q - c.first + 1)
+            self.stats["repaired_chunks"] += 1; return True
+        self.H[s, i] = hh
+        if q + 1 >= c.last:                                      # the runner IS the chunk now: new end state, the successor is verified again
+            end_h[s] = hh; self.end_blob[s] = pipe_obj.get_state(slot)
+            self.stats["runners_to_chunk_end"] += 1; self.stats["repaired_chunks"] += 1; return True
+        return False
+
+    def _replay_runners(self, starts, end_h, on_frame):
+        """runners on the chunks' own streams over the retained steps (tails only); returns the runners that are still not through: {s: (next position, state)}"""
+        T, S, pipe = self.plan.T, self.S, self.pipe
+        for s, (q0, blob) in starts.items():
+            pipe.set_state(s, blob)
+        live = {s: q0 for s, (q0, _) in starts.items()}
+        for k in self.retained:
+            t0 = np.zeros(S, np.int32); t1 = np.zeros(S, np.int32)
+            for s, q in live.items():
+                c = self.mine[s]; lo = max(q - c.start, k * T); hi = min(c.last - c.start, (k + 1) * T)
+                if lo < hi:
+                    assert lo == q - c.start, "a runner's frames are consecutive"
+                    t0[s] = lo - k * T; t1[s] = hi - k * T
+            if not (t1 > t0).any():
+                continue
+            pipe.replay(k, t0, t1); hh = pipe.state_hashes()
+            self.stats["replay_calls"] += 1; self.stats["replay_frames"] += int((t1 - t0).sum())
+            for s in list(live):
+                c = self.mine[s]
+                for t in range(int(t0[s]), int(t1[s])):
+                    q = c.start + k * T + t
+                    if self._take(s, q, hh[s, t], pipe, s, t, end_h, on_frame):
+                        del live[s]; break
+                    live[s] = q + 1
+        left = {s: (q, pipe.get_state(s)) for s, q in live.items()}
+        self.stats["runners_past_replay"] += len(left)
+        return left
+
+    def _run_runners(self, batch, end_h, on_frame):
+        """full re-processing on the repair pipeline: batch = {my chunk s: (first position, state before it)}, at most repair.S of them"""
+        rp, Tr = self.repair, self.repair.T
+        slots = {}
+        for j, (s, (q0, blob)) in enumerate(sorted(batch.items())):
+            rp.prime(j, self.src.host_frame(q0 - 1), self.src.host_frame(q0 - 2)); rp.set_state(j, blob)
+            slots[j] = [s, q0]
+        while slots:
             pos = np.zeros((rp.S, Tr), np.int64); act = np.zeros(rp.S, np.int32)
             for j in range(rp.S):
-                if j in live:
-                    c = self.mine[live[j]]; base = c.first + k * Tr
-                    act[j] = min(Tr, c.last - base); pos[j] = base + np.arange(Tr)
+                if j in slots:
+                    s, q = slots[j]; act[j] = min(Tr, self.mine[s].last - q); pos[j] = q + np.arange(Tr)
                 else:
                     pos[j] = np.arange(Tr)                                   # idle slot: any valid frames, no tail runs
             rp.set_active_frames(act)
             inp = self.src.device_batch(pos)
             rp.process_dev(inp[0], inp[1])
             hh = rp.state_hashes(); self.stats["repair_steps"] += 1; self.stats["repair_frames"] += int(act.sum())
-            for j, s in list(live.items()):
-                c = self.mine[s]; done = False
+            for j in list(slots):
+                s = slots[j][0]
                 for t in range(int(act[j])):
-                    q = int(pos[j, t]); i = q - c.start
-                    if on_frame is not None:
-                        on_frame(s, q, rp, j, t)
-                    self.stats["overridden_frames"] += 1
-                    if np.array_equal(hh[j, t], self.H[s, i]):               # same state as the chain that is already there: the rest of it stands
-                        self.stats["max_frames_to_converge"] = max(self.stats["max_frames_to_converge"], q - c.first + 1)
-                        done = True; break
-                    self.H[s, i] = hh[j, t]
-                if not done and int(pos[j, 0]) + int(act[j]) >= c.last:      # the runner IS the chunk now: new end state, the successor is verified again
-                    end_h[s] = self.H[s, c.last - 1 - c.start]; self.end_blob[s] = rp.get_state(j)
-                    self.stats["runners_to_chunk_end"] += 1; done = True
-                if done:
-                    del live[j]; self.stats["repaired_chunks"] += 1
-            k += 1
+                    if self._take(s, int(pos[j, t]), hh[j, t], rp, j, t, end_h, on_frame):
+                        del slots[j]; break
+                    slots[j][1] = int(pos[j, t]) + 1
 
 
 def lockstep_for(frames: int, n_chunks: int, frames_per_step: int, warmup: int) -> LockstepPlan:
@@ -297,7 +359,7 @@ def lockstep_for(frames: int, n_chunks: int, frames_per_step: int, warmup: int) 
 def process_sequence(bgr: np.ndarray, depth: np.ndarray, intr: dict, streams: int = 8, frames_per_step: int = 4, warmup: int = 16,
                      nfeatures: int = 1500, scale_factor: float = 1.2, nlevels: int = 8, orb_gray_rgb_order: int = 1, device: int = 0,
                      rank: int = 0, world: int = 1, want_keypoints: bool = True, group=None, repair_streams: int = 0, repair_frames_per_step: int = 4,
-                     verify: bool = True, stats: dict | None = None, pipeline_factory=None, source=None):
+                     verify: bool = True, stats: dict | None = None, pipeline_factory=None, source=None, retain_frames: int = 32):
     """bgr u8 [N, H, W, 3], depth u16 [N, H, W] (host) -> dict with dyna / label / mask u8 [N, H, W] (frame 0 stays zero, like the reference's first frame)
     and, if asked, per-frame keypoint / descriptor lists, for the frames this rank owns (`owned` = sorted frame indices).  All ranks must pass the same
     sequence and parameters.  The sequence runs on streams * world lock-step chunks (VerifiedChunks): with verify (default) every owned frame equals the
@@ -319,7 +381,7 @@ def process_sequence(bgr: np.ndarray, depth: np.ndarray, intr: dict, streams: in
             for j in range(rp.S):
                 rp.prime(j, src.host_frame(-1), src.host_frame(-2))
             rp.set_state_hashing(True)
-        vc = VerifiedChunks(plan, streams, pipe, rp, src, rank, world, group)
+        vc = VerifiedChunks(plan, streams, pipe, rp, src, rank, world, group, retain_frames=retain_frames if rp is not None else 0)
         vc.prime()
 
         def take(p, s_, t_, q):

@@ -70,6 +70,8 @@ class FakePipeline:
 
     def _run(self, handle):
         pos = self.src.batches[handle]; assert pos.shape == (self.S, self.T)
+        if getattr(self, "retain_tag", None) is not None:
+            self.kept[self.retain_tag] = pos.copy(); self.retain_tag = None
         act = self.active or [self.T] * self.S; self.active = None
         res = dict(dyna=np.zeros_like(self.dyna), hash=np.zeros((self.S, self.T, 2), np.uint64))
         for s in range(self.S):
@@ -84,6 +86,21 @@ class FakePipeline:
             if act[s] < self.T:
                 self.next_q[s] = None                                          # ragged step: the stream has to be primed again
         return res
+
+    # retained steps: the fake keeps the step's positions; a replay runs the toy from the streams' current states over a frame range
+    def reserve_retained(self, n): self.reserve = n; self.kept = getattr(self, "kept", {})
+    def release_retained(self, tag=-1): self.kept = {} if tag < 0 else {k: v for k, v in getattr(self, "kept", {}).items() if k != tag}
+    def retain_next(self, tag):
+        assert tag not in self.kept and len(self.kept) < self.reserve; self.retain_tag = tag
+
+    def replay(self, tag, first, last):
+        assert self.pending is None
+        pos = self.kept[tag]
+        for s in range(self.S):
+            for t in range(int(first[s]), int(last[s])):
+                q = int(pos[s, t]); o, self.x[s] = self.toy.step(self.x[s], min(q, self.src.frames - 1))
+                self.dyna[s, t] = o; self.label[s, t] = o // 2; self.mask[s, t] = 255 - o; self.hash_out[s, t] = (self.x[s] + 1, 77)
+                self.kp[s][t] = np.array([(float(o), 1.0)], KP); self.frames_replayed = getattr(self, "frames_replayed", 0) + 1
 
     def _publish(self, res):
         self.dyna[:] = res["dyna"]; self.label[:] = res["dyna"] // 2; self.mask[:] = 255 - res["dyna"]; self.hash_out = res["hash"]

@@ -90,7 +90,7 @@ def test_verified_chunks_equal_the_oracle_on_125_frames():
     n = 126
     bgr, depth = SyntheticStream(seed=2024).frames(0, n)
     st = {}
-    got = process_sequence(bgr, depth, TUM3, streams=5, frames_per_step=4, warmup=6, repair_streams=4, repair_frames_per_step=4, stats=st)
+    got = process_sequence(bgr, depth, TUM3, streams=5, frames_per_step=4, warmup=6, repair_streams=4, repair_frames_per_step=4, stats=st, retain_frames=6)      # replay (tails only) on the first frames, then the repair pipeline
     print("5 chunks / warm-up 6:", {k: v for k, v in st.items() if k != "plan"}, st["plan"].chunks)
     assert got["owned"] == list(range(1, n)) and st["seams"] == 4
     ref = O.sequence_run(bgr, depth, TUM3, threads=12)
@@ -105,7 +105,7 @@ def test_verified_chunks_forced_mismatch_no_warmup():
     n = 31
     bgr, depth = SyntheticStream(seed=4242).frames(0, n)
     st = {}
-    got = process_sequence(bgr, depth, TUM3, streams=3, frames_per_step=2, warmup=0, repair_streams=2, repair_frames_per_step=3, stats=st, want_keypoints=False)
+    got = process_sequence(bgr, depth, TUM3, streams=3, frames_per_step=2, warmup=0, repair_streams=2, repair_frames_per_step=3, stats=st, want_keypoints=False, retain_frames=0)
     raw = process_sequence(bgr, depth, TUM3, streams=3, frames_per_step=2, warmup=0, verify=False, want_keypoints=False)
     ref = _sequential_gpu(bgr, depth)
     print("3 chunks / no warm-up:", {k: v for k, v in st.items() if k != "plan"})

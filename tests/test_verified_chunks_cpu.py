@@ -11,12 +11,12 @@ from fake_pipeline import FakePipeline, FakeSource, Toy
 from sindslam_amd.sequence import lockstep_for, plan_lockstep, process_sequence
 
 
-def _run(n_frames, streams, T, warmup, toy, world=1, rank=0, group=None, repair_streams=2, repair_T=3, verify=True):
+def _run(n_frames, streams, T, warmup, toy, world=1, rank=0, group=None, repair_streams=2, repair_T=3, verify=True, retain=0):
     src = FakeSource(n_frames - 1)
     stats = {}
     bgr = np.zeros((n_frames, 2, 3, 3), np.uint8); depth = np.zeros((n_frames, 2, 3), np.uint16)
     out = process_sequence(bgr, depth, {}, streams=streams, frames_per_step=T, warmup=warmup, rank=rank, world=world, group=group, repair_streams=repair_streams,
-                           repair_frames_per_step=repair_T, verify=verify, stats=stats, pipeline_factory=lambda S_, T_: FakePipeline(S_, T_, toy, src), source=src)
+                           repair_frames_per_step=repair_T, verify=verify, stats=stats, pipeline_factory=lambda S_, T_: FakePipeline(S_, T_, toy, src), source=src, retain_frames=retain)
     return out, stats
 
 
@@ -79,6 +79,27 @@ def test_ragged_plans(n, streams, T, warmup):
     assert out["owned"] == list(range(1, n)); _check(out, toy, n)
 
 
+@pytest.mark.parametrize("retain", [4, 7, 16, 40])
+def test_replay_of_retained_steps_then_the_repair_pipeline(retain):
+    """memory of 14 frames against a warm-up of 3: a runner needs 11 frames.  With 4 or 7 retained frames it starts on the retained steps (tails only) and finishes on
+    the repair pipeline; with 16 or 40 it never leaves them"""
+    toy = Toy(bits=14)
+    out, st = _run(150, 5, 3, 3, toy, retain=retain)
+    _check(out, toy, 150)
+    assert st["mismatched_seams"] == 4 and st["replay_frames"] > 0 and st["max_frames_to_converge"] == 11
+    if retain >= 16:
+        assert st["runners_past_replay"] == 0 and st["repair_frames"] == 0 and 40 <= st["replay_frames"] <= 4 * 12          # whole step ranges are replayed: a few frames past the one that matched
+    else:
+        assert st["runners_past_replay"] >= 3 and st["repair_frames"] > 0          # (the last, shorter chunk may end inside the retained frames)
+
+
+def test_replay_cascade_and_resets():
+    for bits, reset in [(60, 0), (40, 17), (9, 0)]:
+        toy = Toy(bits=bits, reset_every=reset)
+        out, st = _run(160, 6, 4, 2, toy, repair_streams=2, repair_T=3, retain=10)
+        _check(out, toy, 160)
+
+
 def test_lockstep_for_respects_the_step_size():
     for frames, n, T, W in [(4000, 26, 9, 16), (100, 4, 4, 8), (5, 3, 2, 1)]:
         p = lockstep_for(frames, n, T, W)
@@ -91,7 +112,7 @@ def _rank_worker(rank, world, port, q, bits, reset_every):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     toy = Toy(bits=bits, reset_every=reset_every)
-    out, st = _run(140, 3, 4, 2, toy, world=world, rank=rank, repair_streams=2, repair_T=3)
+    out, st = _run(140, 3, 4, 2, toy, world=world, rank=rank, repair_streams=2, repair_T=3, retain=6 if bits != 9 else 0)
     q.put((rank, out["owned"], [int(out["dyna"][f, 0, 0]) for f in out["owned"]], st["mismatched_seams"], st["rounds"], st["runners_to_chunk_end"]))
     dist.destroy_process_group()
 

@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--repair-frames-per-step", type=int, default=4)
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
     ap.add_argument("--exact-leg-frames", type=int, default=480, help="sequence workload: frames of the in-order re-run the chunked masks are compared with")
+    ap.add_argument("--pipelines", type=int, default=0, help="independent pipelines a step is cut into on one GPU (experiment; 0 = one; results do not depend on it)")
     ap.add_argument("--no-n1-leg", action="store_true", help="sequence workload on N > 1 ranks: skip the one-rank run of the same job on rank 0 after the timed region (sequence.n1_value)")
     ap.add_argument("--no-sequence-leg", action="store_true", help="streams workload on one GPU: skip the fixed-length sequence job that is run after the timed region (line field `sequence`)")
     ap.add_argument("--no-exact-leg", action="store_true", help="sequence workload: skip the in-order re-run of the first chunks (seam IoU, exact-mode rate)")
@@ -280,37 +281,67 @@ class StepAcc:
         self.tail_wait += st["tail_wait_ms"] if pipelined else 0.0
 
 
-def roofline_of(acc, K, dt, pairs_per_launch, config_name):
-    """`roofline` object of the solver kernel.  The batch runs as `sor_slices` slices on concurrent HIP streams, so solver launches overlap on the GPU:
-    achieved = algorithmic bytes of all launches / time with at least one solver launch in flight (union of the HIP-event intervals of all slices on a
-    common time base); with one slice this is exactly bytes per launch / average launch duration.  The per-launch figures (a launch that shares the GPU
-    with the other slices) are reported next to it, and frac_wall prices the same bytes against the whole timed region."""
-    achieved = acc.sor_bytes / (acc.sor_union * 1e-3) / 1e9 if acc.sor_union > 0 else 0.0      # GB/s
+def flow_level_pixels(width, height, max_levels=0):
+    """pixels of every DeepFlow pyramid level of the flow grid (0.6 x the frame, then x 0.95 per level until a side is <= 25; deepflow.cpp)"""
+    import numpy as np
+    w, h = int(np.float32(0.6) * width), int(np.float32(0.6) * height); out = []
+    while True:
+        out.append(w * h)
+        nw, nh = int(np.float32(w) * np.float32(0.95) + np.float32(0.5)), int(np.float32(h) * np.float32(0.95) + np.float32(0.5))
+        if nw <= 25 or nh <= 25 or len(out) >= 200:
+            break
+        w, h = nw, nh
+    return out[:max_levels] if max_levels else out
+
+
+def roofline_of(acc, K, dt, pairs_per_launch, config_name, cfg=None):
+    """`roofline` object of the solver kernel (k_sor_stream on the levels above 8192 pixels, k_sor_fused on the one-workgroup levels).
+
+    frac is the fraction of the BINDING resource, <= 1 by construction: max(frac_hbm, valu_busy) --
+      frac_hbm   = real HBM bytes (committed rocprofv3 PMC passes of this command: FETCH_SIZE x 2 + WRITE_SIZE per launch, the guide's gfx950 correction) x launches
+                   / time with at least one solver launch in flight / 8 TB/s;
+      valu_busy  = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES of the streaming kernel alone (committed SQ-counter passes).
+    The SURVEY 8d yardstick -- 44 algorithmic bytes per pixel update against the HBM peak -- is kept as achieved_algorithmic / frac_algorithmic; it prices
+    nine reads per update that a five-iteration register-resident kernel never issues, so it can exceed 1 and ranks nothing.  What the kernel HAS to move is
+    compulsory_bytes_per_launch = 40 B per pixel of a streamed launch (8 planes read, 2 written, once per 5 iterations); traffic_over_compulsory says how far the
+    measured traffic is from that.  The batch runs as `concurrent_launches` slices on their own HIP streams: times are unions of HIP-event intervals."""
+    busy_s = acc.sor_union * 1e-3
+    alg = acc.sor_bytes / busy_s / 1e9 if busy_s > 0 else 0.0                                   # algorithmic GB/s, device level
     per_launch = acc.sor_bytes / (acc.sor_ms * 1e-3) / 1e9 if acc.sor_ms > 0 else 0.0
     pmc = pmc_profile() if config_name == "tum3" else None
-    traffic = pmc["hbm_bytes_per_launch_per_pair"] * pairs_per_launch if pmc else None
-    # bound: the contract's yardstick is the HBM roofline on the ALGORITHMIC bytes (44 B per pixel and iteration, SURVEY 8d) and `frac` keeps that meaning;
-    # the fused kernel moves ~0.18 of those bytes and its SQ counters show the VALU pipes as the busiest unit, so the binding resource is named here
-    roof = {"bound": "valu", "bound_note": "frac = algorithmic bytes (44 B per pixel update, SURVEY 8d) against the HBM peak, the yardstick of the metric; the solver keeps a row pair's "
-                                           "system in registers for five iterations and really moves hbm_frac_measured of the peak -- the busiest unit by the SQ counters is the VALU (valu_busy_measured)",
-            "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "frac_wall": (acc.sor_bytes / dt / 1e9 / 8000.0) if dt > 0 else None, "traffic": traffic,
-            "traffic_source": (pmc["file"] + " (committed rocprofv3 --pmc passes of this command, per pair x pairs per launch; not re-measured in this run)") if pmc else None,
-            "kernel": "k_sor_stream (levels above 8192 pixels, from 48 pairs per launch) + k_sor_fused (one-workgroup levels)", "launches": acc.sor_launches, "avg_launch_us": (acc.sor_ms * 1e3 / acc.sor_launches) if acc.sor_launches else None,
+    traffic = pmc["hbm_bytes_per_launch_per_pair"] * pairs_per_launch if pmc else None           # average over all solver launches (streaming + one-workgroup)
+    roof = {"kernel": "k_sor_stream (levels above 8192 pixels, from 48 pairs per launch) + k_sor_fused (one-workgroup levels)", "peak": 8000.0, "unit": "GB/s",
+            "launches": acc.sor_launches, "avg_launch_us": (acc.sor_ms * 1e3 / acc.sor_launches) if acc.sor_launches else None,
+            "concurrent_launches": acc.sor_slices, "solver_busy_ms_per_step": acc.sor_union / K,
             "alg_bytes_per_launch": (acc.sor_bytes / acc.sor_launches) if acc.sor_launches else None,
-            "concurrent_launches": acc.sor_slices, "achieved_per_launch": per_launch, "solver_busy_ms_per_step": acc.sor_union / K}
-    if pmc and acc.sor_launches and acc.sor_union > 0:
-        # real HBM bytes of all launches over the time the solver was busy, against the 8 TB/s peak
-        roof["hbm_frac_measured"] = traffic * acc.sor_launches / (acc.sor_union * 1e-3) / 8e12
+            "achieved_algorithmic": alg, "frac_algorithmic": alg / 8000.0, "achieved_per_launch_algorithmic": per_launch,
+            "frac_wall_algorithmic": (acc.sor_bytes / dt / 1e9 / 8000.0) if dt > 0 else None,
+            "traffic": traffic,
+            "traffic_source": (pmc["file"] + " (committed rocprofv3 --pmc passes of this command, per pair x pairs per launch; not re-measured in this run)") if pmc else None}
+    frac_hbm = valu = None
+    if pmc and acc.sor_launches and busy_s > 0:
+        hbm = traffic * acc.sor_launches / busy_s                                                # real HBM bytes per second while the solver is busy
+        frac_hbm = hbm / 8e12; roof["achieved"] = hbm / 1e9; roof["frac_hbm"] = frac_hbm
+        bk = pmc.get("by_kernel", {}).get("k_sor_stream")
+        if bk and cfg is not None:
+            px = [n for n in flow_level_pixels(cfg["width"], cfg["height"], cfg["flow_max_levels"]) if n > 8192]
+            comp = 40.0 * (sum(px) / len(px)) * pairs_per_launch                                # per streaming launch: every streamed level has the same number of launches
+            tr_s = (2.0 * bk["FETCH_SIZE_kb_per_launch"] + bk["WRITE_SIZE_kb_per_launch"]) * 1024.0 * pairs_per_launch / pmc["pairs_per_launch"]
+            roof["compulsory_bytes_per_launch"] = comp; roof["traffic_streaming_per_launch"] = tr_s; roof["traffic_over_compulsory"] = tr_s / comp
     if pmc and pmc.get("valu_busy_measured") is not None:
-        roof["valu_busy_measured"] = pmc["valu_busy_measured"]; roof["valu_busy_source"] = pmc.get("sq_counters")
-    # VALU share: pixel updates (algorithmic bytes / 44 B) x VALU lane-instructions per update (the committed SQ-counter figure of the PMC file, which already
-    # holds the halo columns and the loader waves; without that file: an ISA count of the tiled loop x its halo redundancy),
-    # over the FP32 vector peak of 78.6e12 lane-operations/s (157.3 TFLOP/s / 2 flops per FMA lane; MI355X_MICROARCH.md)
+        valu = pmc["valu_busy_measured"]; roof["valu_busy"] = valu; roof["valu_busy_source"] = pmc.get("sq_counters")
+    if frac_hbm is None and valu is None:          # no committed counters for this config: only the algorithmic yardstick is known
+        roof.update({"bound": "valu", "achieved": None, "frac": None, "bound_note": "no committed PMC passes for this config; see frac_algorithmic"})
+    else:
+        hb = frac_hbm or 0.0; vb = valu or 0.0
+        roof["bound"] = "valu" if vb >= hb else "hbm"; roof["frac"] = min(1.0, max(hb, vb))
+        roof["bound_note"] = ("frac = max(frac_hbm, valu_busy): the busiest unit's share of its peak.  The solver keeps a row pair's system in registers for five iterations, moves "
+                              "traffic_over_compulsory x its compulsory 40 B per pixel and launch, and is bound by VALU issue plus the step barriers of its row pipeline (DESIGN.md 3.1)")
+    # VALU share from instruction counts: pixel updates (algorithmic bytes / 44 B) x measured VALU lane-instructions per kept update over the chip's 39.3e12 lane-instructions/s
     valu_ops_per_update = (pmc or {}).get("valu_ops_per_pixel_update", 44); halo = (pmc or {}).get("halo_redundancy", 2.1)
-    valu_peak = (pmc or {}).get("valu_peak_lane_instructions_per_s", 78.6e12)      # the measured figure counts a packed operation as one instruction: 39.3e12 lane-instructions/s
-    if acc.sor_union > 0:
-        roof["valu_frac"] = (acc.sor_bytes / 44.0) * valu_ops_per_update * halo / valu_peak / (acc.sor_union * 1e-3)
+    valu_peak = (pmc or {}).get("valu_peak_lane_instructions_per_s", 78.6e12)
+    if busy_s > 0:
+        roof["valu_frac_from_counts"] = (acc.sor_bytes / 44.0) * valu_ops_per_update * halo / valu_peak / busy_s
     return roof
 
 
@@ -346,10 +377,20 @@ def host_load_fields(loads):
             "host_by_rank": [{"rank": r, "host_cores_busy": l[0], "cpu_quota": quota(l), "sizing": sizing(l)} for r, l in enumerate(loads)]}
 
 
-def make_pipeline(cfg, intr, S, T, local, host_threads=0):
-    from sindslam_amd.pipeline import Pipeline
-    return Pipeline(S, T, cfg["width"], cfg["height"], intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],
-                    orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=host_threads, flow_max_levels=cfg["flow_max_levels"])
+def pipelines_for(S, T, asked=0):
+    """independent pipelines a step of S x T frame pairs is cut into (sindslam_amd.pipeline.PipelineGroup): small steps are chains of dependent launches whose
+    latency sets the step time; two or three chains side by side were expected to fill each other's gaps, but measured they do not (profiles/r04/small_steps.txt:
+    651 -> 561 -> 502 pairs/s at 32 pairs per step for 1 -> 2 -> 3 pipelines), so the default stays one pipeline"""
+    if asked > 0:
+        return max(1, min(asked, S))
+    return 1          # measured (profiles/r04/small_steps.txt): at 30-96 pairs per step one pipeline is the fastest; the group exists for experiments (--pipelines N)
+
+
+def make_pipeline(cfg, intr, S, T, local, host_threads=0, parts=1):
+    from sindslam_amd.pipeline import Pipeline, PipelineGroup
+    a = (S, T, cfg["width"], cfg["height"], intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"])
+    kw = dict(orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=host_threads, flow_max_levels=cfg["flow_max_levels"])
+    return PipelineGroup(parts, *a, **kw) if parts > 1 else Pipeline(*a, **kw)
 
 
 def sequence_streams(world, frames, cfg_streams, steps, warm=None):
@@ -413,7 +454,8 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     if S * T > 4096:
         raise SystemExit(f"sequence workload: {S} chunks x {T} frames per step is more than one step should hold; use more --steps, fewer --streams or a shorter --sequence-frames")
     src = BenchFrames(base_b, base_d); bb, bd = src.bb, src.bd; fidx = src.fidx
-    pipe = make_pipeline(cfg, intr, S, T, local, args.host_threads)
+    parts = pipelines_for(S, T, args.pipelines)
+    pipe = make_pipeline(cfg, intr, S, T, local, args.host_threads, parts)
     # the runners that repair mismatching chunks: a second, small pipeline (created and warmed before the clock starts, like the main one)
     R = args.repair_streams or max(2, min(16, (S + 1) // 2)); Tr = max(1, args.repair_frames_per_step)
     rp = make_pipeline(cfg, intr, R, Tr, local, args.host_threads) if (n > 1 and not args.no_verify) else None
@@ -478,8 +520,10 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     thr0 = cgroup_throttle(); t0 = time.perf_counter(); c0 = time.process_time()
     acc = StepAcc()
 
+    step_wall = []
+
     def after_submit(i, seconds):
-        acc.submit_wall += seconds; acc.add(pipe.stats(), True)
+        acc.submit_wall += seconds; acc.add(pipe.stats(), True); step_wall.append(round(seconds * 1e3, 1))
     vc.run_main(on_step=lambda i, p_: gather(i), inputs=lambda i: (dev_b[i].data_ptr(), dev_d[i].data_ptr()), after_submit=after_submit)
     flush_ms = vc.flush_seconds * 1e3
     t_main = time.perf_counter() - t0
@@ -525,7 +569,9 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
             "processed_frames_per_chunk": plan.processed, "state_warmup_frames": SW, "state_warmup_steps": -(-SW // T),
             "processed_frames": plan.processed_total, "warmup_overhead": plan.processed_total / owned - 1.0,
             "value": owned / dt, "value_excl_warmup": plan.processed_total / dt, "seconds": dt, "final_flush_ms": flush_ms, "region_grow_gpu_quarters": grow_q, "kmeans_groups": km_groups,
-            "exact": rp is not None or n == 1,
+            "exact": rp is not None or n == 1, "pipelines_per_gpu": parts, "host_cores_busy": loads[0][0], "submit_wall_ms_by_step": step_wall,
+            "cpu_quota": (None if loads[0][1] < 0 else {"periods": int(loads[0][1]), "throttled_periods": int(loads[0][2]), "throttled_ms": loads[0][3]}),
+            "stage_ms_per_step": {"dense_flow": acc.stages[1] / K, "tails": acc.stages[3] / K, "total": acc.stages[4] / K, "tails_wait_after_phase_a": acc.tail_wait / K},
             "verify": {"seams": vstats["seams"], "mismatched_seams": vstats["mismatched_seams"], "rounds": vstats["rounds"], "repaired_chunks": vstats["repaired_chunks"],
                        "repair_frames": vstats["repair_frames"], "repair_steps": vstats["repair_steps"], "runners_to_chunk_end": vstats["runners_to_chunk_end"],
                        "replay_frames": vstats["replay_frames"], "replay_calls": vstats["replay_calls"], "runners_past_replay": vstats["runners_past_replay"], "retained_steps": len(vc.retained),
@@ -589,6 +635,11 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
 # ------------------------------------------------------------------------------------------------------------------ main
 def main():
     args = parse_args()
+    # HIP streams are multiplexed onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The pipeline drives ~45 streams per handle (three flow slices, ORB, one per pool
+    # worker, k-means, CalOccluded, region grow) and a sequence job carries a second, small handle for the repair runs: with four queues the flow slices of a
+    # stand-alone sequence job share queues with tail streams and run 17 % slower than the same job after a streams run in the same process (250 vs 208 ms of dense
+    # flow per step); with eight the two agree and the streams headline gains 3 % (profiles/r04/hw_queues.txt).  Read by the runtime when it starts: set before torch / HIP load.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     args.pipelined = not args.sync and not args.host_input
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -653,6 +704,9 @@ def main():
     seq_info = None; first_dyna = first_kps = None
 
     if workload == "sequence":
+        if os.environ.get("SIND_BENCH_PRE"):          # experiment: a pipeline created and destroyed before the job (what the one-GPU line's streams workload leaves behind)
+            ps, pt = [int(x) for x in os.environ["SIND_BENCH_PRE"].split("x")]
+            pre = make_pipeline(cfg, intr, ps, pt, local, args.host_threads); pre.close(); del pre
         dt, acc, seq_info, loads = sequence_job(args, cfg, intr, seq_b, seq_d, rank, world, local, pg, comm_dev, S, K, Wm, not args.no_exact_leg)
         T = seq_info["frames_per_step_per_chunk"]; pairs = seq_info["owned_frames"]; flush_ms = seq_info["final_flush_ms"]; loop_ms = sync_ms = None
         if world > 1 and not args.no_n1_leg:
@@ -670,7 +724,8 @@ def main():
             rs = torch.ones(1, device=comm_dev); dist.all_reduce(rs); ranks_seen = int(rs.item())
     else:
         from sindslam_amd.parallel import gather_masks
-        pipe = make_pipeline(cfg, intr, S, T, local, args.host_threads)
+        parts = pipelines_for(S, T, args.pipelines)
+        pipe = make_pipeline(cfg, intr, S, T, local, args.host_threads, parts)
         # inputs resident in HBM before the timed region, laid out [step][S][T]...
         for s in range(S):
             pipe.prime(s, bgr[s, 1], bgr[s, 0])
@@ -765,10 +820,11 @@ def main():
                                                       % (args.sequence_frames, world * S, "RCCL" if args.backend == "nccl" else args.backend) if seq else ""),
                        "name": args.config, "mode": workload, "streams_per_gpu": S, "frames_per_step": T, "frame_pairs_per_step": S * T * world,
                        "parallelism": ("frame-sharded x%d" if seq else "stream-sharded x%d") % world, "pipelined": bool(args.pipelined or seq),
+                       "pipelines_per_gpu": (seq_info.get("pipelines_per_gpu") if seq else parts),
                        "flow_pyramid_levels": cfg["flow_max_levels"] or "all (49 at 640x480)",
                        "inputs": "host buffers, H2D inside the timed region" if args.host_input else "resident in HBM"},
             "ranks_seen": ranks_seen,
-            "roofline": roofline_of(acc, K, dt, S * T / max(acc.sor_slices, 1), args.config),
+            "roofline": roofline_of(acc, K, dt, S * T / max(acc.sor_slices, 1), args.config, cfg),
             "stage_ms_per_step": {"front": acc.stages[0] / K, "dense_flow": acc.stages[1] / K, "orb_front": acc.stages[2] / K, "tails": acc.stages[3] / K, "host_upload": acc.stages[5] / K, "total": acc.stages[4] / K,
                                   "tails_wait_after_phase_a": acc.tail_wait / K, "final_flush_total": flush_ms, "submit_call_wall": acc.submit_wall * 1e3 / K, "loop_total": loop_ms, "final_sync": sync_ms},
         }

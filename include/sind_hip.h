@@ -226,6 +226,9 @@ int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms);
 /* how the handle sized its host side: {CPU share of this process (cores), pool workers, CPU tokens (max), cores the process may run on, cgroup cpu.max quota in
  * cores or -1, ranks sharing the node (LOCAL_WORLD_SIZE)}.  share = min(cores, quota) / ranks, at least 4, at most 16. */
 int sind_pipe_host_info(sind_pipe* p, int* out6);
+/* several handles driven concurrently on one GPU share the process's CPU share: give each its part (cores >= 1; tokens of the pool tasks and the
+ * CalOccluded runners follow; the worker threads stay as created) */
+int sind_pipe_set_cpu_share(sind_pipe* p, int cores);
 int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes);      /* size of one step's dyna / label / mask array: streams * frames_per_step * height * width */
 
 /* ------------------------------------------------------------------------------------------------------------

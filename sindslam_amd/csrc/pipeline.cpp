@@ -830,6 +830,17 @@ int sind_pipe_set_kmeans_groups(sind_pipe* p, int groups) {
     p->km_groups_fixed = groups; if (groups > 0) p->km_groups = groups; return SIND_OK;
 }
 int sind_pipe_get_kmeans_groups(sind_pipe* p, int* groups) { if (!p || !groups) { sind_set_error("sind_pipe_get_kmeans_groups: null argument"); return SIND_E_ARG; } *groups = p->batch_km ? p->km_groups : 0; return SIND_OK; }
+// several handles on one GPU (sindslam_amd.pipeline.PipelineGroup: the streams of a small step cut into independent pipelines whose launch chains interleave):
+// each takes its part of the process's CPU share -- the tokens of its pool tasks and its CalOccluded runners follow
+int sind_pipe_set_cpu_share(sind_pipe* p, int cores) {
+    if (!p || cores < 1) { sind_set_error("sind_pipe_set_cpu_share: at least one core"); return SIND_E_ARG; }
+    if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_set_cpu_share: a submitted step is still pending"); return SIND_E_STATE; }
+    cores = std::min(cores, 16); p->cpu_share = cores; p->host_info[0] = cores;
+    p->cpu_tokens_max = std::max(2, cores - 1); p->cpu_tokens_min = std::max(2, cores - 3); if (!p->cpu_tokens_fixed) p->cpu_tokens = p->cpu_tokens_min;
+    p->host_info[2] = p->cpu_tokens_max;
+    p->occ_workers = std::max(1, std::min(p->workers.size(), std::max(1, cores - 2)));
+    return SIND_OK;
+}
 int sind_pipe_host_info(sind_pipe* p, int* out6) { if (!p || !out6) { sind_set_error("sind_pipe_host_info: null argument"); return SIND_E_ARG; } std::memcpy(out6, p->host_info, sizeof(p->host_info)); return SIND_OK; }
 int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes) { if (!p || !bytes) { sind_set_error("sind_pipe_mask_bytes: null argument"); return SIND_E_ARG; } *bytes = (size_t)p->S * p->T * p->c.width * p->c.height; return SIND_OK; }
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms) { if (!p || !ms) return SIND_E_ARG; *ms = p->tail_wait_ms; return SIND_OK; }

@@ -108,7 +108,10 @@ class Comm:
         C = self._C
         if out is None:
             out = torch.empty((self.world,) + pipe.dyna.shape, dtype=torch.uint8, device=f"cuda:{self.device}")
-        self._check(self._lib.sind_pipe_gather_masks(pipe._h, self._h, pipe.dyna.ctypes.data_as(C.c_void_p), C.c_void_p(out.data_ptr()), None), "sind_pipe_gather_masks")
+        if hasattr(pipe, "_h"):
+            self._check(self._lib.sind_pipe_gather_masks(pipe._h, self._h, pipe.dyna.ctypes.data_as(C.c_void_p), C.c_void_p(out.data_ptr()), None), "sind_pipe_gather_masks")
+        else:                               # a PipelineGroup: its members write into one contiguous mask array
+            self._check(self._lib.sind_comm_allgather_u8(self._h, pipe.dyna.ctypes.data_as(C.c_void_p), C.c_size_t(pipe.dyna.size), C.c_void_p(out.data_ptr()), None), "sind_comm_allgather_u8")
         return out
 
     def close(self):

@@ -19,7 +19,7 @@ class PipeConfig(C.Structure):
 
 class Pipeline:
     def __init__(self, streams: int, frames_per_step: int, width=640, height=480, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_scale=5000.0,
-                 nfeatures=1500, scale_factor=1.2, nlevels=8, ini_th=15, min_th=5, orb_gray_rgb_order=0, device=0, host_threads=0, flow_max_levels=0):
+                 nfeatures=1500, scale_factor=1.2, nlevels=8, ini_th=15, min_th=5, orb_gray_rgb_order=0, device=0, host_threads=0, flow_max_levels=0, _out=None):
         self.S, self.T, self.w, self.h = streams, frames_per_step, width, height
         self.cap = 2 * nfeatures + 256
         cfg = PipeConfig(width, height, fx, fy, cx, cy, depth_scale, nfeatures, scale_factor, nlevels, ini_th, min_th, orb_gray_rgb_order,
@@ -31,6 +31,9 @@ class Pipeline:
         # outputs live in page-locked memory when torch is there (plumbing only): the multi-GPU gather uploads the masks every step
         shape = (streams, frames_per_step, height, width)
         self.dyna_pinned = None
+        if _out is not None:                 # a PipelineGroup hands every member its slice of the group's output arrays
+            self.dyna, self.label, self.mask, self.kps, self.nkp, self.desc = _out
+            return
         try:
             import torch
             if torch.cuda.is_available():
@@ -161,3 +164,95 @@ class Pipeline:
         tw = C.c_double(); check(lib().sind_pipe_tail_wait_ms(self._h, C.byref(tw)))
         return dict(front_ms=st[0], flow_ms=st[1], orb_ms=st[2], upload_ms=st[3], tails_ms=st[4], total_ms=st[5], tail_wait_ms=tw.value, sor_launches=nl.value, sor_ms=sm.value, sor_alg_bytes=by.value,
                     sor_union_ms=un.value, sor_slices=sl.value)
+
+
+class PipelineGroup:
+    """P independent pipelines on one GPU, each with a contiguous share of the S streams, driven concurrently (one host thread each; ctypes calls release the
+    GIL) behind the interface of ONE Pipeline(S, T).  Why: a small step (a rank of a multi-GPU sequence job sees ~30 frame pairs per step) is a chain of
+    ~2000 dependent launches whose latency, not the GPU's throughput, sets its time; two or three such chains side by side fill the gaps of each other.  The streams are
+    independent (one reference DynaDetect instance each), so the results do not depend on the partition (tests/test_pipeline_gpu.py)."""
+
+    def __init__(self, parts: int, streams: int, frames_per_step: int, *args, **kw):
+        from concurrent.futures import ThreadPoolExecutor
+        parts = max(1, min(parts, streams))
+        self.S, self.T = streams, frames_per_step
+        probe_w = kw.get("width", args[0] if len(args) > 0 else 640); probe_h = kw.get("height", args[1] if len(args) > 1 else 480)
+        self.w, self.h = probe_w, probe_h
+        nfeatures = kw.get("nfeatures", args[7] if len(args) > 7 else 1500)
+        self.cap = 2 * nfeatures + 256
+        B = streams * frames_per_step; shape = (streams, frames_per_step, probe_h, probe_w)
+        self.dyna_pinned = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                self.dyna_pinned = torch.zeros(shape, dtype=torch.uint8).pin_memory()
+        except ImportError:
+            pass
+        self.dyna = self.dyna_pinned.numpy() if self.dyna_pinned is not None else np.zeros(shape, np.uint8)
+        self.label = np.zeros(shape, np.uint8); self.mask = np.zeros(shape, np.uint8)
+        self.kps = np.zeros((B, self.cap), KP_DTYPE); self.nkp = np.zeros(B, np.int32); self.desc = np.zeros((B, self.cap, 32), np.uint8)
+        self.first = [streams * i // parts for i in range(parts + 1)]
+        self.pipes = []
+        for i in range(parts):
+            s0, s1 = self.first[i], self.first[i + 1]; T = frames_per_step
+            out = (self.dyna[s0:s1], self.label[s0:s1], self.mask[s0:s1], self.kps[s0 * T:s1 * T], self.nkp[s0 * T:s1 * T], self.desc[s0 * T:s1 * T])
+            self.pipes.append(Pipeline(s1 - s0, frames_per_step, *args, _out=out, **kw))
+        share = self.pipes[0].host_info()["cpu_share"]
+        for p in self.pipes:
+            check(lib().sind_pipe_set_cpu_share(p._h, max(2, -(-share // parts))), "sind_pipe_set_cpu_share")
+        self._ex = ThreadPoolExecutor(parts) if parts > 1 else None
+
+    def _all(self, fn):
+        if self._ex is None:
+            return [fn(0, self.pipes[0])]
+        return list(self._ex.map(lambda ip: fn(*ip), enumerate(self.pipes)))
+
+    def _of(self, s):
+        for i, p in enumerate(self.pipes):
+            if self.first[i] <= s < self.first[i + 1]:
+                return p, s - self.first[i]
+        raise IndexError(s)
+
+    def _ptrs(self, i, b, d):
+        off = self.first[i] * self.T * self.h * self.w
+        return b + off * 3, d + off * 2
+
+    def close(self):
+        for p in getattr(self, "pipes", []):
+            p.close()
+        if getattr(self, "_ex", None):
+            self._ex.shutdown(); self._ex = None
+
+    __del__ = close
+
+    def prime(self, s, a, b): p, k = self._of(s); p.prime(k, a, b)
+    def process_dev(self, b, d): self._all(lambda i, p: p.process_dev(*self._ptrs(i, b, d)))
+    def process(self, bgr, depth): self._all(lambda i, p: p.process(bgr[self.first[i]:self.first[i + 1]], depth[self.first[i]:self.first[i + 1]]))
+    def submit_dev(self, b, d): return all(self._all(lambda i, p: p.submit_dev(*self._ptrs(i, b, d))))
+    def flush(self): return all(self._all(lambda i, p: p.flush()))
+    def set_state_hashing(self, on=True): [p.set_state_hashing(on) for p in self.pipes]
+    def state_hashes(self): return np.concatenate([p.state_hashes() for p in self.pipes])
+    def get_state_bytes(self): return self.pipes[0].get_state_bytes()
+    def get_state(self, s=0): p, k = self._of(s); return p.get_state(k)
+    def set_state(self, s, blob): p, k = self._of(s); p.set_state(k, blob)
+    def reserve_retained(self, n): [p.reserve_retained(n) for p in self.pipes]
+    def retain_next(self, tag): [p.retain_next(tag) for p in self.pipes]
+    def release_retained(self, tag=-1): [p.release_retained(tag) for p in self.pipes]
+    def keypoints(self, s, t): k = s * self.T + t; n = self.nkp[k]; return self.kps[k, :n], self.desc[k, :n]
+    def grow_share(self): return self.pipes[0].grow_share()
+    def kmeans_groups(self): return self.pipes[0].kmeans_groups()
+    def host_info(self): h = self.pipes[0].host_info(); h["pipelines"] = len(self.pipes); return h
+
+    def set_active_frames(self, a):
+        for i, p in enumerate(self.pipes):
+            p.set_active_frames(None if a is None else np.asarray(a, np.int32)[self.first[i]:self.first[i + 1]])
+
+    def replay(self, tag, first, last):
+        f = np.asarray(first, np.int32); l = np.asarray(last, np.int32)
+        self._all(lambda i, p: p.replay(tag, f[self.first[i]:self.first[i + 1]], l[self.first[i]:self.first[i + 1]]) if (l[self.first[i]:self.first[i + 1]] > f[self.first[i]:self.first[i + 1]]).any() else None)
+
+    def stats(self):
+        st = [p.stats() for p in self.pipes]; out = {}
+        for k in st[0]:
+            out[k] = max(x[k] for x in st) if k.endswith("_ms") and not k.startswith("sor") else sum(x[k] for x in st)
+        return out

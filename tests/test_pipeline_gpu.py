@@ -300,3 +300,40 @@ def test_pipeline_in_the_shape_the_bench_runs_streaming_solver_and_ragged_step(f
     pipe.process(sb[:, 2:5], sd[:, 2:5])
     assert np.array_equal(pipe.state_hashes(), h_full) and np.array_equal(pipe.dyna, keep_dyna)
     one.close(); pipe.close()
+
+
+@pytest.mark.timeout(900)
+def test_pipeline_group_equals_one_pipeline(frames):
+    """the streams of a step cut into three independent pipelines driven concurrently (PipelineGroup, the small-step schedule of a multi-GPU rank): every output,
+    state fingerprint and state blob equals the one-pipeline run; pipelined submit / flush and a ragged step included"""
+    import torch
+    from sindslam_amd.pipeline import Pipeline, PipelineGroup
+    bgr, depth = frames
+    S, T = 7, 2
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    sb = np.stack([np.roll(bgr, 3 * s, axis=2) if s % 2 else np.ascontiguousarray(bgr[:, ::-1] if s % 4 == 2 else bgr) for s in range(S)])
+    sd = np.stack([np.roll(depth, 3 * s, axis=2) if s % 2 else np.ascontiguousarray(depth[:, ::-1] if s % 4 == 2 else depth) for s in range(S)])
+    a = (S, T, 640, 480) + K + (1500, 1.2, 8, 15, 5)
+    one = Pipeline(*a, orb_gray_rgb_order=1); grp = PipelineGroup(3, *a, orb_gray_rgb_order=1)
+    assert [p.S for p in grp.pipes] == [2, 2, 3] and grp.host_info()["pipelines"] == 3
+    dev = [(torch.from_numpy(np.ascontiguousarray(sb[:, 2 + i * T: 4 + i * T])).cuda(), torch.from_numpy(np.ascontiguousarray(sd[:, 2 + i * T: 4 + i * T]).view(np.int16)).cuda()) for i in range(2)]
+    res = {}
+    for name, p in (("one", one), ("grp", grp)):
+        p.set_state_hashing(True)
+        for s in range(S):
+            p.prime(s, sb[s, 1], sb[s, 0])
+        got = []
+        assert not p.submit_dev(dev[0][0].data_ptr(), dev[0][1].data_ptr())
+        p.set_active_frames(np.array([2, 1, 0, 2, 2, 1, 2], np.int32))
+        assert p.submit_dev(dev[1][0].data_ptr(), dev[1][1].data_ptr())
+        got.append((p.dyna.copy(), p.label.copy(), p.mask.copy(), p.nkp.copy(), p.kps.copy(), p.desc.copy(), p.state_hashes()))
+        assert p.flush()
+        got.append((p.dyna.copy(), p.label.copy(), p.mask.copy(), p.nkp.copy(), p.kps.copy(), p.desc.copy(), p.state_hashes()))
+        res[name] = (got, [p.get_state(s) for s in range(S)])
+    for step in range(2):
+        for x, y in zip(res["one"][0][step], res["grp"][0][step]):
+            assert np.array_equal(x, y), step
+    for s in range(S):
+        assert np.array_equal(res["one"][1][s], res["grp"][1][s]), s
+    h = res["grp"][0][1][6]; assert (h[2] == 0).all() and (h[1, 1] == 0).all() and (h[1, 0] != 0).any()
+    one.close(); grp.close()

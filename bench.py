@@ -65,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--repair-streams", type=int, default=0, help="sequence workload: runners of the repair pipeline (0 = half the chunks of a GPU, 2..16)")
     ap.add_argument("--repair-frames-per-step", type=int, default=4)
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
-    ap.add_argument("--exact-leg-frames", type=int, default=480, help="sequence workload: frames of the in-order re-run the chunked masks are compared with")
+    ap.add_argument("--exact-leg-frames", type=int, default=0, help="sequence workload: frames of the in-order re-run the chunked masks are compared with (0 = chunk 0, chunks 1-2 and what else fits into 320-480 frames)")
     ap.add_argument("--pipelines", type=int, default=0, help="independent pipelines a step is cut into on one GPU (experiment; 0 = one; results do not depend on it)")
     ap.add_argument("--no-n1-leg", action="store_true", help="sequence workload on N > 1 ranks: skip the one-rank run of the same job on rank 0 after the timed region (sequence.n1_value)")
     ap.add_argument("--no-sequence-leg", action="store_true", help="streams workload on one GPU: skip the fixed-length sequence job that is run after the timed region (line field `sequence`)")
@@ -594,7 +594,7 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     if rank == 0 and exact_leg and n > 1:
         from sindslam_amd.pipeline import Pipeline
         P = plan.processed
-        E = min(max(320, P + 2 * (P - SW)), plan.frames, args.exact_leg_frames)      # chunk 0, chunks 1-2 and what else fits: long enough for a steady-state rate
+        E = min(plan.frames, args.exact_leg_frames) if args.exact_leg_frames > 0 else min(max(320, P + 2 * (P - SW)), plan.frames, 480)      # chunk 0, chunks 1-2 and what else fits: long enough for a steady-state rate
         Te = 32 if E >= 64 else 16
         nst = -(-E // Te); E = nst * Te
         ex = make_pipeline(cfg, intr, 1, Te, local)

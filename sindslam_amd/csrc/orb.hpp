@@ -6,7 +6,7 @@
 namespace sind {
 
 #define ORB_PAD 19            /* EDGE_THRESHOLD, reference ORBextractor.cc:74 */
-#define ORB_WIN_MAX 48        /* largest FAST cell window side (cell + 6) supported */
+#define ORB_WIN_MAX 66        /* largest FAST cell window side: a cell is ceil(extent / int(extent / 30)) <= 59 px (ORBextractor.cc:789-807), + 6 px overlap; 640 x 480 needs 40 */
 #define ORB_CELL_CAP 256      /* NMS keeps at most one corner per 2x2 -> <= 21x21 for a 42x42 window interior */
 
 struct OrbLevel { int w, h; size_t off, blur_off; };                  // padded level inside the slab; interior inside the blur buffer

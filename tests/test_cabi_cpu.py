@@ -64,3 +64,33 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"oracle[/_]|liboracle|oracle_lib", t) and "never" not in t.lower():
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """the collective's loader on a box without RCCL (SIND_RCCL_LIB points the dlopen at a file that does not exist): sind_comm_unique_id and sind_comm_create
+    return SIND_E_STATE with a message -- the first version read dlerror() twice and built a std::string from NULL"""
+    import subprocess, sys
+    code = (
+        "import ctypes as C, sys; sys.path.insert(0, %r)\n"
+        "from sindslam_amd._lib import lib\n"
+        "L = lib(); buf = (C.c_char * 128)(); h = C.c_void_p()\n"
+        "rc1 = L.sind_comm_unique_id(buf, 128); e1 = L.sind_last_error().decode()\n"
+        "rc2 = L.sind_comm_create(buf, 0, 1, 0, C.byref(h)); e2 = L.sind_last_error().decode()\n"
+        "assert rc1 == -4 and rc2 == -4, (rc1, rc2)\n"
+        "assert 'RCCL is not available' in e1 and 'no_such_librccl' in e1 and 'RCCL is not available' in e2, (e1, e2)\n"
+        "assert L.sind_comm_unique_id(buf, 8) == -1\n"            # too small a buffer is an argument error before anything is loaded
+        "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SIND_RCCL_LIB="/nonexistent/no_such_librccl.so"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-800:])
+
+
+def test_region_grow_size_gate_and_chunk_calls_without_a_gpu():
+    """argument checks of the round-4 entry points that need no device: ragged steps, retained steps, state fingerprints on a null / unbuilt handle"""
+    from sindslam_amd._lib import lib
+    L = lib()
+    for fn in ("sind_pipe_set_state_hashing", "sind_pipe_set_active_frames", "sind_pipe_reserve_retained", "sind_pipe_retain_next", "sind_pipe_release_retained",
+               "sind_pipe_host_info", "sind_pipe_set_cpu_share", "sind_pipe_get_state_hashes", "sind_pipe_replay"):
+        assert hasattr(L, fn), fn
+    assert L.sind_pipe_set_state_hashing(None, 1) == -1 and L.sind_pipe_set_active_frames(None, None) == -1 and L.sind_pipe_reserve_retained(None, 1) == -1
+    assert L.sind_pipe_retain_next(None, 0) == -1 and L.sind_pipe_host_info(None, None) == -1 and L.sind_pipe_get_state_hashes(None, None, 0) == -1
+    assert L.sind_pipe_replay(None, 0, None, None, None, None, None, None, 0, None, None) == -1

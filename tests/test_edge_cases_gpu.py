@@ -104,3 +104,36 @@ def test_bonn_configuration():
         k, d = orb(gray, mask); rk, rdesc = rorb.extract(gray, O.dilate15(rd))
         assert k.tobytes() == rk.tobytes() and np.array_equal(d, rdesc)
     gpu.close(); orb.close()
+
+
+@pytest.mark.timeout(900)
+def test_sizes_the_region_grow_kernel_does_not_take_grow_on_the_host():
+    """640 x 360 (the height is not a whole number of 16 x 16 blocks): the PEAC region grow kernel does not take the size (PeacGrowBatch::supports), so the frames are
+    grown by the host statement of the same FIFO -- single-frame API and batched pipeline (B >= 4: the batched CalOccluded path), both equal to the oracle"""
+    from sindslam_amd.dyna import DynaDetect
+    from sindslam_amd.pipeline import Pipeline
+    s = SyntheticStream(width=640, height=360, seed=77)
+    bgr, depth = s.frames(0, 4)
+    Kd = (s.fx, s.fy, s.cx, s.cy, TUM3["depth_factor"])
+    gpu = DynaDetect(bgr[1], bgr[0], *Kd); ref = O.DynaDetect(bgr[1], bgr[0], *Kd)
+    outs = []
+    for f in (2, 3):
+        gd, gl = gpu.DetectDynaArea(bgr[f], depth[f], f); rd, rl = ref.detect(bgr[f], depth[f])
+        assert np.array_equal(gd, rd) and np.array_equal(gl, rl), f
+        outs.append((gd, gl))
+    # ORB at this size: pyramid level 6 is 214 x 121 -> two rows of 45-px FAST cells (+ 6 px overlap = 51; the window limit used to be 48)
+    from sindslam_amd.orb import ORBextractor
+    gray = O.bgr2gray(bgr[3], swap_rb=True); mask = gpu.dilate15(outs[1][0])
+    k, d = ORBextractor(1500, 1.2, 8, 15, 5)(gray, mask); rk, rdesc = O.ORBextractor(1500, 1.2, 8, 15, 5).extract(gray, mask)
+    assert k.tobytes() == rk.tobytes() and np.array_equal(d, rdesc) and len(k) > 300
+    gpu.close()
+    pipe = Pipeline(4, 2, 640, 360, *Kd, 1500, 1.2, 8, 15, 5, orb_gray_rgb_order=1)
+    for k in range(4):
+        pipe.prime(k, bgr[1], bgr[0])
+    pipe.process(np.stack([bgr[2:4]] * 4), np.stack([depth[2:4]] * 4))
+    for k in range(4):
+        for t in range(2):
+            assert np.array_equal(pipe.dyna[k, t], outs[t][0]) and np.array_equal(pipe.label[k, t], outs[t][1]), (k, t)
+    kk, dd = pipe.keypoints(0, 1); assert kk.tobytes() == rk.tobytes() and np.array_equal(dd, rdesc)
+    assert pipe.grow_share() >= 0
+    pipe.close()

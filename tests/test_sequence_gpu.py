@@ -161,3 +161,37 @@ def test_exact_sequence_two_ranks_hand_the_state_over(tmp_path):
         for f in z["owned"]:
             assert np.array_equal(z["dyna"][f], one["dyna"][f]) and np.array_equal(z["label"][f], one["label"][f]), (r, int(f))
     assert sorted(np.concatenate([np.load(tmp_path / f"rank{r}.npz")["owned"] for r in range(2)]).tolist()) == list(range(1, n))
+
+
+@pytest.mark.timeout(900)
+def test_verified_chunks_1280x720_three_level_pyramid_and_bonn():
+    """the other BASELINE configs through the chunked mode: (i) 1280 x 720, D455 intrinsics x 2, depth factor 1000, FAST 20 / 7, 3-level flow pyramid, BGR2GRAY for ORB;
+    (ii) 640 x 480 with the Bonn intrinsics and FAST 20 / 7 -- 3 chunks with a 2-frame warm-up each, against the in-order mode on the same pipeline configuration"""
+    from sindslam_amd.pipeline import Pipeline
+    from sindslam_amd.sequence import process_sequence_exact
+    from sindslam_amd.synth import BONN, D455
+    n = 20
+    s = SyntheticStream(width=1280, height=720, intr=D455, motion_scale=0.5)
+    bgr, depth = s.frames(0, n)
+    intr = dict(D455, fx=s.fx, fy=s.fy, cx=s.cx, cy=s.cy)
+    mk = lambda S_, T_: Pipeline(S_, T_, 1280, 720, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],
+                                 orb_gray_rgb_order=0, flow_max_levels=3)
+    st = {}
+    got = process_sequence(bgr, depth, intr, streams=3, frames_per_step=3, warmup=2, repair_streams=2, repair_frames_per_step=2, stats=st, pipeline_factory=mk, retain_frames=4)
+    print("1280x720:", {k: v for k, v in st.items() if k != "plan"})
+    # reference: one stream, one frame per step, synchronous -- the sequential loop on the same pipeline configuration
+    one = mk(1, 1); one.prime(0, bgr[0], bgr[0])
+    for f in range(1, n):
+        one.process(bgr[f][None, None], depth[f][None, None])
+        assert np.array_equal(got["dyna"][f], one.dyna[0, 0]) and np.array_equal(got["label"][f], one.label[0, 0]) and np.array_equal(got["mask"][f], one.mask[0, 0]), f
+        k, d = one.keypoints(0, 0)
+        assert got["keypoints"][f].tobytes() == k.tobytes() and np.array_equal(got["descriptors"][f], d), f
+    one.close()
+    assert st["seams"] == 2
+    bgr, depth = SyntheticStream(seed=5, intr=BONN).frames(0, n)
+    st = {}
+    got = process_sequence(bgr, depth, BONN, streams=3, frames_per_step=3, warmup=2, repair_streams=2, repair_frames_per_step=2, stats=st, want_keypoints=False)
+    ex = process_sequence_exact(bgr, depth, BONN, frames_per_step=8, want_keypoints=False)
+    print("bonn:", {k: v for k, v in st.items() if k != "plan"})
+    for f in range(1, n):
+        assert np.array_equal(got["dyna"][f], ex["dyna"][f]) and np.array_equal(got["label"][f], ex["label"][f]) and np.array_equal(got["mask"][f], ex["mask"][f]), f

@@ -33,6 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TUM_SEQUENCE_FRAMES = 830       # frames of the one-GPU `sequence_tum_length` leg: TUM fr3/walking_xyz has ~820-860 associated frames
 SEQ_BASE_FRAMES = 50            # generated frames of the sequence workload, walked forth and back
 SEQ_WARMUP_FRAMES = 16          # state warm-up frames of a chunk: most rebuilt states equal the sequential one after ~16 frames; the others are found by the seam verification and repaired
 
@@ -68,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--exact-leg-frames", type=int, default=0, help="sequence workload: frames of the in-order re-run the chunked masks are compared with (0 = chunk 0, chunks 1-2 and what else fits into 320-480 frames)")
     ap.add_argument("--pipelines", type=int, default=0, help="independent pipelines a step is cut into on one GPU (experiment; 0 = one; results do not depend on it)")
     ap.add_argument("--no-n1-leg", action="store_true", help="sequence workload on N > 1 ranks: skip the one-rank run of the same job on rank 0 after the timed region (sequence.n1_value)")
+    ap.add_argument("--no-tum-leg", action="store_true", help="streams workload on one GPU: skip the TUM-length single sequence (line field `sequence_tum_length`)")
     ap.add_argument("--no-sequence-leg", action="store_true", help="streams workload on one GPU: skip the fixed-length sequence job that is run after the timed region (line field `sequence`)")
     ap.add_argument("--no-exact-leg", action="store_true", help="sequence workload: skip the in-order re-run of the first chunks (seam IoU, exact-mode rate)")
     ap.add_argument("--host-input", action="store_true", help="hand over HOST buffers each step (sind_pipe_process, PCIe-inclusive rate; DESIGN.md 6) instead of HBM-resident inputs")
@@ -701,7 +703,7 @@ def main():
         dist.init_process_group(args.backend, rank=rank, world_size=world)     # backend "nccl" is RCCL on ROCm
     comm_dev = "cuda" if (pg and args.backend == "nccl") else "cpu"
     H, W = cfg["height"], cfg["width"]
-    seq_info = None; first_dyna = first_kps = None
+    seq_info = None; tum_info = None; first_dyna = first_kps = None
 
     if workload == "sequence":
         if os.environ.get("SIND_BENCH_PRE"):          # experiment: a pipeline created and destroyed before the job (what the one-GPU line's streams workload leaves behind)
@@ -809,6 +811,16 @@ def main():
             sdt, sacc, seq_info, _ = sequence_job(args, cfg, intr, seq_b, seq_d, 0, 1, local, False, "cpu", Ss, max(K, 10), min(Wm, 2), not args.no_exact_leg)
             seq_info["solver_busy_ms_per_step"] = sacc.sor_union / max(K, 10); seq_info["ms_per_step"] = sdt / max(K, 10) * 1e3
             seq_info["leg_note"] = "same job as the headline of --gpus N > 1 (strong scaling over the ranks), run here after the timed region of the streams workload"
+            if not args.no_tum_leg:
+                # BASELINE.json configs[1] read literally: ONE sequence of TUM fr3/walking_xyz's length (the committed sample trajectory has 823 poses) on one GPU,
+                # every frame equal to the sequential loop (verified chunks), checked against the in-order run over the WHOLE sequence
+                import copy
+                a2 = copy.copy(args); a2.sequence_frames = TUM_SEQUENCE_FRAMES; a2.exact_leg_frames = TUM_SEQUENCE_FRAMES
+                torch.cuda.empty_cache()
+                K2, S2 = 6, 14               # measured (profiles/r04/tum_length_chunking.txt): 14 chunks x 13 frames per step; more chunks pay more warm-up, fewer make the tail chain the step time
+                tdt, _, tum_info, _ = sequence_job(a2, cfg, intr, seq_b, seq_d, 0, 1, local, False, "cpu", S2, K2, 1, not args.no_exact_leg)
+                tum_info["leg_note"] = ("one sequence of %d frames (the length of TUM fr3/walking_xyz) on this GPU in %d steps: frames/s with verification and repairs inside the clock; "
+                                        "seam_masks_equal counts the frames byte-identical to the in-order run over the whole sequence" % (TUM_SEQUENCE_FRAMES, K2))
 
     if rank == 0:
         seq = workload == "sequence"
@@ -835,6 +847,8 @@ def main():
         out["kmeans_groups"] = km_groups if not seq else seq_info.get("kmeans_groups")
         if seq_info:
             out["sequence"] = seq_info
+        if tum_info:
+            out["sequence_tum_length"] = tum_info
         if not args.no_cpu_baseline and world == 1 and first_dyna is not None:
             out["cpu_baseline"], out["parity"] = cpu_baseline(frames_of_stream, intr, cfg, min(T, 4), first_dyna, first_kps, threads=args.cpu_threads, n_streams=NPS)
         else:

@@ -214,13 +214,14 @@ class VerifiedChunks:
         import torch
         import torch.distributed as dist
         dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
-        reqs = []; recv_t = None
+        ops = []; recv_t = None; keep = None
         if self.rank + 1 < self.world and need[(self.rank + 1) * self.S]:
-            blob = torch.from_numpy(self._end_blob(self.S - 1).copy()).to(dev); reqs.append(dist.isend(blob, dst=self.rank + 1, group=self.group))
+            keep = torch.from_numpy(self._end_blob(self.S - 1).copy()).to(dev); ops.append(dist.P2POp(dist.isend, keep, self.rank + 1, group=self.group))
         if self.rank > 0 and need[self.rank * self.S]:
-            recv_t = torch.empty(self.pipe.get_state_bytes(), dtype=torch.uint8, device=dev); reqs.append(dist.irecv(recv_t, src=self.rank - 1, group=self.group))
-        for r in reqs:
-            r.wait()
+            recv_t = torch.empty(self.pipe.get_state_bytes(), dtype=torch.uint8, device=dev); ops.append(dist.P2POp(dist.irecv, recv_t, self.rank - 1, group=self.group))
+        if ops:                                  # one batch per rank: a rank in the middle both sends and receives, and the pairs must not wait for each other in a chain
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
         if recv_t is not None:
             got[0] = recv_t.cpu().numpy()
         return got

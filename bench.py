@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--seq-warmup-frames", type=int, default=SEQ_WARMUP_FRAMES, help="sequence workload: frames every chunk after the first starts early to rebuild the inter-frame state (speculation; the seams are verified and repaired)")
     ap.add_argument("--retain-frames", type=int, default=64, help="sequence workload: the steps holding the first N owned frames of every chunk keep their phase-A outputs, so that a repair run "
                                                                   "re-runs only the stateful tails of those frames (sind_pipe_replay); 0 = repair runs re-process whole frames")
+    ap.add_argument("--chain-max", type=int, default=-1, help="sequence workload: replayed steps with at most this many live runners run as per-stream chains (-1 = library default 6, 0 = always rounds)")
     ap.add_argument("--repair-streams", type=int, default=0, help="sequence workload: runners of the repair pipeline (0 = half the chunks of a GPU, 2..16)")
     ap.add_argument("--repair-frames-per-step", type=int, default=4)
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
@@ -461,6 +462,8 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     # the runners that repair mismatching chunks: a second, small pipeline (created and warmed before the clock starts, like the main one)
     R = args.repair_streams or max(2, min(16, (S + 1) // 2)); Tr = max(1, args.repair_frames_per_step)
     rp = make_pipeline(cfg, intr, R, Tr, local, args.host_threads) if (n > 1 and not args.no_verify) else None
+    if args.chain_max >= 0 and hasattr(pipe, "set_chain_max_streams"):
+        pipe.set_chain_max_streams(args.chain_max)
     vc = VerifiedChunks(plan, S, pipe, rp, src, rank, world, retain_frames=args.retain_frames if rp is not None else 0)
     mine = vc.mine
 

@@ -82,7 +82,8 @@ struct sind_pipe {
     // Where a frame's region grow runs: grow_q of every 4 frames on the GPU (one CU for ~6 ms per frame), the others on the host (one core for ~5 ms); both give
     // the same bits, so the share only moves load.  grow_q_fixed < 0: adapted step by step (grow_adapt) -- towards the GPU while the step waits for host work
     // (CalOccluded or tails not done when the dense flow is), back towards the host while no step waits.
-    int grow_q = 1, grow_q_fixed = -1, grow_idle_steps = 0; int cpu_share = 16; int host_info[6] = {0, 0, 0, 0, -1, 1};      // host_info: share, workers, tokens, cores usable, cgroup quota (-1 none), ranks of the node
+    // (the share starts with every grow on the GPU: measured in round 4, the controller ends there within a few steps at both sizes, and a run that starts there keeps the host two cores cooler at the same rate)
+    int grow_q = 4, grow_q_fixed = -1, grow_idle_steps = 0; int cpu_share = 16; int host_info[6] = {0, 0, 0, 0, -1, 1};      // host_info: share, workers, tokens, cores usable, cgroup quota (-1 none), ranks of the node
     DevBuf<uint8_t> bgr_d, gray, gray_orb, pool; DevBuf<uint16_t> depth_d;
     // two sets of phase-A outputs: step i's phase A (GPU) overlaps with step i-1's phase B (host threads + small kernels)
     struct StepBuf {
@@ -99,6 +100,7 @@ struct sind_pipe {
         std::vector<int> depth_rc; std::vector<std::string> depth_err;
         TaskGroup occ_group, tail_group, km_tails[4]; int km_groups = 1, km_first[5] = {0, 0, 0, 0, 0};       /* (4 = sind_pipe::KM_GROUPS) the step's own partition of the streams */ std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
         std::vector<int> active, first; std::vector<uint64_t> state_hash;      // tails of stream s run for first[s] <= t < active[s] (empty: 0 / all T); per-frame state fingerprints [S][T][2]
+        bool few_chain = false;                                        // this step runs a handful of streams as per-stream chains (see phase_b_start)
         int retain_tag = -1;                                           // >= 0: the phase-A outputs of this step are kept under this tag when its tails are done
     } sb[2];
     // Phase-A outputs of a step kept beyond the step (sind_pipe_retain_next): everything the tails read -- dense flow, depth copies, ORB front results,
@@ -118,7 +120,7 @@ struct sind_pipe {
     std::vector<char> primed;
     // Chunked sequences (sindslam_amd/sequence.py): hashing = every tail leaves the fingerprint of its rolled state per frame (last_hash: the step whose results
     // were returned last, [S][T][2]); active_next = per-stream number of frames whose TAILS run in the next step (one step only; empty = all T)
-    bool hashing = false; std::vector<uint64_t> last_hash; std::vector<int> active_next;
+    bool hashing = false; std::vector<uint64_t> last_hash; std::vector<int> active_next; int chain_max_streams = 6;
     double stage_ms[6] = {0}; double tail_wait_ms = 0; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;
     SindHostGate gate;           // CPU tokens of this handle's pool tasks (common.hpp)
     WorkerPool workers;          // declared last: joined first
@@ -561,9 +563,10 @@ static bool tail_one(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int
     return true;
 }
 static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int worker, const KmFrameResult* km = nullptr, bool chain = true) {
+    struct Spin { int keep; explicit Spin(bool on) : keep(t_sind_spin_us) { if (on) t_sind_spin_us = 400; } ~Spin() { t_sind_spin_us = keep; } } spin(sb->few_chain);      // few chains, idle host: poll before sleeping (common.hpp)
     for (;;) {
         if (!tail_one(p, sb, o, s, t, worker, km) || !chain || t + 1 >= (sb->active.empty() ? p->T : std::min(p->T, sb->active[s]))) return;
-        if (p->S == 1) { t++; km = nullptr; continue; }      // one stream: the next frame's chain link right here (no hand-over to another worker)
+        if (p->S == 1 || sb->few_chain) { t++; km = nullptr; continue; }      // one stream / a few chains: the next frame's chain link right here (no hand-over to another worker)
         p->workers.push(sb->tail_group, [p, sb, o, s, t](int w) { tail_task(p, sb, o, s, t + 1, w); }); return;
     }
 }
@@ -571,7 +574,13 @@ static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o
     const int S = p->S;
     sb.tail_rc.assign(S, SIND_OK); sb.tail_err.assign(S, std::string());
     sind_pipe::StepBuf* sbp = &sb;
-    if (p->batch_km && !sb.depth_ahead) {
+    // A step in which only a few streams have frames (the repair runs of the chunked sequence mode: the slow runners of a round, sind_pipe_replay) runs them as
+    // per-stream chains with their own k-means launches instead of rounds: a round costs the batched k-means' ~60 dependent launches for every frame whatever the
+    // batch, and its barrier makes every stream wait for the slowest tail -- with a handful of streams on an otherwise idle GPU the chains are about twice as fast.
+    int nact = 0; for (int s = 0; s < S; s++) nact += (sb.first.empty() ? 0 : sb.first[s]) < (sb.active.empty() ? p->T : sb.active[s]);
+    const bool few = (!sb.first.empty() || !sb.active.empty()) && nact <= p->chain_max_streams;
+    sb.few_chain = few && S > 1;
+    if (p->batch_km && !sb.depth_ahead && !few) {
         // rounds: frame t of every stream -- the batched k-means chain on its own stream, then the S tails of that frame on the pool
         sbp->km_groups = p->km_groups; for (int g = 0; g <= sbp->km_groups; g++) sbp->km_first[g] = (int)((long long)S * g / sbp->km_groups);
         for (int g = 0; g < sbp->km_groups; g++) p->round_threads.emplace_back([p, sbp, o, g] {
@@ -840,6 +849,10 @@ int sind_pipe_set_cpu_share(sind_pipe* p, int cores) {
     p->host_info[2] = p->cpu_tokens_max;
     p->occ_workers = std::max(1, std::min(p->workers.size(), std::max(1, cores - 2)));
     return SIND_OK;
+}
+int sind_pipe_set_chain_max_streams(sind_pipe* p, int n) {
+    if (!p || n < 0) { sind_set_error("sind_pipe_set_chain_max_streams: n >= 0"); return SIND_E_ARG; }
+    p->chain_max_streams = n; return SIND_OK;
 }
 int sind_pipe_host_info(sind_pipe* p, int* out6) { if (!p || !out6) { sind_set_error("sind_pipe_host_info: null argument"); return SIND_E_ARG; } std::memcpy(out6, p->host_info, sizeof(p->host_info)); return SIND_OK; }
 int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes) { if (!p || !bytes) { sind_set_error("sind_pipe_mask_bytes: null argument"); return SIND_E_ARG; } *bytes = (size_t)p->S * p->T * p->c.width * p->c.height; return SIND_OK; }

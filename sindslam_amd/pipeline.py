@@ -153,6 +153,10 @@ class Pipeline:
     def release_retained(self, tag: int = -1):
         check(lib().sind_pipe_release_retained(self._h, int(tag)), "sind_pipe_release_retained")
 
+    def set_chain_max_streams(self, n: int):
+        """ragged / replayed steps with at most n active streams run as per-stream chains instead of batched rounds (default 6, 0 = never)"""
+        check(lib().sind_pipe_set_chain_max_streams(self._h, int(n)), "sind_pipe_set_chain_max_streams")
+
     def keypoints(self, s: int, t: int):
         k = s * self.T + t; n = self.nkp[k]; return self.kps[k, :n], self.desc[k, :n]
 

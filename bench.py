@@ -337,9 +337,14 @@ def roofline_of(acc, K, dt, pairs_per_launch, config_name, cfg=None):
         roof.update({"bound": "valu", "achieved": None, "frac": None, "bound_note": "no committed PMC passes for this config; see frac_algorithmic"})
     else:
         hb = frac_hbm or 0.0; vb = valu or 0.0
-        roof["bound"] = "valu" if vb >= hb else "hbm"; roof["frac"] = min(1.0, max(hb, vb))
-        roof["bound_note"] = ("frac = max(frac_hbm, valu_busy): the busiest unit's share of its peak.  The solver keeps a row pair's system in registers for five iterations, moves "
-                              "traffic_over_compulsory x its compulsory 40 B per pixel and launch, and is bound by VALU issue plus the step barriers of its row pipeline (DESIGN.md 3.1)")
+        roof["achieved_hbm"] = roof.get("achieved"); roof["peak_hbm"] = 8000.0
+        if vb >= hb:                               # achieved / peak / unit / frac describe the BINDING resource, so that frac = achieved / peak holds whichever it is
+            vpeak = (pmc or {}).get("valu_peak_lane_instructions_per_s", 39.3e12) / 1e12
+            roof.update({"bound": "valu", "achieved": vb * vpeak, "peak": vpeak, "unit": "T lane-instructions/s (a packed FP32 operation counts once)", "frac": min(1.0, vb)})
+        else:
+            roof.update({"bound": "hbm", "frac": min(1.0, hb)})
+        roof["bound_note"] = ("frac = max(frac_hbm, valu_busy) = achieved / peak of the busiest unit.  The solver keeps a row pair's system in registers for five iterations, moves "
+                              "traffic_over_compulsory x its compulsory 40 B per pixel and launch (achieved_hbm of peak_hbm GB/s), and is bound by VALU issue plus the step barriers of its row pipeline (DESIGN.md 3.1)")
     # VALU share from instruction counts: pixel updates (algorithmic bytes / 44 B) x measured VALU lane-instructions per kept update over the chip's 39.3e12 lane-instructions/s
     valu_ops_per_update = (pmc or {}).get("valu_ops_per_pixel_update", 44); halo = (pmc or {}).get("halo_redundancy", 2.1)
     valu_peak = (pmc or {}).get("valu_peak_lane_instructions_per_s", 78.6e12)

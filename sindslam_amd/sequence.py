@@ -2,21 +2,19 @@
 
 The state-free work of DynaDetect + ORB (>99 % of the bytes) needs only frames n, n-1, n-2 and depth n; the light stateful tail (k-means
 warm labels, sample weights, previous high mask; reference DynaDetect.h:172-178, rolled at DynaDetect.cc:1660-1664) needs frame order.
-So a sequence of N frames is cut into contiguous CHUNKS, one per pipeline stream (and `streams` chunks per rank): every chunk is an
-independent stream that starts `warmup` frames before its first owned frame, so that its tail state has settled when the owned frames
-begin; the outputs of the warm-up frames are dropped.  Chunk 0 starts at frame 1 primed with frame 0 twice, exactly like the reference
-loop (Examples/RGB-D/rgbd_tum_noros.cc:103-107, 131-139), so its frames equal a sequential run bit for bit; later chunks deviate from a sequential run only through the state they rebuilt
-in `warmup` frames -- the state steers the masks, and a rebuilt state re-synchronises with the sequential run only after ~16-24 frames
-(measured: warm-up 4 or 8 leaves per-frame IoU of 0.05-0.9 over whole chunks, 16 frames >= 0.98, 20 frames mean 0.9995), hence the
-default of 24; the masks of later chunks are valid but not guaranteed identical.  With several ranks, rank r owns chunks
-[r * streams, (r + 1) * streams); process_sequence performs NO collective -- the caller assembles the per-frame masks of all ranks with
-parallel.gather_sequence_masks (one all_gather of padded blocks).
+So a sequence is cut into contiguous lock-step CHUNKS, one per pipeline stream (and `streams` chunks per rank); chunk 0 starts at frame 1
+primed with frame 0 twice, exactly like the reference loop (Examples/RGB-D/rgbd_tum_noros.cc:103-107, 131-139); a later chunk starts `warmup`
+frames early from an empty state (speculation).  VerifiedChunks then makes every chunk the sequential result: each chunk seam is verified by
+comparing 128-bit fingerprints of the inter-frame state, and a chunk whose rebuilt state differs from its predecessor's true end state is
+repaired by re-running the stateful tails of its first frames (on retained phase-A outputs) until the states agree.  process_sequence returns
+the frames a rank owns; with several ranks the fingerprints travel in one small all_gather per round and the 1.2 MB state blob of a
+mismatching seam between two ranks in one send / recv -- there is no other cross-rank dependency; the caller assembles the per-frame masks
+with parallel.gather_sequence_masks (one all_gather of padded blocks).
 
-Where the masks must EQUAL one sequential run (the parity mode, "exact"), use process_sequence_exact: the state-free phase A is still
-batched (and sharded over ranks by contiguous frame ranges), the stateful tails run strictly in frame order -- one chain per half
-(depth half: k-means warm labels; flow half: sample weights, previous high mask), the depth chain of step i+1 next to the flow
-chain of step i -- and the state blob is handed from rank r to rank r+1 (point-to-point send / recv).  Its rate is bounded by
-1 / (per-frame chain latency), not by the GPU, and does not grow with the number of ranks.
+process_sequence_exact is the in-order mode: phase A batched (and sharded over ranks by contiguous frame ranges), the stateful tails strictly
+in frame order -- one chain per half (depth half: k-means warm labels; flow half: sample weights, previous high mask), the depth chain of step
+i+1 next to the flow chain of step i -- and the state blob handed from rank r to rank r+1.  Its rate is bounded by 1 / (per-frame chain
+latency) and does not grow with the number of ranks; it is the independent check the chunked results are compared with.
 """
 from __future__ import annotations
 

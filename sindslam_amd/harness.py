@@ -174,12 +174,68 @@ def run_sequence(settings_path: str, sequence_dir: str, association_path: str, o
     return results
 
 
+def run_sequence_chunked(settings_path: str, sequence_dir: str, association_path: str, out_dir: str | None = None, max_frames: int | None = None,
+                         device: int = 0, verbose: bool = True, chunks: int = 14, frames_per_step: int = 13, warmup: int = 16):
+    """The same folder, the same results (every frame equal to run_sequence's, i.e. to the reference's in-order loop), at several times the rate: the frames are
+    decoded up front and go through the batched pipeline as `chunks` verified chunks (sindslam_amd.sequence.process_sequence: speculate, verify the chunk seams by
+    state fingerprints, repair).  Offline use -- the whole sequence has to be there; a live camera is run_sequence / the DynaDetect class."""
+    from .orb import ORBextractor
+    from .sequence import process_sequence
+    S = read_settings(settings_path)
+    ts, rgbs, deps = load_associations(association_path)
+    if len(rgbs) != len(deps):
+        raise ValueError("Different number of images for rgb and depth.")
+    n = len(rgbs) if max_frames is None else min(len(rgbs), max_frames)
+    if n < 3:
+        return run_sequence(settings_path, sequence_dir, association_path, out_dir, max_frames, device, verbose)
+    t_load = time.perf_counter()
+    first = read_png(os.path.join(sequence_dir, rgbs[0])); h, w = first.shape[:2]
+    bgr = np.empty((n, h, w, 3), np.uint8); depth = np.empty((n, h, w), np.uint16)
+    for ni in range(n):
+        b = read_png(os.path.join(sequence_dir, rgbs[ni])); d = read_png(os.path.join(sequence_dir, deps[ni]))
+        if b.ndim != 3 or d.dtype != np.uint16 or b.shape[:2] != (h, w) or d.shape != (h, w):
+            raise ValueError(f"frame {ni}: expected an 8-bit colour image and a 16-bit depth image of {w} x {h}")
+        bgr[ni] = b; depth[ni] = d
+    t_load = time.perf_counter() - t_load
+    intr = dict(fx=S["Camera.fx"], fy=S["Camera.fy"], cx=S["Camera.cx"], cy=S["Camera.cy"], depth_factor=S["DepthMapFactor"],
+                ini_th=int(S["ORBextractor.iniThFAST"]), min_th=int(S["ORBextractor.minThFAST"]))
+    rgb_order = int(S.get("Camera.RGB", 0)) == 1
+    nf, sf, nl = int(S["ORBextractor.nFeatures"]), float(S["ORBextractor.scaleFactor"]), int(S["ORBextractor.nLevels"])
+    st = {}; t0 = time.perf_counter()
+    got = process_sequence(bgr, depth, intr, streams=max(1, min(chunks, (n - 1) // 2)), frames_per_step=frames_per_step, warmup=warmup, nfeatures=nf, scale_factor=sf, nlevels=nl,
+                           orb_gray_rgb_order=1 if rgb_order else 0, device=device, stats=st)
+    t_run = time.perf_counter() - t0
+    # frame 0 passes through with an all-zero mask (rgbd_tum_noros.cc:100-116): its keypoints come from the extractor alone
+    orb = ORBextractor(nf, sf, nl, intr["ini_th"], intr["min_th"], device=device)
+    b, g, r = bgr[0][..., 0].astype(np.int32), bgr[0][..., 1].astype(np.int32), bgr[0][..., 2].astype(np.int32)
+    gray0 = ((b * (4899 if rgb_order else 1868) + g * 9617 + r * (1868 if rgb_order else 4899) + 8192) >> 14).astype(np.uint8)
+    zero = np.zeros((h, w), np.uint8); k0, d0 = orb(gray0, zero); orb.close()
+    results = [dict(timestamp=ts[0], dyna=zero, label=zero.copy(), mask=zero.copy(), keypoints=k0, descriptors=d0)]
+    for ni in range(1, n):
+        results.append(dict(timestamp=ts[ni], dyna=got["dyna"][ni], label=got["label"][ni], mask=got["mask"][ni], keypoints=got["keypoints"][ni], descriptors=got["descriptors"][ni]))
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        for ni in range(n):
+            write_png(os.path.join(out_dir, f"dynaMask_{ni:05d}.png"), results[ni]["mask"]); write_png(os.path.join(out_dir, f"label_{ni:05d}.png"), results[ni]["label"])
+    if verbose:
+        print("-------\n")
+        print(f"Images in the sequence: {n}")
+        print(f"decoded in {t_load:.2f} s; DynaDetect + ORB on {st['plan'].n_chunks} verified chunks: {t_run:.2f} s = {(n - 1) / t_run:.1f} frames/s "
+              f"({st['mismatched_seams']} of {st['seams']} chunk seams repaired, {st['replay_frames'] + st['repair_frames']} frames re-run)")
+        print(f"mean dynamic detecting time: {t_run / max(n - 1, 1):.6f}")
+    return results
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="rgbd_tum_noros-shaped driver for the GPU DynaDetect + ORBextractor")
     ap.add_argument("settings"); ap.add_argument("sequence"); ap.add_argument("association")
     ap.add_argument("--out", default=None); ap.add_argument("--max", type=int, default=None)
+    ap.add_argument("--chunks", type=int, default=0, help="offline: run the folder as this many verified chunks on the batched pipeline (same results as the frame loop, several times its rate)")
     a = ap.parse_args(argv)
-    run_sequence(a.settings, a.sequence, a.association, a.out, a.max)
+    if a.chunks > 0:
+        run_sequence_chunked(a.settings, a.sequence, a.association, a.out, a.max, chunks=a.chunks)
+    else:
+        run_sequence(a.settings, a.sequence, a.association, a.out, a.max)
 
 
 if __name__ == "__main__":

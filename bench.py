@@ -61,9 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the first cpu_baseline setting (the reference pins its OpenMP loops to 8)")
     ap.add_argument("--sequence-frames", type=int, default=4000, help="sequence workload: length of the ONE sequence (BASELINE.json configs[3]: 4000 frames); fixed as --gpus grows = strong scaling")
     ap.add_argument("--seq-warmup-frames", type=int, default=SEQ_WARMUP_FRAMES, help="sequence workload: frames every chunk after the first starts early to rebuild the inter-frame state (speculation; the seams are verified and repaired)")
-    ap.add_argument("--retain-frames", type=int, default=64, help="sequence workload: the steps holding the first N owned frames of every chunk keep their phase-A outputs, so that a repair run "
-                                                                  "re-runs only the stateful tails of those frames (sind_pipe_replay); 0 = repair runs re-process whole frames")
-    ap.add_argument("--chain-max", type=int, default=-1, help="sequence workload: replayed steps with at most this many live runners run as per-stream chains (-1 = library default 6, 0 = always rounds)")
+    ap.add_argument("--retain-frames", type=int, default=-1, help="sequence workload: the steps holding the first N owned frames of every chunk keep their phase-A outputs, so that a repair run "
+                                                                  "re-runs only the stateful tails of those frames (sind_pipe_replay); -1 = every step (default: how long a runner needs "
+                                                                  "depends on the data), 0 = repair runs re-process whole frames")
+    ap.add_argument("--chain-max", type=int, default=-1, help="sequence workload: replayed steps with at most this many live runners run as per-stream chains (-1 = library default 12, 0 = always rounds)")
     ap.add_argument("--repair-streams", type=int, default=0, help="sequence workload: runners of the repair pipeline (0 = half the chunks of a GPU, 2..16)")
     ap.add_argument("--repair-frames-per-step", type=int, default=4)
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")

@@ -213,8 +213,10 @@ int sind_pipe_retain_next(sind_pipe* p, int tag);
 int sind_pipe_replay(sind_pipe* p, int tag, const int* first, const int* last, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated,
                      sind_keypoint* kps, int cap, int* nkp, uint8_t* desc);
 int sind_pipe_release_retained(sind_pipe* p, int tag);
-/* A ragged or replayed step in which at most n streams have frames runs them as per-stream chains (own k-means launches, no round barrier) instead of batched rounds
- * (default 6; 0 = always rounds).  Same results; with a handful of streams on an otherwise idle GPU the chains are faster (the slow runners of a repair). */
+/* A ragged or replayed step in which at most n streams have frames runs them as two chains per stream -- the depth half (k-means from the previous frame's merged
+ * labels, SegAndMerge) ahead of the flow half (flow masks, fusion, dilation, keypoint filter), own k-means launches, no round barrier -- instead of batched rounds
+ * (default 12; 0 = always rounds).  Same results; for a handful of streams on an otherwise idle GPU a frame costs max(depth, flow) instead of a whole round (the slow
+ * runners of a repair: 1.10 -> 0.70 s on the Bonn-shaped stream, profiles/r04/repair_latency.txt). */
 int sind_pipe_set_chain_max_streams(sind_pipe* p, int n);
 /* per-stage wall times of the last step in milliseconds: {front_gray, dense_flow, orb_front, host_upload (sind_pipe_process only, else 0), tails, total},
  * plus HIP-event statistics of the flow solver: sor_launches, sor_ms (sum of event-bracketed SOR launch groups),

@@ -101,6 +101,7 @@ struct sind_pipe {
         TaskGroup occ_group, tail_group, km_tails[4]; int km_groups = 1, km_first[5] = {0, 0, 0, 0, 0};       /* (4 = sind_pipe::KM_GROUPS) the step's own partition of the streams */ std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
         std::vector<int> active, first; std::vector<uint64_t> state_hash;      // tails of stream s run for first[s] <= t < active[s] (empty: 0 / all T); per-frame state fingerprints [S][T][2]
         bool few_chain = false;                                        // this step runs a handful of streams as per-stream chains (see phase_b_start)
+        bool two_chain = false; std::unique_ptr<std::atomic<int>[]> fgate; int fgate_n = 0;      // ... each as a depth chain running ahead of a flow chain; per frame: depth stage done + previous flow stage done
         int retain_tag = -1;                                           // >= 0: the phase-A outputs of this step are kept under this tag when its tails are done
     } sb[2];
     // Phase-A outputs of a step kept beyond the step (sind_pipe_retain_next): everything the tails read -- dense flow, depth copies, ORB front results,
@@ -120,7 +121,7 @@ struct sind_pipe {
     std::vector<char> primed;
     // Chunked sequences (sindslam_amd/sequence.py): hashing = every tail leaves the fingerprint of its rolled state per frame (last_hash: the step whose results
     // were returned last, [S][T][2]); active_next = per-stream number of frames whose TAILS run in the next step (one step only; empty = all T)
-    bool hashing = false; std::vector<uint64_t> last_hash; std::vector<int> active_next; int chain_max_streams = 6;
+    bool hashing = false; std::vector<uint64_t> last_hash; std::vector<int> active_next; int chain_max_streams = 12;
     double stage_ms[6] = {0}; double tail_wait_ms = 0; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;
     SindHostGate gate;           // CPU tokens of this handle's pool tasks (common.hpp)
     WorkerPool workers;          // declared last: joined first
@@ -541,7 +542,7 @@ static bool tail_one(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int
     static thread_local std::vector<uint8_t> dy, lb, dil;
     dy.resize(np); lb.resize(np); dil.resize(np);
     const int k = s * T + t;
-    int r = sb->depth_ahead ? p->tails[s]->flow_stage(sb->U.p + np * k, sb->V.p + np * k, sb->dout[k], dy.data(), lb.data(), sb->occ[k].gridFlow)
+    int r = (sb->depth_ahead || sb->two_chain) ? p->tails[s]->flow_stage(sb->U.p + np * k, sb->V.p + np * k, sb->dout[k], dy.data(), lb.data(), sb->occ[k].gridFlow)
                             : p->tails[s]->process(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, sb->U.p + np * k, sb->V.p + np * k, dy.data(), lb.data(), &sb->occ[k],
                                                    p->dtails.empty() ? nullptr : (p->dtails[s]->stream = p->worker_streams[worker], p->dtails[s].get()), km);
     if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return false; }
@@ -570,6 +571,28 @@ static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, in
         p->workers.push(sb->tail_group, [p, sb, o, s, t](int w) { tail_task(p, sb, o, s, t + 1, w); }); return;
     }
 }
+// Two chains per stream for a handful of live streams (the slow runners of a repair): the depth chain -- k-means from the previous frame's merged labels, SegAndMerge; it
+// needs nothing from the flow half -- runs ahead on the stream's depth-half object, the flow chain (flow masks, fusion, dilation, keypoint filter) follows frame by frame
+// as soon as its frame's depth stage and the previous frame's flow stage are done.  A frame then costs max(depth, flow) instead of their sum (the in-order mode's schedule).
+static void flow_chain(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int t1, int worker) {
+    struct Spin { int keep; Spin() : keep(t_sind_spin_us) { t_sind_spin_us = 400; } ~Spin() { t_sind_spin_us = keep; } } spin;
+    for (;;) {
+        if (!tail_one(p, sb, o, s, t, worker, nullptr) || t + 1 >= t1) return;
+        if (sb->fgate[s * p->T + t + 1].fetch_add(1) != 1) return;          // the next frame's depth stage is still out: its completion starts the flow stage
+        t++;
+    }
+}
+static void depth_chain(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t0, int t1, int worker) {
+    struct Spin { int keep; Spin() : keep(t_sind_spin_us) { t_sind_spin_us = 400; } ~Spin() { t_sind_spin_us = keep; } } spin;
+    const size_t np = (size_t)p->c.width * p->c.height;
+    DynaTail* dt = p->dtails[s].get(); dt->stream = p->worker_streams_lo[worker];
+    for (int t = t0; t < t1; t++) {
+        const int k = s * p->T + t;
+        const int r = dt->depth_stage(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, &sb->occ[k], sb->dout[k], nullptr);
+        if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return; }      // the flow chain of this stream stops at the frame before
+        if (sb->fgate[k].fetch_add(1) == 1) p->workers.push(sb->tail_group, [p, sb, o, s, t, t1](int w) { flow_chain(p, sb, o, s, t, t1, w); });
+    }
+}
 static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
     const int S = p->S;
     sb.tail_rc.assign(S, SIND_OK); sb.tail_err.assign(S, std::string());
@@ -579,7 +602,19 @@ static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o
     // batch, and its barrier makes every stream wait for the slowest tail -- with a handful of streams on an otherwise idle GPU the chains are about twice as fast.
     int nact = 0; for (int s = 0; s < S; s++) nact += (sb.first.empty() ? 0 : sb.first[s]) < (sb.active.empty() ? p->T : sb.active[s]);
     const bool few = (!sb.first.empty() || !sb.active.empty()) && nact <= p->chain_max_streams;
-    sb.few_chain = few && S > 1;
+    sb.few_chain = few && S > 1; sb.two_chain = false;
+    if (sb.few_chain && !sb.depth_ahead && ensure_dtails(p) == SIND_OK) {
+        const int B = S * p->T;
+        if (sb.fgate_n < B) { sb.fgate.reset(new std::atomic<int>[B]); sb.fgate_n = B; }
+        sb.dout.assign(B, DepthStageOut()); sb.two_chain = true;
+        for (int s = 0; s < S; s++) {
+            const int t0 = sb.first.empty() ? 0 : sb.first[s], t1 = sb.active.empty() ? p->T : sb.active[s];
+            if (t0 >= t1) continue;
+            for (int t = t0; t < t1; t++) sb.fgate[s * p->T + t].store(t == t0 ? 1 : 0);
+            p->workers.push(sb.tail_group, [p, sbp, o, s, t0, t1](int w) { depth_chain(p, sbp, o, s, t0, t1, w); });
+        }
+        return;
+    }
     if (p->batch_km && !sb.depth_ahead && !few) {
         // rounds: frame t of every stream -- the batched k-means chain on its own stream, then the S tails of that frame on the pool
         sbp->km_groups = p->km_groups; for (int g = 0; g <= sbp->km_groups; g++) sbp->km_first[g] = (int)((long long)S * g / sbp->km_groups);

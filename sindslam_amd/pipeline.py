@@ -154,7 +154,7 @@ class Pipeline:
         check(lib().sind_pipe_release_retained(self._h, int(tag)), "sind_pipe_release_retained")
 
     def set_chain_max_streams(self, n: int):
-        """ragged / replayed steps with at most n active streams run as per-stream chains instead of batched rounds (default 6, 0 = never)"""
+        """ragged / replayed steps with at most n active streams run as per-stream chains instead of batched rounds (default 12, 0 = never)"""
         check(lib().sind_pipe_set_chain_max_streams(self._h, int(n)), "sind_pipe_set_chain_max_streams")
 
     def keypoints(self, s: int, t: int):
@@ -235,6 +235,8 @@ class PipelineGroup:
     def submit_dev(self, b, d): return all(self._all(lambda i, p: p.submit_dev(*self._ptrs(i, b, d))))
     def flush(self): return all(self._all(lambda i, p: p.flush()))
     def set_state_hashing(self, on=True): [p.set_state_hashing(on) for p in self.pipes]
+    def set_depth_ahead(self, on): [p.set_depth_ahead(on) for p in self.pipes]
+    def set_chain_max_streams(self, n): [p.set_chain_max_streams(n) for p in self.pipes]
     def state_hashes(self): return np.concatenate([p.state_hashes() for p in self.pipes])
     def get_state_bytes(self): return self.pipes[0].get_state_bytes()
     def get_state(self, s=0): p, k = self._of(s); return p.get_state(k)

@@ -140,7 +140,12 @@ class VerifiedChunks:
         # such chunk: the chunks run in lock-step, so these are the same few steps for all of them) keep their phase-A outputs (sind_pipe_retain_next), and a
         # runner re-runs only the stateful tails of those frames on the chunk's own stream (sind_pipe_replay) -- the state-free 99 % of a frame (dense flow, ORB
         # front, CalOccluded) is not computed again.  A runner that is still not through after the retained frames continues on the repair pipeline.
+        # retain_frames < 0: every step from the first owned frame on (how long a runner needs is a property of the data -- the k-means of a chunk that started from other
+        # labels can sit in another local optimum for as long as the scene stays similar: 46 frames at most on the bench's TUM-shaped stream, 129 with the Bonn
+        # parameters, whole 92-frame chunks at 1280 x 720 --, and a replayed frame costs a third of a re-processed one; a retained step of 224 frames is ~0.8 GB of HBM)
         T = plan.T
+        if retain_frames < 0:
+            retain_frames = max(1, plan.processed - plan.warmup)
         self.retained = list(range(plan.warmup // T, min(plan.steps, (plan.warmup + retain_frames - 1) // T + 1))) if (retain_frames > 0 and plan.n_chunks > 1) else []
         self.mine = plan.chunks[rank * S:(rank + 1) * S]
         self.H = np.zeros((S, plan.processed, 2), np.uint64)             # fingerprint of the state after every processed frame of my chunks (current best chain)
@@ -155,6 +160,10 @@ class VerifiedChunks:
         self.pipe.set_state_hashing(True)
         if self.retained:
             self.pipe.release_retained(-1); self.pipe.reserve_retained(len(self.retained))
+            if hasattr(self.pipe, "set_depth_ahead"):
+                # the last runners of a repair run as two chains per stream (depth half ahead of the flow half) on separate depth-half objects: switching depth-ahead on
+                # and off again creates them now, outside any timed region, instead of at the first replay
+                self.pipe.set_depth_ahead(True); self.pipe.set_depth_ahead(False)
 
     def positions(self, step: int) -> np.ndarray:
         T = self.plan.T
@@ -358,7 +367,7 @@ def lockstep_for(frames: int, n_chunks: int, frames_per_step: int, warmup: int) 
 def process_sequence(bgr: np.ndarray, depth: np.ndarray, intr: dict, streams: int = 8, frames_per_step: int = 4, warmup: int = 16,
                      nfeatures: int = 1500, scale_factor: float = 1.2, nlevels: int = 8, orb_gray_rgb_order: int = 1, device: int = 0,
                      rank: int = 0, world: int = 1, want_keypoints: bool = True, group=None, repair_streams: int = 0, repair_frames_per_step: int = 4,
-                     verify: bool = True, stats: dict | None = None, pipeline_factory=None, source=None, retain_frames: int = 32):
+                     verify: bool = True, stats: dict | None = None, pipeline_factory=None, source=None, retain_frames: int = -1):
     """bgr u8 [N, H, W, 3], depth u16 [N, H, W] (host) -> dict with dyna / label / mask u8 [N, H, W] (frame 0 stays zero, like the reference's first frame)
     and, if asked, per-frame keypoint / descriptor lists, for the frames this rank owns (`owned` = sorted frame indices).  All ranks must pass the same
     sequence and parameters.  The sequence runs on streams * world lock-step chunks (VerifiedChunks): with verify (default) every owned frame equals the

@@ -118,6 +118,11 @@ int sind_dyna_debug(sind_dyna* d, float* flow_deep, float* flow_refined, float* 
 /* parity-test access to the k-means centre sums: out = the FP32 value of  acc = 0; for (i) acc += x[i]  (round to nearest even, exactly cv::kmeans'
  * centre accumulation, kmeans.cpp) computed by the wave-parallel window arithmetic of k_km_seqsum (csrc/depth_kernels.hip) */
 int sind_debug_seqsum(const float* x, int n, int device, float* out);
+/* k-means pyramid levels of at most n points (default 81920 = the three coarse levels at 640 x 480) of a batch of at least b frames (default 32: the batched rounds of a
+ * many-stream step) run every pass in ONE launch, one workgroup per frame (k_km_level_fused); n = 0: the per-pass kernels everywhere.  Same labels and centres bit for bit
+ * (tests/test_kmeans_fused_gpu.py); process-wide, for parity tests and A/B timing. */
+int sind_debug_set_kmeans_fused_max(int n);
+int sind_debug_set_kmeans_fused_min_batch(int b);
 /* exhaustive check of the solver's division: for every float significand and the binary exponents exp_lo..exp_hi, out[0] = reciprocals (hardware
  * estimate + one Newton step) that differ from the correctly rounded 1 / a, out[1] = quotients through that reciprocal (Markstein) that differ
  * from the IEEE division (16 numerators per divisor), out[2] = smallest failing significand (all ones if none) */

@@ -11,6 +11,7 @@ struct sind_dyna {
     std::vector<float> deep, refined;
 };
 
+namespace sind { extern int g_km_fused_max, g_km_fused_min_batch; }       // depth_kernels.hip
 extern "C" {
 
 int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float ds, int device, sind_dyna** out) {
@@ -41,6 +42,9 @@ int sind_debug_seqsum(const float* x, int n, int device, float* out) {
     HIP_TRY(hipMemcpy(xd.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     return sind::debug_seqsum(nullptr, xd.p, n, scratch.p, out);
 }
+// parity-test / A-B access: k-means levels of at most n points run in the fused one-launch kernel (default 81920; 0 = the per-pass kernels everywhere).  Process-wide.
+int sind_debug_set_kmeans_fused_max(int n) { if (n < 0) return SIND_E_ARG; sind::g_km_fused_max = n; return SIND_OK; }
+int sind_debug_set_kmeans_fused_min_batch(int b) { if (b < 1) return SIND_E_ARG; sind::g_km_fused_min_batch = b; return SIND_OK; }
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n) { if (!d || n < 0) return SIND_E_ARG; d->front.flow.max_levels = n; return SIND_OK; }
 int sind_dyna_destroy(sind_dyna* d) {
     if (!d) return SIND_OK;

@@ -465,6 +465,154 @@ __global__ void __launch_bounds__(256) k_km_seqsum(const int* __restrict__ segcn
     __threadfence();                                       // acquire: the other 35 sums (written by other CUs) are read from memory, not from a stale L1 line
     if (px) km_centre_step(segcnt, nseg, seqsums, st, px + blockIdx.y * ks.pt, py + blockIdx.y * ks.pt, pz + blockIdx.y * ks.pt, labels + blockIdx.y * ks.lab, n);
 }
+// ---- coarse pyramid levels: cv::kmeans of one level in ONE launch, one workgroup (16 waves) per frame.
+// The chain of a frame's k-means is ~60 dependent launches (count, then <= 4 x (assign + count, compact, sums + centre step) on each of four levels); on the three coarse
+// levels (60 x 80 ... 240 x 320) a launch has a few microseconds of work, so the chain's time there is launch latency -- and next to the flow solver, whose workgroups
+// hold every CU for the length of a launch, each of those small kernels also waits for a slot.  Here the passes of a level are phases of one workgroup separated by
+// barriers: the same assignment arithmetic, the same stable partition, the same exact sequential sums (km_seq_step on windows read from memory instead of the LDS ring:
+// each wave sums whole runs by itself, 36 runs over 16 waves) and the same centre step (km_centre_step), so the labels and centres are bit for bit those of the
+// per-pass kernels (tests/test_dyna_gpu.py, test_kmeans_fused_gpu.py).
+#define KMF_WAVES 16
+__device__ __forceinline__ void km_window_g(const float* __restrict__ p, int nk, int lane, int pos, float (&x)[KM_EPL]) {
+    struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+    const int g0 = pos + KM_EPL * lane;
+    if (g0 + KM_EPL <= nk) { const F4u a = *reinterpret_cast<const F4u*>(p + g0), b = *reinterpret_cast<const F4u*>(p + g0 + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w; }
+    else {
+        #pragma unroll
+        for (int q = 0; q < KM_EPL; q++) x[q] = (g0 + q < nk) ? p[g0 + q] : 0.f;       // behind the run's end: zeros, like the ring
+    }
+}
+__device__ __forceinline__ void km_seq_serial_g(const float* __restrict__ p, int nk, int lane, float& acc, int pos, int cnt) {
+    float a = acc;
+    float v = (pos + lane < nk) ? p[pos + lane] : 0.f;
+    for (int i = 0; i < cnt; i += 64) {
+        const int gn = pos + i + 64 + lane; const float vn = (gn < nk) ? p[gn] : 0.f;
+        #pragma unroll
+        for (int q = 0; q < 64; q++) a = a + km_rlf(v, q);
+        v = vn;
+    }
+    acc = km_unif(a);
+}
+// the sequential FP32 sum of p[0 .. nk) by ONE wave: the loop of k_km_seqsum's summing wave, windows and stretches read from memory
+__device__ float km_run_sum_wave(const float* __restrict__ p, int nk, int lane) {
+    static_assert(KM_EPL == 8, "km_window_g loads two 16-byte pieces per lane");
+    float acc = 0.f; int pos = 0, ser = 0;
+    if (nk <= 0) return acc;
+    float x[KM_EPL]; km_window_g(p, nk, lane, pos, x);
+    while (pos < nk) {
+        float xn[KM_EPL]; km_window_g(p, nk, lane, pos + KM_WIN, xn);
+        bool broke; const int from = pos;
+        pos = km_uni(km_seq_step(x, lane, acc, pos, broke));
+        if (broke) {
+            ser = km_uni(ser ? min(2 * ser, KM_SER_MAX) : 64);
+            km_seq_serial_g(p, nk, lane, acc, pos, ser); pos += ser;
+            km_window_g(p, nk, lane, pos, x);
+        } else if (pos == from + KM_WIN) {
+            ser = 0;
+            #pragma unroll
+            for (int q = 0; q < KM_EPL; q++) x[q] = xn[q];
+        } else km_window_g(p, nk, lane, pos, x);
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(64 * KMF_WAVES) k_km_level_fused(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int* __restrict__ labels, int n, int seg_len,
+                                                                   int* __restrict__ segcnt, float* __restrict__ comp, KmState* __restrict__ st, KmStride ks, int maxCount, double eps2, int iters) {
+    px += blockIdx.y * ks.pt; py += blockIdx.y * ks.pt; pz += blockIdx.y * ks.pt; labels += blockIdx.y * ks.lab; segcnt += blockIdx.y * ks.seg; comp += blockIdx.y * ks.comp; st += blockIdx.y * ks.st;
+    float* seqsums = reinterpret_cast<float*>(segcnt + (KM_MAX_BLOCKS * 4 + 1) * KM_K);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nseg = KMF_WAVES;
+    const int lo = wv * seg_len, hi = min(n, lo + seg_len);
+    __shared__ float ctr[KM_K][3];
+    __shared__ int s_go[2];                                // {the level goes on (not done), the assignment pass applies (phase == 1)}
+    if (tid == 0) {
+        st->iter = 0; st->done = 0; st->phase = 0; st->overflow = 0; st->fix_k = -1; st->max_k = 0; st->far = 0ull; st->maxCount = maxCount; st->eps2 = eps2;
+        for (int k = 0; k < KM_K; k++) { st->cnt[k] = 0; for (int j = 0; j < 3; j++) { st->ctr[k][j] = 0.f; st->old[k][j] = 0.f; } }
+    }
+    {   // counts of the given labels (k_km_count)
+        int c[KM_K];
+        #pragma unroll
+        for (int k = 0; k < KM_K; k++) c[k] = 0;
+        for (int i = lo + lane; i - lane < hi; i += 64) {
+            const int l = i < hi ? labels[i] : -1;
+            #pragma unroll
+            for (int k = 0; k < KM_K; k++) c[k] += __popcll(__ballot(l == k));
+        }
+        km_count_store(c, segcnt, wv, lane);
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; it++) {
+        if (tid == 0) { s_go[0] = !st->done; s_go[1] = !st->done && st->phase == 1; }
+        if (tid < KM_K * 3) ctr[tid / 3][tid % 3] = st->ctr[tid / 3][tid % 3];
+        __syncthreads();
+        if (!s_go[0]) break;                               // uniform
+        if (it > 0 && s_go[1]) {                           // re-assignment to the nearest centre + the counts of the new labels (k_km_assign_count)
+            int c[KM_K];
+            #pragma unroll
+            for (int k = 0; k < KM_K; k++) c[k] = 0;
+            for (int i = lo + lane; i - lane < hi; i += 64) {
+                int best = -1;
+                if (i < hi) {
+                    const float xf = px[i], yf = py[i], zf = pz[i];
+                    float md = 3.402823466e+38f; best = 0;
+                    #pragma unroll
+                    for (int k = 0; k < KM_K; k++) {
+                        float t = xf - ctr[k][0]; float dist = 0.f; dist += t * t;
+                        t = yf - ctr[k][1]; dist += t * t;
+                        t = zf - ctr[k][2]; dist += t * t;
+                        if (md > dist) { md = dist; best = k; }
+                    }
+                    labels[i] = best;
+                }
+                #pragma unroll
+                for (int k = 0; k < KM_K; k++) c[k] += __popcll(__ballot(best == k));
+            }
+            km_count_store(c, segcnt, wv, lane);
+        }
+        __syncthreads();
+        {   // stable partition by label into per-cluster runs (k_km_compact)
+            int before[KM_K], total[KM_K];
+            #pragma unroll
+            for (int k = 0; k < KM_K; k++) { before[k] = 0; total[k] = 0; }
+            if (lane < nseg) {
+                #pragma unroll
+                for (int k = 0; k < KM_K; k++) { const int v = segcnt[lane * KM_K + k]; total[k] = v; if (lane < wv) before[k] = v; }
+            }
+            #pragma unroll
+            for (int k = 0; k < KM_K; k++) for (int o = 32; o > 0; o >>= 1) { before[k] += __shfl_xor(before[k], o); total[k] += __shfl_xor(total[k], o); }
+            int pos[KM_K]; int run = 0;
+            #pragma unroll
+            for (int k = 0; k < KM_K; k++) { pos[k] = run + before[k]; run += total[k]; }
+            if (wv == 0 && lane < KM_K) { int v = 0;
+                #pragma unroll
+                for (int k = 0; k < KM_K; k++) if (lane == k) v = total[k];
+                segcnt[nseg * KM_K + lane] = v; }
+            float* cx = comp; float* cy = comp + n; float* cz = comp + 2 * (size_t)n;
+            for (int i = lo + lane; i - lane < hi; i += 64) {
+                const bool in = i < hi; const int l = in ? labels[i] : -1;
+                const float x = in ? px[i] : 0.f, y = in ? py[i] : 0.f, z = in ? pz[i] : 0.f;
+                #pragma unroll
+                for (int k = 0; k < KM_K; k++) {
+                    const unsigned long long m = __ballot(l == k);
+                    if (l == k) { const int d = pos[k] + __popcll(m & ((1ull << lane) - 1ull)); cx[d] = x; cy[d] = y; cz[d] = z; }
+                    pos[k] += __popcll(m);
+                }
+            }
+        }
+        __syncthreads();
+        {   // the 36 sequential sums: wave w takes the runs w, w + 16, w + 32
+            const int* tot = segcnt + nseg * KM_K;
+            for (int r = wv; r < KM_K * 3; r += KMF_WAVES) {
+                const int k = r / 3, j = r % 3;
+                int start = 0; for (int q = 0; q < k; q++) start += tot[q];
+                const float acc = km_run_sum_wave(comp + (size_t)j * n + start, tot[k], lane);
+                if (lane == 0) seqsums[r] = acc;
+            }
+        }
+        __syncthreads();
+        km_centre_step(segcnt, nseg, seqsums, st, px, py, pz, labels, n);
+        __syncthreads();
+    }
+}
 __global__ void k_labels_to_u8(const int* __restrict__ labels, uint8_t* __restrict__ out, int n, size_t lab_stride, size_t out_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     labels += blockIdx.y * lab_stride; out += blockIdx.y * out_stride;
@@ -724,6 +872,8 @@ int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw,
     hipLaunchKernelGGL(k_labels_resize<uint8_t>, dim3(divup(dw, 128), dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh), src_stride, dst_stride, use_prev); return SIND_OK; }
 int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh, int B, size_t src_stride, size_t dst_stride) {
     hipLaunchKernelGGL(k_labels_resize<int>, dim3(divup(dw, 128), dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh), src_stride, dst_stride, (const int*)nullptr); return SIND_OK; }
+int g_km_fused_min_batch = 32;      // ... and only for batches of at least this many frames
+int g_km_fused_max = 81920;          // levels of at most this many points run in the fused kernel (640 x 480: 4 800 / 19 200 / 76 800; 1280 x 720: 14 400 / 57 600); 0 = never
 int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, int* segcnt, float* comp, KmState* st,
                         int maxCount, double eps2, int B, size_t pt_stride, size_t lab_stride, size_t seg_stride, size_t comp_stride, size_t st_stride) {
     // nseg wave-segments of seg_len (multiple of 64) contiguous points; at most KM_MAX_BLOCKS * KM_WAVES rows in the count table, then the totals row
@@ -731,6 +881,14 @@ int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const f
     const int nb = std::min(divup(n, 1024), KM_MAX_BLOCKS), nseg = nb * 4, seg_len = divup(divup(n, nseg), 64) * 64, iters = std::max(maxCount, 2);
     float* seqsums = reinterpret_cast<float*>(segcnt + (KM_MAX_BLOCKS * 4 + 1) * KM_K);
     const KmStride ks{pt_stride, lab_stride, seg_stride, comp_stride, st_stride};
+    // A coarse level of a BATCH of frames: every pass in one launch, one workgroup per frame (k_km_level_fused).  Measured (profiles/r04/kmeans_fused.txt): next to the flow
+    // solver a round of 128 frames takes 17-18 ms instead of 23.4 (the ~40 small launches it replaces each wait for a CU slot); a single frame or a small batch on an idle GPU is
+    // FASTER with the per-pass kernels, whose blocks spread over many CUs (in-order mode 245 frames/s against 190; a round of 13 replayed frames 2.4 ms against 3.4).
+    if (n <= g_km_fused_max && B >= g_km_fused_min_batch && KMF_WAVES <= KM_MAX_BLOCKS * 4) {
+        const int fseg = divup(divup(n, KMF_WAVES), 64) * 64;
+        hipLaunchKernelGGL(k_km_level_fused, dim3(1, B), dim3(64 * KMF_WAVES), 0, s, px, py, pz, labels, n, fseg, segcnt, comp, st, ks, maxCount, eps2, iters);
+        return SIND_OK;
+    }
     const int ticket_word = (KM_MAX_BLOCKS * 4 + 1) * KM_K + KM_TICKET;
     hipLaunchKernelGGL(k_km_count, dim3(nb, B), dim3(256), 0, s, labels, n, seg_len, segcnt, st, ks, maxCount, eps2, ticket_word);
     for (int it = 0; it < iters; it++) {           // every kernel is a no-op for a frame whose centre step has set st->done

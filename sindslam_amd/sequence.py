@@ -159,7 +159,15 @@ class VerifiedChunks:
             self.pipe.prime(s, self.src.host_frame(c.start - 1), self.src.host_frame(c.start - 2))
         self.pipe.set_state_hashing(True)
         if self.retained:
-            self.pipe.release_retained(-1); self.pipe.reserve_retained(len(self.retained))
+            self.pipe.release_retained(-1)
+            while self.retained:                 # a retained step is ~4 KB of HBM and ~0.6 KB of page-locked host memory per pixel-frame: take what the machine gives, earliest steps first
+                try:
+                    self.pipe.reserve_retained(len(self.retained)); break
+                except Exception as e:           # (SindError of the real pipeline: allocation failed)
+                    if len(self.retained) == 1 or self.repair is None:
+                        raise
+                    self.stats["retained_steps_dropped"] = self.stats.get("retained_steps_dropped", 0) + len(self.retained) - len(self.retained) // 2
+                    self.retained = self.retained[:len(self.retained) // 2]
             if hasattr(self.pipe, "set_depth_ahead"):
                 # the last runners of a repair run as two chains per stream (depth half ahead of the flow half) on separate depth-half objects: switching depth-ahead on
                 # and off again creates them now, outside any timed region, instead of at the first replay

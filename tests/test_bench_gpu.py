@@ -72,3 +72,19 @@ def test_sequence_at_the_drivers_chunk_count_every_seam_equal():
     assert s["chunks"] == 26 and s["steps"] == 20 and s["frames_per_step_per_chunk"] == 3 and v["seams"] == 22 and s["exact"] is True
     assert s["seam_frames_compared"] == 940 and s["seam_masks_equal"] == s["seam_frames_compared"] and s["seam_iou_min"] == 1.0
     assert v["repaired_chunks"] >= v["mismatched_seams"] and v["repair_seconds"] < s["seconds"]
+
+
+@pytest.mark.timeout(900)
+def test_three_ranks_short_warmup_repairs_across_rank_seams():
+    """three ranks on this one card (gloo), 2 chunks each, a 2-frame warm-up: seams mismatch, the middle rank both receives its predecessor's end-state blob and sends its own,
+    repaired masks travel in the per-round exchange -- and every compared frame equals the in-order run"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env["MASTER_PORT"] = str(27400 + os.getpid() % 1500)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--streams", "2",
+                        "--sequence-frames", "150", "--seq-warmup-frames", "2", "--exact-leg-frames", "150", "--no-n1-leg", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0]); s = d["sequence"]; v = s["verify"]
+    print({k: s[k] for k in ("value", "chunks", "frames_per_step_per_chunk", "seam_frames_compared", "seam_masks_equal")}, v)
+    assert d["n_gpus"] == 3 and d["ranks_seen"] == 3 and s["chunks"] == 6 and s["exact"] is True and len(d["host_by_rank"]) == 3
+    assert all(h["sizing"]["ranks_on_node"] == 3 and h["sizing"]["cpu_share"] >= 4 for h in d["host_by_rank"])
+    assert s["seam_masks_equal"] == s["seam_frames_compared"] >= 100 and s["seam_iou_min"] == 1.0

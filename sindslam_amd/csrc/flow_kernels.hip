@@ -143,21 +143,23 @@ __global__ void k_warp_avg_iz(const float* __restrict__ I0, const float* __restr
 __device__ __forceinline__ float kc_rcp(float a) { const float y0 = __builtin_amdgcn_rcpf(a); const float e = fmaf(-a, y0, 1.f); return fmaf(e, y0, y0); }
 __device__ __forceinline__ float kc_div(float n, float a, float r) { const float q0 = n * r; const float e = fmaf(-a, q0, n); return fmaf(e, r, q0); }
 #define KC_ROWS 4
-__global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
+// IN: every pixel this wave touches in these rows -- the four rows of its 64 columns and their stencils (two columns / rows to every side) -- lies inside the image: no index is
+// clamped and no border case exists, so every neighbour is a load at a CONSTANT offset from one of a few row pointers.  (The clamped form spends ~3 integer VALU instructions on
+// each of its 49 loads per pixel: ~150 of the kernel's 376 VALU instructions per pixel, disassembly of round 4; the interior is > 95 % of a 384 x 288 level.)  Same loads of the
+// same values, same arithmetic: bit-identical by construction (tests/test_flow_gpu.py).
+template <bool IN>
+__device__ __forceinline__ void kc_rows(const VarParams& P, int w, int h, int x, int y0, size_t base, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
                        const float* __restrict__ gWv,
                        const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
                        float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11,
                        float* __restrict__ R22) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z, y0 = blockIdx.y * KC_ROWS;
-    if (x >= w) return;
-    const size_t base = (size_t)b * w * h;
     const float zeta2 = P.zeta * P.zeta, eps2 = P.epsilon * P.epsilon, gamma2 = P.gamma / 2, delta2 = P.delta / 2, alpha2 = P.alpha / 2;
     // The seven Sobel(ksize = 1, BORDER_REPLICATE) derivative images of prepareBuffers are formed here from the warped average and
     // the temporal difference (the float operations k_derivs used to store, evaluated at the same replicated positions): two planes
     // are read through the cache instead of eight from memory, in each of the five fixed-point iterations of a level.
     const float* A = gAvg + base; const float* Z = gIz + base;
-    auto cx = [&](int v) { return min(max(v, 0), w - 1); };
-    auto cy = [&](int v) { return min(max(v, 0), h - 1); };
+    auto cx = [&](int v) { return IN ? v : min(max(v, 0), w - 1); };
+    auto cy = [&](int v) { return IN ? v : min(max(v, 0), h - 1); };
     auto dX = [&](const float* Pp, int yy, int xx) { return Pp[yy * w + cx(xx + 1)] - Pp[yy * w + cx(xx - 1)]; };
     auto dY = [&](const float* Pp, int yy, int xx) { return Pp[cy(yy + 1) * w + xx] - Pp[cy(yy - 1) * w + xx]; };
     // tempW = W + dW is formed on the fly (OpenCV keeps it in a buffer that it refreshes after every fixed-point iteration with this
@@ -165,7 +167,7 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
     // dW = 0, and W + 0 differs from W only in the sign of a zero, which the squared differences below cannot see.
     const float* WU = gWu + base; const float* WV = gWv + base; const float* DU = gdWu + base; const float* DV = gdWv + base;
     auto wgt_at = [&](int yy, int xx) {
-        const int xn = min(xx + 1, w - 1), yn = min(yy + 1, h - 1);
+        const int xn = IN ? xx + 1 : min(xx + 1, w - 1), yn = IN ? yy + 1 : min(yy + 1, h - 1);
         const int ic = yy * w + xx, ix = yy * w + xn, iy = yn * w + xx;
         const float c_u = WU[ic] + DU[ic], c_v = WV[ic] + DV[ic];
         const float ux = (WU[ix] + DU[ix]) - c_u, vx = (WV[ix] + DV[ix]) - c_v;
@@ -177,7 +179,7 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
     #pragma unroll
     for (int r = 0; r < KC_ROWS; r++) {
         const int y = y0 + r;
-        if (y >= h) break;                                  // uniform over the block
+        if (!IN && y >= h) break;                           // uniform over the block
         const int i = y * w + x;
         const float Ix = dX(A, y, x), Iy = dY(A, y, x), Iz = Z[i], Ixz = dX(Z, y, x), Iyz = dY(Z, y, x);
         const float Ixx = dX(A, y, cx(x + 1)) - dX(A, y, cx(x - 1));
@@ -211,15 +213,15 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
 
         const float wp = wgt_at(y, x);
         const float w_from_lane = __shfl_up(wp, 1);          // the left neighbour's own weight (same row, lane - 1)
-        const float wl = (x > 0) ? (wave_first ? wgt_at(y, x - 1) : w_from_lane) : 0.f;
-        const float wq = (y > 0) ? (r == 0 ? wgt_at(y - 1, x) : w_up) : 0.f;
+        const float wl = (IN || x > 0) ? (wave_first ? wgt_at(y, x - 1) : w_from_lane) : 0.f;
+        const float wq = (IN || y > 0) ? (r == 0 ? wgt_at(y - 1, x) : w_up) : 0.f;
         const float wu_c = WU[i], wv_c = WV[i];
         const bool red = ((x + y) & 1) == 0;
         // the four link updates (no-ops at the image border)
-        #define OWN_H() if (x < w - 1) { b1 += wp * (WU[i + 1] - wu_c); a11 += wp; b2 += wp * (WV[i + 1] - wv_c); a22 += wp; }
-        #define LEFT_H() if (x > 0) { b1 -= wl * (wu_c - WU[i - 1]); a11 += wl; b2 -= wl * (wv_c - WV[i - 1]); a22 += wl; }
-        #define OWN_V() if (y < h - 1) { b1 += wp * (WU[i + w] - wu_c); a11 += wp; b2 += wp * (WV[i + w] - wv_c); a22 += wp; }
-        #define UP_V() if (y > 0) { b1 -= wq * (wu_c - WU[i - w]); a11 += wq; b2 -= wq * (wv_c - WV[i - w]); a22 += wq; }
+        #define OWN_H() if (IN || x < w - 1) { b1 += wp * (WU[i + 1] - wu_c); a11 += wp; b2 += wp * (WV[i + 1] - wv_c); a22 += wp; }
+        #define LEFT_H() if (IN || x > 0) { b1 -= wl * (wu_c - WU[i - 1]); a11 += wl; b2 -= wl * (wv_c - WV[i - 1]); a22 += wl; }
+        #define OWN_V() if (IN || y < h - 1) { b1 += wp * (WU[i + w] - wu_c); a11 += wp; b2 += wp * (WV[i + w] - wv_c); a22 += wp; }
+        #define UP_V() if (IN || y > 0) { b1 -= wq * (wu_c - WU[i - w]); a11 += wq; b2 -= wq * (wv_c - WV[i - w]); a22 += wq; }
         if (red) { OWN_H() LEFT_H() OWN_V() UP_V() }
         else     { LEFT_H() OWN_H() UP_V() OWN_V() }
         #undef OWN_H
@@ -231,6 +233,146 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
         w_up = wp;
     }
 }
+__global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
+                       const float* __restrict__ gWv,
+                       const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
+                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11,
+                       float* __restrict__ R22) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z, y0 = blockIdx.y * KC_ROWS;
+    if (x >= w) return;
+    const size_t base = (size_t)b * w * h;
+    // interior: rows y0 - 2 .. y0 + KC_ROWS + 1 and, for every lane of the wave, columns x - 2 .. x + 2 exist (wave-uniform: a ballot over the wave's live lanes)
+    const bool in = y0 >= 2 && y0 + KC_ROWS + 1 < h && __builtin_amdgcn_ballot_w64(x < 2 || x + 2 >= w) == 0ull;
+    if (in) kc_rows<true>(P, w, h, x, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22);
+    else kc_rows<false>(P, w, h, x, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22);
+}
+// ---- k_coef_lanes: the same coefficients, neighbours taken from the neighbouring LANES instead of from memory ----------------------------------------------------------------------
+// k_coef above is bound by the texture-address path, not by arithmetic: 49 dword loads + 8 stores per pixel are 57 x 4 = 228 address cycles per 64-pixel wave row against ~94 CU
+// cycles of VALU work (376 instructions per pixel over four SIMDs): 170 pairs of 384 x 288 -> 94 us predicted, 85 - 91 us measured (profiles/r04/k_coef.txt).  Here a wave owns
+// 64 consecutive columns of KL_ROWS rows and loads each plane's rows ONCE (one dword per lane and row: 8 rows of the average, 6 of Iz and of each of the four flow planes for four
+// output rows: 9.5 loads per pixel); x +- 1 and x +- 2 come from the lanes to the left and right with whole-wave DPP shifts (gfx9 wave_shl / wave_shr, VALU rate), y +- 1 and
+// y +- 2 from the rows held in registers.  The two lanes at either end only feed their neighbours (60 of 64 lanes store).  Values and the order of every float operation are
+// those of kc_rows: the results are bit-identical (tests/test_flow_gpu.py compares the two kernels and both with the oracle).
+#define KL_ROWS 4
+#define KL_COLS 60
+__device__ __forceinline__ float lane_next(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }   // wave_shl:1 -- the value of lane + 1
+__device__ __forceinline__ float lane_prev(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }   // wave_shr:1 -- the value of lane - 1
+// BORDER: the wave touches the image border (columns or rows clamp; BORDER_REPLICATE applies to the DERIVATIVE images too, hence the explicit cases below)
+template <bool BORDER>
+__device__ __forceinline__ void kc_lanes(const VarParams& P, int w, int h, int col, int y0, size_t base, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
+                       const float* __restrict__ gWv, const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
+                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11, float* __restrict__ R22, bool store_lane) {
+    const float zeta2 = P.zeta * P.zeta, eps2 = P.epsilon * P.epsilon, gamma2 = P.gamma / 2, delta2 = P.delta / 2, alpha2 = P.alpha / 2;
+    const unsigned xc = BORDER ? (unsigned)min(max(col, 0), w - 1) : (unsigned)col;          // the column this lane loads (replicated outside the image)
+    auto row_of = [&](int yy) { return (unsigned)(BORDER ? min(max(yy, 0), h - 1) : yy) * (unsigned)w * 4u; };   // byte offset of a row in its plane; wave-uniform: scalar arithmetic
+    // rows held in registers: a[j] = average at row y0 - 2 + j; z[j], wu[j], ... at row y0 - 1 + j
+    float a[KL_ROWS + 4], z[KL_ROWS + 2], wu[KL_ROWS + 2], wv[KL_ROWS + 2], du[KL_ROWS + 2], dv[KL_ROWS + 2];
+    // one buffer descriptor per plane of this pair (scalar registers), the row as the scalar offset, this lane's column as the 32-bit vector offset: addressing without vector
+    // arithmetic (as flat loads the 38 + 24 addresses are 64-bit VALU adds, ~30 of 270 instructions per pixel)
+    const unsigned xoff = xc * 4u, plane_bytes = (unsigned)w * h * 4u;
+    auto rs = [&](const float* plane) { return __builtin_amdgcn_make_buffer_rsrc((void*)(plane + base), 0, plane_bytes, 0x00020000); };
+    const auto rA = rs(gAvg), rZ = rs(gIz), rWu = rs(gWu), rWv = rs(gWv), rDu = rs(gdWu), rDv = rs(gdWv);
+    const auto oA11 = rs(A11), oA12 = rs(A12), oA22 = rs(A22), oB1 = rs(B1), oB2 = rs(B2), oW = rs(Wgt);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& r, unsigned row_bytes) { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, xoff, row_bytes, 0)); };
+    #pragma unroll
+    for (int j = 0; j < KL_ROWS + 4; j++) a[j] = ld(rA, row_of(y0 - 2 + j));
+    #pragma unroll
+    for (int j = 0; j < KL_ROWS + 2; j++) {
+        const unsigned ro = row_of(y0 - 1 + j);
+        z[j] = ld(rZ, ro); wu[j] = ld(rWu, ro); wv[j] = ld(rWv, ro); du[j] = ld(rDu, ro); dv[j] = ld(rDv, ro);
+    }
+    // x derivative of the average on the rows y0 - 1 .. y0 + KL_ROWS (dxa[j] at row y0 - 1 + j), tempW = W + dW on the same rows
+    float dxa[KL_ROWS + 2], tu[KL_ROWS + 2], tv[KL_ROWS + 2];
+    #pragma unroll
+    for (int j = 0; j < KL_ROWS + 2; j++) { dxa[j] = lane_next(a[j + 1]) - lane_prev(a[j + 1]); tu[j] = wu[j] + du[j]; tv[j] = wv[j] + dv[j]; }
+    // own weight of (row y0 - 1 + j, this column); wgt_row(0) only serves as the upper neighbour of the first row
+    auto wgt_row = [&](int j) {
+        const float c_u = tu[j], c_v = tv[j];
+        const float ux = lane_next(c_u) - c_u, vx = lane_next(c_v) - c_v;
+        const float uy = tu[j + 1] - c_u, vy = tv[j + 1] - c_v;
+        return alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
+    };
+    float w_up = wgt_row(0);
+    #pragma unroll
+    for (int r = 0; r < KL_ROWS; r++) {
+        const int y = y0 + r;
+        if (BORDER && y >= h) break;                        // wave-uniform
+        const float Ix = dxa[r + 1], Iy = a[r + 3] - a[r + 1], Iz = z[r + 1];
+        const float Ixz = lane_next(z[r + 1]) - lane_prev(z[r + 1]), Iyz = z[r + 2] - z[r];
+        // second derivatives = the first-derivative images differenced again, each replicated at ITS border
+        const float dx_next = lane_next(dxa[r + 1]), dx_prev = lane_prev(dxa[r + 1]);      // every lane takes part in a shift: never inside a per-lane condition
+        const float dx_hi = (BORDER && col == w - 1) ? dxa[r + 1] : dx_next, dx_lo = (BORDER && col == 0) ? dxa[r + 1] : dx_prev;
+        const float Ixx = dx_hi - dx_lo;
+        const float Ixy = dxa[r + 2] - dxa[r];
+        const float dy_hi = (BORDER && y == h - 1) ? Iy : a[r + 4] - a[r + 2], dy_lo = (BORDER && y == 0) ? Iy : a[r + 2] - a[r];
+        const float Iyy = dy_hi - dy_lo;
+        const float dU = du[r + 1], dV = dv[r + 1];
+        float derivNorm = Ix * Ix + Iy * Iy + zeta2;
+        const float Ik1z = Iz + Ix * dU + Iy * dV;
+        const float rN0 = kc_rcp(derivNorm);
+        float weight = kc_div(delta2 / sqrtf(kc_div(Ik1z * Ik1z, derivNorm, rN0) + eps2), derivNorm, rN0);
+        float a11 = weight * (Ix * Ix) + zeta2;
+        float a12 = weight * (Ix * Iy);
+        float a22 = weight * (Iy * Iy) + zeta2;
+        float b1 = -weight * (Iz * Ix);
+        float b2 = -weight * (Iz * Iy);
+        derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
+        const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
+        const float Ik1zx = Ixz + Ixx * dU + Ixy * dV;
+        const float Ik1zy = Iyz + Ixy * dU + Iyy * dV;
+        const float rN1 = kc_rcp(derivNorm), rN2 = kc_rcp(derivNorm2);
+        #define D1(n) kc_div((n), derivNorm, rN1)
+        #define D2(n) kc_div((n), derivNorm2, rN2)
+        weight = gamma2 / sqrtf(D1(Ik1zx * Ik1zx) + D2(Ik1zy * Ik1zy) + eps2);
+        a11 += weight * (D1(Ixx * Ixx) + D2(Ixy * Ixy));
+        a12 += weight * (D1(Ixx * Ixy) + D2(Ixy * Iyy));
+        a22 += weight * (D1(Ixy * Ixy) + D2(Iyy * Iyy));
+        b1 += -weight * (D1(Ixx * Ixz) + D2(Ixy * Iyz));
+        b2 += -weight * (D1(Ixy * Ixz) + D2(Iyy * Iyz));
+        #undef D1
+        #undef D2
+
+        const float wp = wgt_row(r + 1);
+        const float wl = lane_prev(wp), wq = w_up;
+        const float wu_c = wu[r + 1], wv_c = wv[r + 1];
+        const float wu_r = lane_next(wu_c), wu_l = lane_prev(wu_c), wv_r = lane_next(wv_c), wv_l = lane_prev(wv_c);
+        const bool red = ((col + y) & 1) == 0;
+        // the four link updates (no-ops at the image border)
+        #define OWN_H() if (!BORDER || col < w - 1) { b1 += wp * (wu_r - wu_c); a11 += wp; b2 += wp * (wv_r - wv_c); a22 += wp; }
+        #define LEFT_H() if (!BORDER || col > 0) { b1 -= wl * (wu_c - wu_l); a11 += wl; b2 -= wl * (wv_c - wv_l); a22 += wl; }
+        #define OWN_V() if (!BORDER || y < h - 1) { b1 += wp * (wu[r + 2] - wu_c); a11 += wp; b2 += wp * (wv[r + 2] - wv_c); a22 += wp; }
+        #define UP_V() if (!BORDER || y > 0) { b1 -= wq * (wu_c - wu[r]); a11 += wq; b2 -= wq * (wv_c - wv[r]); a22 += wq; }
+        if (red) { OWN_H() LEFT_H() OWN_V() UP_V() }
+        else     { LEFT_H() OWN_H() UP_V() OWN_V() }
+        #undef OWN_H
+        #undef LEFT_H
+        #undef OWN_V
+        #undef UP_V
+        if (store_lane) {
+            const unsigned ro = (unsigned)y * (unsigned)w * 4u;
+            auto st = [&](const __amdgpu_buffer_rsrc_t& r, float val) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val), r, xoff, ro, 0); };
+            st(oA11, a11); st(oA12, a12); st(oA22, a22); st(oB1, b1); st(oB2, b2); st(oW, wp);
+            if (R11) { st(rs(R11), 1.f / a11); st(rs(R22), 1.f / a22); }
+        }
+        w_up = wp;
+    }
+}
+// grid (tiles of KL_COLS columns, groups of 4 x KL_ROWS rows, pairs), 256 threads: wave k of a workgroup takes the rows (4 * blockIdx.y + k) * KL_ROWS ...
+__global__ __launch_bounds__(256) void k_coef_lanes(VarParams P, int w, int h, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
+                       const float* __restrict__ gWv, const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
+                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11, float* __restrict__ R22) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = blockIdx.x * KL_COLS - 2, y0 = (blockIdx.y * 4 + wave) * KL_ROWS;
+    if (y0 >= h) return;                                    // whole wave
+    const size_t base = (size_t)blockIdx.z * w * h;
+    const int col = c0 + lane;
+    const bool store_lane = lane >= 2 && lane < 2 + KL_COLS && col < w;
+    if (c0 >= 0 && c0 + 63 < w && y0 >= 2 && y0 + KL_ROWS + 1 < h)
+        kc_lanes<false>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
+    else
+        kc_lanes<true>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
+}
+int g_coef_lanes = 1;            // 1: k_coef_lanes (neighbours from lanes), 0: k_coef (neighbours from memory) -- kept for the A/B test
 
 // ---------------------------------------------------------------------------------------------------------
 // RedBlackSOR_ParBody: one colour of one SOR iteration (plain version: one thread per pixel of the colour).
@@ -1499,8 +1641,12 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     const dim3 g = grid2d(w, h, B), blk(128);
     hipLaunchKernelGGL(k_warp_avg_iz, g, blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, P.dWu, P.dWv, w, h);
     for (int it = 0; it < V.fixedPointIterations; it++) {
-        hipLaunchKernelGGL(k_coef, dim3(divup(w, 128), divup(h, KC_ROWS), B), blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
-                           P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr);
+        if (g_coef_lanes)
+            hipLaunchKernelGGL(k_coef_lanes, dim3(divup(w, KL_COLS), divup(h, 4 * KL_ROWS), B), dim3(256), 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
+                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr);
+        else
+            hipLaunchKernelGGL(k_coef, dim3(divup(w, 128), divup(h, KC_ROWS), B), blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
+                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr);
         if (timer) timer->begin(s);
         long long nlaunch = 0;
         SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch));

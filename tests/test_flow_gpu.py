@@ -150,6 +150,35 @@ def test_streaming_solver_on_the_768x432_pyramid(fs_big):
     assert np.abs(ru).max() > 0.5                   # a real flow field, not zeros
 
 
+# widths around the 60-column tiles of k_coef_lanes (one tile with idle lanes, a last tile of 1, 2, 3 columns, a right border inside the two feeding lanes) and heights around its
+# 4-row groups / 16-row workgroups (a last group of 1, 2, 3 rows, images lower than the 5-row vertical stencil)
+COEF_SHAPES = [(7, 3), (33, 26), (58, 5), (59, 17), (60, 16), (61, 15), (62, 18), (63, 33), (64, 4), (120, 35), (121, 9), (122, 64), (123, 65), (181, 30), (240, 66), (384, 288), (768, 432)]
+
+
+@pytest.mark.parametrize("w,h", COEF_SHAPES)
+def test_coefficients_from_lanes_equal_coefficients_from_memory(fs_big, w, h):
+    """k_coef_lanes (neighbours through whole-wave shifts, rows in registers) against k_coef (every neighbour loaded with clamped indices): the refinement's flow is
+    bit-identical; the small sizes also against the oracle"""
+    import ctypes as C
+    from sindslam_amd._lib import lib
+    i0, i1 = _textured_pair(w, h, 3 * w + h)
+    rng = np.random.default_rng(w + 977 * h)
+    u0 = rng.normal(0, 1.5, (h, w)).astype(np.float32); v0 = rng.normal(0, 1.5, (h, w)).astype(np.float32)
+    a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
+    args = (np.stack([i0, i1]), np.stack([i1, i0]), np.stack([u0, v0]), np.stack([v0, u0]), 3, 7, a, d, g, 1.6)
+    try:
+        assert lib().sind_debug_set_coef_lanes(0) == 0; mu, mv = fs_big.varref_f32(*args)
+        assert lib().sind_debug_set_coef_lanes(1) == 0; lu, lv = fs_big.varref_f32(*args)
+    finally:
+        lib().sind_debug_set_coef_lanes(1)
+    assert lib().sind_debug_set_coef_lanes(2) == -1
+    assert np.array_equal(lu.view(np.uint32), mu.view(np.uint32)) and np.array_equal(lv.view(np.uint32), mv.view(np.uint32)), (w, h, float(np.abs(lu - mu).max()))
+    assert np.isfinite(lu).all() and np.abs(lu - np.stack([u0, v0])).max() > 1e-3          # the refinement moved the field
+    if w * h <= 130 * 70:
+        ou, ov = O.varref(i0, i1, u0, v0, 3, 7, a, d, g, 1.6)
+        assert np.array_equal(lu[0].view(np.uint32), ou.view(np.uint32)) and np.array_equal(lv[0].view(np.uint32), ov.view(np.uint32))
+
+
 def test_division_through_the_reciprocal_is_exact():
     """the solver's division (hardware reciprocal + one Newton step, then Markstein's correction) against the IEEE division: every one of the 2^23
     float significands, binary exponents -24..24 (the step is scale invariant; the system's diagonal lies in [0.01, 1e4]), 16 numerators per divisor,

@@ -3,6 +3,7 @@
 // the oracle without a GPU.  Not part of libsind_hip.so's ABI and never used by the product path.
 #include <cstring>
 #include "host.hpp"
+#include "peac_fit4.hpp"
 #include "../orb.hpp"
 
 using namespace sind;
@@ -70,6 +71,16 @@ void sindh_peac(const uint16_t* depth, int w, int h, float fx, float fy, float c
     BitImg pc; PeacInput in{blocks.data(), depth, w, h, fx, fy, cx, cy, depthScale};
     peac_plane_contours(in, pc);
     pc.to_u8(out, w, 255);
+}
+// n plane fits from their moments (9 doubles each) and point counts, four at a time (peac_fit4) or one at a time (peac_fit): out = n x {centre 3, normal 3, mse}
+void sindh_peac_fits(const double* moments, const int* counts, int n, int four_lanes, double* out) {
+    for (int i = 0; i < n; i += 4) {
+        const int c = std::min(4, n - i); PeacFitIn in[4]; PeacFitOut o[4];
+        for (int k = 0; k < c; k++) { std::memcpy(in[k].m, moments + 9 * (size_t)(i + k), 72); in[k].N = counts[i + k]; }
+        if (four_lanes) peac_fit4(in, c, o);
+        else for (int k = 0; k < c; k++) peac_fit(in[k].m, in[k].N, o[k].center, o[k].normal, o[k].mse);
+        for (int k = 0; k < c; k++) { double* r = out + 7 * (size_t)(i + k); for (int q = 0; q < 3; q++) { r[q] = o[k].center[q]; r[3 + q] = o[k].normal[q]; } r[6] = o[k].mse; }
+    }
 }
 int sindh_octree(const float* xyr, int n, int minX, int maxX, int minY, int maxY, int N, float* out_xyr, int cap) {
     std::vector<OctKp> in(n), out; for (int i = 0; i < n; i++) in[i] = {xyr[3 * i], xyr[3 * i + 1], xyr[3 * i + 2]};

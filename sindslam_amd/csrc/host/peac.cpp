@@ -17,6 +17,7 @@
 #include <iterator>
 #include "host.hpp"
 #include "peac_fit.hpp"
+#include "peac_fit4.hpp"
 
 namespace sind {
 namespace {
@@ -77,13 +78,28 @@ struct Fitter {
             // the candidate with the smallest MSE (the first one among equals) becomes a node -- whether or not the merge then passes the threshold, as in the
             // reference; the candidates that lose never enter the pool (node indices only order the neighbour sets, and only relatively)
             int cand = -1, cand_nb = -1; bool have = false; Seg best;
+            // the candidates' fits four at a time (peac_fit4.hpp: the scalar fit's operations in the lanes of a vector register, same bits)
+            int cnb[4]; PeacFitIn fin[4]; PeacFitOut fout[4]; int nc = 0;
+            auto flush = [&]() {
+                peac_fit4(fin, nc, fout);
+                for (int k = 0; k < nc; k++) {
+                    if (have && !(best.mse > fout[k].mse)) continue;
+                    const Seg &a = pool[p], &b = pool[cnb[k]]; const double* m = fin[k].m;
+                    best.sx = m[0]; best.sy = m[1]; best.sz = m[2]; best.sxx = m[3]; best.syy = m[4]; best.szz = m[5]; best.sxy = m[6]; best.syz = m[7]; best.sxz = m[8];
+                    best.N = fin[k].N; best.rid = a.N >= b.N ? a.rid : b.rid; best.mse = fout[k].mse; best.nouse = false;
+                    for (int q = 0; q < 3; q++) { best.center[q] = fout[k].center[q]; best.normal[q] = fout[k].normal[q]; }
+                    have = true; cand_nb = cnb[k];
+                }
+                nc = 0;
+            };
             for (int nb : nbs[p]) {
                 if (pool[p].similarity(pool[nb]) < P.simMerge) continue;
-                Seg m; const Seg &a = pool[p], &b = pool[nb];
-                m.sx = a.sx + b.sx; m.sy = a.sy + b.sy; m.sz = a.sz + b.sz; m.sxx = a.sxx + b.sxx; m.syy = a.syy + b.syy; m.szz = a.szz + b.szz;
-                m.sxy = a.sxy + b.sxy; m.syz = a.syz + b.syz; m.sxz = a.sxz + b.sxz; m.N = a.N + b.N; m.rid = a.N >= b.N ? a.rid : b.rid; m.fit();
-                if (!have || best.mse > m.mse) { best = m; have = true; cand_nb = nb; }
+                const Seg &a = pool[p], &b = pool[nb]; double* m = fin[nc].m;
+                m[0] = a.sx + b.sx; m[1] = a.sy + b.sy; m[2] = a.sz + b.sz; m[3] = a.sxx + b.sxx; m[4] = a.syy + b.syy; m[5] = a.szz + b.szz;
+                m[6] = a.sxy + b.sxy; m[7] = a.syz + b.syz; m[8] = a.sxz + b.sxz; fin[nc].N = a.N + b.N; cnb[nc] = nb;
+                if (++nc == 4) flush();
             }
+            if (nc) flush();
             if (have) cand = add_node(best);
             if (cand >= 0 && pool[cand].mse < P.mse_merge(pool[cand].center[2])) {
                 q.push(cand);

@@ -92,6 +92,29 @@ def test_homography_identical_to_oracle(H):
     assert ok and np.array_equal(out.reshape(3, 3), ref)                         # same specification, same bits
 
 
+def test_four_lane_plane_fit_equals_scalar(H):
+    """peac_fit4 (the merge candidates' fits, four in the lanes of an AVX2 register) == peac_fit (one at a time, the function the device and the oracle's restatement use):
+    centre, normal and MSE bit for bit -- random point sets, exactly planar and axis-aligned sets (zero pivots: rotations skipped per lane), lanes that converge after
+    different numbers of sweeps, groups of 1-3"""
+    rng = np.random.default_rng(11)
+    sets = []
+    for k in range(403):
+        n = int(rng.integers(4, 400)); kind = k % 6
+        if kind == 0: pts = rng.normal(0, 1, (n, 3)) * rng.uniform(0.01, 3, 3) + rng.normal(0, 2, 3)
+        elif kind == 1: pts = np.c_[rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), np.full(n, 1.5)]                      # exactly planar, axis aligned
+        elif kind == 2: xy = rng.uniform(-1, 1, (n, 2)); pts = np.c_[xy, 0.3 * xy[:, 0] - 0.2 * xy[:, 1] + 2 + rng.normal(0, 1e-3, n)]   # a tilted wall with depth noise
+        elif kind == 3: pts = np.repeat(rng.normal(0, 1, (1, 3)), n, 0)                                                  # one point n times: the zero matrix
+        elif kind == 4: pts = np.c_[rng.uniform(-1, 1, n), np.zeros(n), np.zeros(n)]                                     # a line along x
+        else: pts = rng.normal(0, 1, (n, 3)) * np.array([1.0, 1.0, 1e-6])
+        x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+        sets.append(([x.sum(), y.sum(), z.sum(), (x * x).sum(), (y * y).sum(), (z * z).sum(), (x * y).sum(), (y * z).sum(), (x * z).sum()], n))
+    m = np.ascontiguousarray([s[0] for s in sets], np.float64); cnt = np.ascontiguousarray([s[1] for s in sets], np.int32)
+    a = np.zeros((len(sets), 7)); b = np.zeros((len(sets), 7))
+    H.sindh_peac_fits(P(m), P(cnt), len(sets), 0, P(a)); H.sindh_peac_fits(P(m), P(cnt), len(sets), 1, P(b))
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), np.argwhere(a.view(np.uint64) != b.view(np.uint64))[:5]
+    assert np.isfinite(a[::6]).all() and np.abs(np.linalg.norm(a[::6, 3:6], axis=1) - 1).max() < 1e-12
+
+
 def test_peac_plane_contours_identical(H, frames):
     from sindslam_amd.synth import TUM3
     bgr, depth = frames

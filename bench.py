@@ -304,7 +304,8 @@ def roofline_of(acc, K, dt, pairs_per_launch, config_name, cfg=None):
     frac is the fraction of the BINDING resource, <= 1 by construction: max(frac_hbm, valu_busy) --
       frac_hbm   = real HBM bytes (committed rocprofv3 PMC passes of this command: FETCH_SIZE x 2 + WRITE_SIZE per launch, the guide's gfx950 correction) x launches
                    / time with at least one solver launch in flight / 8 TB/s;
-      valu_busy  = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES of the streaming kernel alone (committed SQ-counter passes).
+      valu_busy  = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES of the streaming kernel with every workgroup slot of the chip taken, as under the bench's three concurrent
+                   slices (committed SQ-counter passes over 512 pairs; the same kernel alone on one 170-pair slice is printed as valu_busy_solver_alone).
     The SURVEY 8d yardstick -- 44 algorithmic bytes per pixel update against the HBM peak -- is kept as achieved_algorithmic / frac_algorithmic; it prices
     nine reads per update that a five-iteration register-resident kernel never issues, so it can exceed 1 and ranks nothing.  What the kernel HAS to move is
     compulsory_bytes_per_launch = 40 B per pixel of a streamed launch (8 planes read, 2 written, once per 5 iterations); traffic_over_compulsory says how far the
@@ -334,6 +335,8 @@ def roofline_of(acc, K, dt, pairs_per_launch, config_name, cfg=None):
             roof["compulsory_bytes_per_launch"] = comp; roof["traffic_streaming_per_launch"] = tr_s; roof["traffic_over_compulsory"] = tr_s / comp
     if pmc and pmc.get("valu_busy_measured") is not None:
         valu = pmc["valu_busy_measured"]; roof["valu_busy"] = valu; roof["valu_busy_source"] = pmc.get("sq_counters")
+        if pmc.get("valu_busy_solver_alone_170_pairs") is not None:
+            roof["valu_busy_solver_alone"] = pmc["valu_busy_solver_alone_170_pairs"]
     if frac_hbm is None and valu is None:          # no committed counters for this config: only the algorithmic yardstick is known
         roof.update({"bound": "valu", "achieved": None, "frac": None, "bound_note": "no committed PMC passes for this config; see frac_algorithmic"})
     else:

@@ -21,6 +21,7 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 units = {
     "k_sor_stream": ("44 B / pixel update (SURVEY 8d; 40 B / pixel / launch compulsory)", 44.0 * big * 125),
     "k_sor_fused": ("44 B / pixel update, one-workgroup levels", 44.0 * (pyr - big) * 125),
+    "k_coef_lanes": ("48 B / pixel / fixed-point iteration (6 planes read once, neighbours from lanes / registers; 6 written)", 48.0 * pyr * 5),
     "k_coef": ("48 B / pixel / fixed-point iteration (4 planes read, 6 written + stencil through L1/L2)", 48.0 * pyr * 5),
     "k_resize_f32_pair": ("16 B / destination pixel (two images or two flow components)", 16.0 * pyr * 2),
     "k_warp_avg_iz": ("20 B / pixel / level", 20.0 * pyr),

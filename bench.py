@@ -54,6 +54,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=12)            # a pipelined run ends with one drained tail phase (~160 ms): 12 steps keep it at 3 % of the timed region
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="tum3", help="BASELINE.json config (default: the one the metric is quoted on)")
+    ap.add_argument("--solver-workgroups", type=int, default=None, help="streaming solver: at most this many (persistent) workgroups per launch; 0 = one per (strip, image) item")
+    ap.add_argument("--flow-levels", type=int, default=None, help="experiment: cap the DeepFlow pyramid at this many levels (NOT the config's workload: the line says so in config.flow_pyramid_levels)")
     ap.add_argument("--workload", choices=["auto", "streams", "sequence"], default="auto", help="auto: streams at 1 GPU, sequence (frame-sharded, RCCL mask gather) at N > 1")
     ap.add_argument("--streams", type=int, default=0, help="streams (= sequence chunks) per GPU; 0 = the config's default")
     ap.add_argument("--frames-per-step", type=int, default=4)
@@ -681,7 +683,13 @@ def main():
         return
 
     import numpy as np
-    cfg = dict(CONFIGS[args.config]); workload = args.workload if args.workload != "auto" else ("sequence" if world > 1 else "streams")
+    cfg = dict(CONFIGS[args.config])
+    if args.flow_levels is not None:
+        cfg["flow_max_levels"] = args.flow_levels
+    if args.solver_workgroups is not None:
+        from sindslam_amd._lib import check, lib
+        check(lib().sind_flow_set_solver_workgroups(args.solver_workgroups), "sind_flow_set_solver_workgroups")
+    workload = args.workload if args.workload != "auto" else ("sequence" if world > 1 else "streams")
     T, K, Wm = args.frames_per_step, args.steps, args.warmup
     S = args.streams or (cfg["streams"] if workload == "streams" else sequence_streams(world, args.sequence_frames, cfg["streams"], K, args.seq_warmup_frames))
     seq_leg = workload == "streams" and world == 1 and not args.no_sequence_leg and not args.host_input       # N = 1 point of the sequence curve next to the streams headline

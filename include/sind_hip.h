@@ -59,6 +59,9 @@ int sind_flow_set_max_levels(sind_flow* f, int n);
  * (tile height 48 for mode 3, 64 otherwise). */
 int sind_flow_set_sor(int mode, int fuse, int tile_w);
 int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h);
+/* streaming solver: at most `cap` workgroups per launch, each taking several (column strip, image) items in turn (persistent workgroups); 0 = one workgroup per item.
+ * Same results; process-wide.  See DESIGN.md 3.1-12 for when it pays. */
+int sind_flow_set_solver_workgroups(int cap);
 int sind_lab_build(void);        /* 1: built with -DSIND_LAB (dormant solver variants and the SIND_* experiment switches of the measurement rounds), 0: the shipped drop-in */
 /* HIP-event timing of everything enqueued on the handle's stream between begin and end (bench.py roofline leg) */
 int sind_flow_timer_begin(sind_flow* f);

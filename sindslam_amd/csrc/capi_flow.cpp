@@ -141,6 +141,7 @@ int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h) {
 #endif
     sind::g_sor_mode = mode; sind::g_sor_fuse = fuse; sind::g_sor_tile_w = tile_w; sind::g_sor_tile_h = tile_h; return SIND_OK;
 }
+int sind_flow_set_solver_workgroups(int cap) { if (cap < 0) return SIND_E_ARG; sind::g_sor_stream_wg_cap = cap; return SIND_OK; }
 int sind_debug_set_coef_lanes(int on) { if (on != 0 && on != 1) return SIND_E_ARG; sind::g_coef_lanes = on; return SIND_OK; }
 int sind_flow_set_sor(int mode, int fuse, int tile_w) {
     if (tile_w != 64 && tile_w != 128) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }

@@ -639,12 +639,18 @@ __global__ void k_median5_u16(const uint16_t* __restrict__ src, uint16_t* __rest
     const int med = p[12];
     dst[y * w + x] = (uint16_t)med;
 }
+// (16-byte loads, eight samples each: with one 2-byte load per lane and turn the kernel took 0.5 ms for the 39 MB of a 64-frame round and 3 % of a step's wave cycles)
 __global__ void k_max_u16(const uint16_t* __restrict__ src, int n, unsigned* __restrict__ out, int out_stride) {
     src += (size_t)blockIdx.y * n; out += (size_t)blockIdx.y * out_stride;
     unsigned m = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, (unsigned)src[i]);
+    const int n8 = n >> 3; const uint4* s8 = reinterpret_cast<const uint4*>(src);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += gridDim.x * blockDim.x) {
+        const uint4 v = s8[i];
+        m = max(m, max(max(max(v.x & 0xffffu, v.x >> 16), max(v.y & 0xffffu, v.y >> 16)), max(max(v.z & 0xffffu, v.z >> 16), max(v.w & 0xffffu, v.w >> 16))));
+    }
+    for (int i = (n8 << 3) + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, (unsigned)src[i]);      // n % 8 samples at the end
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 // 5x5 max-difference depth edge + valid-area mask (DD:443-482); the 3-px frame is left 0 in both outputs
 __global__ void k_grad_edge(const uint16_t* __restrict__ filt, const unsigned* __restrict__ dmax, uint8_t* __restrict__ edge,
@@ -688,52 +694,60 @@ __global__ void k_morph(const uint8_t* __restrict__ src, uint8_t* __restrict__ d
     dst[y * w + x] = (uint8_t)m;
 }
 
-// ---------------------------------------------------------------- PEAC initial block statistics (16 x 16 blocks): one wave per block.
-// The lanes form the block's points and its validity in parallel (a block with a missing point or a depth jump to the right / lower neighbour is
-// dropped as a whole, so the order of that test is free); the nine FP64 moments are then accumulated by nine lanes, each adding its 256 terms in the
-// reference's row-major order (bit-exact with a sequential CPU loop).  One thread per block took 0.3 ms of dependent loads on every frame's tail chain.
+// ---------------------------------------------------------------- PEAC initial block statistics (16 x 16 blocks): one wave per SEVEN blocks.
+// Phase 1, all lanes: the points of the wave's blocks (x, y, z as the FLOATS the reference forms before it widens them) and each block's validity (a block with a missing
+// point or a depth jump to the right / lower neighbour is dropped as a whole, so the order of that test is free) go to LDS.  Phase 2: the nine FP64 moments of a block are
+// accumulated by nine lanes, each adding its 256 terms in the reference's row-major order (bit-exact with a sequential CPU loop) -- 63 lanes = 7 blocks x 9 moments, and a term
+// is two LDS reads, two conversions and one product.  (One block per wave with every term's point re-derived inside the sequential loop -- two float divisions per term on 9 of
+// 64 lanes -- was 6.9 % of ALL VALU cycles of a step and 2.8 % of its CU-busy cycles: profiles/r04/pmc_by_kernel.txt.)
 #define PEAC_BW 16
-__global__ void __launch_bounds__(256) k_peac_block_stats(const uint16_t* __restrict__ depth, int w, int h, int Nw, int nblk, float fx, float fy, float cx, float cy,
-                                                          float depthScale, double depthAlpha, double depthChangeTol, PeacBlockStats* __restrict__ out) {
-    __shared__ float pz[4][PEAC_BW * PEAC_BW];                      // zf per point (x, y follow from the pixel position)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, blk = blockIdx.x * 4 + wv;
-    if (blk >= nblk) return;                                        // whole waves leave; no block-wide barrier below
+#define PEAC_BPW 7                                                  // blocks per wave
+__global__ void __launch_bounds__(64) k_peac_block_stats(const uint16_t* __restrict__ depth, int w, int h, int Nw, int nblk, float fx, float fy, float cx, float cy,
+                                                         float depthScale, double depthAlpha, double depthChangeTol, PeacBlockStats* __restrict__ out) {
+    __shared__ float pt[PEAC_BPW][3][PEAC_BW * PEAC_BW];            // x, y, z per point of the wave's blocks
+    const int lane = threadIdx.x, blk0 = blockIdx.x * PEAC_BPW;
     depth += (size_t)blockIdx.y * w * h; out += (size_t)blockIdx.y * nblk;
-    const int by = blk / Nw, bx = blk - by * Nw;
     const float inv = 1.0f / depthScale;
     auto zat = [&](int i, int j, float& zf) -> bool { const float d = (float)depth[i * w + j]; if (d < 1e-3f) return false; zf = d * inv; return true; };
-    bool ok = true;
-    #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int p = k * 64 + lane, i = by * PEAC_BW + (p >> 4), j = bx * PEAC_BW + (p & 15);
-        float zf = 0.f, zn;
-        if (!zat(i, j, zf)) ok = false;
-        else {
-            const double z = (double)zf, tol = depthAlpha * fabs(z) + depthChangeTol;
-            if (j + 1 < w && zat(i, j + 1, zn) && fabs(z - (double)zn) > tol) ok = false;
-            if (i + 1 < h && zat(i + 1, j, zn) && fabs(z - (double)zn) > tol) ok = false;
+    unsigned validbits = 0;                                         // wave-uniform
+    for (int b = 0; b < PEAC_BPW; b++) {
+        const int blk = blk0 + b;
+        if (blk >= nblk) break;
+        const int by = blk / Nw, bx = blk - by * Nw;
+        bool ok = true;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p = k * 64 + lane, i = by * PEAC_BW + (p >> 4), j = bx * PEAC_BW + (p & 15);
+            float zf = 0.f, zn;
+            if (!zat(i, j, zf)) ok = false;
+            else {
+                const double z = (double)zf, tol = depthAlpha * fabs(z) + depthChangeTol;
+                if (j + 1 < w && zat(i, j + 1, zn) && fabs(z - (double)zn) > tol) ok = false;
+                if (i + 1 < h && zat(i + 1, j, zn) && fabs(z - (double)zn) > tol) ok = false;
+            }
+            pt[b][0][p] = (j - cx) * zf / fx; pt[b][1][p] = (i - cy) * zf / fy; pt[b][2][p] = zf;
         }
-        pz[wv][p] = zf;
+        if (__all(ok)) validbits |= 1u << b;
     }
-    const bool valid = __all(ok);
     __builtin_amdgcn_s_waitcnt(0xc07f);                             // lgkmcnt(0): the wave's own LDS stores (wave-synchronous, no barrier needed)
     __builtin_amdgcn_wave_barrier();
-    if (lane < 9 && valid) {
-        // lane m accumulates moment m: sx sy sz sxx syy szz sxy syz sxz
-        double acc = 0;
+    const int b = lane / 9, m = lane - 9 * b, blk = blk0 + b;
+    if (b >= PEAC_BPW || blk >= nblk) return;
+    const bool valid = (validbits >> b) & 1u;
+    // lane (b, m) accumulates moment m of block b: sx sy sz sxx syy szz sxy syz sxz = the sums of A, or of A x B
+    const int ia = (m == 1 || m == 4 || m == 7) ? 1 : (m == 2 || m == 5) ? 2 : 0, ib = (m == 3) ? 0 : (m == 4 || m == 6) ? 1 : 2;      // (x, y, z) = (0, 1, 2): xx yy zz xy yz xz
+    const bool single = m < 3;
+    double acc = 0;
+    if (valid) {
+        const float* A = pt[b][ia]; const float* B = pt[b][ib];
+        #pragma unroll 4
         for (int p = 0; p < PEAC_BW * PEAC_BW; p++) {
-            const int i = by * PEAC_BW + (p >> 4), j = bx * PEAC_BW + (p & 15);
-            const float zf = pz[wv][p];
-            const double x = (double)((j - cx) * zf / fx), y = (double)((i - cy) * zf / fy), z = (double)zf;
-            double t;
-            switch (lane) { case 0: t = x; break; case 1: t = y; break; case 2: t = z; break; case 3: t = x * x; break; case 4: t = y * y; break;
-                            case 5: t = z * z; break; case 6: t = x * y; break; case 7: t = y * z; break; default: t = x * z; }
-            acc += t;
+            const double av = (double)A[p], bv = (double)B[p];
+            acc += single ? av : av * bv;
         }
-        double* o = &out[blk].sx; o[lane] = acc;
     }
-    if (lane == 0) { out[blk].N = valid ? PEAC_BW * PEAC_BW : 0; out[blk].valid = valid ? 1 : 0; }
-    if (lane < 9 && !valid) { double* o = &out[blk].sx; o[lane] = 0; }
+    double* o = &out[blk].sx; o[m] = acc;
+    if (m == 0) { out[blk].N = valid ? PEAC_BW * PEAC_BW : 0; out[blk].valid = valid ? 1 : 0; }
 }
 // Plane fit of every valid block (host/peac_fit.hpp, the host's own function): the 1200 (640 x 480) to 3600 (1280 x 720) initial nodes are a third of all the
 // fits of a frame's graph clustering (~1 us each on a host core: a 3 x 3 Jacobi iteration).  One thread per block.
@@ -917,7 +931,8 @@ int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int
 int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out, int B, int out_stride) {
     if (B == 1 || out_stride == 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * sizeof(unsigned), s));
     else for (int b = 0; b < B; b++) HIP_TRY(hipMemsetAsync(out + (size_t)b * out_stride, 0, sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_max_u16, dim3(std::min(divup(n, 256), 256), B), dim3(256), 0, s, src, n, out, out_stride); return SIND_OK; }
+    if (((size_t)n * sizeof(uint16_t)) % 16 != 0 && B > 1) { sind_set_error("max_u16: %d samples per image (a batch needs a multiple of 8)", n); return SIND_E_ARG; }
+    hipLaunchKernelGGL(k_max_u16, dim3(std::max(1, std::min(divup(n, 8 * 256), 64)), B), dim3(256), 0, s, src, n, out, out_stride); return SIND_OK; }
 int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, uint8_t* edge, uint8_t* total_area, int w, int h, float depthScale, int B, int dmax_stride) {
     hipLaunchKernelGGL(k_grad_edge, dim3(divup(w, 128), h, B), dim3(128), 0, s, filt, dmax, edge, total_area, w, h, depthScale, dmax_stride); return SIND_OK; }
 MorphElem make_ellipse(int n) {
@@ -936,7 +951,7 @@ int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, 
 int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out, int B) {
     if (bw != PEAC_BW || bh != PEAC_BW) { sind_set_error("peac_block_stats: %d x %d blocks (only %d x %d)", bw, bh, PEAC_BW, PEAC_BW); return SIND_E_ARG; }
     const int nb = (w / bw) * (h / bh);
-    hipLaunchKernelGGL(k_peac_block_stats, dim3(divup(nb, 4), B), dim3(256), 0, s, depth, w, h, w / bw, nb, fx, fy, cx, cy, depthScale, 0.04, 0.02 * 1000, out);
+    hipLaunchKernelGGL(k_peac_block_stats, dim3(divup(nb, PEAC_BPW), B), dim3(64), 0, s, depth, w, h, w / bw, nb, fx, fy, cx, cy, depthScale, 0.04, 0.02 * 1000, out);
     hipLaunchKernelGGL(k_peac_block_fit, dim3(divup(nb * B, 64)), dim3(64), 0, s, out, nb * B); return SIND_OK; }
 int launch_depth_norm(hipStream_t s, const uint16_t* depth, const unsigned* dmax, uint8_t* out, int n, int B, int dmax_stride) {
     hipLaunchKernelGGL(k_depth_norm, dim3(divup(n, 256), B), dim3(256), 0, s, depth, dmax, out, n, dmax_stride); return SIND_OK; }

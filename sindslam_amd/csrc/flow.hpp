@@ -41,7 +41,7 @@ int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int s
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img, int d_group = 0, int d_skip = 0);       // d_group > 0: d_skip destination slots stay free after every d_group images
 int launch_roll_history(hipStream_t s, uint8_t* pool, int S, int T, size_t frame_bytes);      // history slots 0, 1 <- slots T, T + 1 of every stream's T + 2 pool slots
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb);
-extern int g_coef_lanes; extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd, g_sor_tile_h, g_sor_stream_min_b, g_sor_stream_min_px; extern double g_sor_plan_cost;
+extern int g_coef_lanes, g_sor_stream_wg_cap; extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd, g_sor_tile_h, g_sor_stream_min_b, g_sor_stream_min_px; extern double g_sor_plan_cost;
 int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev);
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch);
 int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr);

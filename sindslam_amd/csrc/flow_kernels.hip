@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void k_coef_lanes(VarParams P, int w, int h, c
     else
         kc_lanes<true>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
 }
+int g_sor_stream_wg_cap = 0;    // k_sor_stream: at most this many workgroups per launch (0 = one per item)
 int g_coef_lanes = 1;            // 1: k_coef_lanes (neighbours from lanes), 0: k_coef (neighbours from memory) -- kept for the A/B test
 
 // ---------------------------------------------------------------------------------------------------------
@@ -836,21 +837,21 @@ struct SsRow { float a11[4], a12[4], a22[4], b1[4], b2[4], wp[4], r11[4], r22[4]
 // MAXSW: widest column strip (in 4-pixel strips) the instance is laid out for.  The LDS layout is fixed at compile time (every plane at a constant offset:
 // an access is one base register per ring row plus an immediate); 38 strips = 152 columns need 69 KB and 512 threads (6 compute waves + 2 loaders):
 // two workgroups per CU.  Wider levels are cut into column strips (grid x), each with its own pipeline.
+// One (column strip, image) of a launch: the whole row pipeline of that strip, top to bottom.
 template <int MAXSW>
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per_eu(4, 4))) k_sor_stream(int w, int h, int SW, int HT, int IW, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
+__device__ __forceinline__ void ss_item(float* lds, const int strip, const int image, int w, int h, int SW, int HT, int IW, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
                                                      const float* __restrict__ gA22, const float* __restrict__ gB1, const float* __restrict__ gB2,
                                                      const float* __restrict__ gW, const float* __restrict__ gU, const float* __restrict__ gV, float* __restrict__ gUo, float* __restrict__ gVo) {
-    extern __shared__ float4 lds4s[];
-    float* lds = reinterpret_cast<float*>(lds4s);
     constexpr int HS = 2 * MAXSW + 4, EWS = 4 * MAXSW;            // floats per row: split plane (two guard floats on each side), staging
     constexpr int PL = SS_RING * HS;                              // one parity plane of a ring
     constexpr int O_DU = 2, O_DV = 2 * PL + 2, O_W = 4 * PL + 2, O_ST = 6 * PL, STP = SS_STG * EWS;      // float offsets (rings: + parity * PL + slot * HS + x / 2)
     constexpr int total = 6 * PL + SS_NST * STP;
-    const int tid = threadIdx.x;
-    const size_t base = (size_t)blockIdx.y * w * h;
+    int tid_ = threadIdx.x; asm volatile("" : "+v"(tid_));     // (opaque per item: nothing derived from it is hoisted out of the kernel's item loop and kept in registers across items)
+    const int tid = tid_;
+    const size_t base = (size_t)image * w * h;
     // column strip of this workgroup: it keeps the columns [ix0, ix1) and works on [ex0, ex0 + 4 SW), 12 columns more on every side that is not an image
     // border (a cut edge reads zeros from outside; what that falsifies creeps inwards one column per half-sweep, 10 columns in a launch; 12 keeps ex0 a multiple of 4)
-    const int ix0 = (int)blockIdx.x * IW, ix1 = min(ix0 + IW, w), ex0 = max(ix0 - 12, 0);
+    const int ix0 = strip * IW, ix1 = min(ix0 + IW, w), ex0 = max(ix0 - 12, 0);
     for (int i = tid; i < total; i += blockDim.x) lds[i] = 0.f;   // guards, the row above the image, and everything not yet loaded read as zero
     // roles: threads [0, 10 SW) compute -- slot group g (parity of the pair index: first 5 SW threads even slots, next 5 SW odd), slot within the group, strip;
     // the LAST TWO waves of the block are the loaders, one for the even and one for the odd row of every pair (their own registers hold two rows of 16-byte
@@ -1089,6 +1090,21 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_wave
     #undef SS_HALF_B
     #undef SS_UPDATE
     #undef SS_STORE
+}
+// The launch: workgroup k takes the items k, k + gridDim.x, ... (item = strip + strips * image).  With as many workgroups as items (the default) a workgroup has one item;
+// with FEWER (sor_iterations: g_sor_stream_wg_cap) the workgroups are persistent: they keep their place on their compute units for the whole launch instead of handing it back
+// after every item -- and a place that is handed back while other kernels' small workgroups are queued at a higher stream priority comes back in pieces.
+template <int MAXSW>
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per_eu(4, 4))) k_sor_stream(int strips, int items, int w, int h, int SW, int HT, int IW, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
+                                                     const float* __restrict__ gA22, const float* __restrict__ gB1, const float* __restrict__ gB2,
+                                                     const float* __restrict__ gW, const float* __restrict__ gU, const float* __restrict__ gV, float* __restrict__ gUo, float* __restrict__ gVo) {
+    extern __shared__ float4 lds4s[];
+    float* lds = reinterpret_cast<float*>(lds4s);
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int image = item / strips, strip = item - image * strips;
+        ss_item<MAXSW>(lds, strip, image, w, h, SW, HT, IW, omega, gA11, gA12, gA22, gB1, gB2, gW, gU, gV, gUo, gVo);
+        __syncthreads();                                          // every wave is through with the item's LDS before the next item clears it
+    }
 }
 
 #ifdef SIND_LAB
@@ -1605,7 +1621,8 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         if (fits && (g_sor_mode == 5 || (g_sor_mode == 4 && B >= g_sor_stream_min_b && w * h >= g_sor_stream_min_px))) {
             const size_t shm = ((size_t)6 * SS_RING * (2 * SS_MAXSW + 4) + (size_t)SS_NST * SS_STG * 4 * SS_MAXSW) * sizeof(float);
             for (int done = 0; done < total; done += SS_NQ / 2) {
-                hipLaunchKernelGGL(k_sor_stream<SS_MAXSW>, dim3(n, B), dim3(CT + 128), shm, s, w, h, SW, HT, IW, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
+                const int items = n * B, wgs = (g_sor_stream_wg_cap > 0 && items > g_sor_stream_wg_cap) ? divup(items, divup(items, g_sor_stream_wg_cap)) : items;      // persistent: every workgroup the same number of items (+- 1)
+                hipLaunchKernelGGL(k_sor_stream<SS_MAXSW>, dim3(wgs), dim3(CT + 128), shm, s, n, items, w, h, SW, HT, IW, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
                 std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);      // column strips read each other's halo columns: not in place
                 *nlaunch += 1;
             }

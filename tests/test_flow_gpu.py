@@ -179,6 +179,27 @@ def test_coefficients_from_lanes_equal_coefficients_from_memory(fs_big, w, h):
         assert np.array_equal(lu[0].view(np.uint32), ou.view(np.uint32)) and np.array_equal(lv[0].view(np.uint32), ov.view(np.uint32))
 
 
+@pytest.mark.parametrize("w,h,cap", [(384, 287, 2), (300, 101, 1), (153, 99, 3), (129, 67, 1)])
+def test_persistent_solver_workgroups_equal_one_workgroup_per_item(fs_big, w, h, cap):
+    """sind_flow_set_solver_workgroups: `cap` workgroups walk the (strip, image) items of a streaming launch in turn (2 images x 1-3 strips here: 2-6 items, so a workgroup takes
+    two, three or all six of them, and the LDS of an item is cleared behind a barrier) -- the flow equals the oracle's bit for bit"""
+    from sindslam_amd._lib import lib
+    from sindslam_amd.flow import set_sor_variant
+    i0, i1 = _textured_pair(w, h, 5 * w + h)
+    rng = np.random.default_rng(w + 31 * h)
+    u0 = rng.normal(0, 1.0, (h, w)).astype(np.float32); v0 = rng.normal(0, 1.0, (h, w)).astype(np.float32)
+    a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
+    ou, ov = O.varref(i0, i1, u0, v0, 2, 10, a, d, g, 1.6); ou2, ov2 = O.varref(i1, i0, v0, u0, 2, 10, a, d, g, 1.6)
+    try:
+        set_sor_variant(5, 5, 64, 64); assert lib().sind_flow_set_solver_workgroups(cap) == 0
+        gu, gv = fs_big.varref_f32(np.stack([i0, i1]), np.stack([i1, i0]), np.stack([u0, v0]), np.stack([v0, u0]), 2, 10, a, d, g, 1.6)
+    finally:
+        set_sor_variant(); lib().sind_flow_set_solver_workgroups(0)
+    assert lib().sind_flow_set_solver_workgroups(-1) == -1
+    assert np.array_equal(gu[0].view(np.uint32), ou.view(np.uint32)) and np.array_equal(gv[0].view(np.uint32), ov.view(np.uint32))
+    assert np.array_equal(gu[1].view(np.uint32), ou2.view(np.uint32)) and np.array_equal(gv[1].view(np.uint32), ov2.view(np.uint32))
+
+
 def test_division_through_the_reciprocal_is_exact():
     """the solver's division (hardware reciprocal + one Newton step, then Markstein's correction) against the IEEE division: every one of the 2^23
     float significands, binary exponents -24..24 (the step is scale invariant; the system's diagonal lies in [0.01, 1e4]), 16 numerators per divisor,

@@ -621,23 +621,38 @@ __global__ void k_labels_to_u8(const int* __restrict__ labels, uint8_t* __restri
 
 // ---------------------------------------------------------------- medianBlur(5) on the depth image (values are integers, so the float median == u16 median)
 // (the CalOccluded kernels take the frame from blockIdx.z: the pipeline runs them once for all frames of a step)
+// A thread makes MED_ROWS outputs of one column: the 5 x (MED_ROWS + 4) window is loaded once (10 loads per pixel instead of 25) and a launch has a quarter of the waves.
+#define MED_ROWS 4
 __global__ void k_median5_u16(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int w, int h) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * MED_ROWS;
     if (x >= w) return;
     src += (size_t)blockIdx.z * w * h; dst += (size_t)blockIdx.z * w * h;
-    int p[25];
+    int xs[5];
     #pragma unroll
-    for (int dy = -2; dy <= 2; dy++) {
-        const uint16_t* r = src + (size_t)min(max(y + dy, 0), h - 1) * w;
+    for (int dx = -2; dx <= 2; dx++) xs[dx + 2] = min(max(x + dx, 0), w - 1);
+    int win[MED_ROWS + 4][5];
+    #pragma unroll
+    for (int j = 0; j < MED_ROWS + 4; j++) {
+        const uint16_t* r = src + (size_t)min(max(y0 - 2 + j, 0), h - 1) * w;
         #pragma unroll
-        for (int dx = -2; dx <= 2; dx++) p[(dy + 2) * 5 + dx + 2] = r[min(max(x + dx, 0), w - 1)];
+        for (int k = 0; k < 5; k++) win[j][k] = r[xs[k]];
     }
-    // 99 compare-exchanges instead of the 625 comparisons of a rank count (median25_net.inc)
-    #define S(a, b) { const int lo_ = min(p[a], p[b]), hi_ = max(p[a], p[b]); p[a] = lo_; p[b] = hi_; }
-    #include "median25_net.inc"
-    #undef S
-    const int med = p[12];
-    dst[y * w + x] = (uint16_t)med;
+    #pragma unroll
+    for (int q = 0; q < MED_ROWS; q++) {
+        const int y = y0 + q;
+        if (y >= h) break;
+        int p[25];
+        #pragma unroll
+        for (int j = 0; j < 5; j++) {
+            #pragma unroll
+            for (int k = 0; k < 5; k++) p[j * 5 + k] = win[q + j][k];
+        }
+        // 99 compare-exchanges instead of the 625 comparisons of a rank count (median25_net.inc)
+        #define S(a, b) { const int lo_ = min(p[a], p[b]), hi_ = max(p[a], p[b]); p[a] = lo_; p[b] = hi_; }
+        #include "median25_net.inc"
+        #undef S
+        dst[y * w + x] = (uint16_t)p[12];
+    }
 }
 // (16-byte loads, eight samples each: with one 2-byte load per lane and turn the kernel took 0.5 ms for the 39 MB of a 64-frame round and 3 % of a step's wave cycles)
 __global__ void k_max_u16(const uint16_t* __restrict__ src, int n, unsigned* __restrict__ out, int out_stride) {
@@ -653,29 +668,44 @@ __global__ void k_max_u16(const uint16_t* __restrict__ src, int n, unsigned* __r
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 // 5x5 max-difference depth edge + valid-area mask (DD:443-482); the 3-px frame is left 0 in both outputs
+#define GE_ROWS 4
 __global__ void k_grad_edge(const uint16_t* __restrict__ filt, const unsigned* __restrict__ dmax, uint8_t* __restrict__ edge,
                             uint8_t* __restrict__ total_area, int w, int h, float depthScale, int dmax_stride) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, row0 = blockIdx.y * GE_ROWS;
     if (col >= w) return;
     { const size_t fo = (size_t)blockIdx.z * w * h; filt += fo; edge += fo; total_area += fo; dmax += (size_t)blockIdx.z * dmax_stride; }
-    uint8_t e = 0, t = 0;
-    if (row >= 3 && row < h - 3 && col >= 3 && col < w - 3) {
-        const float depth_max = (float)(*dmax);
-        const float depth1 = (float)filt[row * w + col];
-        if (depth1 > 0.0f && depth1 / depthScale < 6.0f) t = 255;
-        float val_max = 0.0f;
+    const bool col_in = col >= 3 && col < w - 3;
+    // the 5 x (GE_ROWS + 4) window of this column's rows, loaded once (rows / columns outside the image are never used: the 3-pixel frame has no window)
+    float win[GE_ROWS + 4][5];
+    #pragma unroll
+    for (int j = 0; j < GE_ROWS + 4; j++) {
+        const int r = row0 - 2 + j; const bool in = col_in && r >= 0 && r < h;
         #pragma unroll
-        for (int i = -2; i <= 2; i++)
-            #pragma unroll
-            for (int j = -2; j <= 2; j++) {
-                const float nb = (float)filt[(row + i) * w + col + j];
-                if ((depth1 - nb) > depth_max * 0.5f) continue;
-                const float a = fabsf(depth1 - nb);
-                val_max = fabsf(val_max) > a ? fabsf(val_max) : a;
-            }
-        if (val_max > depth1 * 0.03f && val_max > 400.0f) e = 255;
+        for (int k = 0; k < 5; k++) win[j][k] = in ? (float)filt[r * w + col + k - 2] : 0.f;
     }
-    edge[row * w + col] = e; total_area[row * w + col] = t;
+    const float depth_max = (float)(*dmax);
+    #pragma unroll
+    for (int q = 0; q < GE_ROWS; q++) {
+        const int row = row0 + q;
+        if (row >= h) break;
+        uint8_t e = 0, t = 0;
+        if (row >= 3 && row < h - 3 && col_in) {
+            const float depth1 = win[q + 2][2];
+            if (depth1 > 0.0f && depth1 / depthScale < 6.0f) t = 255;
+            float val_max = 0.0f;
+            #pragma unroll
+            for (int i = -2; i <= 2; i++)
+                #pragma unroll
+                for (int j = -2; j <= 2; j++) {
+                    const float nb = win[q + 2 + i][j + 2];
+                    if ((depth1 - nb) > depth_max * 0.5f) continue;
+                    const float a = fabsf(depth1 - nb);
+                    val_max = fabsf(val_max) > a ? fabsf(val_max) : a;
+                }
+            if (val_max > depth1 * 0.03f && val_max > 400.0f) e = 255;
+        }
+        edge[row * w + col] = e; total_area[row * w + col] = t;
+    }
 }
 
 // ---------------------------------------------------------------- morphology with an elliptical element (max / min over in-image pixels)
@@ -694,6 +724,36 @@ __global__ void k_morph(const uint8_t* __restrict__ src, uint8_t* __restrict__ d
     dst[y * w + x] = (uint8_t)m;
 }
 
+// The 4 x 4 ellipse of CalOccluded's MORPH_OPEN ({(0, 0)} in the row two above, columns -2 .. +1 in the rows -1, 0, +1), a thread walking MO_ROWS rows of one column: four
+// byte loads per source row serve every output row that sees it (5.5 loads per pixel instead of 13) and a launch has an eighth of the waves.  Same values as k_morph.
+#define MO_ROWS 8
+__global__ void k_morph_e4(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int w, int h, int is_dilate) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * MO_ROWS;
+    if (x >= w) return;
+    src += (size_t)blockIdx.z * w * h; dst += (size_t)blockIdx.z * w * h;
+    const int none = is_dilate ? 0 : 255;
+    auto op = [&](int a, int b) { return is_dilate ? max(a, b) : min(a, b); };
+    int own[MO_ROWS + 3], four[MO_ROWS + 3];                 // source row y0 - 2 + j: the pixel itself, the extreme of its columns x - 2 .. x + 1 (inside the image)
+    #pragma unroll
+    for (int j = 0; j < MO_ROWS + 3; j++) {
+        const int yy = y0 - 2 + j;
+        own[j] = none; four[j] = none;
+        if (yy >= 0 && yy < h) {
+            const uint8_t* r = src + (size_t)yy * w;
+            const int c = r[x]; own[j] = c; int m = c;
+            if (x >= 2) m = op(m, (int)r[x - 2]);
+            if (x >= 1) m = op(m, (int)r[x - 1]);
+            if (x + 1 < w) m = op(m, (int)r[x + 1]);
+            four[j] = m;
+        }
+    }
+    #pragma unroll
+    for (int q = 0; q < MO_ROWS; q++) {
+        const int y = y0 + q;
+        if (y >= h) break;
+        dst[y * w + x] = (uint8_t)op(op(own[q], four[q + 1]), op(four[q + 2], four[q + 3]));
+    }
+}
 // ---------------------------------------------------------------- PEAC initial block statistics (16 x 16 blocks): one wave per SEVEN blocks.
 // Phase 1, all lanes: the points of the wave's blocks (x, y, z as the FLOATS the reference forms before it widens them) and each block's validity (a block with a missing
 // point or a depth jump to the right / lower neighbour is dropped as a whole, so the order of that test is free) go to LDS.  Phase 2: the nine FP64 moments of a block are
@@ -927,14 +987,14 @@ int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev /* 2
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n, int B, size_t lab_stride, size_t out_stride) {
     hipLaunchKernelGGL(k_labels_to_u8, dim3(divup(n, 256), B), dim3(256), 0, s, labels, out, n, lab_stride, out_stride); return SIND_OK; }
 // B frames per launch (frame b at offset b * w * h of every image argument; maxima at out + b * out_stride)
-int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h, int B) { hipLaunchKernelGGL(k_median5_u16, dim3(divup(w, 64), h, B), dim3(64), 0, s, src, dst, w, h); return SIND_OK; }
+int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int h, int B) { hipLaunchKernelGGL(k_median5_u16, dim3(divup(w, 64), divup(h, MED_ROWS), B), dim3(64), 0, s, src, dst, w, h); return SIND_OK; }
 int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out, int B, int out_stride) {
     if (B == 1 || out_stride == 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * sizeof(unsigned), s));
     else for (int b = 0; b < B; b++) HIP_TRY(hipMemsetAsync(out + (size_t)b * out_stride, 0, sizeof(unsigned), s));
     if (((size_t)n * sizeof(uint16_t)) % 16 != 0 && B > 1) { sind_set_error("max_u16: %d samples per image (a batch needs a multiple of 8)", n); return SIND_E_ARG; }
     hipLaunchKernelGGL(k_max_u16, dim3(std::max(1, std::min(divup(n, 8 * 256), 64)), B), dim3(256), 0, s, src, n, out, out_stride); return SIND_OK; }
 int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, uint8_t* edge, uint8_t* total_area, int w, int h, float depthScale, int B, int dmax_stride) {
-    hipLaunchKernelGGL(k_grad_edge, dim3(divup(w, 128), h, B), dim3(128), 0, s, filt, dmax, edge, total_area, w, h, depthScale, dmax_stride); return SIND_OK; }
+    hipLaunchKernelGGL(k_grad_edge, dim3(divup(w, 128), divup(h, GE_ROWS), B), dim3(128), 0, s, filt, dmax, edge, total_area, w, h, depthScale, dmax_stride); return SIND_OK; }
 MorphElem make_ellipse(int n) {
     MorphElem e; e.n = n; e.ax = n / 2; e.ay = n / 2;
     for (int i = 0; i < MORPH_MAX; i++) { e.j1[i] = 0; e.j2[i] = 0; }
@@ -947,6 +1007,7 @@ MorphElem make_ellipse(int n) {
     return e;
 }
 int launch_morph(hipStream_t s, const uint8_t* src, uint8_t* dst, int w, int h, int n, bool dilate, int B) {
+    if (n == 4) { hipLaunchKernelGGL(k_morph_e4, dim3(divup(w, 128), divup(h, MO_ROWS), B), dim3(128), 0, s, src, dst, w, h, dilate ? 1 : 0); return SIND_OK; }
     hipLaunchKernelGGL(k_morph, dim3(divup(w, 128), h, B), dim3(128), 0, s, src, dst, w, h, make_ellipse(n), dilate ? 1 : 0); return SIND_OK; }
 int launch_peac_block_stats(hipStream_t s, const uint16_t* depth, int w, int h, int bw, int bh, float fx, float fy, float cx, float cy, float depthScale, PeacBlockStats* out, int B) {
     if (bw != PEAC_BW || bh != PEAC_BW) { sind_set_error("peac_block_stats: %d x %d blocks (only %d x %d)", bw, bh, PEAC_BW, PEAC_BW); return SIND_E_ARG; }

@@ -179,27 +179,47 @@ __global__ void __launch_bounds__(256) k_ic_angle(const uint8_t* __restrict__ sl
 // GaussianBlur(7x7, sigma 2) on the level interior, BORDER_REFLECT_101 at the INTERIOR's edges (the reference
 // blurs a clone of the ROI): horizontal pass 8.8 fixed point (u16), vertical pass 16.16, (v + 2^15) >> 16.
 struct Taps7 { int k[7]; };
+// A thread makes BH_COLS neighbouring outputs of a row from one window of BH_COLS + 6 bytes (2.5 loads per pixel instead of 7, a quarter of the waves) ...
+#define BH_COLS 4
 __global__ void k_blur7_h(const uint8_t* __restrict__ slab, size_t slab_stride, size_t off, int lw, int lh, Taps7 T,
                           uint16_t* __restrict__ tmp, size_t tmp_stride, size_t tmp_off) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    if (x >= lw) return;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * BH_COLS, y = blockIdx.y, b = blockIdx.z;
+    if (x0 >= lw) return;
     const int pitch = lw + 2 * ORB_PAD;
     const uint8_t* R = slab + (size_t)b * slab_stride + off + (size_t)(y + ORB_PAD) * pitch + ORB_PAD;
-    unsigned s = 0;
+    unsigned win[BH_COLS + 6];
     #pragma unroll
-    for (int i = -3; i <= 3; i++) s += (unsigned)T.k[i + 3] * R[d_reflect101(x + i, lw)];
-    tmp[(size_t)b * tmp_stride + tmp_off + (size_t)y * lw + x] = (uint16_t)min(s, 65535u);
+    for (int j = 0; j < BH_COLS + 6; j++) win[j] = (x0 - 3 + j <= lw + 2) ? (unsigned)R[d_reflect101(x0 - 3 + j, lw)] : 0u;      // (columns right of x = lw - 1 + 3 belong to no output)
+    uint16_t* o = tmp + (size_t)b * tmp_stride + tmp_off + (size_t)y * lw + x0;
+    #pragma unroll
+    for (int q = 0; q < BH_COLS; q++) {
+        if (x0 + q >= lw) break;
+        unsigned s = 0;
+        #pragma unroll
+        for (int i = 0; i < 7; i++) s += (unsigned)T.k[i] * win[q + i];
+        o[q] = (uint16_t)min(s, 65535u);
+    }
 }
+// ... and BV_ROWS outputs of a column from one window of BV_ROWS + 6 rows (1.75 loads per pixel instead of 7, an eighth of the waves)
+#define BV_ROWS 8
 __global__ void k_blur7_v(const uint16_t* __restrict__ tmp, size_t tmp_stride, size_t tmp_off, int lw, int lh, Taps7 T,
                           uint8_t* __restrict__ blurred, size_t bl_stride, size_t bl_off) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * BV_ROWS, b = blockIdx.z;
     if (x >= lw) return;
     const uint16_t* P = tmp + (size_t)b * tmp_stride + tmp_off;
-    unsigned s = 0;
+    unsigned win[BV_ROWS + 6];
     #pragma unroll
-    for (int i = -3; i <= 3; i++) s += (unsigned)T.k[i + 3] * P[(size_t)d_reflect101(y + i, lh) * lw + x];
-    const unsigned r = (s + (1u << 15)) >> 16;
-    blurred[(size_t)b * bl_stride + bl_off + (size_t)y * lw + x] = (uint8_t)min(r, 255u);
+    for (int j = 0; j < BV_ROWS + 6; j++) win[j] = (y0 - 3 + j <= lh + 2) ? (unsigned)P[(size_t)d_reflect101(y0 - 3 + j, lh) * lw + x] : 0u;
+    #pragma unroll
+    for (int q = 0; q < BV_ROWS; q++) {
+        const int y = y0 + q;
+        if (y >= lh) break;
+        unsigned s = 0;
+        #pragma unroll
+        for (int i = 0; i < 7; i++) s += (unsigned)T.k[i] * win[q + i];
+        const unsigned r = (s + (1u << 15)) >> 16;
+        blurred[(size_t)b * bl_stride + bl_off + (size_t)y * lw + x] = (uint8_t)min(r, 255u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -258,8 +278,8 @@ int launch_ic_angle(hipStream_t s, const uint8_t* slab, size_t slab_stride, cons
 int launch_blur7(hipStream_t s, const uint8_t* slab, size_t slab_stride, size_t off, int lw, int lh, const int taps[7], uint16_t* tmp,
                  size_t tmp_stride, size_t tmp_off, uint8_t* blurred, size_t bl_stride, size_t bl_off, int B) {
     Taps7 T; for (int i = 0; i < 7; i++) T.k[i] = taps[i];
-    hipLaunchKernelGGL(k_blur7_h, dim3(divup(lw, 128), lh, B), dim3(128), 0, s, slab, slab_stride, off, lw, lh, T, tmp, tmp_stride, tmp_off);
-    hipLaunchKernelGGL(k_blur7_v, dim3(divup(lw, 128), lh, B), dim3(128), 0, s, tmp, tmp_stride, tmp_off, lw, lh, T, blurred, bl_stride, bl_off);
+    hipLaunchKernelGGL(k_blur7_h, dim3(divup(divup(lw, BH_COLS), 128), lh, B), dim3(128), 0, s, slab, slab_stride, off, lw, lh, T, tmp, tmp_stride, tmp_off);
+    hipLaunchKernelGGL(k_blur7_v, dim3(divup(lw, 128), divup(lh, BV_ROWS), B), dim3(128), 0, s, tmp, tmp_stride, tmp_off, lw, lh, T, blurred, bl_stride, bl_off);
     return SIND_OK;
 }
 int launch_brief(hipStream_t s, const uint8_t* blurred, size_t bl_stride, const OrbLevel* levels, const OrbSelKp* sel, const int* nsel, int cap,

@@ -194,14 +194,24 @@ __global__ void __launch_bounds__(64 * KM_WAVES) k_km_compact(const float* __res
         tot_out[lane] = v; }
     float* cx = comp; float* cy = comp + n; float* cz = comp + 2 * (size_t)n;
     const int lo = seg * seg_len, hi = min(n, lo + seg_len);
-    for (int i = lo + lane; i - lane < hi; i += 64) {
-        const bool in = i < hi; const int l = in ? labels[i] : -1;
-        const float x = in ? px[i] : 0.f, y = in ? py[i] : 0.f, z = in ? pz[i] : 0.f;
+    // four turns of 64 samples are requested together (a turn's loads are one memory round trip; a wave spent its life waiting for ~13 of them in a row)
+    for (int i0 = lo; i0 < hi; i0 += 4 * 64) {
+        int l4[4]; float x4[4], y4[4], z4[4];
         #pragma unroll
-        for (int k = 0; k < KM_K; k++) {
-            const unsigned long long m = __ballot(l == k);
-            if (l == k) { const int d = pos[k] + __popcll(m & ((1ull << lane) - 1ull)); cx[d] = x; cy[d] = y; cz[d] = z; }
-            pos[k] += __popcll(m);
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 64 + lane; const bool in = i < hi;
+            l4[u] = in ? labels[i] : -1; x4[u] = in ? px[i] : 0.f; y4[u] = in ? py[i] : 0.f; z4[u] = in ? pz[i] : 0.f;
+        }
+        #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + u * 64 >= hi) break;                      // wave-uniform
+            const int l = l4[u];
+            #pragma unroll
+            for (int k = 0; k < KM_K; k++) {
+                const unsigned long long m = __ballot(l == k);
+                if (l == k) { const int d = pos[k] + __popcll(m & ((1ull << lane) - 1ull)); cx[d] = x4[u]; cy[d] = y4[u]; cz[d] = z4[u]; }
+                pos[k] += __popcll(m);
+            }
         }
     }
 }

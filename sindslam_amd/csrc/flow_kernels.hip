@@ -130,27 +130,34 @@ __global__ void k_resize_f32(const float* __restrict__ src, float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 // VariationalRefinementImpl::prepareBuffers, part 1: warp I1 by the level's initial flow (cv::remap, INTER_LINEAR,
 // BORDER_REPLICATE, coordinates quantised to 1/32 px), averaged image and temporal difference.
+#define WARP_ROWS 4                                             // rows of its column a thread makes (a quarter of the waves; the per-pixel expressions are unchanged)
 __global__ void k_warp_avg_iz(const float* __restrict__ I0, const float* __restrict__ I1, const float* __restrict__ Wu,
                               const float* __restrict__ Wv, float* __restrict__ avg, float* __restrict__ Iz, float* __restrict__ dWu,
                               float* __restrict__ dWv, int w, int h) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, yb = blockIdx.y * WARP_ROWS, b = blockIdx.z;
     if (x >= w) return;
-    const size_t base = (size_t)b * w * h; const int i = y * w + x;
-    dWu[base + i] = 0.f; dWv[base + i] = 0.f;               // the level's flow increment starts at zero (two fills less per level)
+    const size_t base = (size_t)b * w * h;
     const float* S = I1 + base;
-    const float mx = x + Wu[base + i], my = y + Wv[base + i];
-    int sx = d_cvRound(mx * 32.f), sy = d_cvRound(my * 32.f);
-    const int fxq = sx & 31, fyq = sy & 31;
-    sx >>= 5; sy >>= 5;
-    sx = max(-32768, min(32767, sx)); sy = max(-32768, min(32767, sy));
-    const float tx1 = fxq * (1.f / 32), tx0 = 1.f - tx1, ty1 = fyq * (1.f / 32), ty0 = 1.f - ty1;
-    const float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
-    const int x0 = d_clip(sx, 0, w), x1 = d_clip(sx + 1, 0, w), y0 = d_clip(sy, 0, h), y1 = d_clip(sy + 1, 0, h);
-    const float v0 = S[y0 * w + x0], v1 = S[y0 * w + x1], v2 = S[y1 * w + x0], v3 = S[y1 * w + x1];
-    const float wv = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
-    const float i0 = I0[base + i];
-    avg[base + i] = i0 * 0.5f + wv * 0.5f;
-    Iz[base + i] = wv - i0;
+    #pragma unroll
+    for (int r = 0; r < WARP_ROWS; r++) {
+        const int y = yb + r;
+        if (y >= h) break;
+        const int i = y * w + x;
+        dWu[base + i] = 0.f; dWv[base + i] = 0.f;           // the level's flow increment starts at zero (two fills less per level)
+        const float mx = x + Wu[base + i], my = y + Wv[base + i];
+        int sx = d_cvRound(mx * 32.f), sy = d_cvRound(my * 32.f);
+        const int fxq = sx & 31, fyq = sy & 31;
+        sx >>= 5; sy >>= 5;
+        sx = max(-32768, min(32767, sx)); sy = max(-32768, min(32767, sy));
+        const float tx1 = fxq * (1.f / 32), tx0 = 1.f - tx1, ty1 = fyq * (1.f / 32), ty0 = 1.f - ty1;
+        const float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
+        const int x0 = d_clip(sx, 0, w), x1 = d_clip(sx + 1, 0, w), y0 = d_clip(sy, 0, h), y1 = d_clip(sy + 1, 0, h);
+        const float v0 = S[y0 * w + x0], v1 = S[y0 * w + x1], v2 = S[y1 * w + x0], v3 = S[y1 * w + x1];
+        const float wv = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+        const float i0 = I0[base + i];
+        avg[base + i] = i0 * 0.5f + wv * 0.5f;
+        Iz[base + i] = wv - i0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1115,8 +1122,21 @@ int debug_ss_profile(unsigned long long* out, int reset) {
 }
 #endif
 
+// four elements per thread (16-byte accesses; `n4` whole quads, the n % 4 elements behind them by the last threads)
 __global__ void k_add_flow(const float* Wu, const float* Wv, const float* __restrict__ dWu,
                            const float* __restrict__ dWv, float* tWu, float* tWv, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n4 = n >> 2;
+    if (i < n4) {
+        const float4 a = reinterpret_cast<const float4*>(Wu)[i], b = reinterpret_cast<const float4*>(dWu)[i], c = reinterpret_cast<const float4*>(Wv)[i], d = reinterpret_cast<const float4*>(dWv)[i];
+        reinterpret_cast<float4*>(tWu)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        reinterpret_cast<float4*>(tWv)[i] = make_float4(c.x + d.x, c.y + d.y, c.z + d.z, c.w + d.w);
+    } else {
+        const size_t k = (n4 << 2) + (i - n4);
+        if (k < n) { tWu[k] = Wu[k] + dWu[k]; tWv[k] = Wv[k] + dWv[k]; }
+    }
+}
+__global__ void k_add_flow_1(const float* Wu, const float* Wv, const float* __restrict__ dWu,
+                             const float* __restrict__ dWv, float* tWu, float* tWv, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     tWu[i] = Wu[i] + dWu[i]; tWv[i] = Wv[i] + dWv[i];
@@ -1678,8 +1698,8 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
 // VariationalRefinement::calcUV on one pyramid level for B pairs.  Wu/Wv: initial flow in, refined flow out.
 int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer) {
     const size_t n = (size_t)w * h * B;
-    const dim3 g = grid2d(w, h, B), blk(128);
-    hipLaunchKernelGGL(k_warp_avg_iz, g, blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, P.dWu, P.dWv, w, h);
+    const dim3 blk(128);
+    hipLaunchKernelGGL(k_warp_avg_iz, grid2d(w, divup(h, WARP_ROWS), B), blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, P.dWu, P.dWv, w, h);
     for (int it = 0; it < V.fixedPointIterations; it++) {
         if (g_coef_lanes)
             hipLaunchKernelGGL(k_coef_lanes, dim3(divup(w, KL_COLS), divup(h, 4 * KL_ROWS), B), dim3(256), 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
@@ -1693,7 +1713,10 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
         // algorithmic bytes: 44 B per pixel per red+black iteration (9 reads + 2 writes of f32), SURVEY.md §8d
         if (timer) timer->end(s, nlaunch, 44.0 * (double)w * h * B * V.sorIterations);
     }
-    hipLaunchKernelGGL(k_add_flow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.Wu, P.Wv, n);      // W = W + dW, in place
+    if ((((uintptr_t)P.Wu | (uintptr_t)P.Wv | (uintptr_t)P.dWu | (uintptr_t)P.dWv) & 15) == 0)
+        hipLaunchKernelGGL(k_add_flow, dim3((unsigned)(((n >> 2) + (n & 3) + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.Wu, P.Wv, n);      // W = W + dW, in place
+    else
+        hipLaunchKernelGGL(k_add_flow_1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.Wu, P.Wv, n);
     HIP_TRY(hipGetLastError());
     return SIND_OK;
 }

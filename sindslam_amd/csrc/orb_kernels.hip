@@ -38,6 +38,14 @@ __global__ void k_copy_into_slab(const uint8_t* __restrict__ gray, uint8_t* __re
 // 0 if the pixel is not a corner at `threshold`.
 __device__ __forceinline__ int fast_score(const uint8_t* win, int stride, int idx, int threshold) {
     const int v = win[idx];
+    // A 9-arc of the 16-ring holds at least two of the four compass pixels (0, 4, 8, 12): unless two of them are brighter than v + threshold or two darker than v - threshold
+    // no arc passes, and the score is 0 without looking at the other twelve (most pixels of an image).  The score of the pixels that do pass is computed as before.
+    {
+        const int c0 = v - win[idx + 3 * stride], c4 = v - win[idx + 3], c8 = v - win[idx - 3 * stride], c12 = v - win[idx - 3];
+        const int darker = (c0 > threshold) + (c4 > threshold) + (c8 > threshold) + (c12 > threshold);             // ring pixel darker than the centre by more than the threshold
+        const int brighter = (c0 < -threshold) + (c4 < -threshold) + (c8 < -threshold) + (c12 < -threshold);
+        if (darker < 2 && brighter < 2) return 0;
+    }
     int d[16];
     d[0] = v - win[idx + 3 * stride];       d[1] = v - win[idx + 3 * stride + 1];  d[2] = v - win[idx + 2 * stride + 2];
     d[3] = v - win[idx + stride + 3];       d[4] = v - win[idx + 3];               d[5] = v - win[idx - stride + 3];

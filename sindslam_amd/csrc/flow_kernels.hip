@@ -1449,9 +1449,20 @@ __global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict_
     const uint8_t* p = bgr + i * 3;
     gray[i] = (uint8_t)((p[0] * cb + p[1] * 9617 + p[2] * cr + 8192) >> 14);
 }
+// four pixels per thread: three 4-byte loads, one 4-byte store (n4 = whole quads; needs 4-byte aligned images)
+__global__ void k_bgr2gray4(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, size_t n4, int cb, int cr) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const unsigned* p = reinterpret_cast<const unsigned*>(bgr) + i * 3;
+    const unsigned a = p[0], b = p[1], c = p[2];             // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+    auto g = [&](unsigned bb, unsigned gg, unsigned rr) { return (unsigned)(((int)bb * cb + (int)gg * 9617 + (int)rr * cr + 8192) >> 14) & 0xffu; };
+    const unsigned g0 = g(a & 0xff, (a >> 8) & 0xff, (a >> 16) & 0xff), g1 = g(a >> 24, b & 0xff, (b >> 8) & 0xff);
+    const unsigned g2 = g((b >> 16) & 0xff, b >> 24, c & 0xff), g3 = g((c >> 8) & 0xff, (c >> 16) & 0xff, c >> 24);
+    reinterpret_cast<unsigned*>(gray)[i] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+}
 __global__ void k_resize_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int sw, int sh, int dw, int dh,
                             double scale_x, double scale_y, int s_stride, int d_stride, size_t s_img, size_t d_img, int d_group, int d_skip) {
-    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, b = blockIdx.z;
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy0 = blockIdx.y * RZ_ROWS, b = blockIdx.z;      // RZ_ROWS destination rows of a column per thread, like k_resize_f32_pair
     if (dx >= dw) return;
     const uint8_t* S = src + (size_t)b * s_img;
     const int db = d_group > 0 ? b + (b / d_group) * d_skip : b;       // destination slot: groups of d_group images, d_skip slots left free after each group
@@ -1460,16 +1471,21 @@ __global__ void k_resize_u8(const uint8_t* __restrict__ src, uint8_t* __restrict
     const bool two = sx + 1 < sw;
     if (sx < 0) { fx = 0; sx = 0; }
     if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-    float fy = (float)((dy + 0.5) * scale_y - 0.5);
-    int sy = d_cvFloorf(fy); fy -= sy;
-    const int y0 = d_clip(sy, 0, sh), y1 = d_clip(sy + 1, 0, sh);
     const int ax0 = (short)d_cvRound((1.f - fx) * 2048), ax1 = (short)d_cvRound(fx * 2048);
-    const int b0 = (short)d_cvRound((1.f - fy) * 2048), b1 = (short)d_cvRound(fy * 2048);
-    const uint8_t* R0 = S + (size_t)y0 * s_stride; const uint8_t* R1 = S + (size_t)y1 * s_stride;
-    int r0, r1;
-    if (two) { r0 = R0[sx] * ax0 + R0[sx + 1] * ax1; r1 = R1[sx] * ax0 + R1[sx + 1] * ax1; }
-    else     { r0 = R0[sx] * 2048;                   r1 = R1[sx] * 2048; }
-    dst[(size_t)db * d_img + (size_t)dy * d_stride + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    #pragma unroll
+    for (int r = 0; r < RZ_ROWS; r++) {
+        const int dy = dy0 + r;
+        if (dy >= dh) break;
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = d_cvFloorf(fy); fy -= sy;
+        const int y0 = d_clip(sy, 0, sh), y1 = d_clip(sy + 1, 0, sh);
+        const int b0 = (short)d_cvRound((1.f - fy) * 2048), b1 = (short)d_cvRound(fy * 2048);
+        const uint8_t* R0 = S + (size_t)y0 * s_stride; const uint8_t* R1 = S + (size_t)y1 * s_stride;
+        int r0, r1;
+        if (two) { r0 = R0[sx] * ax0 + R0[sx + 1] * ax1; r1 = R1[sx] * ax0 + R1[sx + 1] * ax1; }
+        else     { r0 = R0[sx] * 2048;                   r1 = R1[sx] * 2048; }
+        dst[(size_t)db * d_img + (size_t)dy * d_stride + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
 }
 
 // frames of the gray history pool picked by index into a dense batch: out[b] = pool[idx[b]] (16 bytes per thread; the indices travel as
@@ -1539,11 +1555,14 @@ int launch_roll_history(hipStream_t s, uint8_t* pool, int S, int T, size_t frame
 }
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img, int d_group, int d_skip) {
     const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
-    hipLaunchKernelGGL(k_resize_u8, grid2d(dw, dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, scale_x, scale_y, s_stride, d_stride, s_img, d_img, d_group, d_skip);
+    hipLaunchKernelGGL(k_resize_u8, grid2d(dw, divup(dh, RZ_ROWS), B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, scale_x, scale_y, s_stride, d_stride, s_img, d_img, d_group, d_skip);
     return SIND_OK;
 }
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb) {
-    hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, bgr, gray, npix, swap_rb ? 4899 : 1868, swap_rb ? 1868 : 4899);
+    if ((npix & 3) == 0 && (((uintptr_t)bgr | (uintptr_t)gray) & 3) == 0)
+        hipLaunchKernelGGL(k_bgr2gray4, dim3((unsigned)((npix / 4 + 255) / 256)), dim3(256), 0, s, bgr, gray, npix / 4, swap_rb ? 4899 : 1868, swap_rb ? 1868 : 4899);
+    else
+        hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, bgr, gray, npix, swap_rb ? 4899 : 1868, swap_rb ? 1868 : 4899);
     return SIND_OK;
 }
 

@@ -16,12 +16,16 @@ __constant__ signed char c_brief[1024];
 __constant__ int c_umax[16];
 
 // copyMakeBorder(BORDER_REFLECT_101) of the level interior (already written at offset (19,19)) into its border.
+// One thread per BORDER pixel (the interior is 7/8 of a 640 x 480 level: a thread per padded pixel started eight waves to move one): border pixel k of the padded image, the
+// 2 pad full rows above and below first, then the 2 pad columns beside each interior row.
 __global__ void k_pad_reflect101(uint8_t* __restrict__ slab, size_t slab_stride, size_t off, int lw, int lh, int pad) {
-    const int pw = lw + 2 * pad;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    if (x >= pw) return;
+    const int pw = lw + 2 * pad, nrow = 2 * pad * pw, nall = nrow + 2 * pad * lh;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
+    if (k >= nall) return;
+    int x, y;
+    if (k < nrow) { const int r = k / pw; x = k - r * pw; y = r < pad ? r : lh + r; }                                  // rows 0 .. pad - 1 and lh + pad .. lh + 2 pad - 1
+    else { const int q = k - nrow, r = q / (2 * pad), c = q - r * (2 * pad); y = pad + r; x = c < pad ? c : lw + c; }     // columns 0 .. pad - 1 and lw + pad .. lw + 2 pad - 1
     const int ix = x - pad, iy = y - pad;
-    if (ix >= 0 && ix < lw && iy >= 0 && iy < lh) return;       // interior untouched
     uint8_t* L = slab + (size_t)b * slab_stride + off;
     const int sx = d_reflect101(ix, lw) + pad, sy = d_reflect101(iy, lh) + pad;
     L[(size_t)y * pw + x] = L[(size_t)sy * pw + sx];
@@ -264,7 +268,7 @@ int orb_upload_constants(const int umax[16]) {
     return SIND_OK;
 }
 int launch_pad(hipStream_t s, uint8_t* slab, size_t slab_stride, size_t off, int lw, int lh, int B) {
-    hipLaunchKernelGGL(k_pad_reflect101, dim3(divup(lw + 2 * ORB_PAD, 128), lh + 2 * ORB_PAD, B), dim3(128), 0, s, slab, slab_stride, off, lw, lh, ORB_PAD);
+    hipLaunchKernelGGL(k_pad_reflect101, dim3(divup(2 * ORB_PAD * (lw + 2 * ORB_PAD) + 2 * ORB_PAD * lh, 256), 1, B), dim3(256), 0, s, slab, slab_stride, off, lw, lh, ORB_PAD);
     return SIND_OK;
 }
 int launch_copy_into_slab(hipStream_t s, const uint8_t* gray, uint8_t* slab, size_t slab_stride, size_t off, int w, int h, int B) {

@@ -53,6 +53,9 @@ def test_bad_arguments():
     assert lib().sind_flow_set_sor(1, 5, 64) == (0 if lab else -1) and lib().sind_flow_set_sor_tiled(3, 3, 64, 48) == (0 if lab else -1) and lib().sind_flow_set_sor_tiled(4, 0, 64, 64) == (0 if lab else -1)
     assert lib().sind_flow_set_sor_tiled(3, 3, 64, 64) == -1          # 512 threads: no three-waves-per-SIMD instance
     assert lib().sind_flow_set_sor_tiled(4, 5, 64, 64) == 0           # back to the default
+    # round-4 switches of the flow stage: persistent solver workgroups (0 = one per item), coefficient kernel variant
+    assert lib().sind_flow_set_solver_workgroups(-1) == -1 and lib().sind_flow_set_solver_workgroups(160) == 0 and lib().sind_flow_set_solver_workgroups(0) == 0
+    assert lib().sind_debug_set_coef_lanes(2) == -1 and lib().sind_debug_set_coef_lanes(0) == 0 and lib().sind_debug_set_coef_lanes(1) == 0
 
 
 def test_product_never_touches_the_oracle():

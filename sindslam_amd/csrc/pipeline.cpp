@@ -174,9 +174,10 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     const bool flow_hi = sind_lab_env("SIND_FLOW_PRIORITY") && atoi(sind_lab_env("SIND_FLOW_PRIORITY")) != 0;
     SIND_TRY(make_stream(&p->stream, flow_hi)); SIND_TRY(make_stream(&p->orb_stream, false)); HIP_TRY(hipEventCreateWithFlags(&p->ev_gray, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_depth, hipEventDisableTiming));
     const int B = p->S * p->T; const size_t np = (size_t)cfg->width * cfg->height;
-    // dense-flow slices: three concurrent streams keep the GPU busy through the launch tails and the small pyramid levels of each other
-    // (measured at B = 256: 270 -> 253 ms per step); small batches stay in one piece
-    const int nsplit = std::max(1, std::min(sind_lab_env("SIND_FLOW_SPLIT") ? atoi(sind_lab_env("SIND_FLOW_SPLIT")) : (B >= 96 ? 3 : B >= 48 ? 2 : 1), 4)), Bs = (B + nsplit - 1) / nsplit;
+    // dense-flow slices: concurrent streams keep the GPU busy through the launch tails and the small pyramid levels of each other; small batches stay in one piece.
+    // Measured (profiles/r04/split_sweep.txt, lab build): 512 pairs per step: 3 slices 1382-1417 pairs/s, 2: 1377, 4: 1354; 224 pairs (the one-GPU sequence job's step): 2 slices
+    // 1192, 1: 1164, 3: 1150, 4: 1120 -- a slice should hold ~110 pairs or more
+    const int nsplit = std::max(1, std::min(sind_lab_env("SIND_FLOW_SPLIT") ? atoi(sind_lab_env("SIND_FLOW_SPLIT")) : (B >= 320 ? 3 : B >= 48 ? 2 : 1), 4)), Bs = (B + nsplit - 1) / nsplit;
     SIND_TRY(p->front.init(p->dc, nsplit > 1 ? std::max(Bs, 2) : B, p->stream));
     HIP_TRY(hipEventCreate(&p->ev_pool));                   // with timing: also the time base of the solver intervals
     for (int i = 1; i < nsplit; i++) {

@@ -237,7 +237,7 @@ def test_kmeans_stream_groups_do_not_change_the_results(frames):
 
 @pytest.mark.timeout(1200)
 def test_pipeline_in_the_shape_the_bench_runs_streaming_solver_and_ragged_step(frames):
-    """48 streams x 3 frames = 144 pairs per step: the dense flow runs as three slices of 48 pairs, i.e. on the STREAMING solver (k_sor_stream, the bench's
+    """48 streams x 3 frames = 144 pairs per step: the dense flow runs as two slices of 72 pairs (three of 48 before the slice rule of round 4's end), i.e. on the STREAMING solver (k_sor_stream, the bench's
     kernel; smaller test pipelines run the tiled one).  Four sampled streams against the ORACLE: imgDyna / imgLabel / mask / keypoints / descriptors of every
     frame are equal.  Then a ragged step (sind_pipe_set_active_frames): the sampled streams stop after 0, 1, 2 and 3 frames -- their state fingerprints and state
     blobs are exactly those of the oracle-checked prefix."""

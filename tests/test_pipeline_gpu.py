@@ -260,7 +260,7 @@ def test_pipeline_in_the_shape_the_bench_runs_streaming_solver_and_ragged_step(f
     for s in range(S):
         pipe.prime(s, sb[s, 1], sb[s, 0])
     pipe.process(sb[:, 2:5], sd[:, 2:5])
-    st = pipe.stats(); assert st["sor_slices"] == 3
+    st = pipe.stats(); assert st["sor_slices"] == 2          # 144 pairs: two slices of 72 (streaming from 48 pairs per slice)
     sample = [0, 7, 22, 47]
     orb_ref = O.ORBextractor(1500, 1.2, 8, 15, 5)
     h_full = pipe.state_hashes(); assert (h_full != 0).any(axis=2).all()

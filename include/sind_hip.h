@@ -126,9 +126,13 @@ int sind_debug_seqsum(const float* x, int n, int device, float* out);
  * (tests/test_kmeans_fused_gpu.py); process-wide, for parity tests and A/B timing. */
 int sind_debug_set_kmeans_fused_max(int n);
 int sind_debug_set_kmeans_fused_min_batch(int b);
-/* coefficient kernel of the variational refinement: 1 (default) = k_coef_lanes (a wave loads every plane row once and takes x +- 1, x +- 2 from the neighbouring lanes),
- * 0 = k_coef (every neighbour from memory).  Same coefficients bit for bit (tests/test_flow_gpu.py); process-wide, for the parity test and A/B timing. */
+/* coefficient kernel of the variational refinement: 1 (default) = k_coef_lanes (a wave loads every plane row once and takes x +- 1, x +- 2 from the neighbouring lanes; sqrt
+ * and c / sqrt in their short correctly rounded forms), 2 = k_coef_lanes with the compiler's IEEE sequences, 0 = k_coef (every neighbour from memory, IEEE sequences).  Same
+ * coefficients bit for bit (tests/test_flow_gpu.py); process-wide, for the parity tests and A/B timing. */
 int sind_debug_set_coef_lanes(int on);
+/* exhaustive check of the short forms: for every float significand and the binary exponents exp_lo..exp_hi (>= -96), out[0] = arguments whose short-form square root differs
+ * from sqrtf, out[1] = quotients numer[k] / b through the reciprocal (hardware estimate + Newton step + Markstein's correction) that differ from the IEEE division */
+int sind_debug_coef_math_scan(int device, int exp_lo, int exp_hi, const float numer[3], unsigned long long out[2]);
 /* exhaustive check of the solver's division: for every float significand and the binary exponents exp_lo..exp_hi, out[0] = reciprocals (hardware
  * estimate + one Newton step) that differ from the correctly rounded 1 / a, out[1] = quotients through that reciprocal (Markstein) that differ
  * from the IEEE division (16 numerators per divisor), out[2] = smallest failing significand (all ones if none) */

@@ -109,6 +109,16 @@ int sind_debug_rcp_scan(int device, int exp_lo, int exp_hi, unsigned long long o
     HIP_TRY(hipMemcpy(out, d.p, sizeof(init), hipMemcpyDeviceToHost));
     return SIND_OK;
 }
+int sind_debug_coef_math_scan(int device, int exp_lo, int exp_hi, const float numer[3], unsigned long long out[2]) {
+    if (!out || !numer || exp_lo < -96 || exp_hi > 100 || exp_lo > exp_hi) { sind_set_error("sind_debug_coef_math_scan: bad arguments (exponents -96 .. 100)"); return SIND_E_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<unsigned long long> d; SIND_TRY(d.alloc(2));
+    HIP_TRY(hipMemset(d.p, 0, 2 * sizeof(unsigned long long)));
+    SIND_TRY(sind::debug_coef_math_scan(nullptr, exp_lo, exp_hi, numer, d.p));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return SIND_OK;
+}
 #ifdef SIND_LAB
 int sind_lab_ss_profile(unsigned long long* out96, int reset) { return sind::debug_ss_profile(out96, reset); }      // lab builds only: k_sor_stream's per-wave step cycles
 #endif
@@ -142,7 +152,7 @@ int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h) {
     sind::g_sor_mode = mode; sind::g_sor_fuse = fuse; sind::g_sor_tile_w = tile_w; sind::g_sor_tile_h = tile_h; return SIND_OK;
 }
 int sind_flow_set_solver_workgroups(int cap) { if (cap < 0) return SIND_E_ARG; sind::g_sor_stream_wg_cap = cap; return SIND_OK; }
-int sind_debug_set_coef_lanes(int on) { if (on != 0 && on != 1) return SIND_E_ARG; sind::g_coef_lanes = on; return SIND_OK; }
+int sind_debug_set_coef_lanes(int on) { if (on < 0 || on > 2) return SIND_E_ARG; sind::g_coef_lanes = on; return SIND_OK; }
 int sind_flow_set_sor(int mode, int fuse, int tile_w) {
     if (tile_w != 64 && tile_w != 128) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }
     return sind_flow_set_sor_tiled(mode, fuse, tile_w, mode == 3 ? (tile_w == 64 ? 48 : 48) : 64);

@@ -172,6 +172,22 @@ __global__ void k_warp_avg_iz(const float* __restrict__ I0, const float* __restr
 // below the solver kernels; checked exhaustively by sind_debug_rcp_scan) -- 3 instructions per quotient instead of the 10 of an IEEE division.
 __device__ __forceinline__ float kc_rcp(float a) { const float y0 = __builtin_amdgcn_rcpf(a); const float e = fmaf(-a, y0, 1.f); return fmaf(e, y0, y0); }
 __device__ __forceinline__ float kc_div(float n, float a, float r) { const float q0 = n * r; const float e = fmaf(-a, q0, n); return fmaf(e, r, q0); }
+// RN(sqrt(x)) for 2^-96 <= x < inf: the compiler's own correctly rounded sequence (hardware estimate within 1 ulp, then the neighbour whose residual says so) without its
+// guards for tiny, zero and infinite arguments -- 8 instructions instead of 15.  c / sqrt(x) then goes through the root's reciprocal like every other quotient of the kernel
+// (kc_rcp + kc_div: 6 instructions instead of the IEEE division's 11).  sind_debug_coef_math_scan checks both against sqrtf and the IEEE division for EVERY float in a range
+// of binary exponents (tests/test_flow_gpu.py); the arguments here are >= epsilon^2 = 1e-6 and the roots lie in [1e-3, ~1e4].
+__device__ __forceinline__ float kc_sqrt(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+    float r = (0.f >= rd) ? sd : s;
+    r = (0.f < ru) ? su : r;
+    return r;
+}
+template <bool FAST> __device__ __forceinline__ float kc_over_sqrt(float c, float x) {
+    if (FAST) { const float s = kc_sqrt(x); return kc_div(c, s, kc_rcp(s)); }
+    return c / sqrtf(x);
+}
 #define KC_ROWS 4
 // IN: every pixel this wave touches in these rows -- the four rows of its 64 columns and their stencils (two columns / rows to every side) -- lies inside the image: no index is
 // clamped and no border case exists, so every neighbour is a load at a CONSTANT offset from one of a few row pointers.  (The clamped form spends ~3 integer VALU instructions on
@@ -288,7 +304,7 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
 __device__ __forceinline__ float lane_next(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }   // wave_shl:1 -- the value of lane + 1
 __device__ __forceinline__ float lane_prev(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }   // wave_shr:1 -- the value of lane - 1
 // BORDER: the wave touches the image border (columns or rows clamp; BORDER_REPLICATE applies to the DERIVATIVE images too, hence the explicit cases below)
-template <bool BORDER>
+template <bool BORDER, bool FASTM>
 __device__ __forceinline__ void kc_lanes(const VarParams& P, int w, int h, int col, int y0, size_t base, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
                        const float* __restrict__ gWv, const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
                        float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11, float* __restrict__ R22, bool store_lane) {
@@ -320,7 +336,7 @@ __device__ __forceinline__ void kc_lanes(const VarParams& P, int w, int h, int c
         const float c_u = tu[j], c_v = tv[j];
         const float ux = lane_next(c_u) - c_u, vx = lane_next(c_v) - c_v;
         const float uy = tu[j + 1] - c_u, vy = tv[j + 1] - c_v;
-        return alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
+        return kc_over_sqrt<FASTM>(alpha2, ux * ux + vx * vx + uy * uy + vy * vy + eps2);
     };
     float w_up = wgt_row(0);
     #pragma unroll
@@ -340,7 +356,7 @@ __device__ __forceinline__ void kc_lanes(const VarParams& P, int w, int h, int c
         float derivNorm = Ix * Ix + Iy * Iy + zeta2;
         const float Ik1z = Iz + Ix * dU + Iy * dV;
         const float rN0 = kc_rcp(derivNorm);
-        float weight = kc_div(delta2 / sqrtf(kc_div(Ik1z * Ik1z, derivNorm, rN0) + eps2), derivNorm, rN0);
+        float weight = kc_div(kc_over_sqrt<FASTM>(delta2, kc_div(Ik1z * Ik1z, derivNorm, rN0) + eps2), derivNorm, rN0);
         float a11 = weight * (Ix * Ix) + zeta2;
         float a12 = weight * (Ix * Iy);
         float a22 = weight * (Iy * Iy) + zeta2;
@@ -353,7 +369,7 @@ __device__ __forceinline__ void kc_lanes(const VarParams& P, int w, int h, int c
         const float rN1 = kc_rcp(derivNorm), rN2 = kc_rcp(derivNorm2);
         #define D1(n) kc_div((n), derivNorm, rN1)
         #define D2(n) kc_div((n), derivNorm2, rN2)
-        weight = gamma2 / sqrtf(D1(Ik1zx * Ik1zx) + D2(Ik1zy * Ik1zy) + eps2);
+        weight = kc_over_sqrt<FASTM>(gamma2, D1(Ik1zx * Ik1zx) + D2(Ik1zy * Ik1zy) + eps2);
         a11 += weight * (D1(Ixx * Ixx) + D2(Ixy * Ixy));
         a12 += weight * (D1(Ixx * Ixy) + D2(Ixy * Iyy));
         a22 += weight * (D1(Ixy * Ixy) + D2(Iyy * Iyy));
@@ -390,20 +406,25 @@ __device__ __forceinline__ void kc_lanes(const VarParams& P, int w, int h, int c
 // grid (tiles of KL_COLS columns, groups of 4 x KL_ROWS rows, pairs), 256 threads: wave k of a workgroup takes the rows (4 * blockIdx.y + k) * KL_ROWS ...
 __global__ __launch_bounds__(256) void k_coef_lanes(VarParams P, int w, int h, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
                        const float* __restrict__ gWv, const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
-                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11, float* __restrict__ R22) {
+                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11, float* __restrict__ R22, int fast_math) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = blockIdx.x * KL_COLS - 2, y0 = (blockIdx.y * 4 + wave) * KL_ROWS;
     if (y0 >= h) return;                                    // whole wave
     const size_t base = (size_t)blockIdx.z * w * h;
     const int col = c0 + lane;
     const bool store_lane = lane >= 2 && lane < 2 + KL_COLS && col < w;
-    if (c0 >= 0 && c0 + 63 < w && y0 >= 2 && y0 + KL_ROWS + 1 < h)
-        kc_lanes<false>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
-    else
-        kc_lanes<true>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
+    // the short forms of sqrt and c / sqrt need arguments >= 2^-96: every argument carries epsilon^2 (1e-6 with the reference's parameters); any other epsilon takes the IEEE forms
+    const bool interior = c0 >= 0 && c0 + 63 < w && y0 >= 2 && y0 + KL_ROWS + 1 < h, fastm = P.epsilon >= 1e-12f && fast_math != 0;
+    if (fastm) {
+        if (interior) kc_lanes<false, true>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
+        else kc_lanes<true, true>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
+    } else {
+        if (interior) kc_lanes<false, false>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
+        else kc_lanes<true, false>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
+    }
 }
 int g_sor_stream_wg_cap = 0;    // k_sor_stream: at most this many workgroups per launch (0 = one per item)
-int g_coef_lanes = 1;            // 1: k_coef_lanes (neighbours from lanes), 0: k_coef (neighbours from memory) -- kept for the A/B test
+int g_coef_lanes = 1;            // 1: k_coef_lanes (neighbours from lanes; short forms of sqrt and c / sqrt), 2: k_coef_lanes with the IEEE forms, 0: k_coef (neighbours from memory) -- kept for the A/B tests
 
 // ---------------------------------------------------------------------------------------------------------
 // RedBlackSOR_ParBody: one colour of one SOR iteration (plain version: one thread per pixel of the colour).
@@ -484,6 +505,26 @@ __global__ void k_debug_rcp_scan(int exp_lo, int exp_hi, unsigned long long* __r
     if (bad_r) atomicAdd(&out[0], bad_r);
     if (bad_q) atomicAdd(&out[1], bad_q);
     if (bad_r) atomicMin(&out[2], (unsigned long long)m);
+}
+// kc_sqrt against sqrtf, and c / b through kc_rcp + kc_div against the IEEE division for three numerators, for every significand and the binary exponents exp_lo .. exp_hi
+__global__ void k_debug_coef_math_scan(int exp_lo, int exp_hi, float n0, float n1, float n2, unsigned long long* __restrict__ out) {
+    const unsigned m = blockIdx.x * blockDim.x + threadIdx.x;           // all 2^23 significands
+    if (m >= (1u << 23)) return;
+    unsigned long long bad_s = 0, bad_q = 0;
+    for (int e = exp_lo; e <= exp_hi; e++) {
+        const float x = __uint_as_float(((unsigned)(127 + e) << 23) | m);
+        if (__float_as_uint(kc_sqrt(x)) != __float_as_uint(sqrtf(x))) bad_s++;
+        const float r = kc_rcp(x);
+        if (__float_as_uint(kc_div(n0, x, r)) != __float_as_uint(n0 / x)) bad_q++;
+        if (__float_as_uint(kc_div(n1, x, r)) != __float_as_uint(n1 / x)) bad_q++;
+        if (__float_as_uint(kc_div(n2, x, r)) != __float_as_uint(n2 / x)) bad_q++;
+    }
+    if (bad_s) atomicAdd(&out[0], bad_s);
+    if (bad_q) atomicAdd(&out[1], bad_q);
+}
+int debug_coef_math_scan(hipStream_t s, int exp_lo, int exp_hi, const float numer[3], unsigned long long* out_dev) {
+    hipLaunchKernelGGL(k_debug_coef_math_scan, dim3((1u << 23) / 256), dim3(256), 0, s, exp_lo, exp_hi, numer[0], numer[1], numer[2], out_dev);
+    HIP_TRY(hipGetLastError()); return SIND_OK;
 }
 int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev) {
     hipLaunchKernelGGL(k_debug_rcp_scan, dim3((1u << 23) / 256), dim3(256), 0, s, exp_lo, exp_hi, out_dev);
@@ -1722,7 +1763,7 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     for (int it = 0; it < V.fixedPointIterations; it++) {
         if (g_coef_lanes)
             hipLaunchKernelGGL(k_coef_lanes, dim3(divup(w, KL_COLS), divup(h, 4 * KL_ROWS), B), dim3(256), 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
-                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr);
+                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr, g_coef_lanes == 2 ? 0 : 1);
         else
             hipLaunchKernelGGL(k_coef, dim3(divup(w, 128), divup(h, KC_ROWS), B), blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
                                P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr);

@@ -55,7 +55,7 @@ def test_bad_arguments():
     assert lib().sind_flow_set_sor_tiled(4, 5, 64, 64) == 0           # back to the default
     # round-4 switches of the flow stage: persistent solver workgroups (0 = one per item), coefficient kernel variant
     assert lib().sind_flow_set_solver_workgroups(-1) == -1 and lib().sind_flow_set_solver_workgroups(160) == 0 and lib().sind_flow_set_solver_workgroups(0) == 0
-    assert lib().sind_debug_set_coef_lanes(2) == -1 and lib().sind_debug_set_coef_lanes(0) == 0 and lib().sind_debug_set_coef_lanes(1) == 0
+    assert lib().sind_debug_set_coef_lanes(3) == -1 and lib().sind_debug_set_coef_lanes(0) == 0 and lib().sind_debug_set_coef_lanes(2) == 0 and lib().sind_debug_set_coef_lanes(1) == 0
 
 
 def test_product_never_touches_the_oracle():

@@ -168,10 +168,12 @@ def test_coefficients_from_lanes_equal_coefficients_from_memory(fs_big, w, h):
     args = (np.stack([i0, i1]), np.stack([i1, i0]), np.stack([u0, v0]), np.stack([v0, u0]), 3, 7, a, d, g, 1.6)
     try:
         assert lib().sind_debug_set_coef_lanes(0) == 0; mu, mv = fs_big.varref_f32(*args)
-        assert lib().sind_debug_set_coef_lanes(1) == 0; lu, lv = fs_big.varref_f32(*args)
+        assert lib().sind_debug_set_coef_lanes(2) == 0; iu, iv = fs_big.varref_f32(*args)          # lanes, the compiler's IEEE sqrt and division
+        assert lib().sind_debug_set_coef_lanes(1) == 0; lu, lv = fs_big.varref_f32(*args)          # lanes, short forms (the default)
     finally:
         lib().sind_debug_set_coef_lanes(1)
-    assert lib().sind_debug_set_coef_lanes(2) == -1
+    assert lib().sind_debug_set_coef_lanes(3) == -1
+    assert np.array_equal(iu.view(np.uint32), mu.view(np.uint32)) and np.array_equal(iv.view(np.uint32), mv.view(np.uint32)), (w, h, float(np.abs(iu - mu).max()))
     assert np.array_equal(lu.view(np.uint32), mu.view(np.uint32)) and np.array_equal(lv.view(np.uint32), mv.view(np.uint32)), (w, h, float(np.abs(lu - mu).max()))
     assert np.isfinite(lu).all() and np.abs(lu - np.stack([u0, v0])).max() > 1e-3          # the refinement moved the field
     if w * h <= 130 * 70:
@@ -198,6 +200,21 @@ def test_persistent_solver_workgroups_equal_one_workgroup_per_item(fs_big, w, h,
     assert lib().sind_flow_set_solver_workgroups(-1) == -1
     assert np.array_equal(gu[0].view(np.uint32), ou.view(np.uint32)) and np.array_equal(gv[0].view(np.uint32), ov.view(np.uint32))
     assert np.array_equal(gu[1].view(np.uint32), ou2.view(np.uint32)) and np.array_equal(gv[1].view(np.uint32), ov2.view(np.uint32))
+
+
+def test_short_forms_of_sqrt_and_quotient_are_exact():
+    """k_coef_lanes' sqrt (hardware estimate + the neighbour its residual asks for, without the guards for tiny / zero / infinite arguments) and c / b through the reciprocal
+    against sqrtf and the IEEE division: every one of the 2^23 significands x the binary exponents -40..40 (the kernel's arguments are >= epsilon^2 = 2^-20, its roots lie in
+    [2^-10, 2^14]), numerators = alpha / 2, delta / 2, gamma / 2 of DeepFlow's levels and of the refinement's defaults -- not one differs"""
+    import ctypes as C
+    from sindslam_amd._lib import check, lib
+    for numer in ((2.0, np.float32(0.5) / np.float32(3) / 2, np.float32(5.0) / np.float32(3) / 2), (10.0, 2.5, 5.0)):
+        out = (C.c_ulonglong * 2)(); n3 = (C.c_float * 3)(*[float(x) for x in numer])
+        check(lib().sind_debug_coef_math_scan(0, -40, 40, n3, out), "sind_debug_coef_math_scan")
+        assert out[0] == 0 and out[1] == 0, (numer, out[0], out[1])
+    out = (C.c_ulonglong * 2)(); n3 = (C.c_float * 3)(1.0, 3.0, 7.0)
+    check(lib().sind_debug_coef_math_scan(0, -96, -41, n3, out), "sind_debug_coef_math_scan"); assert out[0] == 0          # the square root down to the first argument it is made for
+    assert lib().sind_debug_coef_math_scan(0, -97, 0, n3, out) == -1
 
 
 def test_division_through_the_reciprocal_is_exact():

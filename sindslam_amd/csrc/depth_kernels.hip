@@ -877,12 +877,22 @@ __global__ void __launch_bounds__(256) k_rag_stats(const unsigned long long* __r
             unsigned long long wi = 0, wd = 0, wl = 0;
             if (c < C) { wi = planes[((size_t)0 * C + c) * pw + widx]; wd = planes[((size_t)1 * C + c) * pw + widx]; wl = planes[((size_t)2 * C + c) * pw + widx]; }
             const int cnt = min(64, C - (q << 6));
-            for (int cc = 0; cc < cnt; cc++) {
-                const unsigned long long a = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wi >> 32), cc) << 32) | (unsigned)__builtin_amdgcn_readlane((int)wi, cc);
-                const unsigned long long d = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wd >> 32), cc) << 32) | (unsigned)__builtin_amdgcn_readlane((int)wd, cc);
-                const unsigned long long l = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wl >> 32), cc) << 32) | (unsigned)__builtin_amdgcn_readlane((int)wl, cc);
-                mi[q] |= ((a >> bit) & 1ull) << cc; md[q] |= ((d >> bit) & 1ull) << cc; ml[q] |= ((l >> bit) & 1ull) << cc;
+            // lane `bit` wants bit `bit` of piece cc's words as bit cc of its own: the half of the word the lane's pixel lies in is fixed per lane, the half of the result per cc --
+            // 32-bit operations throughout (three instead of six per plane and piece: the 64-bit shifts by a lane-varying and by a uniform count were two passes each)
+            const bool upper = bit >= 32; const unsigned sh = (unsigned)bit & 31u;
+            unsigned ri[2] = {0u, 0u}, rd[2] = {0u, 0u}, rl[2] = {0u, 0u};
+            #pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int c0 = hh * 32, c1 = min(cnt, c0 + 32);
+                for (int cc = c0; cc < c1; cc++) {
+                    const unsigned alo = (unsigned)__builtin_amdgcn_readlane((int)wi, cc), ahi = (unsigned)__builtin_amdgcn_readlane((int)(wi >> 32), cc);
+                    const unsigned dlo = (unsigned)__builtin_amdgcn_readlane((int)wd, cc), dhi = (unsigned)__builtin_amdgcn_readlane((int)(wd >> 32), cc);
+                    const unsigned llo = (unsigned)__builtin_amdgcn_readlane((int)wl, cc), lhi = (unsigned)__builtin_amdgcn_readlane((int)(wl >> 32), cc);
+                    const unsigned k = (unsigned)(cc - c0);
+                    ri[hh] |= (((upper ? ahi : alo) >> sh) & 1u) << k; rd[hh] |= (((upper ? dhi : dlo) >> sh) & 1u) << k; rl[hh] |= (((upper ? lhi : llo) >> sh) & 1u) << k;
+                }
             }
+            mi[q] = ((unsigned long long)ri[1] << 32) | ri[0]; md[q] = ((unsigned long long)rd[1] << 32) | rd[0]; ml[q] = ((unsigned long long)rl[1] << 32) | rl[0];
         }
         const int dv = depthN[i];
         if (dv < 255) {

@@ -57,12 +57,16 @@ __device__ __forceinline__ int fast_score(const uint8_t* win, int stride, int id
     d[9] = v - win[idx - 3 * stride - 1];   d[10] = v - win[idx - 2 * stride - 2]; d[11] = v - win[idx - stride - 3];
     d[12] = v - win[idx - 3];               d[13] = v - win[idx + stride - 3];     d[14] = v - win[idx + 2 * stride - 2];
     d[15] = v - win[idx + 3 * stride - 1];
+    // extremes of the sixteen 9-arcs by doubling (arcs of 2, 4, 8, then 8 + 1): 64 instead of 128 comparisons per side, the same minima and maxima
+    int n2[16], x2[16], n4[16], x4[16];
+    #pragma unroll
+    for (int s = 0; s < 16; s++) { n2[s] = min(d[s], d[(s + 1) & 15]); x2[s] = max(d[s], d[(s + 1) & 15]); }
+    #pragma unroll
+    for (int s = 0; s < 16; s++) { n4[s] = min(n2[s], n2[(s + 2) & 15]); x4[s] = max(x2[s], x2[(s + 2) & 15]); }
     int A = -256, Bm = -256;
     #pragma unroll
     for (int s = 0; s < 16; s++) {
-        int mn = d[s], mx = d[s];
-        #pragma unroll
-        for (int k = 1; k < 9; k++) { const int e = d[(s + k) & 15]; mn = min(mn, e); mx = max(mx, e); }
+        const int mn = min(min(n4[s], n4[(s + 4) & 15]), d[(s + 8) & 15]), mx = max(max(x4[s], x4[(s + 4) & 15]), d[(s + 8) & 15]);
         A = max(A, mn); Bm = max(Bm, -mx);
     }
     const int best = max(A, Bm);

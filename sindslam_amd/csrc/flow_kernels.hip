@@ -861,6 +861,7 @@ __global__ void __launch_bounds__(1024) k_sor_fused4(int w, int h, int EW, int E
 #define SS_NST 7           /* staging planes: A11, A12, A22, b1, b2 and the reciprocals of A11 and A22 (formed by the loader wave) */
 typedef float ss_f4 __attribute__((ext_vector_type(4)));
 typedef float ss_f2 __attribute__((ext_vector_type(2)));
+typedef float ss_f2a __attribute__((ext_vector_type(2), aligned(4)));      // two neighbouring floats at any 4-byte address (ds_read2_b32)
 __device__ __forceinline__ void ss_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef SIND_LAB
 // lab builds: where a step's cycles go, per wave of the workgroups (0, y): [wave][0] cycles from the step's start to its barrier, [1] cycles in the barrier,
@@ -964,11 +965,14 @@ __device__ __forceinline__ void ss_item(float* lds, const int strip, const int i
         {                                                                                                                          \
             float* rb_ = (RB) + (START) * PL;                                                                                      \
             /* strip-edge horizontal neighbour: left of pixel 0 (an odd column) or right of pixel 3 (the next strip's first, even column) */ \
-            const float eu = (START) == 0 ? rb_[O_DU + PL - 1] : rb_[O_DU - PL + 2], ev = (START) == 0 ? rb_[O_DV + PL - 1] : rb_[O_DV - PL + 2]; \
+            /* ... read TOGETHER with the own pixel beside it (pixel 1 resp. pixel 2: the ring holds the thread's own values too, written a step ago), as the register pair the   \
+               packed operations take: (edge, 1) resp. (2, edge) used to be put together by two moves per plane and half-sweep */                                              \
+            const ss_f2a eup = *reinterpret_cast<const ss_f2a*>((START) == 0 ? rb_ + O_DU + PL - 1 : rb_ + O_DU - PL + 1);           \
+            const ss_f2a evp = *reinterpret_cast<const ss_f2a*>((START) == 0 ? rb_ + O_DV + PL - 1 : rb_ + O_DV - PL + 1);           \
             const float uua[2] = {UU0, UU1}, uda[2] = {UD0, UD1}, vua[2] = {VU0, VU1}, vda[2] = {VD0, VD1}, wua[2] = {WU0, WU1};     \
             /* START 0: pixels 0, 2 between (edge, 1) and (1, 3); START 1: pixels 1, 3 between (0, 2) and (2, edge) */             \
-            const float ula[2] = {(START) == 0 ? eu : R.du[0], (START) == 0 ? R.du[1] : R.du[2]}, ura[2] = {(START) == 0 ? R.du[1] : R.du[2], (START) == 0 ? R.du[3] : eu}; \
-            const float vla[2] = {(START) == 0 ? ev : R.dv[0], (START) == 0 ? R.dv[1] : R.dv[2]}, vra[2] = {(START) == 0 ? R.dv[1] : R.dv[2], (START) == 0 ? R.dv[3] : ev}; \
+            const float ula[2] = {(START) == 0 ? eup.x : R.du[0], (START) == 0 ? eup.y : R.du[2]}, ura[2] = {(START) == 0 ? R.du[1] : eup.x, (START) == 0 ? R.du[3] : eup.y}; \
+            const float vla[2] = {(START) == 0 ? evp.x : R.dv[0], (START) == 0 ? evp.y : R.dv[2]}, vra[2] = {(START) == 0 ? R.dv[1] : evp.x, (START) == 0 ? R.dv[3] : evp.y}; \
             _Pragma("unroll")                                                                                                      \
             for (int k = 0; k < 2; k++) {                                                                                          \
                 const int i = (START) + 2 * k;                                                                                     \

@@ -298,7 +298,8 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
 // 64 consecutive columns of KL_ROWS rows and loads each plane's rows ONCE (one dword per lane and row: 8 rows of the average, 6 of Iz and of each of the four flow planes for four
 // output rows: 9.5 loads per pixel); x +- 1 and x +- 2 come from the lanes to the left and right with whole-wave DPP shifts (gfx9 wave_shl / wave_shr, VALU rate), y +- 1 and
 // y +- 2 from the rows held in registers.  The two lanes at either end only feed their neighbours (60 of 64 lanes store).  Values and the order of every float operation are
-// those of kc_rows: the results are bit-identical (tests/test_flow_gpu.py compares the two kernels and both with the oracle).
+// those of kc_rows -- except that sqrt and c / sqrt take their short correctly rounded forms (kc_sqrt / kc_over_sqrt above: the same VALUES for every float) --: the results are
+// bit-identical (tests/test_flow_gpu.py compares the kernels, with and without the short forms, and all of them with the oracle).
 #define KL_ROWS 4
 #define KL_COLS 60
 __device__ __forceinline__ float lane_next(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }   // wave_shl:1 -- the value of lane + 1

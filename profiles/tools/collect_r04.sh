@@ -7,7 +7,7 @@
 #          (world size 1 with the RCCL calls, torch and C ABI), the sequence job with other warm-ups, the in-order mode's own timing
 set -o pipefail
 tag=${1:-r04}; part=${2:-all}; R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/$tag; mkdir -p $O
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-6}
 cd /tmp && export TMPDIR=/tmp
 if [ "$part" = all ] || [ "$part" = 1 ]; then
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sequence-leg > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err || exit 1

@@ -6,6 +6,6 @@ import os as _os
 
 # The pipeline drives ~45 HIP streams per handle; the runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Eight keep the flow slices'
 # launches clear of the tail streams' (measured: profiles/r04/hw_queues.txt).  Only effective when set before the HIP runtime starts; an explicit setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 
 from ._lib import SindError, SO_PATH  # noqa: F401,E402

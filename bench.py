@@ -655,7 +655,7 @@ def main():
     # HIP streams are multiplexed onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The pipeline drives ~45 streams per handle (three flow slices, ORB, one per pool
     # worker, k-means, CalOccluded, region grow) and a sequence job carries a second, small handle for the repair runs: with four queues the flow slices of a
     # stand-alone sequence job share queues with tail streams and run 17 % slower than the same job after a streams run in the same process (250 vs 208 ms of dense
-    # flow per step); with eight the two agree and the streams headline gains 3 % (profiles/r04/hw_queues.txt).  Read by the runtime when it starts: set before torch / HIP load.
+    # flow per step); with six or eight the two agree and the streams headline gains 3 %; ten and more are catastrophic (profiles/r04/hw_queues.txt).  Read by the runtime when it starts: set before torch / HIP load.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
     args.pipelined = not args.sync and not args.host_input
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

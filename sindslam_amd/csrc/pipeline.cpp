@@ -241,7 +241,9 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     }
     p->batch_occ = B >= 4 && !(sind_lab_env("SIND_OCC_BATCH") && atoi(sind_lab_env("SIND_OCC_BATCH")) == 0);
     if (p->batch_occ) {
-        p->occ_chunk = std::min(B, std::max(1, sind_lab_env("SIND_OCC_CHUNK") ? atoi(sind_lab_env("SIND_OCC_CHUNK")) : 64));
+        // frames per launch of CalOccluded's GPU half and of the region grow: 128 (profiles/r04/lab_settings_sweep.txt, 512 frames per step: 32: 1295, 64: 1438-1468, 128: 1474-1510,
+        // 192: 1506, 256: 1492, 512: 1499 pairs/s)
+        p->occ_chunk = std::min(B, std::max(1, sind_lab_env("SIND_OCC_CHUNK") ? atoi(sind_lab_env("SIND_OCC_CHUNK")) : 128));
         SIND_TRY(make_stream(&p->occ_stream, !(sind_lab_env("SIND_OCC_PRIORITY") && atoi(sind_lab_env("SIND_OCC_PRIORITY")) == 0))); SIND_TRY(p->occb.init(p->dc, p->occ_chunk));
         const size_t nblk = (size_t)(cfg->width / 16) * (cfg->height / 16); const int nch = (B + p->occ_chunk - 1) / p->occ_chunk;
         for (int k = 0; k < 2; k++) {

@@ -178,6 +178,22 @@ public:
         if (k1 < k0) return BitImg(w, h);
         return dilated_win(e, ry0, ry1, k0 - 1, k1 + 1);          // a dilation grows by less than a word: one spare word on each side
     }
+    // dilated(e).get(x, y) without the dilation: is any pixel of the element's window around (x, y) set?  (dst(x, y) = OR over the element's rows i and columns j1[i] .. j2[i] - 1
+    // of src(x + j - ax, y + i - ay), positions outside the image ignored)
+    bool dilation_hits(const EllipseElem& e, int x, int y) const {
+        for (int i = 0; i < e.n; i++) {
+            const int yy = y + i - e.ay;
+            if (yy < 0 || yy >= h || e.j2[i] <= e.j1[i]) continue;
+            const int xa = std::max(x + e.j1[i] - e.ax, 0), xb = std::min(x + e.j2[i] - e.ax, w) - 1;      // [xa, xb]
+            if (xb < xa) continue;
+            const uint64_t* r = row(yy); const int ka = xa >> 6, kb = xb >> 6;
+            for (int k = ka; k <= kb; k++) {
+                uint64_t m = ~0ull; if (k == ka) m &= ~0ull << (xa & 63); if (k == kb) m &= (xb & 63) == 63 ? ~0ull : ((1ull << ((xb & 63) + 1)) - 1);
+                if (r[k] & m) return true;
+            }
+        }
+        return false;
+    }
     // erosion: positions outside the image are ignored, i.e. erode(X) = ~dilate(~X) inside the image
     BitImg eroded(const EllipseElem& e) const { return inverted().dilated(e).inverted(); }
     // erosion of an image whose set pixels all lie in rows [y0, y1]: the result is a subset of the source, so only those rows

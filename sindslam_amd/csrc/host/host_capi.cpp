@@ -72,6 +72,12 @@ void sindh_peac(const uint16_t* depth, int w, int h, float fx, float fy, float c
     peac_plane_contours(in, pc);
     pc.to_u8(out, w, 255);
 }
+// BitImg::dilation_hits against dilated().get at n query points (test of the CalOccluded contour filter's shortcut): returns the number of disagreements
+int sindh_dilation_hits_check(const uint8_t* src, int w, int h, int elem, const int* xy, int n) {
+    const BitImg b = BitImg::from_u8(src, w, h, w); const EllipseElem e(elem); const BitImg d = b.dilated(e);
+    int bad = 0; for (int i = 0; i < n; i++) bad += d.get(xy[2 * i], xy[2 * i + 1]) != b.dilation_hits(e, xy[2 * i], xy[2 * i + 1]);
+    return bad;
+}
 // n plane fits from their moments (9 doubles each) and point counts, four at a time (peac_fit4) or one at a time (peac_fit): out = n x {centre 3, normal 3, mse}
 void sindh_peac_fits(const double* moments, const int* counts, int n, int four_lanes, double* out) {
     for (int i = 0; i < n; i += 4) {

@@ -92,6 +92,18 @@ def test_homography_identical_to_oracle(H):
     assert ok and np.array_equal(out.reshape(3, 3), ref)                         # same specification, same bits
 
 
+def test_dilation_hit_test_equals_the_dilation(H):
+    """BitImg::dilation_hits (the element's window around a query point, read from the source) == dilated().get at that point: sparse and dense random images, the 10 x 10
+    ellipse of the CalOccluded contour filter and others, query points everywhere including the borders and corners"""
+    rng = np.random.default_rng(5)
+    for w, h, dens, elem in ((640, 480, 0.0005, 10), (640, 480, 0.01, 10), (128, 96, 0.02, 7), (192, 64, 0.3, 4), (64, 40, 0.002, 15), (70, 33, 0.05, 3)):
+        img = (rng.random((h, w)) < dens).astype(np.uint8) * 255
+        pts = np.stack([rng.integers(0, w, 4000), rng.integers(0, h, 4000)], axis=1).astype(np.int32)
+        pts[:8] = [[0, 0], [w - 1, 0], [0, h - 1], [w - 1, h - 1], [w // 2, 0], [0, h // 2], [w - 1, h // 2], [w // 2, h - 1]]
+        pts = np.ascontiguousarray(pts)
+        assert H.sindh_dilation_hits_check(P(np.ascontiguousarray(img)), w, h, elem, P(pts), len(pts)) == 0, (w, h, dens, elem)
+
+
 def test_four_lane_plane_fit_equals_scalar(H):
     """peac_fit4 (the merge candidates' fits, four in the lanes of an AVX2 register) == peac_fit (one at a time, the function the device and the oracle's restatement use):
     centre, normal and MSE bit for bit -- random point sets, exactly planar and axis-aligned sets (zero pivots: rotations skipped per lane), lanes that converge after

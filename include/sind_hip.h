@@ -50,6 +50,9 @@ int sind_flow_sync(sind_flow* f);
 /* build-side option (BASELINE.json config 5, "3-level flow pyramid"; no reference counterpart -- OpenCV 4.2's DeepFlow never advances its
  * maxLayers counter): n > 0 keeps only the finest n levels of the 0.95 pyramid, the flow starts from zero at the coarsest of them; 0 = all */
 int sind_flow_set_max_levels(sind_flow* f, int n);
+/* per handle: on != 0 (default) runs every pyramid level that is one workgroup's work (<= 4096 pixels) -- warp, coefficients, SOR, W += dW and the up-sampling, for all
+ * such levels of a DeepFlow pyramid -- in ONE launch (k_coarse_chain); 0 = per-stage kernels on every level (cross-check, A/B timing).  Same bits either way. */
+int sind_flow_set_coarse_chain(sind_flow* f, int on);
 /* solver variant (process-wide; every variant returns the same bits).  Fused register-resident SOR with 1x8 pixel strips: mode 4 = divisions
  * through a reciprocal formed on the fly (hardware estimate + one Newton step, then Markstein's correction; default: 5 iterations per launch on
  * 64 x 64 tiles), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in registers (three waves per SIMD; instances for

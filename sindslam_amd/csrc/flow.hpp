@@ -45,7 +45,11 @@ extern int g_coef_lanes, g_sor_stream_wg_cap; extern int g_sor_mode, g_sor_fuse,
 int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev);
 int debug_coef_math_scan(hipStream_t s, int exp_lo, int exp_hi, const float numer[3], unsigned long long* out_dev);
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch);
-int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr);
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr, bool coarse_chain = true);
+// flow_coarse.hip: the one-workgroup levels of a pyramid (or one such level) in one launch
+int coarse_level_P(int w, int h);
+int launch_coarse_chain(hipStream_t s, FlowPlanes& Pl, const float* pyr0, const float* pyr1, const std::vector<std::pair<int, int>>& levels, const std::vector<size_t>& level_off,
+                        int first, int last, int B, const VarParams& V, bool init_zero, bool upsample_last, float post, float* out_u, float* out_v);
 int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, unsigned* maxbits, int* hist, uint8_t* out_u8, int n, int B);
 int launch_residual(hipStream_t s, const float* u, const float* v, const double H[9], float* mag, unsigned* maxbits, int* hist, uint8_t* magu8, int w, int h, bool already_zero = false);
 // hist: 257 working words (zeroed again by the kernel), res: 261 words = histogram, maximum, lo / hi / otsu / triangle
@@ -75,6 +79,7 @@ public:
     int max_levels = 0;                          // > 0: use only the finest max_levels pyramid levels, zero flow at the coarsest of them (DeepFlow's maxLayers knob made
                                                  // effective -- OpenCV 4.2 never increments its layer counter; BASELINE.json config 5 "3-level flow pyramid"); 0 = all levels
     int launch_ahead = 3;                        // pyramid levels the launching thread may be ahead of the GPU (0 = unbounded)
+    bool coarse_chain = true;                    // the one-workgroup levels (<= ~8 k pixels) run in ONE launch (k_coarse_chain); false: per-stage kernels everywhere (cross-check, A/B timing)
     ~FlowEngine() { for (hipEvent_t e : level_done) (void)hipEventDestroy(e); }
 private:
     DevBuf<float> plane_store, pyr0, pyr1;

@@ -62,17 +62,26 @@ int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, 
     V.alpha = 4 * 1.0f; V.delta = 0.5f / 3; V.gamma = 5.0f / 3; V.fixedPointIterations = 5; V.sorIterations = 25; V.omega = 1.6f;
     const float inv_scale = 1.0f / 0.95f;
     FlowPlanes& P = planes;
-    const size_t nc = (size_t)levels[L - 1].first * levels[L - 1].second * B;
-    HIP_TRY(hipMemsetAsync(P.Wu, 0, nc * sizeof(float), stream));
-    HIP_TRY(hipMemsetAsync(P.Wv, 0, nc * sizeof(float), stream));
+    // the coarsest levels that are one workgroup's work each go through ONE launch (flow_coarse.hip), which leaves the flow up-sampled to the first level above them
+    int lc = L;
+    if (coarse_chain && V.epsilon >= 1e-12f) while (lc > 0 && L - lc < 32 && coarse_level_P(levels[lc - 1].first, levels[lc - 1].second)) lc--;
+    while ((int)level_done.size() < L) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); level_done.push_back(ev); }
+    if (lc < L) {
+        SIND_TRY(launch_coarse_chain(stream, P, pyr0.p, pyr1.p, levels, level_off, L - 1, lc, B, V, true, lc > 0, inv_scale, P.dWu2, P.dWv2));
+        if (lc > 0) { std::swap(P.Wu, P.dWu2); std::swap(P.Wv, P.dWv2); }
+        for (int l = L - 1; l >= lc; --l) HIP_TRY(hipEventRecord(level_done[l], stream));
+    } else {
+        const size_t nc = (size_t)levels[L - 1].first * levels[L - 1].second * B;
+        HIP_TRY(hipMemsetAsync(P.Wu, 0, nc * sizeof(float), stream));
+        HIP_TRY(hipMemsetAsync(P.Wv, 0, nc * sizeof(float), stream));
+    }
     // One level is ~36 launches.  A thread that enqueues the whole pyramid runs far ahead of the GPU, fills the queue and then SPINS inside
     // the launch call for the rest of the solve (measured: a slice thread burnt a full core, 215 ms per step); so the thread stays at
     // most `launch_ahead` levels ahead and sleeps on the level events instead.
-    while ((int)level_done.size() < L) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); level_done.push_back(ev); }
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = lc - 1; l >= 0; --l) {
         const int w = levels[l].first, h = levels[l].second;
         if (launch_ahead > 0 && l + launch_ahead < L) HIP_TRY(sind_event_wait(level_done[l + launch_ahead]));
-        SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V, &sor_timer));
+        SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V, &sor_timer, coarse_chain));
         HIP_TRY(hipEventRecord(level_done[l], stream));
         if (l > 0) {
             const int nw = levels[l - 1].first, nh = levels[l - 1].second;
@@ -99,7 +108,7 @@ int FlowEngine::varref_f32(const float* I0, const float* I1, int w, int h, int B
     const size_t n = (size_t)w * h * B;
     HIP_TRY(hipMemcpyAsync(planes.Wu, u, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(planes.Wv, v, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    SIND_TRY(varref_level(stream, planes, I0, I1, w, h, B, V, &sor_timer));
+    SIND_TRY(varref_level(stream, planes, I0, I1, w, h, B, V, &sor_timer, coarse_chain));
     HIP_TRY(hipMemcpyAsync(u, planes.Wu, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(v, planes.Wv, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return SIND_OK;

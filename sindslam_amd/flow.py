@@ -29,6 +29,10 @@ class FlowStage:
         """finest n levels of the 0.95 pyramid only (BASELINE.json config 5, "3-level flow pyramid"); 0 = the full pyramid of OpenCV's DeepFlow"""
         check(lib().sind_flow_set_max_levels(self._h, int(n)), "sind_flow_set_max_levels")
 
+    def set_coarse_chain(self, on: bool):
+        """the one-workgroup pyramid levels in one launch (default) or through the per-stage kernels (cross-check); same bits"""
+        check(lib().sind_flow_set_coarse_chain(self._h, 1 if on else 0), "sind_flow_set_coarse_chain")
+
     def close(self):
         if getattr(self, "_h", None):
             lib().sind_flow_destroy(self._h); self._h = None

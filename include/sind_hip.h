@@ -53,6 +53,9 @@ int sind_flow_set_max_levels(sind_flow* f, int n);
 /* per handle: on != 0 (default) runs every pyramid level that is one workgroup's work (<= 4096 pixels) -- warp, coefficients, SOR, W += dW and the up-sampling, for all
  * such levels of a DeepFlow pyramid -- in ONE launch (k_coarse_chain); 0 = per-stage kernels on every level (cross-check, A/B timing).  Same bits either way. */
 int sind_flow_set_coarse_chain(sind_flow* f, int on);
+/* per handle: on != 0 (default) solves a tiled level whose tiles all find a compute unit of their own (few images per launch: the launch is latency-bound) with 1024-thread
+ * tiles and up to 13 iterations per launch on deeper halos (k_sor_tile); 0 = the 512-thread tiles / streaming kernel at every batch size.  Same bits either way. */
+int sind_flow_set_latency_tiles(sind_flow* f, int on);
 /* solver variant (process-wide; every variant returns the same bits).  Fused register-resident SOR with 1x8 pixel strips: mode 4 = divisions
  * through a reciprocal formed on the fly (hardware estimate + one Newton step, then Markstein's correction; default: 5 iterations per launch on
  * 64 x 64 tiles), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in registers (three waves per SIMD; instances for

@@ -44,10 +44,14 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 extern int g_coef_lanes, g_sor_stream_wg_cap; extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd, g_sor_tile_h, g_sor_stream_min_b, g_sor_stream_min_px; extern double g_sor_plan_cost;
 int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev);
 int debug_coef_math_scan(hipStream_t s, int exp_lo, int exp_hi, const float numer[3], unsigned long long* out_dev);
-int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch);
-int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr, bool coarse_chain = true);
+int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, bool latency_tiles = false);
+#define FLOW_OPT_COARSE_CHAIN 1      /* levels of <= 4096 pixels: the whole level (all of them, in a pyramid) in one launch (flow_coarse.hip) */
+#define FLOW_OPT_LATENCY_TILES 2     /* tiled levels with a compute unit per tile (few images): 1024-thread tiles, up to 13 iterations per launch (k_sor_tile) */
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr, int opts = FLOW_OPT_COARSE_CHAIN | FLOW_OPT_LATENCY_TILES);
 // flow_coarse.hip: the one-workgroup levels of a pyramid (or one such level) in one launch
 int coarse_level_P(int w, int h);
+int launch_sor_tile(hipStream_t s, FlowPlanes& P, int w, int h, int B, int iters, float omega);
+int sor_tile_count(int w, int h, int iters);
 int launch_coarse_chain(hipStream_t s, FlowPlanes& Pl, const float* pyr0, const float* pyr1, const std::vector<std::pair<int, int>>& levels, const std::vector<size_t>& level_off,
                         int first, int last, int B, const VarParams& V, bool init_zero, bool upsample_last, float post, float* out_u, float* out_v);
 int launch_mag_stats(hipStream_t s, const float* u, const float* v, float* mag, unsigned* maxbits, int* hist, uint8_t* out_u8, int n, int B);
@@ -79,6 +83,8 @@ public:
     int max_levels = 0;                          // > 0: use only the finest max_levels pyramid levels, zero flow at the coarsest of them (DeepFlow's maxLayers knob made
                                                  // effective -- OpenCV 4.2 never increments its layer counter; BASELINE.json config 5 "3-level flow pyramid"); 0 = all levels
     int launch_ahead = 3;                        // pyramid levels the launching thread may be ahead of the GPU (0 = unbounded)
+    bool latency_tiles = true;                   // tiled levels of few images: 1024-thread tiles and deep halos (k_sor_tile) where every tile has a compute unit to itself
+    int opts() const { return (coarse_chain ? FLOW_OPT_COARSE_CHAIN : 0) | (latency_tiles ? FLOW_OPT_LATENCY_TILES : 0); }
     bool coarse_chain = true;                    // the one-workgroup levels (<= ~8 k pixels) run in ONE launch (k_coarse_chain); false: per-stage kernels everywhere (cross-check, A/B timing)
     ~FlowEngine() { for (hipEvent_t e : level_done) (void)hipEventDestroy(e); }
 private:

@@ -194,6 +194,120 @@ __global__ void __launch_bounds__(CL_NT) k_coarse_chain(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Tiled levels when the launch is LATENCY-bound (few images: every tile of the launch has a compute unit to itself).  k_sor_fused's scheme -- an extended tile per workgroup,
+// `iters` iterations per launch inside a halo of 2 * iters pixels, ping-pong between two increment buffers -- at the granularity of the chain kernel above: 64 x 64 extended
+// tiles of 1024 threads (1 x 4 strips, two pixel updates per thread and half-sweep instead of four; system, reciprocals and neighbour weights in registers).  A launch costs
+// ~6 us before its first iteration whatever it does afterwards, and idle compute units make redundant halo work free, so the plan (sor_iterations) runs MORE iterations per
+// launch on deeper halos -- 13 + 12 instead of 5 x 5 where the tiles still fit the chip.  Same arithmetic per pixel update, same bits.
+#define ST_E 64                      /* extended tile edge */
+#define ST_P 2
+#define ST_SW (ST_E / (2 * ST_P))    /* strips per row */
+#define ST_PL 40                     /* floats per plane and row: 2 guard floats, 32 cells, guard */
+#define ST_RS (4 * ST_PL + 16)       /* row stride: rows two apart (a wave's next 16 lanes) fall into the other half of the 64 banks */
+__global__ void __launch_bounds__(1024) k_sor_tile(int w, int h, int IW, int IH, int halo, int ntx, int iters, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
+                                                   const float* __restrict__ gA22, const float* __restrict__ gB1, const float* __restrict__ gB2, const float* __restrict__ gW,
+                                                   const float* __restrict__ gUin, const float* __restrict__ gVin, float* __restrict__ gUout, float* __restrict__ gVout) {
+    constexpr int P = ST_P, NP = 2 * P;
+    typedef ClVec<P>::T VT;
+    __shared__ float4 lds4[(ST_E + 2) * ST_RS / 4];
+    float* lds = reinterpret_cast<float*>(lds4);
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const size_t base = (size_t)blockIdx.y * w * h;
+    const int tx = tile % ntx, ty = tile / ntx;
+    const int ex0 = tx * IW - halo, ey0 = ty * IH - halo;          // origin of the extended tile in the image (may be negative)
+    const bool lowh = tid < 512; const int idx = tid & 511, r2 = idx / ST_SW, j = idx - r2 * ST_SW;
+    const int s0 = __builtin_amdgcn_readfirstlane(lowh ? 0 : 1), ly = 2 * r2 + s0, x0 = NP * j;
+    const int gy = ey0 + ly, gx0 = ex0 + x0;
+    const int off = (ex0 + ey0) & 1;                               // local parity of the globally red pixels
+    float a11[NP], a12[NP], a22[NP], b1[NP], b2[NP], wp[NP], wu[NP], r11[NP], r22[NP], du[NP], dv[NP];
+    float wl0 = 0.f; unsigned valid = 0;
+    #pragma unroll
+    for (int i = 0; i < NP; i++) { a11[i] = 1.f; a12[i] = 0.f; a22[i] = 1.f; b1[i] = 0.f; b2[i] = 0.f; wp[i] = 0.f; wu[i] = 0.f; r11[i] = 0.f; r22[i] = 0.f; du[i] = 0.f; dv[i] = 0.f; }
+    const bool row_ok = gy >= 0 && gy < h;
+    if (row_ok && gx0 >= 0 && gx0 + NP <= w) {                     // whole strip inside the image: 16-byte loads
+        const size_t g = base + (size_t)gy * w + gx0;
+        valid = 0xfu;
+        #define ST_LD(PL, D) { const F4u t_ = *reinterpret_cast<const F4u*>(PL + g); D[0] = t_.x; D[1] = t_.y; D[2] = t_.z; D[3] = t_.w; }
+        ST_LD(gA11, a11) ST_LD(gA12, a12) ST_LD(gA22, a22) ST_LD(gB1, b1) ST_LD(gB2, b2) ST_LD(gW, wp) ST_LD(gUin, du) ST_LD(gVin, dv)
+        if (gy > 0) { const F4u t_ = *reinterpret_cast<const F4u*>(gW + g - w); wu[0] = t_.x; wu[1] = t_.y; wu[2] = t_.z; wu[3] = t_.w; }
+        #undef ST_LD
+    } else if (row_ok) {
+        #pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int gx = gx0 + i;
+            if (gx >= 0 && gx < w) {
+                const size_t g = base + (size_t)gy * w + gx;
+                valid |= 1u << i;
+                a11[i] = gA11[g]; a12[i] = gA12[g]; a22[i] = gA22[g]; b1[i] = gB1[g]; b2[i] = gB2[g]; wp[i] = gW[g]; du[i] = gUin[g]; dv[i] = gVin[g];
+                if (gy > 0) wu[i] = gW[g - w];
+            }
+        }
+    }
+    if (row_ok && gx0 - 1 >= 0 && gx0 - 1 < w) wl0 = gW[base + (size_t)gy * w + gx0 - 1];
+    // a pixel outside the image keeps the reciprocal 0: its update returns exactly 0, with no select in the loop
+    #pragma unroll
+    for (int i = 0; i < NP; i++) if ((valid >> i) & 1u) { r11[i] = sor_rcp(a11[i]); r22[i] = sor_rcp(a22[i]); }
+    for (int i = tid; i < (ST_E + 2) * ST_RS / 4; i += 1024) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);      // guards (and everything else, overwritten below)
+    cl_sync_lds();
+    float* const rM = lds + (ly + 1) * ST_RS + P + P * j; float* const rU = rM - ST_RS; float* const rD = rM + ST_RS;
+    *reinterpret_cast<VT*>(rM + (2 * s0 + 0) * ST_PL) = cl_pack<P>(du); *reinterpret_cast<VT*>(rM + (2 * s0 + 1) * ST_PL) = cl_pack<P>(dv);
+    *reinterpret_cast<VT*>(rM + (2 * (s0 ^ 1) + 0) * ST_PL) = cl_pack<P>(du + 1); *reinterpret_cast<VT*>(rM + (2 * (s0 ^ 1) + 1) * ST_PL) = cl_pack<P>(dv + 1);
+    cl_sync_lds();
+    #define ST_HALF(START, Q)                                                                                                     \
+        {                                                                                                                         \
+            constexpr int oq = (Q) ^ 1;                                                                                           \
+            float uu[P], vu[P], ud[P], vd[P];                                                                                     \
+            cl_unpack<P>(*reinterpret_cast<const VT*>(rU + (2 * oq + 0) * ST_PL), uu); cl_unpack<P>(*reinterpret_cast<const VT*>(rU + (2 * oq + 1) * ST_PL), vu); \
+            cl_unpack<P>(*reinterpret_cast<const VT*>(rD + (2 * oq + 0) * ST_PL), ud); cl_unpack<P>(*reinterpret_cast<const VT*>(rD + (2 * oq + 1) * ST_PL), vd); \
+            const float eu = rM[(2 * oq + 0) * ST_PL + ((START) == 0 ? -1 : P)], ev = rM[(2 * oq + 1) * ST_PL + ((START) == 0 ? -1 : P)]; \
+            _Pragma("unroll")                                                                                                     \
+            for (int k = 0; k < P; k++) {                                                                                         \
+                const int i = (START) + 2 * k;                                                                                    \
+                const float wl = i == 0 ? wl0 : wp[i == 0 ? 0 : i - 1];                                                           \
+                const float ul = i == 0 ? eu : du[i == 0 ? 0 : i - 1], vl = i == 0 ? ev : dv[i == 0 ? 0 : i - 1];                \
+                const float ur = i == NP - 1 ? eu : du[i == NP - 1 ? NP - 1 : i + 1], vr = i == NP - 1 ? ev : dv[i == NP - 1 ? NP - 1 : i + 1]; \
+                const float sigmaU = wl * ul + wp[i] * ur + wu[i] * uu[k] + wp[i] * ud[k];                                        \
+                const float sigmaV = wl * vl + wp[i] * vr + wu[i] * vu[k] + wp[i] * vd[k];                                        \
+                float nu = du[i], nv = dv[i];                                                                                     \
+                nu += omega * (sor_div(sigmaU + b1[i] - nv * a12[i], a11[i], r11[i]) - nu);                                       \
+                nv += omega * (sor_div(sigmaV + b2[i] - nu * a12[i], a22[i], r22[i]) - nv);                                       \
+                du[i] = nu; dv[i] = nv;                                                                                           \
+            }                                                                                                                     \
+            *reinterpret_cast<VT*>(rM + (2 * (Q) + 0) * ST_PL) = cl_pack<P>(du + (START));                                        \
+            *reinterpret_cast<VT*>(rM + (2 * (Q) + 1) * ST_PL) = cl_pack<P>(dv + (START));                                        \
+        }
+    // the globally red pixels have local parity `off`; in this thread's row the pixels of local parity Q are the strip pixels i == Q ^ s0 (mod 2); both are scalars
+    if (off == 0) {
+        if (s0 == 0) for (int it = 0; it < iters; it++) { ST_HALF(0, 0) cl_sync_lds(); ST_HALF(1, 1) cl_sync_lds(); }
+        else         for (int it = 0; it < iters; it++) { ST_HALF(1, 0) cl_sync_lds(); ST_HALF(0, 1) cl_sync_lds(); }
+    } else {
+        if (s0 == 0) for (int it = 0; it < iters; it++) { ST_HALF(1, 1) cl_sync_lds(); ST_HALF(0, 0) cl_sync_lds(); }
+        else         for (int it = 0; it < iters; it++) { ST_HALF(0, 1) cl_sync_lds(); ST_HALF(1, 0) cl_sync_lds(); }
+    }
+    #undef ST_HALF
+    const int ix0 = tx * IW, iy0 = ty * IH;
+    if (row_ok && gy >= iy0 && gy < iy0 + IH) {
+        const size_t g = base + (size_t)gy * w + gx0;
+        if (valid == 0xfu && gx0 >= ix0 && gx0 + NP <= ix0 + IW) {
+            *reinterpret_cast<F4u*>(gUout + g) = F4u{du[0], du[1], du[2], du[3]}; *reinterpret_cast<F4u*>(gVout + g) = F4u{dv[0], dv[1], dv[2], dv[3]};
+        } else {
+            #pragma unroll
+            for (int i = 0; i < NP; i++) if (((valid >> i) & 1u) && gx0 + i >= ix0 && gx0 + i < ix0 + IW) { gUout[g + i] = du[i]; gVout[g + i] = dv[i]; }
+        }
+    }
+}
+// `iters` iterations of one launch over the B images of a level: grid (tiles, B)
+int launch_sor_tile(hipStream_t s, FlowPlanes& P, int w, int h, int B, int iters, float omega) {
+    const int halo = 2 * iters, IW = ST_E - 2 * halo, IH = ST_E - 2 * halo;
+    if (iters < 1 || IW < 4) { sind_set_error("launch_sor_tile: %d iterations per launch do not fit a %d-pixel tile", iters, ST_E); return SIND_E_ARG; }
+    const int ntx = divup(w, IW), nty = divup(h, IH);
+    hipLaunchKernelGGL(k_sor_tile, dim3(ntx * nty, B), dim3(1024), 0, s, w, h, IW, IH, halo, ntx, iters, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
+    std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);
+    return SIND_OK;
+}
+int sor_tile_count(int w, int h, int iters) { const int I = ST_E - 4 * iters; return I < 4 ? (1 << 30) : divup(w, I) * divup(h, I); }
+
 // P for a level, or 0 if the level is not one workgroup's work in the chain kernel
 int coarse_level_P(int w, int h) {
     // (P = 4 -- eight pixels per thread, the levels of 4 k to 8 k pixels -- holds 88 persistent registers per thread and spills at 128: those levels keep the per-stage kernels)

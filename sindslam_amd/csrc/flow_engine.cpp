@@ -81,7 +81,7 @@ int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, 
     for (int l = lc - 1; l >= 0; --l) {
         const int w = levels[l].first, h = levels[l].second;
         if (launch_ahead > 0 && l + launch_ahead < L) HIP_TRY(sind_event_wait(level_done[l + launch_ahead]));
-        SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V, &sor_timer, coarse_chain));
+        SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V, &sor_timer, opts()));
         HIP_TRY(hipEventRecord(level_done[l], stream));
         if (l > 0) {
             const int nw = levels[l - 1].first, nh = levels[l - 1].second;
@@ -108,7 +108,7 @@ int FlowEngine::varref_f32(const float* I0, const float* I1, int w, int h, int B
     const size_t n = (size_t)w * h * B;
     HIP_TRY(hipMemcpyAsync(planes.Wu, u, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(planes.Wv, v, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    SIND_TRY(varref_level(stream, planes, I0, I1, w, h, B, V, &sor_timer, coarse_chain));
+    SIND_TRY(varref_level(stream, planes, I0, I1, w, h, B, V, &sor_timer, opts()));
     HIP_TRY(hipMemcpyAsync(u, planes.Wu, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(v, planes.Wv, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return SIND_OK;

@@ -1485,7 +1485,22 @@ static std::vector<int> sor_fuse_plan(int w, int h, int EW, int EH, int total) {
     cache[key] = plan;
     return plan;
 }
-int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch) {
+// Few images: the launch is latency-bound (a tile per compute unit, most of the chip idle).  Then 1024-thread tiles (k_sor_tile) run MORE iterations per launch on deeper
+// halos: the fewest launches whose tiles all still find a compute unit of their own (a launch costs ~6 us before its first iteration; an iteration ~0.8 us).
+// Returns the iterations of each launch, or nothing if the level at this batch size is throughput-bound (the kernels below).
+static std::vector<int> sor_latency_plan(int w, int h, int B, int total) {
+    const int slots = 256;                                   // compute units: one 1024-thread workgroup each
+    for (int n = 1; n <= total; n++) {
+        const int base = total / n, rem = total % n, kmax = base + (rem ? 1 : 0);
+        if (kmax > 13) continue;                             // 64 - 4 k >= 12 kept pixels per tile edge
+        if ((long long)sor_tile_count(w, h, kmax) * B > slots) { if (kmax <= 5) break; continue; }
+        std::vector<int> plan((size_t)n, base);
+        for (int i = 0; i < rem; i++) plan[(size_t)i]++;
+        return plan;
+    }
+    return {};
+}
+int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, bool latency_tiles) {
     if (g_sor_mode == 0) {
         const dim3 gs(divup(divup(w, 2), 64), h, B), bs(64);
         for (int k = 0; k < total; k++) {
@@ -1507,6 +1522,13 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         for (const void* f : fs) if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         return attr_rc;
     }));
+    if (latency_tiles && (g_sor_mode == 4 || g_sor_mode == 5)) {
+        const std::vector<int> plan = sor_latency_plan(w, h, B, total);
+        if (!plan.empty() && !(plan.size() > 1 && 2 * divup(divup(w, 8) * ((h + 1) / 2), 64) * 64 <= 512)) {      // (a level of <= 4096 pixels that is not in the chain: one launch of the one-workgroup kernel below is as good)
+            for (int k : plan) { SIND_TRY(launch_sor_tile(s, P, w, h, B, k, omega)); *nlaunch += 1; }
+            return SIND_OK;
+        }
+    }
     auto sor_lds_bytes = [](int EW, int nt) { const int NR = 2 * ((nt / 2) / (EW / SOR_PX)); return (size_t)6 * (NR + 2) * sor_row_stride(EW) * sizeof(float4); };
     auto threads_for = [](int EW, int EH) { const int halfn = (EW / SOR_PX) * ((EH + 1) / 2); return 2 * ((halfn + 63) / 64 * 64); };
     const int EWw = (w + SOR_PX - 1) / SOR_PX * SOR_PX;
@@ -1590,7 +1612,8 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
 }
 
 // VariationalRefinement::calcUV on one pyramid level for B pairs.  Wu/Wv: initial flow in, refined flow out.
-int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer, bool coarse_chain) {
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer, int opts) {
+    const bool coarse_chain = (opts & FLOW_OPT_COARSE_CHAIN) != 0, latency_tiles = (opts & FLOW_OPT_LATENCY_TILES) != 0;
     if (coarse_chain && V.epsilon >= 1e-12f && g_sor_mode != 0 && coarse_level_P(w, h)) {       // one workgroup's work: the whole level in one launch (flow_coarse.hip)
         const std::vector<std::pair<int, int>> lv{{w, h}}; const std::vector<size_t> off{0};
         return launch_coarse_chain(s, P, I0, I1, lv, off, 0, 0, B, V, false, false, 1.f, nullptr, nullptr);
@@ -1607,7 +1630,7 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
                                P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr);
         if (timer) timer->begin(s);
         long long nlaunch = 0;
-        SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch));
+        SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch, latency_tiles));
         // algorithmic bytes: 44 B per pixel per red+black iteration (9 reads + 2 writes of f32), SURVEY.md §8d
         if (timer) timer->end(s, nlaunch, 44.0 * (double)w * h * B * V.sorIterations);
     }

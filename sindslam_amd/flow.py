@@ -33,6 +33,10 @@ class FlowStage:
         """the one-workgroup pyramid levels in one launch (default) or through the per-stage kernels (cross-check); same bits"""
         check(lib().sind_flow_set_coarse_chain(self._h, 1 if on else 0), "sind_flow_set_coarse_chain")
 
+    def set_latency_tiles(self, on: bool):
+        """tiled levels of few images through the 1024-thread tiles with deep halos (default) or the throughput kernels (cross-check); same bits"""
+        check(lib().sind_flow_set_latency_tiles(self._h, 1 if on else 0), "sind_flow_set_latency_tiles")
+
     def close(self):
         if getattr(self, "_h", None):
             lib().sind_flow_destroy(self._h); self._h = None

@@ -95,13 +95,13 @@ def test_deepflow_384x288_chain_equals_per_stage_and_oracle(fs, frames):
     bgr, _ = frames
     g2 = O.resize_u8(O.bgr2gray(bgr[1]), 384, 288)
     i0 = np.stack([g0, g1, g0]); i1 = np.stack([g1, g0, g2])
-    fs.set_coarse_chain(True)
+    fs.set_coarse_chain(True); fs.set_latency_tiles(True)
     u, v = fs.deepflow(i0, i1)
     try:
-        fs.set_coarse_chain(False)
+        fs.set_coarse_chain(False); fs.set_latency_tiles(False)
         su, sv = fs.deepflow(i0, i1)
     finally:
-        fs.set_coarse_chain(True)
+        fs.set_coarse_chain(True); fs.set_latency_tiles(True)
     assert np.array_equal(u.view(np.uint32), su.view(np.uint32)) and np.array_equal(v.view(np.uint32), sv.view(np.uint32))
     o = O.deepflow(g0, g1)
     assert np.array_equal(u[0].view(np.uint32), o[..., 0].view(np.uint32)) and np.array_equal(v[0].view(np.uint32), o[..., 1].view(np.uint32))
@@ -116,8 +116,42 @@ def test_deepflow_768x432_chain_equals_per_stage():
         a = _textured_pair(768, 432, 21); b = _textured_pair(768, 432, 22)
         i0 = np.stack([a[0], b[0]]).astype(np.uint8); i1 = np.stack([a[1], b[1]]).astype(np.uint8)
         u, v = f.deepflow(i0, i1)
-        f.set_coarse_chain(False)
+        f.set_coarse_chain(False); f.set_latency_tiles(False)
         su, sv = f.deepflow(i0, i1)
         assert np.array_equal(u.view(np.uint32), su.view(np.uint32)) and np.array_equal(v.view(np.uint32), sv.view(np.uint32))
     finally:
         f.close()
+
+
+# k_sor_tile (1024-thread tiles, up to 13 iterations per launch): shapes whose plans are 13 + 12, 9 + 8 + 8, 7 + 6 + 6 + 6 and 5 x 5 iterations per launch at one to three
+# images, tiles clipped at every image border, widths that are not multiples of the 4-pixel strips, odd heights
+TILE_SHAPES = [(100, 80, 1), (104, 78, 3), (129, 67, 2), (153, 99, 1), (155, 70, 3), (300, 101, 1), (303, 65, 2), (384, 287, 1), (383, 288, 2), (384, 288, 3)]
+
+
+@pytest.mark.parametrize("w,h,B", TILE_SHAPES)
+def test_latency_tiles_equal_the_oracle(fs, w, h, B):
+    i0, i1 = _textured_pair(w, h, 7 * w + h)
+    rng = np.random.default_rng(w + 1000 * h)
+    u0 = rng.normal(0, 1.0, (h, w)).astype(np.float32); v0 = rng.normal(0, 1.0, (h, w)).astype(np.float32)
+    a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
+    ou, ov = O.varref(i0, i1, u0, v0, 5, 25, a, d, g, 1.6)
+    fs.set_latency_tiles(True)
+    gu, gv = fs.varref_f32(np.stack([i0] * B), np.stack([i1] * B), np.stack([u0] * B), np.stack([v0] * B), 5, 25, a, d, g, 1.6)
+    for b in range(B):
+        assert np.array_equal(gu[b].view(np.uint32), ou.view(np.uint32)), (w, h, b, float(np.abs(gu[b] - ou).max()))
+        assert np.array_equal(gv[b].view(np.uint32), ov.view(np.uint32)), (w, h, b, float(np.abs(gv[b] - ov).max()))
+
+
+def test_latency_tiles_refinement_defaults(fs, frames):
+    """VariationalRefinement::create()->calc at 384 x 288 (5 x 5 iterations: one launch of five per fixed-point iteration) == the throughput kernels"""
+    g0, g1 = _gray_pair(frames, 384, 288)
+    rng = np.random.default_rng(4)
+    u0 = rng.normal(0, 1.5, (1, 288, 384)).astype(np.float32); v0 = rng.normal(0, 1.5, (1, 288, 384)).astype(np.float32)
+    fs.set_latency_tiles(True)
+    u, v = fs.refine(g0[None], g1[None], u0, v0)
+    try:
+        fs.set_latency_tiles(False)
+        su, sv = fs.refine(g0[None], g1[None], u0, v0)
+    finally:
+        fs.set_latency_tiles(True)
+    assert np.array_equal(u.view(np.uint32), su.view(np.uint32)) and np.array_equal(v.view(np.uint32), sv.view(np.uint32))

@@ -112,6 +112,9 @@ typedef struct sind_dyna sind_dyna;
 int sind_dyna_create(int width, int height, float fx, float fy, float cx, float cy, float depth_scale, int device, sind_dyna** out);
 int sind_dyna_destroy(sind_dyna* d);
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n);      /* see sind_flow_set_max_levels */
+int sind_dyna_set_debug(sind_dyna* d, int on);               /* on: keep the intermediate images sind_dyna_debug reports (costs four flow-sized copies per frame); default off */
+int sind_dyna_set_overlap(sind_dyna* d, int on);             /* default on: the depth half of a frame (k-means, CalOccluded, SegAndMerge) runs beside its dense flow, as the reference's
+                                                                 flow thread runs beside the segmentation (DynaDetect.cc:1396-1398); 0 = one after the other; same results */
 int sind_dyna_prime(sind_dyna* d, const uint8_t* bgr_last, const uint8_t* bgr_lastlast, int stride);
 int sind_dyna_detect(sind_dyna* d, const uint8_t* bgr, int bgr_stride, const uint16_t* depth, int depth_stride,
                      uint8_t* dyna_out, uint8_t* label_out, int n_img);

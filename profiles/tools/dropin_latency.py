@@ -17,7 +17,7 @@ pp = lambda f: (f % (2 * P - 2)) if (f % (2 * P - 2)) < P else 2 * P - 2 - (f % 
 gray = [((b[..., 0].astype(np.int32) * 4899 + b[..., 1].astype(np.int32) * 9617 + b[..., 2].astype(np.int32) * 1868 + 8192) >> 14).astype(np.uint8) for b in bgr]   # Tracking.cc:246 (caller side)
 out = {}
 if "--flow-only" not in sys.argv:
-    gpu = DynaDetect(bgr[1], bgr[0], TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    gpu = DynaDetect(bgr[1], bgr[0], TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"], debug=False, overlap="--no-overlap" not in sys.argv)
     orb = ORBextractor(1500, 1.2, 8, TUM3["ini_th"], TUM3["min_th"])
     td, tm, to = [], [], []
     for f in range(2, 2 + n + 10):

@@ -5,11 +5,15 @@
 #include "peac_grow.hpp"
 
 struct sind_dyna {
-    sind::DynaConfig cfg; hipStream_t stream = nullptr; sind::DynaFront front; sind::DynaTail tail;
+    sind::DynaConfig cfg; hipStream_t stream = nullptr, tail_stream = nullptr; hipEvent_t flow_done = nullptr; sind::DynaFront front; sind::DynaTail tail;
     DevBuf<uint8_t> bgr, gray, pool, dil_a, dil_b; DevBuf<uint16_t> depth; DevBuf<float> U, V;
-    int t = 0; bool primed = false; int largeMotion = 0;
+    PinnedBuf<uint16_t> depth_h; PinnedBuf<uint8_t> bgr_h, dil_h;       // page-locked staging of the caller's frames (a copy from pageable memory is staged by the runtime and blocks the call)
+    int t = 0; bool primed = false; int largeMotion = 0; bool debug = false, overlap = true;
     std::vector<float> deep, refined;
 };
+#include <string>
+#include <thread>
+namespace { struct SpinScope { int keep; SpinScope() : keep(t_sind_spin_us) { t_sind_spin_us = 2000; } ~SpinScope() { t_sind_spin_us = keep; } }; }      // one camera, idle host: poll before sleeping (common.hpp)
 
 namespace sind { extern int g_km_fused_max, g_km_fused_min_batch; }       // depth_kernels.hip
 extern "C" {
@@ -20,8 +24,15 @@ int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float
     sind_dyna* d = new sind_dyna();
     d->cfg.W = w; d->cfg.H = h; d->cfg.fx = fx; d->cfg.fy = fy; d->cfg.cx = cx; d->cfg.cy = cy; d->cfg.depthScale = ds; d->cfg.device = device;
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { delete d; sind_set_error("sind_dyna_create: hipStreamCreate failed"); return SIND_E_HIP; }
+    // the depth half of a frame (k-means, CalOccluded, SegAndMerge: everything that does not need the flow) runs on its own stream and host thread beside the dense flow, as
+    // the reference runs its flow thread beside the segmentation (DynaDetect.cc:1396-1398, 1553-1554)
+    if (hipStreamCreateWithFlags(&d->tail_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->flow_done, hipEventDisableTiming) != hipSuccess) {
+        hipStream_t a = d->stream, b = d->tail_stream; delete d; (void)hipStreamDestroy(a); if (b) (void)hipStreamDestroy(b); sind_set_error("sind_dyna_create: hipStreamCreate failed"); return SIND_E_HIP; }
     int r = d->front.init(d->cfg, 1, d->stream);
-    if (r == SIND_OK) r = d->tail.init(d->cfg, d->stream);
+    if (r == SIND_OK) r = d->tail.init(d->cfg, d->tail_stream);
+    if (r == SIND_OK) r = d->depth_h.alloc((size_t)w * h);
+    if (r == SIND_OK) r = d->bgr_h.alloc((size_t)w * h * 3);
+    if (r == SIND_OK) r = d->dil_h.alloc((size_t)w * h);
     const size_t np = (size_t)w * h;
     if (r == SIND_OK) r = d->bgr.alloc(np * 3);
     if (r == SIND_OK) r = d->gray.alloc(np);
@@ -31,8 +42,8 @@ int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float
     if (r == SIND_OK) r = d->V.alloc(np);
     if (r == SIND_OK) r = d->dil_a.alloc(np);
     if (r == SIND_OK) r = d->dil_b.alloc(np);
-    if (r != SIND_OK) { hipStream_t st = d->stream; delete d; (void)hipStreamDestroy(st); return r; }
-    d->tail.keep_debug = true;
+    if (r != SIND_OK) { hipStream_t st = d->stream, ts = d->tail_stream; hipEvent_t ev = d->flow_done; delete d; (void)hipStreamDestroy(st); (void)hipStreamDestroy(ts); (void)hipEventDestroy(ev); return r; }
+    d->tail.keep_debug = false; d->tail.piece_threads = 4;      // (one camera per handle: the host cores are idle while a frame is in flight)
     *out = d; return SIND_OK;
 }
 int sind_debug_seqsum(const float* x, int n, int device, float* out) {
@@ -45,17 +56,25 @@ int sind_debug_seqsum(const float* x, int n, int device, float* out) {
 // parity-test / A-B access: k-means levels of at most n points run in the fused one-launch kernel (default 81920; 0 = the per-pass kernels everywhere).  Process-wide.
 int sind_debug_set_kmeans_fused_max(int n) { if (n < 0) return SIND_E_ARG; sind::g_km_fused_max = n; return SIND_OK; }
 int sind_debug_set_kmeans_fused_min_batch(int b) { if (b < 1) return SIND_E_ARG; sind::g_km_fused_min_batch = b; return SIND_OK; }
+// debug != 0: keep what sind_dyna_debug reports (intermediate images of every stage, the raw and refined flow copied back every frame); off by default
+int sind_dyna_set_debug(sind_dyna* d, int on) { if (!d) return SIND_E_ARG; d->debug = on != 0; d->tail.keep_debug = d->debug; return SIND_OK; }
+// overlap != 0 (default): the depth half of a frame runs beside its dense flow (own stream, own host thread); 0 = one after the other.  Same results.
+int sind_dyna_set_overlap(sind_dyna* d, int on) { if (!d) return SIND_E_ARG; d->overlap = on != 0; return SIND_OK; }
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n) { if (!d || n < 0) return SIND_E_ARG; d->front.flow.max_levels = n; return SIND_OK; }
 int sind_dyna_destroy(sind_dyna* d) {
     if (!d) return SIND_OK;
     (void)hipSetDevice(d->cfg.device);
-    hipStream_t s = d->stream; if (s) (void)hipStreamSynchronize(s);
-    delete d; if (s) (void)hipStreamDestroy(s);
+    hipStream_t s = d->stream, ts = d->tail_stream; hipEvent_t ev = d->flow_done;
+    if (s) (void)hipStreamSynchronize(s);
+    if (ts) (void)hipStreamSynchronize(ts);
+    delete d; if (s) (void)hipStreamDestroy(s); if (ts) (void)hipStreamDestroy(ts); if (ev) (void)hipEventDestroy(ev);
     return SIND_OK;
 }
 static int upload_bgr(sind_dyna* d, const uint8_t* bgr, int stride, int slot) {
     const int w = d->cfg.W, h = d->cfg.H;
-    HIP_TRY(hipMemcpy2DAsync(d->bgr.p, (size_t)w * 3, bgr, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));            // (the staging buffer of the previous upload is free)
+    for (int y = 0; y < h; y++) std::memcpy(d->bgr_h.p + (size_t)y * w * 3, bgr + (size_t)y * stride, (size_t)w * 3);
+    HIP_TRY(hipMemcpyAsync(d->bgr.p, d->bgr_h.p, (size_t)w * h * 3, hipMemcpyHostToDevice, d->stream));
     return d->front.gray_and_min(d->bgr.p, 1, d->gray.p, d->pool.p + (size_t)d->front.fw * d->front.fh * slot);
 }
 int sind_dyna_prime(sind_dyna* d, const uint8_t* last, const uint8_t* lastlast, int stride) {
@@ -76,14 +95,26 @@ int sind_dyna_detect(sind_dyna* d, const uint8_t* bgr, int bstride, const uint16
     if (bstride <= 0) bstride = w * 3;
     if (dstride <= 0) dstride = w * 2;
     const int cur = d->t % 3, p1 = (d->t + 2) % 3, p2 = (d->t + 1) % 3;
+    SpinScope spin;
     SIND_TRY(upload_bgr(d, bgr, bstride, cur));
-    std::vector<uint16_t> dh((size_t)w * h);
-    for (int y = 0; y < h; y++) std::memcpy(&dh[(size_t)y * w], (const uint8_t*)depth + (size_t)y * dstride, (size_t)w * 2);
-    HIP_TRY(hipMemcpyAsync(d->depth.p, dh.data(), dh.size() * 2, hipMemcpyHostToDevice, d->stream));
+    uint16_t* dh = d->depth_h.p;
+    for (int y = 0; y < h; y++) std::memcpy(dh + (size_t)y * w, (const uint8_t*)depth + (size_t)y * dstride, (size_t)w * 2);
+    HIP_TRY(hipMemcpyAsync(d->depth.p, dh, (size_t)w * h * 2, hipMemcpyHostToDevice, d->tail_stream));      // the depth frame is the tail's input only
     const size_t nf = (size_t)d->front.fw * d->front.fh;
-    d->deep.resize(nf * 2); d->refined.resize(nf * 2);
-    SIND_TRY(d->front.dense_flow(d->pool.p, &cur, &p1, &p2, 1, d->U.p, d->V.p, &d->largeMotion, d->deep.data(), d->deep.data() + nf, d->refined.data(), d->refined.data() + nf));
-    SIND_TRY(d->tail.process(dh.data(), d->depth.p, d->U.p, d->V.p, dyna_out, label_out));
+    float *du = nullptr, *dv = nullptr, *ru = nullptr, *rv = nullptr;
+    if (d->debug) { d->deep.resize(nf * 2); d->refined.resize(nf * 2); du = d->deep.data(); dv = du + nf; ru = d->refined.data(); rv = ru + nf; }
+    sind::DepthStageOut dso; int rc_depth = SIND_OK; std::string err_depth;
+    std::thread side;
+    if (d->overlap) side = std::thread([&] { SpinScope sp; rc_depth = d->tail.depth_stage(dh, d->depth.p, nullptr, dso, nullptr); if (rc_depth != SIND_OK) err_depth = sind_last_error(); });
+    const int rc_flow = d->front.dense_flow(d->pool.p, &cur, &p1, &p2, 1, d->U.p, d->V.p, &d->largeMotion, du, dv, ru, rv);
+    if (side.joinable()) side.join();
+    SIND_TRY(rc_flow);
+    if (!d->overlap) rc_depth = d->tail.depth_stage(dh, d->depth.p, nullptr, dso, nullptr);
+    else if (rc_depth != SIND_OK) sind_set_error("%s", err_depth.c_str());
+    SIND_TRY(rc_depth);
+    HIP_TRY(hipEventRecord(d->flow_done, d->stream));
+    HIP_TRY(hipStreamWaitEvent(d->tail_stream, d->flow_done, 0));       // the flow masks read U / V on the tail's stream
+    SIND_TRY(d->tail.flow_stage(d->U.p, d->V.p, dso, dyna_out, label_out));
     d->t++;
     return SIND_OK;
 }
@@ -91,10 +122,13 @@ int sind_dyna_dilate15(sind_dyna* d, uint8_t* io) {
     if (!d || !io) return SIND_E_ARG;
     HIP_TRY(hipSetDevice(d->cfg.device));
     const size_t np = (size_t)d->cfg.W * d->cfg.H;
-    HIP_TRY(hipMemcpyAsync(d->dil_a.p, io, np, hipMemcpyHostToDevice, d->stream));
+    SpinScope spin;
+    std::memcpy(d->dil_h.p, io, np);
+    HIP_TRY(hipMemcpyAsync(d->dil_a.p, d->dil_h.p, np, hipMemcpyHostToDevice, d->stream));
     SIND_TRY(sind::launch_morph(d->stream, d->dil_a.p, d->dil_b.p, d->cfg.W, d->cfg.H, 15, true));
-    HIP_TRY(hipMemcpyAsync(io, d->dil_b.p, np, hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(hipMemcpyAsync(d->dil_h.p, d->dil_b.p, np, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(sind_stream_wait(d->stream));
+    std::memcpy(io, d->dil_h.p, np);
     return SIND_OK;
 }
 int sind_dyna_debug(sind_dyna* d, float* flow_deep, float* flow_refined, float* flow_full, double* H9, float* thr5, int* hist256, uint8_t* mask_low,

@@ -12,13 +12,15 @@ class DynaDetect:
     """DynaDetect(imgLast, imgLastLast, fx, fy, cx, cy, depthScale); DetectDynaArea(img, imgDepth, nImg) -> (imgDyna, imgLabel)."""
 
     def __init__(self, imgLast: np.ndarray, imgLastLast: np.ndarray, fx: float, fy: float, cx: float, cy: float, depthScale: float,
-                 device: int = 0):
+                 device: int = 0, debug: bool = True, overlap: bool = True):
         assert imgLast.dtype == np.uint8 and imgLast.ndim == 3 and imgLast.shape[2] == 3, "CV_8UC3 BGR expected"
         self.h, self.w = imgLast.shape[:2]
         h = C.c_void_p()
         check(lib().sind_dyna_create(self.w, self.h, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_float(depthScale), device,
                                      C.byref(h)), "sind_dyna_create")
         self._h = h
+        check(lib().sind_dyna_set_debug(self._h, 1 if debug else 0), "sind_dyna_set_debug")        # debug(): the stage images of the last frame (off = the lean drop-in path)
+        check(lib().sind_dyna_set_overlap(self._h, 1 if overlap else 0), "sind_dyna_set_overlap")
         check(lib().sind_dyna_prime(self._h, ptr(np.ascontiguousarray(imgLast)), ptr(np.ascontiguousarray(imgLastLast)), self.w * 3), "sind_dyna_prime")
 
     def set_flow_max_levels(self, n: int):

@@ -72,6 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--repair-frames-per-step", type=int, default=4)
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
     ap.add_argument("--exact-leg-frames", type=int, default=0, help="sequence workload: frames of the in-order re-run the chunked masks are compared with (0 = chunk 0, chunks 1-2 and what else fits into 320-480 frames)")
+    ap.add_argument("--flow-slices", type=int, default=0, help="experiment: dense-flow slices of a step (sind_pipe_config.flow_slices; 0 = the library's rule by step size)")
     ap.add_argument("--pipelines", type=int, default=0, help="independent pipelines a step is cut into on one GPU (experiment; 0 = one; results do not depend on it)")
     ap.add_argument("--no-n1-leg", action="store_true", help="sequence workload on N > 1 ranks: skip the one-rank run of the same job on rank 0 after the timed region (sequence.n1_value)")
     ap.add_argument("--no-tum-leg", action="store_true", help="streams workload on one GPU: skip the TUM-length single sequence (line field `sequence_tum_length`)")
@@ -404,7 +405,7 @@ def pipelines_for(S, T, asked=0):
 def make_pipeline(cfg, intr, S, T, local, host_threads=0, parts=1):
     from sindslam_amd.pipeline import Pipeline, PipelineGroup
     a = (S, T, cfg["width"], cfg["height"], intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"])
-    kw = dict(orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=host_threads, flow_max_levels=cfg["flow_max_levels"])
+    kw = dict(orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=host_threads, flow_max_levels=cfg["flow_max_levels"], flow_slices=cfg.get("flow_slices", 0))
     return PipelineGroup(parts, *a, **kw) if parts > 1 else Pipeline(*a, **kw)
 
 
@@ -687,6 +688,7 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.flow_levels is not None:
         cfg["flow_max_levels"] = args.flow_levels
+    cfg["flow_slices"] = args.flow_slices
     if args.coef_kernel is not None:
         from sindslam_amd._lib import check, lib
         check(lib().sind_debug_set_coef_lanes(args.coef_kernel), "sind_debug_set_coef_lanes")

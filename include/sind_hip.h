@@ -112,6 +112,7 @@ typedef struct sind_dyna sind_dyna;
 int sind_dyna_create(int width, int height, float fx, float fy, float cx, float cy, float depth_scale, int device, sind_dyna** out);
 int sind_dyna_destroy(sind_dyna* d);
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n);      /* see sind_flow_set_max_levels */
+int sind_dyna_timing(sind_dyna* d, double ms6[6], int reset);   /* mean ms per detect call: upload, dense flow, wait for the depth half, flow masks + fusion, depth half, whole call; returns calls */
 int sind_dyna_set_debug(sind_dyna* d, int on);               /* on: keep the intermediate images sind_dyna_debug reports (costs four flow-sized copies per frame); default off */
 int sind_dyna_set_overlap(sind_dyna* d, int on);             /* default on: the depth half of a frame (k-means, CalOccluded, SegAndMerge) runs beside its dense flow, as the reference's
                                                                  flow thread runs beside the segmentation (DynaDetect.cc:1396-1398); 0 = one after the other; same results */
@@ -183,6 +184,7 @@ typedef struct sind_pipe_config {
     int streams, frames_per_step, device;
     int host_threads;            /* 0 = library default (2 x the CPU share of the process) */
     int flow_max_levels;         /* 0 = the reference's full DeepFlow pyramid; n > 0: finest n levels only (see sind_flow_set_max_levels) */
+    int flow_slices;             /* dense-flow slices of a step that run concurrently on their own streams: 0 = by step size (default), 1..4 fixed; same results */
 } sind_pipe_config;
 int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out);
 int sind_pipe_destroy(sind_pipe* p);

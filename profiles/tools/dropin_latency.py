@@ -26,11 +26,14 @@ if "--flow-only" not in sys.argv:
         t1 = time.perf_counter(); mask = gpu.dilate15(dyna)
         t2 = time.perf_counter(); kps, desc = orb(gray[k], mask)
         t3 = time.perf_counter()
+        if f == 11:
+            gpu.timing(True)
         if f >= 12:
             td.append(t1 - t0); tm.append(t2 - t1); to.append(t3 - t2)
     tot = np.array(td) + np.array(tm) + np.array(to)
     out["dropin"] = {"frames": len(td), "ms_per_frame": float(tot.mean() * 1e3), "fps": float(1.0 / tot.mean()), "detect_ms": float(np.mean(td) * 1e3), "dilate15_ms": float(np.mean(tm) * 1e3),
                      "orb_ms": float(np.mean(to) * 1e3), "detect_ms_p50": float(np.median(td) * 1e3), "detect_ms_max": float(np.max(td) * 1e3)}
+    out["dropin"]["detect_stages_ms"] = gpu.timing()
     gpu.close(); orb.close()
 # the flow stage alone: DeepFlow of B pairs (host in / out included) and on device pointers
 fw, fh = 384, 288

@@ -10,6 +10,7 @@ struct sind_dyna {
     PinnedBuf<uint16_t> depth_h; PinnedBuf<uint8_t> bgr_h, dil_h;       // page-locked staging of the caller's frames (a copy from pageable memory is staged by the runtime and blocks the call)
     int t = 0; bool primed = false; int largeMotion = 0; bool debug = false, overlap = true;
     std::vector<float> deep, refined;
+    double t_ms[6] = {0, 0, 0, 0, 0, 0}; long n_timed = 0;       // summed per-call times: upload, dense flow (main thread), wait for the depth half, flow masks + fusion, depth half (its own thread), total
 };
 #include <string>
 #include <thread>
@@ -28,7 +29,8 @@ int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float
     // the reference runs its flow thread beside the segmentation (DynaDetect.cc:1396-1398, 1553-1554)
     if (hipStreamCreateWithFlags(&d->tail_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->flow_done, hipEventDisableTiming) != hipSuccess) {
         hipStream_t a = d->stream, b = d->tail_stream; delete d; (void)hipStreamDestroy(a); if (b) (void)hipStreamDestroy(b); sind_set_error("sind_dyna_create: hipStreamCreate failed"); return SIND_E_HIP; }
-    int r = d->front.init(d->cfg, 1, d->stream);
+    int r = d->front.init(d->cfg, 2, d->stream);       // (2: the candidate of the large-motion pass rides along with every frame, see DynaFront::speculate)
+    d->front.speculate = true;
     if (r == SIND_OK) r = d->tail.init(d->cfg, d->tail_stream);
     if (r == SIND_OK) r = d->depth_h.alloc((size_t)w * h);
     if (r == SIND_OK) r = d->bgr_h.alloc((size_t)w * h * 3);
@@ -60,6 +62,15 @@ int sind_debug_set_kmeans_fused_min_batch(int b) { if (b < 1) return SIND_E_ARG;
 int sind_dyna_set_debug(sind_dyna* d, int on) { if (!d) return SIND_E_ARG; d->debug = on != 0; d->tail.keep_debug = d->debug; return SIND_OK; }
 // overlap != 0 (default): the depth half of a frame runs beside its dense flow (own stream, own host thread); 0 = one after the other.  Same results.
 int sind_dyna_set_overlap(sind_dyna* d, int on) { if (!d) return SIND_E_ARG; d->overlap = on != 0; return SIND_OK; }
+// mean milliseconds per sind_dyna_detect call since the last reset: upload, dense flow (calling thread), wait for the depth half after the flow, flow masks + fusion,
+// depth half (its own thread when overlapped), whole call; returns the number of calls averaged
+int sind_dyna_timing(sind_dyna* d, double ms6[6], int reset) {
+    if (!d || !ms6) return SIND_E_ARG;
+    for (int i = 0; i < 6; i++) ms6[i] = d->n_timed ? d->t_ms[i] / d->n_timed : 0.0;
+    const int n = (int)d->n_timed;
+    if (reset) { for (double& v : d->t_ms) v = 0; d->n_timed = 0; }
+    return n;
+}
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n) { if (!d || n < 0) return SIND_E_ARG; d->front.flow.max_levels = n; return SIND_OK; }
 int sind_dyna_destroy(sind_dyna* d) {
     if (!d) return SIND_OK;
@@ -96,6 +107,8 @@ int sind_dyna_detect(sind_dyna* d, const uint8_t* bgr, int bstride, const uint16
     if (dstride <= 0) dstride = w * 2;
     const int cur = d->t % 3, p1 = (d->t + 2) % 3, p2 = (d->t + 1) % 3;
     SpinScope spin;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now_ms(); double t_depth = 0;
     SIND_TRY(upload_bgr(d, bgr, bstride, cur));
     uint16_t* dh = d->depth_h.p;
     for (int y = 0; y < h; y++) std::memcpy(dh + (size_t)y * w, (const uint8_t*)depth + (size_t)y * dstride, (size_t)w * 2);
@@ -105,16 +118,21 @@ int sind_dyna_detect(sind_dyna* d, const uint8_t* bgr, int bstride, const uint16
     if (d->debug) { d->deep.resize(nf * 2); d->refined.resize(nf * 2); du = d->deep.data(); dv = du + nf; ru = d->refined.data(); rv = ru + nf; }
     sind::DepthStageOut dso; int rc_depth = SIND_OK; std::string err_depth;
     std::thread side;
-    if (d->overlap) side = std::thread([&] { SpinScope sp; rc_depth = d->tail.depth_stage(dh, d->depth.p, nullptr, dso, nullptr); if (rc_depth != SIND_OK) err_depth = sind_last_error(); });
+    const double t1 = now_ms();
+    if (d->overlap) side = std::thread([&] { SpinScope sp; const double a = now_ms(); rc_depth = d->tail.depth_stage(dh, d->depth.p, nullptr, dso, nullptr); t_depth = now_ms() - a; if (rc_depth != SIND_OK) err_depth = sind_last_error(); });
     const int rc_flow = d->front.dense_flow(d->pool.p, &cur, &p1, &p2, 1, d->U.p, d->V.p, &d->largeMotion, du, dv, ru, rv);
+    const double t2 = now_ms();
     if (side.joinable()) side.join();
     SIND_TRY(rc_flow);
-    if (!d->overlap) rc_depth = d->tail.depth_stage(dh, d->depth.p, nullptr, dso, nullptr);
+    if (!d->overlap) { rc_depth = d->tail.depth_stage(dh, d->depth.p, nullptr, dso, nullptr); t_depth = now_ms() - t2; }
     else if (rc_depth != SIND_OK) sind_set_error("%s", err_depth.c_str());
     SIND_TRY(rc_depth);
     HIP_TRY(hipEventRecord(d->flow_done, d->stream));
     HIP_TRY(hipStreamWaitEvent(d->tail_stream, d->flow_done, 0));       // the flow masks read U / V on the tail's stream
+    const double t3 = now_ms();
     SIND_TRY(d->tail.flow_stage(d->U.p, d->V.p, dso, dyna_out, label_out));
+    const double t4 = now_ms();
+    d->t_ms[0] += t1 - t0; d->t_ms[1] += t2 - t1; d->t_ms[2] += t3 - t2; d->t_ms[3] += t4 - t3; d->t_ms[4] += t_depth; d->t_ms[5] += t4 - t0; d->n_timed++;
     d->t++;
     return SIND_OK;
 }

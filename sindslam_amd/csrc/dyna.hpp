@@ -18,6 +18,10 @@ class DynaFront {
 public:
     DynaConfig cfg; int fw = 0, fh = 0, maxB = 0; hipStream_t stream = nullptr;
     FlowEngine flow;
+    // speculate: flow(n, n-1) -- the reference's second DeepFlow pass for large-motion pairs (DD:1121-1131) -- is solved TOGETHER with flow(n, n-2), as the second half of
+    // one batch of 2 B pairs, and the large-motion test then only picks between the two results.  For a batch that leaves most of the chip idle (one camera) the second
+    // half costs next to nothing and a large-motion frame no longer takes two flow latencies in a row.  Same bits: a pair's flow does not depend on its batch.  Needs 2 B <= maxB.
+    bool speculate = false;
     int init(const DynaConfig& c, int maxB, hipStream_t s);
     // bgr: device u8 [n][H][W][3] -> gray [n][H][W] and grayMin [n][fh][fw] (both device, caller-owned)
     int gray_and_min(const uint8_t* bgr, int n, uint8_t* gray, uint8_t* grayMin);

@@ -49,9 +49,17 @@ int DynaFront::dense_flow(const uint8_t* pool, const int* cur, const int* prev1,
                           float* dbg_du, float* dbg_dv, float* dbg_ru, float* dbg_rv) {
     if (B < 1 || B > maxB) { sind_set_error("dense_flow: batch %d outside [1,%d]", B, maxB); return SIND_E_ARG; }
     const int nf = fw * fh; const size_t nfB = (size_t)nf * B;
-    // pass 1: flow(n, n-2) for every pair (DD:1075)
-    SIND_TRY(gather(pool, cur, B, g0.p)); SIND_TRY(gather(pool, prev2, B, g1.p));
-    SIND_TRY(flow.deepflow(g0.p, g1.p, B, u.p, v.p));
+    // pass 1: flow(n, n-2) for every pair (DD:1075); with `speculate` the candidates of pass 2 ride along as pairs B .. 2 B - 1
+    const bool spec = speculate && 2 * B <= maxB;
+    if (spec) {
+        std::vector<int> c2(2 * B), p2x(2 * B);
+        for (int b = 0; b < B; b++) { c2[b] = c2[B + b] = cur[b]; p2x[b] = prev2[b]; p2x[B + b] = prev1[b]; }
+        SIND_TRY(gather(pool, c2.data(), 2 * B, g0.p)); SIND_TRY(gather(pool, p2x.data(), 2 * B, g1.p));
+        SIND_TRY(flow.deepflow(g0.p, g1.p, 2 * B, u.p, v.p));
+    } else {
+        SIND_TRY(gather(pool, cur, B, g0.p)); SIND_TRY(gather(pool, prev2, B, g1.p));
+        SIND_TRY(flow.deepflow(g0.p, g1.p, B, u.p, v.p));
+    }
     // large-motion test on |flow| (DD:1081-1114): max, u8 normalisation, histogram on the GPU, percentile test here
     SIND_TRY(launch_mag_stats(stream, u.p, v.p, mag.p, maxbits.p, hist.p, nullptr, nf, B));
     std::vector<unsigned> h_max(B); std::vector<int> h_hist((size_t)B * 256);
@@ -71,7 +79,12 @@ int DynaFront::dense_flow(const uint8_t* pool, const int* cur, const int* prev1,
     }
     if (large_motion) std::copy(lm.begin(), lm.end(), large_motion);
     // pass 2: flow(n, n-1) for the flagged pairs only (DD:1121-1131)
-    if (!flagged.empty()) {
+    if (!flagged.empty() && spec) {
+        for (int b : flagged) {
+            HIP_TRY(hipMemcpyAsync(u.p + (size_t)nf * b, u.p + (size_t)nf * (B + b), nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(v.p + (size_t)nf * b, v.p + (size_t)nf * (B + b), nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        }
+    } else if (!flagged.empty()) {
         const int B2 = (int)flagged.size();
         std::vector<int> c2(B2), p2(B2);
         for (int k = 0; k < B2; k++) { c2[k] = cur[flagged[k]]; p2[k] = prev1[flagged[k]]; }

@@ -177,7 +177,7 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     // dense-flow slices: concurrent streams keep the GPU busy through the launch tails and the small pyramid levels of each other; small batches stay in one piece.
     // Measured (profiles/r04/split_sweep.txt, lab build): 512 pairs per step: 3 slices 1382-1417 pairs/s, 2: 1377, 4: 1354; 224 pairs (the one-GPU sequence job's step): 2 slices
     // 1192, 1: 1164, 3: 1150, 4: 1120 -- a slice should hold ~110 pairs or more
-    const int nsplit = std::max(1, std::min(sind_lab_env("SIND_FLOW_SPLIT") ? atoi(sind_lab_env("SIND_FLOW_SPLIT")) : (B >= 320 ? 3 : B >= 48 ? 2 : 1), 4)), Bs = (B + nsplit - 1) / nsplit;
+    const int nsplit = std::max(1, std::min(sind_lab_env("SIND_FLOW_SPLIT") ? atoi(sind_lab_env("SIND_FLOW_SPLIT")) : (cfg->flow_slices > 0 ? cfg->flow_slices : B >= 320 ? 3 : B >= 48 ? 2 : 1), std::min(4, B))), Bs = (B + nsplit - 1) / nsplit;
     SIND_TRY(p->front.init(p->dc, nsplit > 1 ? std::max(Bs, 2) : B, p->stream));
     HIP_TRY(hipEventCreate(&p->ev_pool));                   // with timing: also the time base of the solver intervals
     for (int i = 1; i < nsplit; i++) {

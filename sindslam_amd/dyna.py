@@ -27,6 +27,11 @@ class DynaDetect:
         """build-side option of BASELINE.json config 5 ("3-level flow pyramid"): finest n levels of the DeepFlow pyramid only; 0 = all"""
         check(lib().sind_dyna_set_flow_max_levels(self._h, int(n)), "sind_dyna_set_flow_max_levels")
 
+    def timing(self, reset: bool = True):
+        """mean milliseconds per DetectDynaArea call since the last reset, by stage"""
+        ms = (C.c_double * 6)(); n = check(lib().sind_dyna_timing(self._h, ms, 1 if reset else 0), "sind_dyna_timing")
+        return dict(calls=n, upload=ms[0], dense_flow=ms[1], wait_depth_half=ms[2], flow_masks_and_fusion=ms[3], depth_half=ms[4], total=ms[5])
+
     def close(self):
         if getattr(self, "_h", None):
             lib().sind_dyna_destroy(self._h); self._h = None

@@ -73,10 +73,14 @@ def parse_args(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
     ap.add_argument("--exact-leg-frames", type=int, default=0, help="sequence workload: frames of the in-order re-run the chunked masks are compared with (0 = chunk 0, chunks 1-2 and what else fits into 320-480 frames)")
     ap.add_argument("--flow-slices", type=int, default=0, help="experiment: dense-flow slices of a step (sind_pipe_config.flow_slices; 0 = the library's rule by step size)")
+    ap.add_argument("--flow-opts-off", type=int, default=0, help="experiment: bit 0 = no k_coarse_chain, bit 1 = no k_sor_tile (sind_pipe_config.flow_opts_off; same results)")
     ap.add_argument("--pipelines", type=int, default=0, help="independent pipelines a step is cut into on one GPU (experiment; 0 = one; results do not depend on it)")
     ap.add_argument("--no-n1-leg", action="store_true", help="sequence workload on N > 1 ranks: skip the one-rank run of the same job on rank 0 after the timed region (sequence.n1_value)")
     ap.add_argument("--no-tum-leg", action="store_true", help="streams workload on one GPU: skip the TUM-length single sequence (line field `sequence_tum_length`)")
     ap.add_argument("--no-sequence-leg", action="store_true", help="streams workload on one GPU: skip the fixed-length sequence job that is run after the timed region (line field `sequence`)")
+    ap.add_argument("--no-dropin-leg", action="store_true", help="streams workload on one GPU: skip the one-frame-at-a-time run through the two classes' C ABI (line field `dropin`)")
+    ap.add_argument("--no-small-step-leg", action="store_true", help="streams workload on one GPU: skip the 32-pair steps (line field `small_step`)")
+    ap.add_argument("--dropin-frames", type=int, default=120)
     ap.add_argument("--no-exact-leg", action="store_true", help="sequence workload: skip the in-order re-run of the first chunks (seam IoU, exact-mode rate)")
     ap.add_argument("--host-input", action="store_true", help="hand over HOST buffers each step (sind_pipe_process, PCIe-inclusive rate; DESIGN.md 6) instead of HBM-resident inputs")
     ap.add_argument("--thread-cpu", action="store_true", help="print the CPU seconds the live threads used inside the timed region, by thread name (stderr)")
@@ -236,7 +240,8 @@ def cpu_baseline(frames_of_stream, intr, cfg, n_par, gpu_dyna, gpu_kps, threads=
             "sample": f"{threads} threads x (5 warm-up + 7 timed) frame pairs of the bench's first {min(threads, n_streams)} streams, one scalar oracle instance per thread "
                       f"({a['wall_s']:.1f} s wall); second setting: all {cores_all} cores of the quota x (2 + 4) pairs" + ("" if b else " -- skipped, no more cores than threads"),
             "host": info, "threads_8": a, "all_cores": b}
-    parity = {"mask_iou_mean": float(np.mean(ious)), "mask_iou_min": float(np.min(ious)), "orb_keypoints_bit_exact_frames": kp_equal, "frames": len(ious),
+    parity = {"sample_from": "first warm-up step (synchronous call); the pipelined timed steps produce the same bytes (tests/test_pipeline_gpu.py::test_pipelined_submit_equals_sync)",
+              "mask_iou_mean": float(np.mean(ious)), "mask_iou_min": float(np.min(ious)), "orb_keypoints_bit_exact_frames": kp_equal, "frames": len(ious),
               "reference": "CPU oracle (parity unpinned: the reference ships no golden vectors and cannot be built here)"}
     return base, parity
 
@@ -279,12 +284,14 @@ class StepAcc:
     """sums of the per-step pipeline statistics (solver HIP-event brackets, stage times) over the timed steps"""
     def __init__(self):
         import numpy as np
-        self.sor_ms = self.sor_bytes = self.sor_union = 0.0; self.sor_launches = 0; self.sor_slices = 1
+        self.sor_ms = self.sor_bytes = self.sor_union = 0.0; self.sor_launches = 0; self.sor_slices = 1           # streaming solver (k_sor_stream)
+        self.other_ms = self.other_bytes = 0.0; self.other_launches = 0                                           # solver launches of the other kernels (tiles, one-workgroup levels)
         self.stages = np.zeros(6); self.tail_wait = 0.0; self.submit_wall = 0.0
 
     def add(self, st, pipelined):
         import numpy as np
         self.sor_ms += st["sor_ms"]; self.sor_bytes += st["sor_alg_bytes"]; self.sor_launches += st["sor_launches"]; self.sor_union += st["sor_union_ms"]; self.sor_slices = st["sor_slices"]
+        self.other_ms += st.get("sor_other_ms", 0.0); self.other_bytes += st.get("sor_other_alg_bytes", 0.0); self.other_launches += st.get("sor_other_launches", 0)
         self.stages += np.array([st["front_ms"], st["flow_ms"], st["orb_ms"], st["tails_ms"], st["total_ms"], st["upload_ms"]])
         self.tail_wait += st["tail_wait_ms"] if pipelined else 0.0
 
@@ -302,62 +309,61 @@ def flow_level_pixels(width, height, max_levels=0):
     return out[:max_levels] if max_levels else out
 
 
-def roofline_of(acc, K, dt, pairs_per_launch, config_name, cfg=None):
-    """`roofline` object of the solver kernel (k_sor_stream on the levels above 8192 pixels, k_sor_fused on the one-workgroup levels).
+VALU_PEAK = 78.6e12      # float operations per second of the vector units: 1024 SIMDs x 32 lanes x 2.4 GHz, one wave64 v_fma / v_mul / v_add per 2 cycles (MI355X_MICROARCH.md,
+                         # cycle constants).  Measured with every SIMD issuing (profiles/r05/valu_rate.txt): 63 T/s unpacked at the clock the chip holds, and a PACKED FP32 instruction
+                         # (v_pk_mul / v_pk_add / v_pk_fma: two floats per lane) takes the SIMD twice as long as an unpacked one (31 - 34 T instructions/s = 62 - 68 T float operations/s):
+                         # it is priced as TWO operations.  One constant for every VALU figure of the line.
 
-    frac is the fraction of the BINDING resource, <= 1 by construction: max(frac_hbm, valu_busy) --
-      frac_hbm   = real HBM bytes (committed rocprofv3 PMC passes of this command: FETCH_SIZE x 2 + WRITE_SIZE per launch, the guide's gfx950 correction) x launches
-                   / time with at least one solver launch in flight / 8 TB/s;
-      valu_busy  = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES of the streaming kernel with every workgroup slot of the chip taken, as under the bench's three concurrent
-                   slices (committed SQ-counter passes over 512 pairs; the same kernel alone on one 170-pair slice is printed as valu_busy_solver_alone).
-    The SURVEY 8d yardstick -- 44 algorithmic bytes per pixel update against the HBM peak -- is kept as achieved_algorithmic / frac_algorithmic; it prices
-    nine reads per update that a five-iteration register-resident kernel never issues, so it can exceed 1 and ranks nothing.  What the kernel HAS to move is
-    compulsory_bytes_per_launch = 40 B per pixel of a streamed launch (8 planes read, 2 written, once per 5 iterations); traffic_over_compulsory says how far the
-    measured traffic is from that.  The batch runs as `concurrent_launches` slices on their own HIP streams: times are unions of HIP-event intervals."""
+
+def roofline_of(acc, K, dt, pairs_per_launch, config_name, cfg=None):
+    """`roofline` object of the dominant kernel, k_sor_stream (the SOR solver of every pyramid level above 8192 pixels in slices of 80 pairs and more).
+
+    bound = "hbm" (SURVEY 8d).  achieved = REAL HBM bytes per launch (committed rocprofv3 PMC passes of this command: FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction)
+    x the streaming launches of the timed steps / the time with at least one of them in flight (HIP events on the launching streams, union over the concurrent slices);
+    frac = achieved / 8 TB/s, <= 1 by construction.  The kernel is NOT near that roof and the line says why: it keeps a row pair's system in registers for five iterations
+    (temporal blocking), so it moves 40 B per pixel and launch where the 8d yardstick prices 5 x 44 B -- achieved_algorithmic / frac_algorithmic keep that yardstick and can
+    exceed 1 -- and spends its time in VALU issue and the step barriers of its row pipeline: valu_frac_from_counts (instructions counted by SQ_INSTS_VALU per kept pixel update x
+    updates / time / VALU_PEAK) and valu_busy (an occupancy counter: SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES) are reported beside it, never as `frac`."""
     busy_s = acc.sor_union * 1e-3
     alg = acc.sor_bytes / busy_s / 1e9 if busy_s > 0 else 0.0                                   # algorithmic GB/s, device level
-    per_launch = acc.sor_bytes / (acc.sor_ms * 1e-3) / 1e9 if acc.sor_ms > 0 else 0.0
     pmc = pmc_profile() if config_name == "tum3" else None
-    traffic = pmc["hbm_bytes_per_launch_per_pair"] * pairs_per_launch if pmc else None           # average over all solver launches (streaming + one-workgroup)
-    roof = {"kernel": "k_sor_stream (levels above 8192 pixels, from 48 pairs per launch) + k_sor_fused (one-workgroup levels)", "peak": 8000.0, "unit": "GB/s",
+    bk = (pmc or {}).get("by_kernel", {}).get("k_sor_stream")
+    traffic = None
+    if bk:
+        traffic = (2.0 * bk["FETCH_SIZE_kb_per_launch"] + bk["WRITE_SIZE_kb_per_launch"]) * 1024.0 * pairs_per_launch / pmc["pairs_per_launch"]
+    roof = {"kernel": "k_sor_stream (SOR solver of the pyramid levels above 8192 pixels, slices of 80 pairs and more; 5 iterations per launch)", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
             "launches": acc.sor_launches, "avg_launch_us": (acc.sor_ms * 1e3 / acc.sor_launches) if acc.sor_launches else None,
-            "concurrent_launches": acc.sor_slices, "solver_busy_ms_per_step": acc.sor_union / K,
-            "alg_bytes_per_launch": (acc.sor_bytes / acc.sor_launches) if acc.sor_launches else None,
-            "achieved_algorithmic": alg, "frac_algorithmic": alg / 8000.0, "achieved_per_launch_algorithmic": per_launch,
-            "frac_wall_algorithmic": (acc.sor_bytes / dt / 1e9 / 8000.0) if dt > 0 else None,
+            "concurrent_slices": acc.sor_slices, "solver_busy_ms_per_step": acc.sor_union / K,
             "traffic": traffic,
-            "traffic_source": (pmc["file"] + " (committed rocprofv3 --pmc passes of this command, per pair x pairs per launch; not re-measured in this run)") if pmc else None}
-    frac_hbm = valu = None
-    if pmc and acc.sor_launches and busy_s > 0:
-        hbm = traffic * acc.sor_launches / busy_s                                                # real HBM bytes per second while the solver is busy
-        frac_hbm = hbm / 8e12; roof["achieved"] = hbm / 1e9; roof["frac_hbm"] = frac_hbm
-        bk = pmc.get("by_kernel", {}).get("k_sor_stream")
-        if bk and cfg is not None:
+            "traffic_source": (pmc["file"] + " (committed rocprofv3 --pmc passes of this command, per pair x pairs per launch; not re-measured in this run)") if pmc else None,
+            "achieved": None, "frac": None,
+            "alg_bytes_per_launch": (acc.sor_bytes / acc.sor_launches) if acc.sor_launches else None,
+            "achieved_algorithmic": alg, "frac_algorithmic": alg / 8000.0,
+            "algorithmic_note": "SURVEY 8d yardstick: 44 B per pixel update; a launch of five register-resident iterations moves 40 B per pixel, so this figure can exceed the peak and is not `frac`",
+            "other_solver_kernels": {"launches": acc.other_launches, "sum_ms_per_step": acc.other_ms / K, "alg_bytes_per_step": acc.other_bytes / K,
+                                     "note": "k_sor_tile / k_sor_fused launches of the step (tiled levels of small slices, one-workgroup levels of 4 - 8 k pixels); the levels of at most 4096 pixels run inside k_coarse_chain"}}
+    if traffic and acc.sor_launches and busy_s > 0:
+        hbm = traffic * acc.sor_launches / busy_s                                                # real HBM bytes per second while the streaming solver is busy
+        roof["achieved"] = hbm / 1e9; roof["frac"] = min(1.0, hbm / 8e12)
+        roof["achieved_per_launch"] = traffic / (acc.sor_ms * 1e-3 / acc.sor_launches) / 1e9 if acc.sor_ms > 0 else None
+        if cfg is not None:
             px = [n for n in flow_level_pixels(cfg["width"], cfg["height"], cfg["flow_max_levels"]) if n > 8192]
             comp = 40.0 * (sum(px) / len(px)) * pairs_per_launch                                # per streaming launch: every streamed level has the same number of launches
-            tr_s = (2.0 * bk["FETCH_SIZE_kb_per_launch"] + bk["WRITE_SIZE_kb_per_launch"]) * 1024.0 * pairs_per_launch / pmc["pairs_per_launch"]
-            roof["compulsory_bytes_per_launch"] = comp; roof["traffic_streaming_per_launch"] = tr_s; roof["traffic_over_compulsory"] = tr_s / comp
-    if pmc and pmc.get("valu_busy_measured") is not None:
-        valu = pmc["valu_busy_measured"]; roof["valu_busy"] = valu; roof["valu_busy_source"] = pmc.get("sq_counters")
-        if pmc.get("valu_busy_solver_alone_170_pairs") is not None:
-            roof["valu_busy_solver_alone"] = pmc["valu_busy_solver_alone_170_pairs"]
-    if frac_hbm is None and valu is None:          # no committed counters for this config: only the algorithmic yardstick is known
-        roof.update({"bound": "valu", "achieved": None, "frac": None, "bound_note": "no committed PMC passes for this config; see frac_algorithmic"})
+            roof["compulsory_bytes_per_launch"] = comp; roof["traffic_over_compulsory"] = traffic / comp
+        roof["bound_note"] = ("frac = achieved / peak of HBM, the roof SURVEY 8d names.  The solver is a temporally blocked stencil (five iterations per launch out of registers and LDS): it moves "
+                              "traffic_over_compulsory x its compulsory 40 B per pixel and launch and is limited by VALU issue and the step barriers of its row pipeline, not by HBM (DESIGN.md 3.1)")
     else:
-        hb = frac_hbm or 0.0; vb = valu or 0.0
-        roof["achieved_hbm"] = roof.get("achieved"); roof["peak_hbm"] = 8000.0
-        if vb >= hb:                               # achieved / peak / unit / frac describe the BINDING resource, so that frac = achieved / peak holds whichever it is
-            vpeak = (pmc or {}).get("valu_peak_lane_instructions_per_s", 39.3e12) / 1e12
-            roof.update({"bound": "valu", "achieved": vb * vpeak, "peak": vpeak, "unit": "T lane-instructions/s (a packed FP32 operation counts once)", "frac": min(1.0, vb)})
-        else:
-            roof.update({"bound": "hbm", "frac": min(1.0, hb)})
-        roof["bound_note"] = ("frac = max(frac_hbm, valu_busy) = achieved / peak of the busiest unit.  The solver keeps a row pair's system in registers for five iterations, moves "
-                              "traffic_over_compulsory x its compulsory 40 B per pixel and launch (achieved_hbm of peak_hbm GB/s), and is bound by VALU issue plus the step barriers of its row pipeline (DESIGN.md 3.1)")
-    # VALU share from instruction counts: pixel updates (algorithmic bytes / 44 B) x measured VALU lane-instructions per kept update over the chip's 39.3e12 lane-instructions/s
-    valu_ops_per_update = (pmc or {}).get("valu_ops_per_pixel_update", 44); halo = (pmc or {}).get("halo_redundancy", 2.1)
-    valu_peak = (pmc or {}).get("valu_peak_lane_instructions_per_s", 78.6e12)
-    if busy_s > 0:
-        roof["valu_frac_from_counts"] = (acc.sor_bytes / 44.0) * valu_ops_per_update * halo / valu_peak / busy_s
+        roof["bound_note"] = "no committed PMC passes for this config or no streaming launches in the timed steps (slices below 80 pairs run the tiled kernels): see achieved_algorithmic"
+    # VALU side, from COUNTS: pixel updates (algorithmic bytes / 44 B) x VALU instructions per kept update (SQ_INSTS_VALU x 64 lanes / updates; a packed instruction counted as two) / time / VALU_PEAK
+    ipu = (pmc or {}).get("valu_ops_per_pixel_update"); ipu2 = (pmc or {}).get("valu_slots_per_pixel_update", ipu)
+    roof["useful_ops_per_update"] = 32; roof["instr_per_update"] = ipu; roof["valu_peak_ops_per_s"] = VALU_PEAK
+    if busy_s > 0 and ipu2:
+        roof["valu_frac_from_counts"] = (acc.sor_bytes / 44.0) * ipu2 / VALU_PEAK / busy_s
+        roof["valu_note"] = ("instr_per_update VALU instructions per kept pixel update (counter-measured; 32 float operations are the arithmetic of an update, no FMA by contract), priced at "
+                             "%.1f issue slots per update (packed instructions count twice: profiles/r05/valu_rate.txt) against VALU_PEAK" % ipu2)
+    if pmc and pmc.get("valu_busy_measured") is not None:
+        roof["valu_busy"] = pmc["valu_busy_measured"]; roof["valu_busy_source"] = pmc.get("sq_counters")
+        roof["valu_busy_note"] = "occupancy counter (SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES), not achieved / peak"
     return roof
 
 
@@ -405,7 +411,7 @@ def pipelines_for(S, T, asked=0):
 def make_pipeline(cfg, intr, S, T, local, host_threads=0, parts=1):
     from sindslam_amd.pipeline import Pipeline, PipelineGroup
     a = (S, T, cfg["width"], cfg["height"], intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"])
-    kw = dict(orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=host_threads, flow_max_levels=cfg["flow_max_levels"], flow_slices=cfg.get("flow_slices", 0))
+    kw = dict(orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=host_threads, flow_max_levels=cfg["flow_max_levels"], flow_slices=cfg.get("flow_slices", 0), flow_opts_off=cfg.get("flow_opts_off", 0))
     return PipelineGroup(parts, *a, **kw) if parts > 1 else Pipeline(*a, **kw)
 
 
@@ -426,6 +432,64 @@ def sequence_streams(world, frames, cfg_streams, steps, warm=None):
     return best[1]
 
 
+
+
+def dropin_leg(cfg, intr, frames_b, frames_d, device, n_frames=120):
+    """The reference's own call pattern (rgbd_tum_noros.cc:131-139, Frame.cc:308): ONE camera, one frame per call, HOST pointers, in order, through the C ABI the two class
+    shims bind (sind_dyna_detect + sind_dyna_dilate15 + sind_orb_extract).  frames_b / frames_d: host frames of one stream, walked forth and back.  The ORB input gray is
+    formed by the caller before the clock (Tracking::GrabImageRGBD does it on the host in the reference, src/Tracking.cc:246-259); DynaDetect's own three gray conversions,
+    both uploads and all downloads are inside."""
+    import numpy as np
+    from sindslam_amd.dyna import DynaDetect
+    from sindslam_amd.orb import ORBextractor
+    P = frames_b.shape[0]
+    cb, cr = (4899, 1868) if cfg["rgb"] else (1868, 4899)
+    gray = [((b[..., 0].astype(np.int32) * cb + b[..., 1].astype(np.int32) * 9617 + b[..., 2].astype(np.int32) * cr + 8192) >> 14).astype(np.uint8) for b in frames_b]
+    dd = DynaDetect(np.ascontiguousarray(frames_b[1]), np.ascontiguousarray(frames_b[0]), intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], device=device, debug=False)
+    if cfg["flow_max_levels"]:
+        dd.set_flow_max_levels(cfg["flow_max_levels"])
+    orb = ORBextractor(1500, 1.2, 8, intr["ini_th"], intr["min_th"], device=device)
+    td, tm, to = [], [], []; warm = 10
+    for f in range(2, 2 + warm + n_frames):
+        k = pingpong(f, P); b = np.ascontiguousarray(frames_b[k]); d = np.ascontiguousarray(frames_d[k])
+        t0 = time.perf_counter(); dyna, _ = dd.DetectDynaArea(b, d, f)
+        t1 = time.perf_counter(); mask = dd.dilate15(dyna)
+        t2 = time.perf_counter(); orb(gray[k], mask)
+        t3 = time.perf_counter()
+        if f == 1 + warm:
+            dd.timing(True)
+        if f >= 2 + warm:
+            td.append(t1 - t0); tm.append(t2 - t1); to.append(t3 - t2)
+    st = dd.timing(); dd.close(); orb.close()
+    tot = np.array(td) + np.array(tm) + np.array(to)
+    return {"frames": len(td), "ms_per_frame": float(tot.mean() * 1e3), "fps": float(1.0 / tot.mean()), "ms_per_frame_max": float(tot.max() * 1e3),
+            "detect_ms": float(np.mean(td) * 1e3), "dilate15_ms": float(np.mean(tm) * 1e3), "orb_ms": float(np.mean(to) * 1e3), "detect_stages_ms": st,
+            "first_measurement": {"ms_per_frame": 29.1, "fps": 34.4, "where": "profiles/r05/dropin_first_measurement.json (round-4 code, same loop)"},
+            "note": "in-order sind_dyna_detect + sind_dyna_dilate15 + sind_orb_extract at B = 1 with host pointers; the depth half of a frame runs beside its dense flow "
+                    "(own stream and host thread), the large-motion candidate flow rides along as a batch of two"}
+
+
+def small_step_leg(cfg, intr, bgr, depth, local, host_threads, S2=16, T2=2, steps=12, warm=3):
+    """what a rank of an 8-GPU sequence job sees with the driver's --steps 20: ~32 frame pairs per step.  Same pipelined loop as the headline, S2 streams x T2 frames."""
+    import numpy as np
+    import torch
+    pipe = make_pipeline(cfg, intr, S2, T2, local, host_threads)
+    for s_ in range(S2):
+        pipe.prime(s_, bgr[s_, 1], bgr[s_, 0])
+    nd = min(steps + warm, (bgr.shape[1] - 2) // T2)
+    db = [torch.from_numpy(np.ascontiguousarray(bgr[:S2, 2 + i * T2: 2 + (i + 1) * T2])).cuda() for i in range(nd)]
+    dd = [torch.from_numpy(np.ascontiguousarray(depth[:S2, 2 + i * T2: 2 + (i + 1) * T2]).view(np.int16)).cuda() for i in range(nd)]
+    torch.cuda.synchronize()
+    for i in range(warm):
+        pipe.process_dev(db[i % nd].data_ptr(), dd[i % nd].data_ptr())
+    torch.cuda.synchronize(); t0 = time.perf_counter(); flow = tails = 0.0
+    for i in range(warm, warm + steps):
+        pipe.submit_dev(db[i % nd].data_ptr(), dd[i % nd].data_ptr()); st = pipe.stats(); flow += st["flow_ms"]; tails += st["tails_ms"]
+    pipe.flush(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    sl = pipe.stats()["sor_slices"]; pipe.close()
+    return {"pairs": S2 * T2, "streams": S2, "frames_per_step": T2, "steps": steps, "value": S2 * T2 * steps / dt, "unit": "frame-pairs/s", "ms_per_step": dt / steps * 1e3,
+            "dense_flow_ms_per_step": flow / steps, "tails_ms_per_step": tails / steps, "flow_slices": sl,
+            "first_measurement": {"value": 679.3, "shape": "8 streams x 4 frames, one slice", "where": "profiles/r05/small_step_first_measurement.json (round-4 code)"}}
 
 
 class BenchFrames:
@@ -688,7 +752,7 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.flow_levels is not None:
         cfg["flow_max_levels"] = args.flow_levels
-    cfg["flow_slices"] = args.flow_slices
+    cfg["flow_slices"] = args.flow_slices; cfg["flow_opts_off"] = args.flow_opts_off
     if args.coef_kernel is not None:
         from sindslam_amd._lib import check, lib
         check(lib().sind_debug_set_coef_lanes(args.coef_kernel), "sind_debug_set_coef_lanes")
@@ -729,7 +793,7 @@ def main():
         dist.init_process_group(args.backend, rank=rank, world_size=world)     # backend "nccl" is RCCL on ROCm
     comm_dev = "cuda" if (pg and args.backend == "nccl") else "cpu"
     H, W = cfg["height"], cfg["width"]
-    seq_info = None; tum_info = None; first_dyna = first_kps = None
+    seq_info = None; tum_info = None; first_dyna = first_kps = None; dropin_info = small_info = None
 
     if workload == "sequence":
         if os.environ.get("SIND_BENCH_PRE"):          # experiment: a pipeline created and destroyed before the job (what the one-GPU line's streams workload leaves behind)
@@ -737,6 +801,7 @@ def main():
             pre = make_pipeline(cfg, intr, ps, pt, local, args.host_threads); pre.close(); del pre
         dt, acc, seq_info, loads = sequence_job(args, cfg, intr, seq_b, seq_d, rank, world, local, pg, comm_dev, S, K, Wm, not args.no_exact_leg)
         T = seq_info["frames_per_step_per_chunk"]; pairs = seq_info["owned_frames"]; flush_ms = seq_info["final_flush_ms"]; loop_ms = sync_ms = None
+        seq_info["pairs_per_rank_step"] = S * T
         if world > 1 and not args.no_n1_leg:
             # the N = 1 point of the strong-scaling curve in the same line: rank 0 runs the SAME job alone on its GPU after the timed region, the others wait
             if rank == 0:
@@ -746,6 +811,12 @@ def main():
                 seq_info["n1_value"] = i1["value"]; seq_info["n1_seconds"] = d1; seq_info["n1_chunks"] = i1["chunks"]; seq_info["n1_verify"] = i1["verify"]
                 seq_info["speedup_vs_n1"] = seq_info["value"] / i1["value"]; seq_info["scaling_efficiency"] = seq_info["value"] / (world * i1["value"])
                 seq_info["n1_note"] = "the same fixed-length job on rank 0's GPU alone, run after the timed region of the N-rank job (same code path as --gpus 1's `sequence` leg)"
+                # what ONE GPU does at THIS job's step size (chunks per rank x frames per step): efficiency lost to the step size and efficiency lost to the
+                # exchange between the ranks can then be told apart -- value / (world * n1_small_step_value) is the share the communication and the seams cost
+                torch.cuda.empty_cache()
+                vb, vd = stream_variants(seq_b, seq_d, S)
+                ss = small_step_leg(cfg, intr, vb, vd, local, args.host_threads, S2=S, T2=T, steps=max(4, min(K, (SEQ_BASE_FRAMES - 2) // max(T, 1))), warm=2)
+                seq_info["n1_small_step_value"] = ss["value"]; seq_info["n1_small_step"] = ss
             dist.barrier()
         ranks_seen = 1
         if pg:
@@ -830,6 +901,13 @@ def main():
             print(f"[thread-cpu] {'(exited threads)':16s} {(cpu_s - live) / K * 1e3:9.1f} core-ms per step   total {cpu_s / K * 1e3:.1f}", file=sys.stderr)
         grow_q = pipe.grow_share(); km_groups = pipe.kmeans_groups()
         pipe.close(); del dev_b, dev_d, pipe
+        dropin_info = small_info = None
+        if world == 1 and not args.host_input:
+            torch.cuda.empty_cache()
+            if not args.no_small_step_leg and S >= 16:
+                small_info = small_step_leg(cfg, intr, bgr, depth, local, args.host_threads)
+            if not args.no_dropin_leg:
+                dropin_info = dropin_leg(cfg, intr, bgr[0], depth[0], local, args.dropin_frames)
         # ---- one GPU: the fixed-length sequence job as well (the N = 1 point of the curve that --gpus N > 1 reports as its headline)
         if seq_leg:
             torch.cuda.empty_cache()
@@ -871,6 +949,10 @@ def main():
         out["region_grow_gpu_quarters"] = grow_q if not seq else seq_info.get("region_grow_gpu_quarters")
         # groups of streams whose batched k-means rounds run as independent chains at the end of the run (2..4, same controller; same results)
         out["kmeans_groups"] = km_groups if not seq else seq_info.get("kmeans_groups")
+        if not seq and dropin_info:
+            out["dropin"] = dropin_info
+        if not seq and small_info:
+            out["small_step"] = small_info
         if seq_info:
             out["sequence"] = seq_info
         if tum_info:

@@ -185,6 +185,7 @@ typedef struct sind_pipe_config {
     int host_threads;            /* 0 = library default (2 x the CPU share of the process) */
     int flow_max_levels;         /* 0 = the reference's full DeepFlow pyramid; n > 0: finest n levels only (see sind_flow_set_max_levels) */
     int flow_slices;             /* dense-flow slices of a step that run concurrently on their own streams: 0 = by step size (default), 1..4 fixed; same results */
+    int flow_opts_off;           /* A/B switches, same results: bit 0 = no k_coarse_chain (see sind_flow_set_coarse_chain), bit 1 = no k_sor_tile (see sind_flow_set_latency_tiles); 0 = defaults */
 } sind_pipe_config;
 int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out);
 int sind_pipe_destroy(sind_pipe* p);
@@ -252,6 +253,9 @@ int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, do
  * bytes of all slices, sum_ms = sum of the event-bracketed launch groups, union_ms = time during which at least one slice had solver
  * launches in flight (union of those intervals on a common event time base), slices = number of concurrent streams */
 int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, double* union_ms, double* alg_bytes, int* slices);
+/* since round 5 the two calls above count the launch groups of the STREAMING solver only (k_sor_stream: the kernel of slices of 80 pairs and more, the one bench.py's roofline
+ * object describes); this one reports the other solver launches of the step (tiles, one-workgroup levels outside k_coarse_chain, whose solver phases are not separate launches) */
+int sind_pipe_sor_other_stats(sind_pipe* p, long long* launches, double* sum_ms, double* alg_bytes);
 /* last sind_pipe_submit(_dev): time the call still waited for the previous step's tails after its own phase A had finished (0 = hidden) */
 int sind_pipe_tail_wait_ms(sind_pipe* p, double* ms);
 /* how the handle sized its host side: {CPU share of this process (cores), pool workers, CPU tokens (max), cores the process may run on, cgroup cpu.max quota in

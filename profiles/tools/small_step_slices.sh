@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 for cfg in "$@"; do
   set -- $cfg
-  for p in 1 2 3 4; do
+  for p in ${SLICES:-1 2 3 4}; do
     line=$(timeout -k 10 300 python3 bench.py --streams $1 --frames-per-step $2 --steps 16 --warmup 3 --flow-slices $p --no-cpu-baseline --no-sequence-leg 2>/dev/null | tail -1)
     echo "$line" | python3 -c "
 import json,sys

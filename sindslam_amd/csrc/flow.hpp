@@ -22,14 +22,19 @@ struct FlowPlanes {
 // HIP-event brackets around the SOR launch groups of the flow solver (bench.py's roofline leg): events are recorded on the
 // stream the kernels run on; collect() sums the elapsed times after the stream has been synchronised.
 struct SorTimer {
-    std::vector<hipEvent_t> ev; size_t used = 0; bool enabled = false;
-    double alg_bytes = 0; long long launches = 0;
-    void begin(hipStream_t s) { if (!enabled) return; if (used + 2 > ev.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); ev.push_back(a); ev.push_back(b); } (void)hipEventRecord(ev[used], s); }
-    void end(hipStream_t s, long long n_launches, double bytes) { if (!enabled) return; (void)hipEventRecord(ev[used + 1], s); used += 2; launches += n_launches; alg_bytes += bytes; }
-    void reset() { used = 0; alg_bytes = 0; launches = 0; }
-    double collect_ms() { double t = 0; for (size_t i = 0; i + 1 < used; i += 2) { float ms = 0; if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) t += ms; } return t; }
-    // [start, end] of every bracketed launch group in ms after `base` (an event with timing, recorded earlier on any stream)
-    void intervals(hipEvent_t base, std::vector<std::pair<double, double>>& out) { for (size_t i = 0; i + 1 < used; i += 2) { float a = 0, b = 0; if (hipEventElapsedTime(&a, base, ev[i]) == hipSuccess && hipEventElapsedTime(&b, base, ev[i + 1]) == hipSuccess) out.emplace_back(a, b); } }
+    std::vector<hipEvent_t> ev; std::vector<char> kind; size_t used = 0; bool enabled = false;
+    // kind 0: launch groups of the STREAMING solver (k_sor_stream, the kernel the roofline object describes); kind 1: every other solver kernel (tiles, one-workgroup levels)
+    double alg_bytes = 0, alg_bytes_other = 0; long long launches = 0, launches_other = 0;
+    void begin(hipStream_t s) { if (!enabled) return; if (used + 2 > ev.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); ev.push_back(a); ev.push_back(b); kind.push_back(0); } (void)hipEventRecord(ev[used], s); }
+    void end(hipStream_t s, long long n_launches, double bytes, int k = 0) {
+        if (!enabled) return;
+        (void)hipEventRecord(ev[used + 1], s); kind[used / 2] = (char)k; used += 2;
+        if (k == 0) { launches += n_launches; alg_bytes += bytes; } else { launches_other += n_launches; alg_bytes_other += bytes; }
+    }
+    void reset() { used = 0; alg_bytes = alg_bytes_other = 0; launches = launches_other = 0; }
+    double collect_ms(int k = 0) { double t = 0; for (size_t i = 0; i + 1 < used; i += 2) { if (kind[i / 2] != k) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) t += ms; } return t; }
+    // [start, end] of every bracketed launch group of kind k in ms after `base` (an event with timing, recorded earlier on any stream)
+    void intervals(hipEvent_t base, std::vector<std::pair<double, double>>& out, int k = 0) { for (size_t i = 0; i + 1 < used; i += 2) { if (kind[i / 2] != k) continue; float a = 0, b = 0; if (hipEventElapsedTime(&a, base, ev[i]) == hipSuccess && hipEventElapsedTime(&b, base, ev[i + 1]) == hipSuccess) out.emplace_back(a, b); } }
     ~SorTimer() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
 
@@ -44,7 +49,7 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 extern int g_coef_lanes, g_sor_stream_wg_cap; extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd, g_sor_tile_h, g_sor_stream_min_b, g_sor_stream_min_px; extern double g_sor_plan_cost;
 int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev);
 int debug_coef_math_scan(hipStream_t s, int exp_lo, int exp_hi, const float numer[3], unsigned long long* out_dev);
-int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, bool latency_tiles = false);
+int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, bool latency_tiles = false, int* streamed = nullptr);
 #define FLOW_OPT_COARSE_CHAIN 1      /* levels of <= 4096 pixels: the whole level (all of them, in a pyramid) in one launch (flow_coarse.hip) */
 #define FLOW_OPT_LATENCY_TILES 2     /* tiled levels with a compute unit per tile (few images): 1024-thread tiles, up to 13 iterations per launch (k_sor_tile) */
 int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr, int opts = FLOW_OPT_COARSE_CHAIN | FLOW_OPT_LATENCY_TILES);

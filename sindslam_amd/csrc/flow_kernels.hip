@@ -1448,7 +1448,8 @@ int g_sor_mode = 4;          // fused register-resident SOR with 1x8 strips: 4 =
                              // then Markstein's correction; default, fastest), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in
                              // registers (three waves per SIMD); 2 = fused, 1x4 strips + reciprocal division; 0 = one launch per colour (A/B timing, cross-check)
 int g_sor_stream_min_px = 0; // ... and only for levels of at least this many pixels (smaller ones leave workgroup slots empty: one workgroup per image strip)
-int g_sor_stream_min_b = 48; // mode 4: levels that are tiled go to the streaming kernel (one workgroup per image) from this many images per launch on; 5 = always
+int g_sor_stream_min_b = 80; // mode 4: levels that are tiled go to the streaming kernel (one workgroup per image) from this many images per launch on; 5 = always
+                             // (profiles/r05/stream_min_batch.txt: 48 images per launch 907 pairs/s streamed vs 1093-1110 tiled; 112 images 1356 vs 1237; 170 images 1514 vs 1296)
 int g_sor_fuse = 5;          // iterations per launch on the tiled levels; 0 = per-level plan (sor_fuse_plan: measured 1-2 % faster, 10 % more launches; not the default)
 double g_sor_plan_cost = 14; // prologue of a tile in iterations (sor_fuse_plan)
 int g_sor_xcd = 1;           // XCD-aware tile order of the fused kernel (0 = plain blockIdx order, for A/B timing)
@@ -1500,7 +1501,8 @@ static std::vector<int> sor_latency_plan(int w, int h, int B, int total) {
     }
     return {};
 }
-int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, bool latency_tiles) {
+int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, bool latency_tiles, int* streamed) {
+    if (streamed) *streamed = 0;
     if (g_sor_mode == 0) {
         const dim3 gs(divup(divup(w, 2), 64), h, B), bs(64);
         for (int k = 0; k < total; k++) {
@@ -1562,6 +1564,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
                 std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);      // column strips read each other's halo columns: not in place
                 *nlaunch += 1;
             }
+            if (streamed) *streamed = 1;
             return SIND_OK;
         }
         if (g_sor_mode == 5 && !fits) { /* wider than one workgroup's strip: the tiled kernel below */ }
@@ -1629,10 +1632,10 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
             hipLaunchKernelGGL(k_coef, dim3(divup(w, 128), divup(h, KC_ROWS), B), blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
                                P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr);
         if (timer) timer->begin(s);
-        long long nlaunch = 0;
-        SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch, latency_tiles));
+        long long nlaunch = 0; int streamed = 0;
+        SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch, latency_tiles, &streamed));
         // algorithmic bytes: 44 B per pixel per red+black iteration (9 reads + 2 writes of f32), SURVEY.md §8d
-        if (timer) timer->end(s, nlaunch, 44.0 * (double)w * h * B * V.sorIterations);
+        if (timer) timer->end(s, nlaunch, 44.0 * (double)w * h * B * V.sorIterations, streamed ? 0 : 1);
     }
     if ((((uintptr_t)P.Wu | (uintptr_t)P.Wv | (uintptr_t)P.dWu | (uintptr_t)P.dWv) & 15) == 0)
         hipLaunchKernelGGL(k_add_flow, dim3((unsigned)(((n >> 2) + (n & 3) + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.Wu, P.Wv, n);      // W = W + dW, in place

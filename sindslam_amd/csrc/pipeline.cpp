@@ -122,7 +122,8 @@ struct sind_pipe {
     // Chunked sequences (sindslam_amd/sequence.py): hashing = every tail leaves the fingerprint of its rolled state per frame (last_hash: the step whose results
     // were returned last, [S][T][2]); active_next = per-stream number of frames whose TAILS run in the next step (one step only; empty = all T)
     bool hashing = false; std::vector<uint64_t> last_hash; std::vector<int> active_next; int chain_max_streams = 12;
-    double stage_ms[6] = {0}; double tail_wait_ms = 0; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;
+    double stage_ms[6] = {0}; double tail_wait_ms = 0; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;      // streaming solver (k_sor_stream) launch groups of the last step
+    double sor_other_ms = 0, sor_other_bytes = 0; long long sor_other_launches = 0;                             // every other solver kernel outside k_coarse_chain (tiles, one-workgroup levels)
     SindHostGate gate;           // CPU tokens of this handle's pool tasks (common.hpp)
     WorkerPool workers;          // declared last: joined first
 };
@@ -176,8 +177,9 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     const int B = p->S * p->T; const size_t np = (size_t)cfg->width * cfg->height;
     // dense-flow slices: concurrent streams keep the GPU busy through the launch tails and the small pyramid levels of each other; small batches stay in one piece.
     // Measured (profiles/r04/split_sweep.txt, lab build): 512 pairs per step: 3 slices 1382-1417 pairs/s, 2: 1377, 4: 1354; 224 pairs (the one-GPU sequence job's step): 2 slices
-    // 1192, 1: 1164, 3: 1150, 4: 1120 -- a slice should hold ~110 pairs or more
-    const int nsplit = std::max(1, std::min(sind_lab_env("SIND_FLOW_SPLIT") ? atoi(sind_lab_env("SIND_FLOW_SPLIT")) : (cfg->flow_slices > 0 ? cfg->flow_slices : B >= 320 ? 3 : B >= 48 ? 2 : 1), std::min(4, B))), Bs = (B + nsplit - 1) / nsplit;
+    // 1192, 1: 1164, 3: 1150, 4: 1120.  Round 5 (k_coarse_chain, k_sor_tile; profiles/r05/small_step_slices.txt): slices of 12 - 50 pairs keep each other's latency-bound launches
+    // company -- 24 pairs: 2 slices 750 pairs/s (1: 671), 48: 2 -> 935 (1: 607), 64: 2 -> 1042 (1: 741), 96: 3 -> 1130 (2: 991); slices of 80 and more take the streaming solver
+    const int nsplit = std::max(1, std::min(sind_lab_env("SIND_FLOW_SPLIT") ? atoi(sind_lab_env("SIND_FLOW_SPLIT")) : (cfg->flow_slices > 0 ? cfg->flow_slices : B >= 320 ? 3 : B >= 160 ? 2 : B >= 80 ? 3 : B >= 24 ? 2 : 1), std::min(4, B))), Bs = (B + nsplit - 1) / nsplit;
     SIND_TRY(p->front.init(p->dc, nsplit > 1 ? std::max(Bs, 2) : B, p->stream));
     HIP_TRY(hipEventCreate(&p->ev_pool));                   // with timing: also the time base of the solver intervals
     for (int i = 1; i < nsplit; i++) {
@@ -185,6 +187,8 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
         p->extra_fronts.emplace_back(new DynaFront()); SIND_TRY(p->extra_fronts.back()->init(p->dc, Bs, st));
     }
     p->front.flow.max_levels = std::max(0, cfg->flow_max_levels); for (auto& f : p->extra_fronts) f->flow.max_levels = p->front.flow.max_levels;
+    p->front.flow.coarse_chain = !(cfg->flow_opts_off & 1); p->front.flow.latency_tiles = !(cfg->flow_opts_off & 2);
+    for (auto& f : p->extra_fronts) { f->flow.coarse_chain = p->front.flow.coarse_chain; f->flow.latency_tiles = p->front.flow.latency_tiles; }
     p->fw = p->front.fw; p->fh = p->front.fh;
     SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->orb_stream));
     // CPU share of this process: the cores it may run on (affinity), bounded by the container's quota (cgroup v2 cpu.max: 16 cores per GPU on the MI355X
@@ -462,7 +466,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         std::vector<DynaFront*> fr(1, &p->front); for (auto& f : p->extra_fronts) fr.push_back(f.get());
         HIP_TRY(hipEventRecord(p->ev_pool, p->stream));
         std::vector<int> rc(nsl, SIND_OK); std::vector<std::string> er(nsl); std::vector<std::thread> th;
-        std::vector<double> slice_ms(nsl, 0.0); std::vector<std::vector<std::pair<double, double>>> slice_iv(nsl);
+        std::vector<double> slice_ms(nsl, 0.0), slice_other_ms(nsl, 0.0); std::vector<std::vector<std::pair<double, double>>> slice_iv(nsl);
         auto run = [&](int i) {
             const int b0 = i * Bs, nb = std::min(Bs, B - b0); if (nb <= 0) return;
             SindRange r("sind dense flow slice: DeepFlow, large-motion pass, refinement, up-scale");
@@ -476,7 +480,7 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
             if (rc[i] == SIND_OK && sind_stream_wait(f.stream) != hipSuccess) rc[i] = SIND_E_HIP;
             if (rc[i] != SIND_OK) er[i] = sind_last_error();
             // the slice reads its own event brackets (three hipEventElapsedTime per bracket, ~150 brackets) while the other slices still run
-            else { slice_ms[i] = f.flow.sor_timer.collect_ms(); f.flow.sor_timer.intervals(p->ev_pool, slice_iv[i]); }
+            else { slice_ms[i] = f.flow.sor_timer.collect_ms(0); slice_other_ms[i] = f.flow.sor_timer.collect_ms(1); f.flow.sor_timer.intervals(p->ev_pool, slice_iv[i], 0); }
         };
         for (int i = 0; i < nsl; i++) th.emplace_back([&, i] { (void)pthread_setname_np(pthread_self(), "sind-flow"); (void)hipSetDevice(p->c.device); run(i); g_cpu_us_flow += (long long)(thread_cpu_ms() * 1e3); });
         g_cpu_steps++;
@@ -487,9 +491,10 @@ static int phase_a(sind_pipe* p, sind_pipe::StepBuf& sb, const uint8_t* bgr_dev,
         if (depth_ok != hipSuccess) { (void)hipGetLastError(); sind_set_error("copy of the depth frames failed"); return SIND_E_HIP; }
         for (int i = 0; i < nsl; i++) if (rc[i] != SIND_OK) { sind_set_error("dense flow slice %d: %s", i, er[i].c_str()); return rc[i]; }
         for (int k = 0; k < B; k++) sb.occ[k].gridFlow = sb.grid_h.p + gsz * k;
-        p->sor_ms = 0; p->sor_bytes = 0; p->sor_launches = 0; p->sor_slices = nsl;
+        p->sor_ms = 0; p->sor_bytes = 0; p->sor_launches = 0; p->sor_slices = nsl; p->sor_other_ms = 0; p->sor_other_bytes = 0; p->sor_other_launches = 0;
         std::vector<std::pair<double, double>> iv;
-        for (int i = 0; i < nsl; i++) { p->sor_ms += slice_ms[i]; p->sor_bytes += fr[i]->flow.sor_timer.alg_bytes; p->sor_launches += fr[i]->flow.sor_timer.launches; iv.insert(iv.end(), slice_iv[i].begin(), slice_iv[i].end()); }
+        for (int i = 0; i < nsl; i++) { p->sor_ms += slice_ms[i]; p->sor_bytes += fr[i]->flow.sor_timer.alg_bytes; p->sor_launches += fr[i]->flow.sor_timer.launches;
+            p->sor_other_ms += slice_other_ms[i]; p->sor_other_bytes += fr[i]->flow.sor_timer.alg_bytes_other; p->sor_other_launches += fr[i]->flow.sor_timer.launches_other; iv.insert(iv.end(), slice_iv[i].begin(), slice_iv[i].end()); }
         // time during which at least one slice had solver launches in flight (union of the event-bracketed intervals of all slices)
         std::sort(iv.begin(), iv.end()); double un = 0, cs = 0, ce = -1;
         for (const auto& q : iv) { if (q.first > ce) { if (ce > cs) un += ce - cs; cs = q.first; ce = q.second; } else ce = std::max(ce, q.second); }
@@ -902,6 +907,13 @@ int sind_pipe_sor_stats(sind_pipe* p, long long* launches, double* sum_ms, doubl
     if (union_ms) *union_ms = p->sor_union_ms;
     if (alg_bytes) *alg_bytes = p->sor_bytes;
     if (slices) *slices = p->sor_slices;
+    return SIND_OK;
+}
+int sind_pipe_sor_other_stats(sind_pipe* p, long long* launches, double* sum_ms, double* alg_bytes) {
+    if (!p) return SIND_E_ARG;
+    if (launches) *launches = p->sor_other_launches;
+    if (sum_ms) *sum_ms = p->sor_other_ms;
+    if (alg_bytes) *alg_bytes = p->sor_other_bytes;
     return SIND_OK;
 }
 int sind_pipe_stats(sind_pipe* p, double* stage_ms6, long long* sor_launches, double* sor_ms, double* sor_alg_bytes) {

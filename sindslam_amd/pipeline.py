@@ -14,16 +14,16 @@ class PipeConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("depth_scale", C.c_float), ("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
                 ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("orb_gray_rgb_order", C.c_int), ("streams", C.c_int),
-                ("frames_per_step", C.c_int), ("device", C.c_int), ("host_threads", C.c_int), ("flow_max_levels", C.c_int), ("flow_slices", C.c_int)]
+                ("frames_per_step", C.c_int), ("device", C.c_int), ("host_threads", C.c_int), ("flow_max_levels", C.c_int), ("flow_slices", C.c_int), ("flow_opts_off", C.c_int)]
 
 
 class Pipeline:
     def __init__(self, streams: int, frames_per_step: int, width=640, height=480, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_scale=5000.0,
-                 nfeatures=1500, scale_factor=1.2, nlevels=8, ini_th=15, min_th=5, orb_gray_rgb_order=0, device=0, host_threads=0, flow_max_levels=0, flow_slices=0, _out=None):
+                 nfeatures=1500, scale_factor=1.2, nlevels=8, ini_th=15, min_th=5, orb_gray_rgb_order=0, device=0, host_threads=0, flow_max_levels=0, flow_slices=0, flow_opts_off=0, _out=None):
         self.S, self.T, self.w, self.h = streams, frames_per_step, width, height
         self.cap = 2 * nfeatures + 256
         cfg = PipeConfig(width, height, fx, fy, cx, cy, depth_scale, nfeatures, scale_factor, nlevels, ini_th, min_th, orb_gray_rgb_order,
-                         streams, frames_per_step, device, host_threads, flow_max_levels, flow_slices)
+                         streams, frames_per_step, device, host_threads, flow_max_levels, flow_slices, flow_opts_off)
         h = C.c_void_p()
         check(lib().sind_pipe_create(C.byref(cfg), C.byref(h)), "sind_pipe_create")
         self._h = h
@@ -166,8 +166,9 @@ class Pipeline:
         un = C.c_double(); sl = C.c_int(); sm = C.c_double()
         check(lib().sind_pipe_sor_stats(self._h, C.byref(nl), C.byref(sm), C.byref(un), C.byref(by), C.byref(sl)))
         tw = C.c_double(); check(lib().sind_pipe_tail_wait_ms(self._h, C.byref(tw)))
+        ol = C.c_longlong(); om = C.c_double(); ob = C.c_double(); check(lib().sind_pipe_sor_other_stats(self._h, C.byref(ol), C.byref(om), C.byref(ob)))
         return dict(front_ms=st[0], flow_ms=st[1], orb_ms=st[2], upload_ms=st[3], tails_ms=st[4], total_ms=st[5], tail_wait_ms=tw.value, sor_launches=nl.value, sor_ms=sm.value, sor_alg_bytes=by.value,
-                    sor_union_ms=un.value, sor_slices=sl.value)
+                    sor_union_ms=un.value, sor_slices=sl.value, sor_other_launches=ol.value, sor_other_ms=om.value, sor_other_alg_bytes=ob.value)
 
 
 class PipelineGroup:

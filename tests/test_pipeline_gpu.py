@@ -237,8 +237,8 @@ def test_kmeans_stream_groups_do_not_change_the_results(frames):
 
 @pytest.mark.timeout(1200)
 def test_pipeline_in_the_shape_the_bench_runs_streaming_solver_and_ragged_step(frames):
-    """48 streams x 3 frames = 144 pairs per step: the dense flow runs as two slices of 72 pairs (three of 48 before the slice rule of round 4's end), i.e. on the STREAMING solver (k_sor_stream, the bench's
-    kernel; smaller test pipelines run the tiled one).  Four sampled streams against the ORACLE: imgDyna / imgLabel / mask / keypoints / descriptors of every
+    """48 streams x 3 frames = 144 pairs per step, the dense flow in ONE slice (flow_slices = 1; the rule by step size would cut 144 pairs into three slices of 48, below the
+    80 images per launch from which the streaming solver takes over): the STREAMING solver (k_sor_stream, the kernel of the bench's 170-pair slices) inside the pipeline.  Four sampled streams against the ORACLE: imgDyna / imgLabel / mask / keypoints / descriptors of every
     frame are equal.  Then a ragged step (sind_pipe_set_active_frames): the sampled streams stop after 0, 1, 2 and 3 frames -- their state fingerprints and state
     blobs are exactly those of the oracle-checked prefix."""
     from sindslam_amd.pipeline import Pipeline
@@ -255,12 +255,12 @@ def test_pipeline_in_the_shape_the_bench_runs_streaming_solver_and_ragged_step(f
     sb = np.empty((S, 6) + bgr.shape[1:], np.uint8); sd = np.empty((S, 6) + depth.shape[1:], np.uint16)
     for s in range(S):
         sb[s], sd[s] = variant(s)
-    pipe = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5, orb_gray_rgb_order=1)
+    pipe = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5, orb_gray_rgb_order=1, flow_slices=1)
     pipe.set_state_hashing(True)
     for s in range(S):
         pipe.prime(s, sb[s, 1], sb[s, 0])
     pipe.process(sb[:, 2:5], sd[:, 2:5])
-    st = pipe.stats(); assert st["sor_slices"] == 2          # 144 pairs: two slices of 72 (streaming from 48 pairs per slice)
+    st = pipe.stats(); assert st["sor_slices"] == 1          # 144 pairs in one slice: streaming (from 80 images per launch)
     sample = [0, 7, 22, 47]
     orb_ref = O.ORBextractor(1500, 1.2, 8, 15, 5)
     h_full = pipe.state_hashes(); assert (h_full != 0).any(axis=2).all()

@@ -54,8 +54,6 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=12)            # a pipelined run ends with one drained tail phase (~160 ms): 12 steps keep it at 3 % of the timed region
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="tum3", help="BASELINE.json config (default: the one the metric is quoted on)")
-    ap.add_argument("--coef-kernel", type=int, default=None, choices=[0, 1, 2], help="experiment: coefficient kernel of the flow (sind_debug_set_coef_lanes: 1 default, 2 = IEEE sqrt / division, 0 = neighbours from memory)")
-    ap.add_argument("--solver-workgroups", type=int, default=None, help="streaming solver: at most this many (persistent) workgroups per launch; 0 = one per (strip, image) item")
     ap.add_argument("--flow-levels", type=int, default=None, help="experiment: cap the DeepFlow pyramid at this many levels (NOT the config's workload: the line says so in config.flow_pyramid_levels)")
     ap.add_argument("--workload", choices=["auto", "streams", "sequence"], default="auto", help="auto: streams at 1 GPU, sequence (frame-sharded, RCCL mask gather) at N > 1")
     ap.add_argument("--streams", type=int, default=0, help="streams (= sequence chunks) per GPU; 0 = the config's default")
@@ -753,12 +751,6 @@ def main():
     if args.flow_levels is not None:
         cfg["flow_max_levels"] = args.flow_levels
     cfg["flow_slices"] = args.flow_slices; cfg["flow_opts_off"] = args.flow_opts_off
-    if args.coef_kernel is not None:
-        from sindslam_amd._lib import check, lib
-        check(lib().sind_debug_set_coef_lanes(args.coef_kernel), "sind_debug_set_coef_lanes")
-    if args.solver_workgroups is not None:
-        from sindslam_amd._lib import check, lib
-        check(lib().sind_flow_set_solver_workgroups(args.solver_workgroups), "sind_flow_set_solver_workgroups")
     workload = args.workload if args.workload != "auto" else ("sequence" if world > 1 else "streams")
     T, K, Wm = args.frames_per_step, args.steps, args.warmup
     S = args.streams or (cfg["streams"] if workload == "streams" else sequence_streams(world, args.sequence_frames, cfg["streams"], K, args.seq_warmup_frames))

@@ -56,18 +56,20 @@ int sind_flow_set_coarse_chain(sind_flow* f, int on);
 /* per handle: on != 0 (default) solves a tiled level whose tiles all find a compute unit of their own (few images per launch: the launch is latency-bound) with 1024-thread
  * tiles and up to 13 iterations per launch on deeper halos (k_sor_tile); 0 = the 512-thread tiles / streaming kernel at every batch size.  Same bits either way. */
 int sind_flow_set_latency_tiles(sind_flow* f, int on);
-/* solver variant (process-wide; every variant returns the same bits).  Fused register-resident SOR with 1x8 pixel strips: mode 4 = divisions
- * through a reciprocal formed on the fly (hardware estimate + one Newton step, then Markstein's correction; default: 5 iterations per launch on
- * 64 x 64 tiles), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in registers (three waves per SIMD; instances for
- * tiles of 256, 384 and 768 threads); 2 = fused, 1x4 strips + reciprocal division; 0 = one launch per colour (cross-check).  fuse = iterations
- * per launch on tiled levels (default 5), 0 = a plan per level that minimises tiles x (prologue + iterations) over the partitions of the 25
- * iterations; tile_w x tile_h = extended tile (tile_w * tile_h / 8 threads).  sind_flow_set_sor keeps the round-1 signature
+/* solver variant of THIS handle (every variant returns the same bits; nothing here is process-wide).  Fused register-resident SOR with 1x8 pixel strips: mode 4 = divisions
+ * through a reciprocal formed on the fly (hardware estimate + one Newton step, then Markstein's correction; default: 5 iterations per launch on 64 x 64 tiles), 5 = the
+ * streaming kernel on every level it fits, 0 = one launch per colour (cross-check); lab builds also: 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and
+ * held in registers (three waves per SIMD; tiles of 256, 384 and 768 threads), 2 = 1x4 strips + reciprocal division.  fuse = iterations per launch on tiled levels
+ * (default 5), 0 = a plan per level (lab builds); tile_w x tile_h = extended tile (tile_w * tile_h / 8 threads).  sind_flow_set_sor keeps the round-1 argument list
  * (tile height 48 for mode 3, 64 otherwise). */
-int sind_flow_set_sor(int mode, int fuse, int tile_w);
-int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h);
+int sind_flow_set_sor(sind_flow* f, int mode, int fuse, int tile_w);
+int sind_flow_set_sor_tiled(sind_flow* f, int mode, int fuse, int tile_w, int tile_h);
 /* streaming solver: at most `cap` workgroups per launch, each taking several (column strip, image) items in turn (persistent workgroups); 0 = one workgroup per item.
- * Same results; process-wide.  See DESIGN.md 3.1-12 for when it pays. */
-int sind_flow_set_solver_workgroups(int cap);
+ * Same results.  See DESIGN.md 3.1-12 for when it pays. */
+int sind_flow_set_solver_workgroups(sind_flow* f, int cap);
+/* coefficient kernel: 1 = k_coef_lanes (neighbours from lanes, short correctly rounded sqrt / quotient forms; default), 2 = k_coef_lanes with the compiler's IEEE forms,
+ * 0 = k_coef (neighbours from memory).  Same results. */
+int sind_flow_set_coef_kernel(sind_flow* f, int variant);
 int sind_lab_build(void);        /* 1: built with -DSIND_LAB (dormant solver variants and the SIND_* experiment switches of the measurement rounds), 0: the shipped drop-in */
 /* HIP-event timing of everything enqueued on the handle's stream between begin and end (bench.py roofline leg) */
 int sind_flow_timer_begin(sind_flow* f);
@@ -136,10 +138,6 @@ int sind_debug_seqsum(const float* x, int n, int device, float* out);
  * (tests/test_kmeans_fused_gpu.py); process-wide, for parity tests and A/B timing. */
 int sind_debug_set_kmeans_fused_max(int n);
 int sind_debug_set_kmeans_fused_min_batch(int b);
-/* coefficient kernel of the variational refinement: 1 (default) = k_coef_lanes (a wave loads every plane row once and takes x +- 1, x +- 2 from the neighbouring lanes; sqrt
- * and c / sqrt in their short correctly rounded forms), 2 = k_coef_lanes with the compiler's IEEE sequences, 0 = k_coef (every neighbour from memory, IEEE sequences).  Same
- * coefficients bit for bit (tests/test_flow_gpu.py); process-wide, for the parity tests and A/B timing. */
-int sind_debug_set_coef_lanes(int on);
 /* exhaustive check of the short forms: for every float significand and the binary exponents exp_lo..exp_hi (>= -96), out[0] = arguments whose short-form square root differs
  * from sqrtf, out[1] = quotients numer[k] / b through the reciprocal (hardware estimate + Newton step + Markstein's correction) that differ from the IEEE division */
 int sind_debug_coef_math_scan(int device, int exp_lo, int exp_hi, const float numer[3], unsigned long long out[2]);

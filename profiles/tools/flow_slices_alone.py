@@ -16,10 +16,10 @@ img = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 1, np.apply_along
 i0 = np.stack([img[(b % 5):(b % 5) + h, (b % 3):(b % 3) + w] for b in range(B)]).astype(np.uint8)
 i1 = np.stack([img[(b % 5) + 2:(b % 5) + 2 + h, (b % 3) + 3:(b % 3) + 3 + w] for b in range(B)]).astype(np.uint8)
 import torch
-if CAP:
-    from sindslam_amd._lib import lib
-    assert lib().sind_flow_set_solver_workgroups(CAP) == 0
 stages = [FlowStage(w, h, B) for _ in range(S)]
+if CAP:
+    for st_ in stages:
+        st_.set_solver_workgroups(CAP)
 d0 = torch.from_numpy(i0).cuda(); d1 = torch.from_numpy(i1).cuda()
 outs = [(torch.empty((B, h, w), dtype=torch.float32, device="cuda"), torch.empty((B, h, w), dtype=torch.float32, device="cuda")) for _ in range(S)]
 torch.cuda.synchronize()

@@ -140,7 +140,8 @@ int sind_debug_flow_thresholds(const int* hist, int n, int width, int height, in
     }
     return SIND_OK;
 }
-int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h) {
+int sind_flow_set_sor_tiled(sind_flow* f, int mode, int fuse, int tile_w, int tile_h) {
+    if (!f) { sind_set_error("sind_flow_set_sor_tiled: null handle"); return SIND_E_ARG; }
     const int nt = tile_w * tile_h / 8;
     if (mode < 0 || mode > 5 || fuse < 0 || fuse > 12 || tile_w < 16 || tile_w % 8 || tile_h < 8 || tile_h % 2 || nt % 128 || nt > 1024 || 4 * fuse >= tile_w || 4 * fuse >= tile_h ||
         (mode == 3 && nt != 256 && nt != 384 && nt != 768)) {
@@ -151,13 +152,13 @@ int sind_flow_set_sor_tiled(int mode, int fuse, int tile_w, int tile_h) {
     // kernel (5); IEEE-division, reciprocal-plane and 1 x 4-strip variants and the per-level fuse plans are lab builds (make -C sindslam_amd/csrc lab)
     if ((mode != 0 && mode != 4 && mode != 5) || fuse == 0) { sind_set_error("sind_flow_set_sor_tiled: solver variant (mode %d, fuse %d) exists in lab builds only", mode, fuse); return SIND_E_ARG; }
 #endif
-    sind::g_sor_mode = mode; sind::g_sor_fuse = fuse; sind::g_sor_tile_w = tile_w; sind::g_sor_tile_h = tile_h; return SIND_OK;
+    sind::SolverCfg& C = f->eng.solver; C.mode = mode; C.fuse = fuse; C.tile_w = tile_w; C.tile_h = tile_h; return SIND_OK;
 }
-int sind_flow_set_solver_workgroups(int cap) { if (cap < 0) return SIND_E_ARG; sind::g_sor_stream_wg_cap = cap; return SIND_OK; }
-int sind_debug_set_coef_lanes(int on) { if (on < 0 || on > 2) return SIND_E_ARG; sind::g_coef_lanes = on; return SIND_OK; }
-int sind_flow_set_sor(int mode, int fuse, int tile_w) {
+int sind_flow_set_solver_workgroups(sind_flow* f, int cap) { if (!f || cap < 0) return SIND_E_ARG; f->eng.solver.stream_wg_cap = cap; return SIND_OK; }
+int sind_flow_set_coef_kernel(sind_flow* f, int variant) { if (!f || variant < 0 || variant > 2) return SIND_E_ARG; f->eng.solver.coef_kernel = variant; return SIND_OK; }
+int sind_flow_set_sor(sind_flow* f, int mode, int fuse, int tile_w) {
     if (tile_w != 64 && tile_w != 128) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }
-    return sind_flow_set_sor_tiled(mode, fuse, tile_w, mode == 3 ? (tile_w == 64 ? 48 : 48) : 64);
+    return sind_flow_set_sor_tiled(f, mode, fuse, tile_w, mode == 3 ? (tile_w == 64 ? 48 : 48) : 64);
 }
 int sind_lab_build(void) {
 #ifdef SIND_LAB

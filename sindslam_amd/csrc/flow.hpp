@@ -46,13 +46,29 @@ int launch_resize_f32(hipStream_t s, const float* src, float* dst, int sw, int s
 int launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int B, int s_stride, int d_stride, size_t s_img, size_t d_img, int d_group = 0, int d_skip = 0);       // d_group > 0: d_skip destination slots stay free after every d_group images
 int launch_roll_history(hipStream_t s, uint8_t* pool, int S, int T, size_t frame_bytes);      // history slots 0, 1 <- slots T, T + 1 of every stream's T + 2 pool slots
 int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npix, bool swap_rb);
-extern int g_coef_lanes, g_sor_stream_wg_cap; extern int g_sor_mode, g_sor_fuse, g_sor_tile_w, g_sor_xcd, g_sor_tile_h, g_sor_stream_min_b, g_sor_stream_min_px; extern double g_sor_plan_cost;
 int debug_rcp_scan(hipStream_t s, int exp_lo, int exp_hi, unsigned long long* out_dev);
 int debug_coef_math_scan(hipStream_t s, int exp_lo, int exp_hi, const float numer[3], unsigned long long* out_dev);
-int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, bool latency_tiles = false, int* streamed = nullptr);
+struct SolverCfg;
+int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, const SolverCfg& C, int* streamed = nullptr);
 #define FLOW_OPT_COARSE_CHAIN 1      /* levels of <= 4096 pixels: the whole level (all of them, in a pyramid) in one launch (flow_coarse.hip) */
 #define FLOW_OPT_LATENCY_TILES 2     /* tiled levels with a compute unit per tile (few images): 1024-thread tiles, up to 13 iterations per launch (k_sor_tile) */
-int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer = nullptr, int opts = FLOW_OPT_COARSE_CHAIN | FLOW_OPT_LATENCY_TILES);
+// Solver settings of ONE flow handle (every variant returns the same bits; sind_flow_set_sor_tiled / _solver_workgroups / _coef_kernel / _coarse_chain / _latency_tiles).
+struct SolverCfg {
+    int mode = 4;              // fused register-resident SOR with 1x8 strips: 4 = divisions through a reciprocal formed on the fly (hardware estimate + Newton step, then Markstein's
+                               // correction; default), 5 = the streaming kernel on every level it fits, 0 = one launch per colour (cross-check); lab builds: 1 = IEEE division, 3 = reciprocal
+                               // planes held in registers (three waves per SIMD), 2 = 1x4 strips + reciprocal division
+    int fuse = 5;              // iterations per launch on the tiled levels; 0 = per-level plan (sor_fuse_plan: measured 1-2 % faster, 10 % more launches; lab builds)
+    int tile_w = 64, tile_h = 64;      // extended tile (multiple of 8 wide, even height, tile_w * tile_h / 8 threads)
+    int xcd = 1;               // XCD-aware tile order of the fused kernel (0 = plain blockIdx order, for A/B timing)
+    int stream_min_b = 80;     // mode 4: tiled levels go to the streaming kernel (one workgroup per image and column strip) from this many images per launch on
+                               // (profiles/r05/stream_min_batch.txt: 48 images per launch 907 pairs/s streamed vs 1093-1110 tiled; 112 images 1356 vs 1237; 170 images 1514 vs 1296)
+    int stream_min_px = 0;     // ... and only for levels of at least this many pixels
+    int stream_wg_cap = 0;     // k_sor_stream: at most this many (persistent) workgroups per launch (0 = one per item)
+    int coef_kernel = 1;       // 1: k_coef_lanes (neighbours from lanes; short forms of sqrt and c / sqrt), 2: k_coef_lanes with the IEEE forms, 0: k_coef (neighbours from memory)
+    double plan_cost = 14;     // prologue of a tile in iterations (sor_fuse_plan)
+    int opts = FLOW_OPT_COARSE_CHAIN | FLOW_OPT_LATENCY_TILES;
+};
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer, const SolverCfg& C);
 // flow_coarse.hip: the one-workgroup levels of a pyramid (or one such level) in one launch
 int coarse_level_P(int w, int h);
 int launch_sor_tile(hipStream_t s, FlowPlanes& P, int w, int h, int B, int iters, float omega);
@@ -88,8 +104,9 @@ public:
     int max_levels = 0;                          // > 0: use only the finest max_levels pyramid levels, zero flow at the coarsest of them (DeepFlow's maxLayers knob made
                                                  // effective -- OpenCV 4.2 never increments its layer counter; BASELINE.json config 5 "3-level flow pyramid"); 0 = all levels
     int launch_ahead = 3;                        // pyramid levels the launching thread may be ahead of the GPU (0 = unbounded)
+    SolverCfg solver;                            // this handle's solver settings
     bool latency_tiles = true;                   // tiled levels of few images: 1024-thread tiles and deep halos (k_sor_tile) where every tile has a compute unit to itself
-    int opts() const { return (coarse_chain ? FLOW_OPT_COARSE_CHAIN : 0) | (latency_tiles ? FLOW_OPT_LATENCY_TILES : 0); }
+    const SolverCfg& opts() { solver.opts = (coarse_chain ? FLOW_OPT_COARSE_CHAIN : 0) | (latency_tiles ? FLOW_OPT_LATENCY_TILES : 0); return solver; }
     bool coarse_chain = true;                    // the one-workgroup levels (<= ~8 k pixels) run in ONE launch (k_coarse_chain); false: per-stage kernels everywhere (cross-check, A/B timing)
     ~FlowEngine() { for (hipEvent_t e : level_done) (void)hipEventDestroy(e); }
 private:

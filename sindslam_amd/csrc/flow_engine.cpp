@@ -20,14 +20,14 @@ static std::vector<std::pair<int, int>> deepflow_sizes(int w, int h) {
 
 int FlowEngine::init(int fw_, int fh_, int maxB_, hipStream_t s) {
     fw = fw_; fh = fh_; maxB = maxB_; stream = s;
-    if (const char* e = sind_lab_env("SIND_SOR_MODE")) g_sor_mode = atoi(e);       // see g_sor_mode (flow_kernels.hip); the tile / fuse variables are for A/B timing
-    if (const char* e = sind_lab_env("SIND_SOR_TILEW")) g_sor_tile_w = atoi(e);
-    if (const char* e = sind_lab_env("SIND_SOR_FUSE")) g_sor_fuse = std::max(0, std::min(atoi(e), 12));
-    if (const char* e = sind_lab_env("SIND_SOR_PLAN_COST")) g_sor_plan_cost = std::max(0.0, atof(e));
-    if (const char* e = sind_lab_env("SIND_SOR_XCD")) g_sor_xcd = atoi(e) != 0;
-    if (const char* e = sind_lab_env("SIND_SOR_TILEH")) g_sor_tile_h = atoi(e);
-    if (const char* e = sind_lab_env("SIND_SOR_STREAM_MINB")) g_sor_stream_min_b = atoi(e);
-    if (const char* e = sind_lab_env("SIND_SOR_STREAM_MINPX")) g_sor_stream_min_px = atoi(e);       // images per launch from which the tiled levels take the streaming kernel
+    if (const char* e = sind_lab_env("SIND_SOR_MODE")) solver.mode = atoi(e);       // see SolverCfg (flow.hpp); the tile / fuse variables are for A/B timing
+    if (const char* e = sind_lab_env("SIND_SOR_TILEW")) solver.tile_w = atoi(e);
+    if (const char* e = sind_lab_env("SIND_SOR_FUSE")) solver.fuse = std::max(0, std::min(atoi(e), 12));
+    if (const char* e = sind_lab_env("SIND_SOR_PLAN_COST")) solver.plan_cost = std::max(0.0, atof(e));
+    if (const char* e = sind_lab_env("SIND_SOR_XCD")) solver.xcd = atoi(e) != 0;
+    if (const char* e = sind_lab_env("SIND_SOR_TILEH")) solver.tile_h = atoi(e);
+    if (const char* e = sind_lab_env("SIND_SOR_STREAM_MINB")) solver.stream_min_b = atoi(e);
+    if (const char* e = sind_lab_env("SIND_SOR_STREAM_MINPX")) solver.stream_min_px = atoi(e);       // images per launch from which the tiled levels take the streaming kernel
     if (const char* e = sind_lab_env("SIND_LAUNCH_AHEAD")) launch_ahead = std::max(0, atoi(e));       // 0: unbounded
     levels = deepflow_sizes(fw, fh);
     level_off.clear(); pyr_pixels = 0;

@@ -263,8 +263,6 @@ __global__ __launch_bounds__(256) void k_coef_lanes(VarParams P, int w, int h, c
         else kc_lanes<true, false>(P, w, h, col, y0, base, gAvg, gIz, gWu, gWv, gdWu, gdWv, A11, A12, A22, B1, B2, Wgt, R11, R22, store_lane);
     }
 }
-int g_sor_stream_wg_cap = 0;    // k_sor_stream: at most this many workgroups per launch (0 = one per item)
-int g_coef_lanes = 1;            // 1: k_coef_lanes (neighbours from lanes; short forms of sqrt and c / sqrt), 2: k_coef_lanes with the IEEE forms, 0: k_coef (neighbours from memory) -- kept for the A/B tests
 
 // ---------------------------------------------------------------------------------------------------------
 // RedBlackSOR_ParBody: one colour of one SOR iteration (plain version: one thread per pixel of the colour).
@@ -974,7 +972,7 @@ __device__ __forceinline__ void ss_item(float* lds, const int strip, const int i
     #undef SS_STORE
 }
 // The launch: workgroup k takes the items k, k + gridDim.x, ... (item = strip + strips * image).  With as many workgroups as items (the default) a workgroup has one item;
-// with FEWER (sor_iterations: g_sor_stream_wg_cap) the workgroups are persistent: they keep their place on their compute units for the whole launch instead of handing it back
+// with FEWER (sor_iterations: C.stream_wg_cap) the workgroups are persistent: they keep their place on their compute units for the whole launch instead of handing it back
 // after every item -- and a place that is handed back while other kernels' small workgroups are queued at a higher stream priority comes back in pieces.
 template <int MAXSW>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per_eu(4, 4))) k_sor_stream(int strips, int items, int w, int h, int SW, int HT, int IW, float omega, const float* __restrict__ gA11, const float* __restrict__ gA12,
@@ -1444,28 +1442,18 @@ int launch_bgr2gray(hipStream_t s, const uint8_t* bgr, uint8_t* gray, size_t npi
 // `total` red-black SOR iterations on the level's system.  Small levels: the whole image is one tile and all iterations run
 // in one launch; larger levels: 64 x 64 tiles, SOR_FUSE iterations per launch with a 2*SOR_FUSE halo, ping-pong between the
 // two increment buffers (a tile reads its halo from neighbours that another workgroup of the same launch rewrites).
-int g_sor_mode = 4;          // fused register-resident SOR with 1x8 strips: 4 = divisions through a reciprocal formed on the fly (hardware estimate + Newton step,
-                             // then Markstein's correction; default, fastest), 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and held in
-                             // registers (three waves per SIMD); 2 = fused, 1x4 strips + reciprocal division; 0 = one launch per colour (A/B timing, cross-check)
-int g_sor_stream_min_px = 0; // ... and only for levels of at least this many pixels (smaller ones leave workgroup slots empty: one workgroup per image strip)
-int g_sor_stream_min_b = 80; // mode 4: levels that are tiled go to the streaming kernel (one workgroup per image) from this many images per launch on; 5 = always
-                             // (profiles/r05/stream_min_batch.txt: 48 images per launch 907 pairs/s streamed vs 1093-1110 tiled; 112 images 1356 vs 1237; 170 images 1514 vs 1296)
-int g_sor_fuse = 5;          // iterations per launch on the tiled levels; 0 = per-level plan (sor_fuse_plan: measured 1-2 % faster, 10 % more launches; not the default)
-double g_sor_plan_cost = 14; // prologue of a tile in iterations (sor_fuse_plan)
-int g_sor_xcd = 1;           // XCD-aware tile order of the fused kernel (0 = plain blockIdx order, for A/B timing)
-int g_sor_tile_w = 64;       // extended tile (multiple of 8 wide, even height, tile_w * tile_h / 8 threads)
-int g_sor_tile_h = 64;
+// (the solver settings -- variant, iterations per launch, tile, streaming threshold -- are a SolverCfg per flow handle: flow.hpp)
 // How the `total` iterations of a level are cut into launches.  A launch of f iterations needs a halo of 2 f pixels, so it covers the level with
-// ceil(w / (EW - 4 f)) x ceil(h / (EH - 4 f)) tiles, and a tile costs its prologue (coefficient loads, LDS set-up, write-back: g_sor_plan_cost iterations'
+// ceil(w / (EW - 4 f)) x ceil(h / (EH - 4 f)) tiles, and a tile costs its prologue (coefficient loads, LDS set-up, write-back: C.plan_cost iterations'
 // worth, fitted to the measured 4 / 5 / 6-iteration runs) plus f iterations.  With a fixed f = 5 the 26 tiled levels of the 384 x 288 pyramid compute
 // 2.5 x their pixels (levels just above a multiple of the 44-pixel interior up to 3.5 x); the cheapest partition per level (dynamic programme over
 // the remaining iterations) picks e.g. 1 + 6 x 4 iterations for 178 x 133: 12 tiles per launch instead of 20.  Measured (bench --sync, solver busy per step):
 // 370 ms with f = 5 everywhere, 364-369 ms with the plans for a prologue cost of 7-20 iterations, 392 ms for 4 -- the model's 6 % shrink to 1-2 %, so the plan
-// is an option (g_sor_fuse = 0), not the default.
-static std::vector<int> sor_fuse_plan(int w, int h, int EW, int EH, int total) {
-    if (g_sor_fuse > 0) return std::vector<int>((size_t)divup(total, g_sor_fuse), g_sor_fuse);
+// is an option (C.fuse = 0), not the default.
+static std::vector<int> sor_fuse_plan(const SolverCfg& C, int w, int h, int EW, int EH, int total) {
+    if (C.fuse > 0) return std::vector<int>((size_t)divup(total, C.fuse), C.fuse);
     static std::mutex mu; static std::map<std::array<int, 6>, std::vector<int>> cache;
-    const std::array<int, 6> key{w, h, EW, EH, total, (int)std::lrint(g_sor_plan_cost * 16)};
+    const std::array<int, 6> key{w, h, EW, EH, total, (int)std::lrint(C.plan_cost * 16)};
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
@@ -1475,7 +1463,7 @@ static std::vector<int> sor_fuse_plan(int w, int h, int EW, int EH, int total) {
         double best = -1; int bf = 1;
         for (int f = 1; f <= std::min(fmax, rem); f++) {
             const int IW = EW - 4 * f, IH = EH - 4 * f;
-            const double c = (double)divup(w, IW) * divup(h, IH) * (g_sor_plan_cost + f) + cost[(size_t)rem - f];
+            const double c = (double)divup(w, IW) * divup(h, IH) * (C.plan_cost + f) + cost[(size_t)rem - f];
             if (best < 0 || c < best) { best = c; bf = f; }
         }
         cost[(size_t)rem] = best; pick[(size_t)rem] = bf;
@@ -1501,9 +1489,10 @@ static std::vector<int> sor_latency_plan(int w, int h, int B, int total) {
     }
     return {};
 }
-int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, bool latency_tiles, int* streamed) {
+int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, const SolverCfg& C, int* streamed) {
+    const bool latency_tiles = (C.opts & FLOW_OPT_LATENCY_TILES) != 0;
     if (streamed) *streamed = 0;
-    if (g_sor_mode == 0) {
+    if (C.mode == 0) {
         const dim3 gs(divup(divup(w, 2), 64), h, B), bs(64);
         for (int k = 0; k < total; k++) {
             hipLaunchKernelGGL(k_sor_color, gs, bs, 0, s, w, h, omega, 0, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv);
@@ -1524,7 +1513,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         for (const void* f : fs) if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         return attr_rc;
     }));
-    if (latency_tiles && (g_sor_mode == 4 || g_sor_mode == 5)) {
+    if (latency_tiles && C.mode == 4) {       // (mode 5 asks for the streaming kernel wherever it fits)
         const std::vector<int> plan = sor_latency_plan(w, h, B, total);
         if (!plan.empty() && !(plan.size() > 1 && 2 * divup(divup(w, 8) * ((h + 1) / 2), 64) * 64 <= 512)) {      // (a level of <= 4096 pixels that is not in the chain: one launch of the one-workgroup kernel below is as good)
             for (int k : plan) { SIND_TRY(launch_sor_tile(s, P, w, h, B, k, omega)); *nlaunch += 1; }
@@ -1541,7 +1530,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         // <= 512 threads: two waves per SIMD, i.e. up to 256 registers -- room for the run-time tile sizes AND the reciprocal division without spills
         // (all 25 iterations run in this launch, so here the loop is the cost); larger blocks keep the four-waves-per-SIMD IEEE instance
 #ifdef SIND_LAB
-        auto kern1 = (nt <= 512 && (g_sor_mode == 4 || g_sor_mode == 5)) ? k_sor_fused<2, 512, 2, 0, 0> : (g_sor_mode == 4 || g_sor_mode == 5) ? k_sor_fused<2, 1024, 4, 0, 0> : k_sor_fused<0, 1024, 4, 0, 0>;
+        auto kern1 = (nt <= 512 && (C.mode == 4 || C.mode == 5)) ? k_sor_fused<2, 512, 2, 0, 0> : (C.mode == 4 || C.mode == 5) ? k_sor_fused<2, 1024, 4, 0, 0> : k_sor_fused<0, 1024, 4, 0, 0>;
 #else
         auto kern1 = nt <= 512 ? k_sor_fused<2, 512, 2, 0, 0> : k_sor_fused<2, 1024, 4, 0, 0>;
 #endif
@@ -1556,10 +1545,10 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
         while (SW > SS_MAXSW) { n++; IW = divup(divup(w, n), 4) * 4; SW = (IW + 24) / 4; }
         const int HT = divup(5 * SW, 64) * 64, CT = 2 * HT;       // threads of one slot group (whole waves: a wave holding both groups would run both colours' code every step), compute threads; + two loader waves
         const bool fits = h >= 4 && total % (SS_NQ / 2) == 0;
-        if (fits && (g_sor_mode == 5 || (g_sor_mode == 4 && B >= g_sor_stream_min_b && w * h >= g_sor_stream_min_px))) {
+        if (fits && (C.mode == 5 || (C.mode == 4 && B >= C.stream_min_b && w * h >= C.stream_min_px))) {
             const size_t shm = ((size_t)6 * SS_RING * (2 * SS_MAXSW + 4) + (size_t)SS_NST * SS_STG * 4 * SS_MAXSW) * sizeof(float);
             for (int done = 0; done < total; done += SS_NQ / 2) {
-                const int items = n * B, wgs = (g_sor_stream_wg_cap > 0 && items > g_sor_stream_wg_cap) ? divup(items, divup(items, g_sor_stream_wg_cap)) : items;      // persistent: every workgroup the same number of items (+- 1)
+                const int items = n * B, wgs = (C.stream_wg_cap > 0 && items > C.stream_wg_cap) ? divup(items, divup(items, C.stream_wg_cap)) : items;      // persistent: every workgroup the same number of items (+- 1)
                 hipLaunchKernelGGL(k_sor_stream<SS_MAXSW>, dim3(wgs), dim3(CT + 128), shm, s, n, items, w, h, SW, HT, IW, omega, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
                 std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);      // column strips read each other's halo columns: not in place
                 *nlaunch += 1;
@@ -1567,18 +1556,18 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
             if (streamed) *streamed = 1;
             return SIND_OK;
         }
-        if (g_sor_mode == 5 && !fits) { /* wider than one workgroup's strip: the tiled kernel below */ }
+        if (C.mode == 5 && !fits) { /* wider than one workgroup's strip: the tiled kernel below */ }
     }
 #ifdef SIND_LAB
-    if (g_sor_mode == 2) {                             // 1x4 strips + reciprocal division (k_sor_fused4), 64 x 64 tiles, 1024 threads
+    if (C.mode == 2) {                             // 1x4 strips + reciprocal division (k_sor_fused4), 64 x 64 tiles, 1024 threads
         static SindPerDeviceInit attr4_init;
         HIP_TRY(attr4_init.run([] { return hipFuncSetAttribute((const void*)k_sor_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); }));
         const int EW = 64, EH = 64, nt = 1024;
         const size_t shm = (size_t)4 * (EH + 2) * (EW / 4 + 2) * sizeof(float2);
         for (int done = 0; done < total;) {
-            const int k = std::min(g_sor_fuse > 0 ? g_sor_fuse : 5, total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
+            const int k = std::min(C.fuse > 0 ? C.fuse : 5, total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
             const int ntx = divup(w, IW), nty = divup(h, IH);
-            hipLaunchKernelGGL(k_sor_fused4, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
+            hipLaunchKernelGGL(k_sor_fused4, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, k, C.xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
                                P.wgt, P.dWu, P.dWv, P.dWu2, P.dWv2);
             std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);
             done += k; *nlaunch += 1;
@@ -1587,26 +1576,26 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
     }
 #endif
     // tiled levels.  Reciprocal instance (default): EW x EH tiles of EW * EH / 8 threads at three waves per SIMD; IEEE-division instance: four waves per SIMD
-    const int EW = g_sor_tile_w, EH = g_sor_tile_h, nt = threads_for(EW, EH);
-    const bool rcp = g_sor_mode == 3;
+    const int EW = C.tile_w, EH = C.tile_h, nt = threads_for(EW, EH);
+    const bool rcp = C.mode == 3;
     if (rcp && nt != 256 && nt != 384 && nt != 768) { sind_set_error("sor_iterations: %d x %d tiles (%d threads) have no reciprocal-solver instance", EW, EH, nt); return SIND_E_ARG; }
-    if (nt > SOR_NT || (g_sor_fuse > 0 && 2 * 2 * g_sor_fuse >= std::min(EW, EH))) { sind_set_error("sor_iterations: tile %d x %d / %d fused iterations not supported", EW, EH, g_sor_fuse); return SIND_E_ARG; }
+    if (nt > SOR_NT || (C.fuse > 0 && 2 * 2 * C.fuse >= std::min(EW, EH))) { sind_set_error("sor_iterations: tile %d x %d / %d fused iterations not supported", EW, EH, C.fuse); return SIND_E_ARG; }
     const size_t shm = sor_lds_bytes(EW, nt);
     if (shm > 150 * 1024) { sind_set_error("sor_iterations: %d x %d tiles need %zu bytes of LDS", EW, EH, shm); return SIND_E_ARG; }
-    const std::vector<int> plan = sor_fuse_plan(w, h, EW, EH, total);
+    const std::vector<int> plan = sor_fuse_plan(C, w, h, EW, EH, total);
     size_t step = 0;
     for (int done = 0; done < total;) {
         const int k = std::min(plan[step++], total - done), halo = 2 * k, halo_x = halo, IW = EW - 2 * halo_x, IH = EH - 2 * halo;
         const int ntx = divup(w, IW), nty = divup(h, IH);
         const bool t64 = EW == 64 && EH == 64 && nt == 512;           // the default tile has instances with compile-time sizes
 #ifdef SIND_LAB
-        auto kern = (g_sor_mode == 4 || g_sor_mode == 5) ? (t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>) : !rcp ? (t64 ? k_sor_fused<0, 512, 4, 64, 64> : k_sor_fused<0, 1024, 4, 0, 0>)
+        auto kern = (C.mode == 4 || C.mode == 5) ? (t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>) : !rcp ? (t64 ? k_sor_fused<0, 512, 4, 64, 64> : k_sor_fused<0, 1024, 4, 0, 0>)
                     : nt == 384 ? k_sor_fused<1, 384, 3, 0, 0> : nt == 768 ? k_sor_fused<1, 768, 3, 0, 0> : k_sor_fused<1, 256, 3, 0, 0>;
 #else
         auto kern = t64 ? k_sor_fused<2, 512, 4, 64, 64> : k_sor_fused<2, 1024, 4, 0, 0>;
 #endif
         static const int dry = sind_lab_env("SIND_SOR_DRY") ? atoi(sind_lab_env("SIND_SOR_DRY")) : 0;       // timing experiment: 1 = no iterations (prologue + write-back only; results are wrong)
-        hipLaunchKernelGGL(kern, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, dry ? 0 : k, g_sor_xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
+        hipLaunchKernelGGL(kern, dim3(ntx * nty, B), dim3(nt), shm, s, w, h, EW, EH, IW, IH, halo_x, halo, ntx, dry ? 0 : k, C.xcd, omega, P.A11, P.A12, P.A22, P.b1, P.b2,
                            P.wgt, P.r11, P.r22, P.dWu, P.dWv, P.dWu2, P.dWv2);
         std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);
         done += k; *nlaunch += 1;
@@ -1615,9 +1604,9 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
 }
 
 // VariationalRefinement::calcUV on one pyramid level for B pairs.  Wu/Wv: initial flow in, refined flow out.
-int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer, int opts) {
-    const bool coarse_chain = (opts & FLOW_OPT_COARSE_CHAIN) != 0, latency_tiles = (opts & FLOW_OPT_LATENCY_TILES) != 0;
-    if (coarse_chain && V.epsilon >= 1e-12f && g_sor_mode != 0 && coarse_level_P(w, h)) {       // one workgroup's work: the whole level in one launch (flow_coarse.hip)
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer, const SolverCfg& C) {
+    const bool coarse_chain = (C.opts & FLOW_OPT_COARSE_CHAIN) != 0;
+    if (coarse_chain && V.epsilon >= 1e-12f && C.mode != 0 && coarse_level_P(w, h)) {       // one workgroup's work: the whole level in one launch (flow_coarse.hip)
         const std::vector<std::pair<int, int>> lv{{w, h}}; const std::vector<size_t> off{0};
         return launch_coarse_chain(s, P, I0, I1, lv, off, 0, 0, B, V, false, false, 1.f, nullptr, nullptr);
     }
@@ -1625,15 +1614,15 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     const dim3 blk(128);
     hipLaunchKernelGGL(k_warp_avg_iz, grid2d(w, divup(h, WARP_ROWS), B), blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, P.dWu, P.dWv, w, h);
     for (int it = 0; it < V.fixedPointIterations; it++) {
-        if (g_coef_lanes)
+        if (C.coef_kernel)
             hipLaunchKernelGGL(k_coef_lanes, dim3(divup(w, KL_COLS), divup(h, 4 * KL_ROWS), B), dim3(256), 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
-                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr, g_coef_lanes == 2 ? 0 : 1);
+                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, C.mode == 3 ? P.r11 : nullptr, C.mode == 3 ? P.r22 : nullptr, C.coef_kernel == 2 ? 0 : 1);
         else
             hipLaunchKernelGGL(k_coef, dim3(divup(w, 128), divup(h, KC_ROWS), B), blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
-                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, g_sor_mode == 3 ? P.r11 : nullptr, g_sor_mode == 3 ? P.r22 : nullptr);
+                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, C.mode == 3 ? P.r11 : nullptr, C.mode == 3 ? P.r22 : nullptr);
         if (timer) timer->begin(s);
         long long nlaunch = 0; int streamed = 0;
-        SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch, latency_tiles, &streamed));
+        SIND_TRY(sor_iterations(s, P, w, h, B, V.sorIterations, V.omega, &nlaunch, C, &streamed));
         // algorithmic bytes: 44 B per pixel per red+black iteration (9 reads + 2 writes of f32), SURVEY.md §8d
         if (timer) timer->end(s, nlaunch, 44.0 * (double)w * h * B * V.sorIterations, streamed ? 0 : 1);
     }

@@ -8,16 +8,6 @@ import numpy as np
 from ._lib import check, lib, ptr
 
 
-def set_sor_variant(mode: int = 4, fuse: int = 5, tile_w: int = 64, tile_h: int | None = None):
-    """process-wide solver variant (all return the same bits).  Fused register-resident SOR with 1x8 strips: mode 4 = divisions through a reciprocal
-    formed on the fly (default), 1 = IEEE division, 3 = reciprocal planes held in registers (three waves per SIMD; 256/384/768-thread tiles);
-    2 = fused with 1x4 strips and reciprocal division; 0 = one launch per colour (cross-check).  fuse = iterations per launch on the tiled levels,
-    0 = a per-level plan (1-2 % faster, more launches).  tile_h defaults to 48 (mode 3) / 64."""
-    if tile_h is None:
-        tile_h = 48 if mode == 3 else 64
-    check(lib().sind_flow_set_sor_tiled(mode, fuse, tile_w, tile_h), "sind_flow_set_sor_tiled")
-
-
 class FlowStage:
     def __init__(self, fw: int = 384, fh: int = 288, max_batch: int = 8, device: int = 0):
         self.fw, self.fh, self.max_batch = fw, fh, max_batch
@@ -28,6 +18,21 @@ class FlowStage:
     def set_max_levels(self, n: int):
         """finest n levels of the 0.95 pyramid only (BASELINE.json config 5, "3-level flow pyramid"); 0 = the full pyramid of OpenCV's DeepFlow"""
         check(lib().sind_flow_set_max_levels(self._h, int(n)), "sind_flow_set_max_levels")
+
+    def set_sor_variant(self, mode: int = 4, fuse: int = 5, tile_w: int = 64, tile_h: int | None = None):
+        """solver variant of this handle (all return the same bits).  Fused register-resident SOR with 1x8 strips: mode 4 = divisions through a reciprocal formed on the fly
+        (default), 5 = the streaming kernel wherever it fits, 0 = one launch per colour (cross-check); lab builds: 1 = IEEE division, 3 = reciprocal planes held in registers
+        (three waves per SIMD; 256/384/768-thread tiles), 2 = 1x4 strips and reciprocal division.  fuse = iterations per launch on the tiled levels, 0 = a per-level plan
+        (lab builds).  tile_h defaults to 48 (mode 3) / 64."""
+        if tile_h is None:
+            tile_h = 48 if mode == 3 else 64
+        check(lib().sind_flow_set_sor_tiled(self._h, mode, fuse, tile_w, tile_h), "sind_flow_set_sor_tiled")
+
+    def set_solver_workgroups(self, cap: int):
+        check(lib().sind_flow_set_solver_workgroups(self._h, int(cap)), "sind_flow_set_solver_workgroups")
+
+    def set_coef_kernel(self, variant: int):
+        check(lib().sind_flow_set_coef_kernel(self._h, int(variant)), "sind_flow_set_coef_kernel")
 
     def set_coarse_chain(self, on: bool):
         """the one-workgroup pyramid levels in one launch (default) or through the per-stage kernels (cross-check); same bits"""

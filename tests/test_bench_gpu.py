@@ -31,8 +31,8 @@ def test_two_ranks_frame_sharded_sequence_line():
     assert s["state_warmup_frames"] == 16 and s["state_warmup_steps"] == 1
     assert d["value"] > 0 and abs(d["value"] - s["value"]) < 1e-6 * d["value"] and s["value"] <= s["value_excl_warmup"]
     assert abs(s["value_excl_warmup"] / s["value"] - 256 / 200) < 1e-6
-    assert d["roofline"]["launches"] > 0 and d["roofline"]["frac_wall_algorithmic"] <= d["roofline"]["frac_algorithmic"] * 1.001
-    assert d["roofline"]["frac"] is None or 0 < d["roofline"]["frac"] <= 1.0
+    rf = d["roofline"]       # (two chunks per rank: no streaming launches; the tiled / one-workgroup launches are counted beside them)
+    assert rf["bound"] == "hbm" and rf["launches"] + rf["other_solver_kernels"]["launches"] > 0 and (rf["frac"] is None or 0 < rf["frac"] <= 1.0)
     assert len(d["host_by_rank"]) == 2 and all(h["host_cores_busy"] > 0 for h in d["host_by_rank"])
     # chunked masks vs the in-order run of the same frames (owned frames of chunks 1..3 inside the first E frames)
     # verified chunks: every compared frame is byte-identical to the in-order run, whatever the seams needed (verification and repairs are inside the clock)
@@ -41,6 +41,8 @@ def test_two_ranks_frame_sharded_sequence_line():
     v = s["verify"]; assert v["seams"] == 3 and 0 <= v["mismatched_seams"] <= 3 and (v["repair_frames"] + v["replay_frames"] > 0) == (v["mismatched_seams"] > 0)
     # the line carries its own N = 1 point (same job on rank 0 alone, after the timed region)
     assert s["n1_value"] > 0 and abs(s["speedup_vs_n1"] - s["value"] / s["n1_value"]) < 1e-9 and abs(s["scaling_efficiency"] - s["speedup_vs_n1"] / 2) < 1e-9
+    # ... and the one-GPU rate AT THIS JOB'S STEP SIZE, so that efficiency lost to the step size and to the exchange can be told apart
+    assert s["pairs_per_rank_step"] == 2 * 16 and s["n1_small_step_value"] > 0 and s["n1_small_step"]["pairs"] == s["pairs_per_rank_step"]
 
 
 @pytest.mark.timeout(900)
@@ -54,8 +56,12 @@ def test_one_gpu_line_carries_the_sequence_leg():
     assert d["config"]["mode"] == "streams" and d["scaling"] == "weak" and d["warmup"] == 1 and d["steps"] == 2 and d["config"]["frame_pairs_per_step"] == 32
     assert s["frames"] == 300 and s["owned_frames"] == 300 and s["steps"] == 10 and 0 < s["value"] <= s["value_excl_warmup"]
     t = d["sequence_tum_length"]; assert t["frames"] == 830 and t["owned_frames"] == 830 and t["steps"] == 6 and t["exact"] is True and t["value"] > 0
-    r = d["roofline"]; assert r["bound"] in ("valu", "hbm") and 0 < r["frac"] <= 1.0 and abs(r["frac"] - max(r["frac_hbm"], r["valu_busy"])) < 1e-9 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["frac_wall_algorithmic"] > 0
-    assert r["traffic_over_compulsory"] > 0.9 and r["compulsory_bytes_per_launch"] > 0
+    # the roofline object says one thing: the HBM roof of the streaming solver (no field above its peak); 32 pairs per step never reach that kernel, so frac is absent here
+    r = d["roofline"]; assert r["bound"] == "hbm" and r["peak"] == 8000.0 and (r["frac"] is None or (0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9))
+    assert r["valu_peak_ops_per_s"] == 78.6e12 and r["useful_ops_per_update"] == 32 and r["other_solver_kernels"]["launches"] > 0
+    # the reference's call pattern, one frame per call with host pointers
+    dr = d["dropin"]; assert dr["frames"] >= 100 and dr["fps"] > 0 and abs(dr["fps"] * dr["ms_per_frame"] - 1000.0) < 1e-6 and dr["detect_stages_ms"]["calls"] == dr["frames"]
+    assert d.get("parity") is None or "sample_from" in d["parity"]
 
 
 @pytest.mark.timeout(1200)

@@ -48,14 +48,10 @@ def test_bad_arguments():
     assert lib().sind_frame_create(None, 640, 480, 1, 16, 0, C.byref(h)) == -1
     assert lib().sind_match_create(None, C.byref(h)) == -1
     assert lib().sind_cloud_create(C.c_double(0.0), C.c_double(1.0), C.c_double(0.0), C.c_double(0.0), C.c_double(5000.0), 640, 480, 1, 0, C.byref(h)) == -1
-    lab = lib().sind_lab_build()             # the shipped library carries solver modes 0 (per-colour reference), 4 (tiled) and 5 (streaming); the other variants are lab builds
-    assert lib().sind_flow_set_sor(7, 5, 64) == -1 and lib().sind_flow_set_sor_tiled(4, 5, 64, 64) == 0 and lib().sind_flow_set_sor_tiled(5, 5, 64, 64) == 0 and lib().sind_flow_set_sor_tiled(0, 5, 64, 64) == 0
-    assert lib().sind_flow_set_sor(1, 5, 64) == (0 if lab else -1) and lib().sind_flow_set_sor_tiled(3, 3, 64, 48) == (0 if lab else -1) and lib().sind_flow_set_sor_tiled(4, 0, 64, 64) == (0 if lab else -1)
-    assert lib().sind_flow_set_sor_tiled(3, 3, 64, 64) == -1          # 512 threads: no three-waves-per-SIMD instance
-    assert lib().sind_flow_set_sor_tiled(4, 5, 64, 64) == 0           # back to the default
-    # round-4 switches of the flow stage: persistent solver workgroups (0 = one per item), coefficient kernel variant
-    assert lib().sind_flow_set_solver_workgroups(-1) == -1 and lib().sind_flow_set_solver_workgroups(160) == 0 and lib().sind_flow_set_solver_workgroups(0) == 0
-    assert lib().sind_debug_set_coef_lanes(3) == -1 and lib().sind_debug_set_coef_lanes(0) == 0 and lib().sind_debug_set_coef_lanes(2) == 0 and lib().sind_debug_set_coef_lanes(1) == 0
+    # solver settings are per flow handle (round 5): a null handle is an argument error, nothing is process-wide
+    assert lib().sind_flow_set_sor(None, 4, 5, 64) == -1 and lib().sind_flow_set_sor_tiled(None, 4, 5, 64, 64) == -1
+    assert lib().sind_flow_set_solver_workgroups(None, 0) == -1 and lib().sind_flow_set_coef_kernel(None, 1) == -1
+    assert lib().sind_flow_set_coarse_chain(None, 1) == -1 and lib().sind_flow_set_latency_tiles(None, 1) == -1
 
 
 def test_product_never_touches_the_oracle():

@@ -73,21 +73,20 @@ def test_deepflow_full_size(fs, frames):
 def test_sor_variants_agree_bitwise(fs, frames):
     """both fused register-resident SOR kernels (IEEE division / reciprocal division; several fuse depths and tile widths)
     == one-launch-per-colour SOR, bit for bit"""
-    from sindslam_amd.flow import set_sor_variant
     g0, g1 = _small_pair(frames, 384, 288)
     i0 = np.stack([g0, g1]); i1 = np.stack([g1, g0])
     try:
         from sindslam_amd._lib import lib
         lab = bool(lib().sind_lab_build())           # IEEE-division / reciprocal-plane / 1x4-strip variants and fuse plans exist in lab builds only
-        set_sor_variant(0, 5, 64, 64); ru, rv = fs.deepflow(i0, i1)
+        fs.set_sor_variant(0, 5, 64, 64); ru, rv = fs.deepflow(i0, i1)
         for mode, fuse, tw, th in [(2, 5, 64, 64), (2, 3, 64, 64), (2, 7, 64, 64), (2, 1, 64, 64), (1, 5, 64, 64), (1, 3, 64, 64), (1, 7, 64, 64), (1, 5, 128, 64),
                                    (1, 1, 64, 64), (5, 5, 64, 64), (4, 0, 64, 64), (4, 5, 64, 64), (4, 3, 64, 64), (4, 5, 128, 64), (1, 0, 64, 64), (3, 3, 64, 48), (3, 5, 64, 48), (3, 1, 64, 48), (3, 2, 64, 32), (3, 4, 96, 64), (3, 5, 128, 48), (3, 3, 48, 64)]:
             if not lab and (mode not in (0, 4, 5) or fuse == 0):
                 continue
-            set_sor_variant(mode, fuse, tw, th); u, v = fs.deepflow(i0, i1)
+            fs.set_sor_variant(mode, fuse, tw, th); u, v = fs.deepflow(i0, i1)
             assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32)), (mode, fuse, tw, th)
     finally:
-        set_sor_variant()
+        fs.set_sor_variant()
 
 
 @pytest.fixture(scope="module")
@@ -118,17 +117,16 @@ STREAM_SHAPES = [(129, 67), (152, 65), (153, 99), (155, 70), (300, 101), (302, 7
 def test_streaming_solver_equals_the_oracle_on_strip_cuts(fs_big, w, h):
     """the kernel the bench runs (k_sor_stream, solver mode 5 = streaming on every level it fits) against the ORACLE's VariationalRefinement directly, at widths
     that exercise every column-strip cut and heights that are odd: 5 fixed-point iterations x 25 SOR iterations with DeepFlow's level parameters"""
-    from sindslam_amd.flow import set_sor_variant
     i0, i1 = _textured_pair(w, h, 7 * w + h)
     rng = np.random.default_rng(w + 1000 * h)
     u0 = rng.normal(0, 1.0, (h, w)).astype(np.float32); v0 = rng.normal(0, 1.0, (h, w)).astype(np.float32)
     a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
     ou, ov = O.varref(i0, i1, u0, v0, 5, 25, a, d, g, 1.6)
     try:
-        set_sor_variant(5, 5, 64, 64)
+        fs_big.set_sor_variant(5, 5, 64, 64)
         gu, gv = fs_big.varref_f32(np.stack([i0, i0]), np.stack([i1, i1]), np.stack([u0, u0]), np.stack([v0, v0]), 5, 25, a, d, g, 1.6)
     finally:
-        set_sor_variant()
+        fs_big.set_sor_variant()
     for b in range(2):
         assert np.array_equal(gu[b].view(np.uint32), ou.view(np.uint32)), (w, h, b, float(np.abs(gu[b] - ou).max()))
         assert np.array_equal(gv[b].view(np.uint32), ov.view(np.uint32)), (w, h, b, float(np.abs(gv[b] - ov).max()))
@@ -137,15 +135,14 @@ def test_streaming_solver_equals_the_oracle_on_strip_cuts(fs_big, w, h):
 def test_streaming_solver_on_the_768x432_pyramid(fs_big):
     """DeepFlow on the 1280 x 720 configuration's flow grid (768 x 432, 57 levels, six column strips of 128 on the top level): streaming (mode 5) ==
     one launch per colour (mode 0) on every pixel of both pairs"""
-    from sindslam_amd.flow import set_sor_variant
     assert len(fs_big.levels()) == 57 and fs_big.levels()[0] == (768, 432)
     a0, a1 = _textured_pair(768, 432, 5); b0, b1 = _textured_pair(768, 432, 6)
     i0 = np.stack([a0, b1]).astype(np.uint8); i1 = np.stack([a1, b0]).astype(np.uint8)
     try:
-        set_sor_variant(0, 5, 64, 64); ru, rv = fs_big.deepflow(i0, i1)
-        set_sor_variant(5, 5, 64, 64); u, v = fs_big.deepflow(i0, i1)
+        fs_big.set_sor_variant(0, 5, 64, 64); ru, rv = fs_big.deepflow(i0, i1)
+        fs_big.set_sor_variant(5, 5, 64, 64); u, v = fs_big.deepflow(i0, i1)
     finally:
-        set_sor_variant()
+        fs_big.set_sor_variant()
     assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32))
     assert np.abs(ru).max() > 0.5                   # a real flow field, not zeros
 
@@ -167,12 +164,12 @@ def test_coefficients_from_lanes_equal_coefficients_from_memory(fs_big, w, h):
     a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
     args = (np.stack([i0, i1]), np.stack([i1, i0]), np.stack([u0, v0]), np.stack([v0, u0]), 3, 7, a, d, g, 1.6)
     try:
-        assert lib().sind_debug_set_coef_lanes(0) == 0; mu, mv = fs_big.varref_f32(*args)
-        assert lib().sind_debug_set_coef_lanes(2) == 0; iu, iv = fs_big.varref_f32(*args)          # lanes, the compiler's IEEE sqrt and division
-        assert lib().sind_debug_set_coef_lanes(1) == 0; lu, lv = fs_big.varref_f32(*args)          # lanes, short forms (the default)
+        fs_big.set_coef_kernel(0); mu, mv = fs_big.varref_f32(*args)
+        fs_big.set_coef_kernel(2); iu, iv = fs_big.varref_f32(*args)          # lanes, the compiler's IEEE sqrt and division
+        fs_big.set_coef_kernel(1); lu, lv = fs_big.varref_f32(*args)          # lanes, short forms (the default)
     finally:
-        lib().sind_debug_set_coef_lanes(1)
-    assert lib().sind_debug_set_coef_lanes(3) == -1
+        fs_big.set_coef_kernel(1)
+    assert lib().sind_flow_set_coef_kernel(fs_big._h, 3) == -1
     assert np.array_equal(iu.view(np.uint32), mu.view(np.uint32)) and np.array_equal(iv.view(np.uint32), mv.view(np.uint32)), (w, h, float(np.abs(iu - mu).max()))
     assert np.array_equal(lu.view(np.uint32), mu.view(np.uint32)) and np.array_equal(lv.view(np.uint32), mv.view(np.uint32)), (w, h, float(np.abs(lu - mu).max()))
     assert np.isfinite(lu).all() and np.abs(lu - np.stack([u0, v0])).max() > 1e-3          # the refinement moved the field
@@ -186,18 +183,17 @@ def test_persistent_solver_workgroups_equal_one_workgroup_per_item(fs_big, w, h,
     """sind_flow_set_solver_workgroups: `cap` workgroups walk the (strip, image) items of a streaming launch in turn (2 images x 1-3 strips here: 2-6 items, so a workgroup takes
     two, three or all six of them, and the LDS of an item is cleared behind a barrier) -- the flow equals the oracle's bit for bit"""
     from sindslam_amd._lib import lib
-    from sindslam_amd.flow import set_sor_variant
     i0, i1 = _textured_pair(w, h, 5 * w + h)
     rng = np.random.default_rng(w + 31 * h)
     u0 = rng.normal(0, 1.0, (h, w)).astype(np.float32); v0 = rng.normal(0, 1.0, (h, w)).astype(np.float32)
     a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
     ou, ov = O.varref(i0, i1, u0, v0, 2, 10, a, d, g, 1.6); ou2, ov2 = O.varref(i1, i0, v0, u0, 2, 10, a, d, g, 1.6)
     try:
-        set_sor_variant(5, 5, 64, 64); assert lib().sind_flow_set_solver_workgroups(cap) == 0
+        fs_big.set_sor_variant(5, 5, 64, 64); fs_big.set_solver_workgroups(cap)
         gu, gv = fs_big.varref_f32(np.stack([i0, i1]), np.stack([i1, i0]), np.stack([u0, v0]), np.stack([v0, u0]), 2, 10, a, d, g, 1.6)
     finally:
-        set_sor_variant(); lib().sind_flow_set_solver_workgroups(0)
-    assert lib().sind_flow_set_solver_workgroups(-1) == -1
+        fs_big.set_sor_variant(); fs_big.set_solver_workgroups(0)
+    assert lib().sind_flow_set_solver_workgroups(fs_big._h, -1) == -1
     assert np.array_equal(gu[0].view(np.uint32), ou.view(np.uint32)) and np.array_equal(gv[0].view(np.uint32), ov.view(np.uint32))
     assert np.array_equal(gu[1].view(np.uint32), ou2.view(np.uint32)) and np.array_equal(gv[1].view(np.uint32), ov2.view(np.uint32))
 

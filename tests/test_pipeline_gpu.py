@@ -36,7 +36,7 @@ def test_pipeline_two_streams(frames):
                 k, d = pipe.keypoints(s, t)
                 assert k.tobytes() == rk.tobytes() and np.array_equal(d, rdesc), (step, s, t)
     st = pipe.stats()
-    assert st["sor_launches"] > 0 and st["sor_ms"] > 0
+    assert st["sor_launches"] + st["sor_other_launches"] > 0 and st["sor_ms"] + st["sor_other_ms"] > 0       # (a two-stream step has no streaming launches: those count under sor_*)
     pipe.close()
 
 

@@ -392,7 +392,7 @@ def host_info_list(pipe):
 def host_load_fields(loads):
     quota = lambda l: None if l[1] < 0 else {"periods": int(l[1]), "throttled_periods": int(l[2]), "throttled_ms": l[3]}
     sizing = lambda l: None if len(l) < 9 else {"cpu_share": int(l[4]), "pool_workers": int(l[5]), "cores_usable": int(l[6]), "cgroup_quota_cores": None if l[7] < 0 else int(l[7]), "ranks_on_node": int(l[8]),
-                                                "rule": "share = min(cores usable, cgroup quota) / ranks on the node, at least 4, at most 16"}
+                                                "rule": "share = min(cores usable, cgroup quota) / ranks on the node, at most 16, at least 4 without a quota / 2 with one (the shares of all ranks stay inside the quota)"}
     return {"host_cores_busy": loads[0][0], "cpu_quota": quota(loads[0]),
             "host_by_rank": [{"rank": r, "host_cores_busy": l[0], "cpu_quota": quota(l), "sizing": sizing(l)} for r, l in enumerate(loads)]}
 

@@ -135,7 +135,7 @@ int sind_dyna_debug(sind_dyna* d, float* flow_deep, float* flow_refined, float* 
 int sind_debug_seqsum(const float* x, int n, int device, float* out);
 /* k-means pyramid levels of at most n points (default 81920 = the three coarse levels at 640 x 480) of a batch of at least b frames (default 32: the batched rounds of a
  * many-stream step) run every pass in ONE launch, one workgroup per frame (k_km_level_fused); n = 0: the per-pass kernels everywhere.  Same labels and centres bit for bit
- * (tests/test_kmeans_fused_gpu.py); process-wide, for parity tests and A/B timing. */
+ * (tests/test_kmeans_fused_gpu.py).  They set the DEFAULTS that handles created AFTERWARDS copy; an existing handle keeps what it was created with (parity tests, A/B timing). */
 int sind_debug_set_kmeans_fused_max(int n);
 int sind_debug_set_kmeans_fused_min_batch(int b);
 /* exhaustive check of the short forms: for every float significand and the binary exponents exp_lo..exp_hi (>= -96), out[0] = arguments whose short-form square root differs
@@ -232,7 +232,8 @@ int sind_pipe_set_active_frames(sind_pipe* p, const int* frames_per_stream);
  * submitted step under `tag` once its tails have run; sind_pipe_replay(tag, first, last, outputs) runs the tails (DynaDetect.cc:315-420, 653-1018, 1163-1367,
  * 1553-1664 + dilation + mask filter of the keypoints) of frames [first[s], last[s]) of that step again for every stream, from the state the stream holds now
  * (sind_pipe_set_state) -- nothing may be pending; outputs in the step layout, only the frames that ran are written; sind_pipe_release_retained(tag) hands the
- * buffers back (tag < 0: all).  Not available with depth-ahead. */
+ * buffers back (tag < 0: all).  Not available with depth-ahead.  The reserve is EXACTLY n sets: unused sets beyond n are freed by the call (n = 0 frees all unused ones),
+ * a call that fails for lack of memory keeps the sets it had completed -- call again with a smaller n to give the surplus back. */
 int sind_pipe_reserve_retained(sind_pipe* p, int steps);
 int sind_pipe_retain_next(sind_pipe* p, int tag);
 int sind_pipe_replay(sind_pipe* p, int tag, const int* first, const int* last, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated,

@@ -16,7 +16,6 @@ struct sind_dyna {
 #include <thread>
 namespace { struct SpinScope { int keep; SpinScope() : keep(t_sind_spin_us) { t_sind_spin_us = 2000; } ~SpinScope() { t_sind_spin_us = keep; } }; }      // one camera, idle host: poll before sleeping (common.hpp)
 
-namespace sind { extern int g_km_fused_max, g_km_fused_min_batch; }       // depth_kernels.hip
 extern "C" {
 
 int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float ds, int device, sind_dyna** out) {
@@ -55,9 +54,10 @@ int sind_debug_seqsum(const float* x, int n, int device, float* out) {
     HIP_TRY(hipMemcpy(xd.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     return sind::debug_seqsum(nullptr, xd.p, n, scratch.p, out);
 }
-// parity-test / A-B access: k-means levels of at most n points run in the fused one-launch kernel (default 81920; 0 = the per-pass kernels everywhere).  Process-wide.
-int sind_debug_set_kmeans_fused_max(int n) { if (n < 0) return SIND_E_ARG; sind::g_km_fused_max = n; return SIND_OK; }
-int sind_debug_set_kmeans_fused_min_batch(int b) { if (b < 1) return SIND_E_ARG; sind::g_km_fused_min_batch = b; return SIND_OK; }
+// parity-test / A-B access: k-means levels of at most n points run in the fused one-launch kernel (default 81920; 0 = the per-pass kernels everywhere).  These set the DEFAULTS
+// that handles created afterwards copy; a handle that exists keeps what it was created with.
+int sind_debug_set_kmeans_fused_max(int n) { if (n < 0) return SIND_E_ARG; sind::g_km_fuse_default.max_points = n; return SIND_OK; }
+int sind_debug_set_kmeans_fused_min_batch(int b) { if (b < 1) return SIND_E_ARG; sind::g_km_fuse_default.min_batch = b; return SIND_OK; }
 // debug != 0: keep what sind_dyna_debug reports (intermediate images of every stage, the raw and refined flow copied back every frame); off by default
 int sind_dyna_set_debug(sind_dyna* d, int on) { if (!d) return SIND_E_ARG; d->debug = on != 0; d->tail.keep_debug = d->debug; return SIND_OK; }
 // overlap != 0 (default): the depth half of a frame runs beside its dense flow (own stream, own host thread); 0 = one after the other.  Same results.

@@ -25,7 +25,11 @@ int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw,
 int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh, int B = 1, size_t src_stride = 0, size_t dst_stride = 0);
 // segcnt: (KM_MAX_BLOCKS * 4 + 1) * KM_K ints (per wave-segment cluster counts + the totals row) + 64 floats (the pass's 36 sequential sums); comp: 3 * n floats (per-cluster runs of every coordinate)
 #define KM_SEG_WORDS ((KM_MAX_BLOCKS * 4 + 1) * KM_K + 64)
-int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, int* segcnt, float* comp, KmState* st,
+// when a level runs in the fused one-launch kernel: levels of at most `max_points` points (640 x 480: 4 800 / 19 200 / 76 800; 1280 x 720: 14 400 / 57 600; 0 = never) of batches of
+// at least `min_batch` frames.  A handle copies the defaults when it is created and keeps them (the parity tests set other defaults before creating theirs).
+struct KmFuse { int max_points = 81920, min_batch = 32; };
+extern KmFuse g_km_fuse_default;
+int launch_kmeans_level(hipStream_t s, const KmFuse& fuse, const float* px, const float* py, const float* pz, int* labels, int n, int* segcnt, float* comp, KmState* st,
                         int maxCount, double eps2, int B = 1, size_t pt_stride = 0, size_t lab_stride = 0, size_t seg_stride = 0, size_t comp_stride = 0, size_t st_stride = 0);
 int debug_seqsum(hipStream_t s, const float* x_dev, int n, int* scratch_dev, float* out_host);
 int launch_labels_to_u8(hipStream_t s, const int* labels, uint8_t* out, int n, int B = 1, size_t lab_stride = 0, size_t out_stride = 0);

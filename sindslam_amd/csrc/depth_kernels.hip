@@ -665,10 +665,10 @@ __global__ void k_median5_u16(const uint16_t* __restrict__ src, uint16_t* __rest
     }
 }
 // (16-byte loads, eight samples each: with one 2-byte load per lane and turn the kernel took 0.5 ms for the 39 MB of a 64-frame round and 3 % of a step's wave cycles)
-__global__ void k_max_u16(const uint16_t* __restrict__ src, int n, unsigned* __restrict__ out, int out_stride) {
+__global__ void k_max_u16(const uint16_t* __restrict__ src, int n, unsigned* __restrict__ out, int out_stride, int wide) {
     src += (size_t)blockIdx.y * n; out += (size_t)blockIdx.y * out_stride;
     unsigned m = 0;
-    const int n8 = n >> 3; const uint4* s8 = reinterpret_cast<const uint4*>(src);
+    const int n8 = wide ? n >> 3 : 0; const uint4* s8 = reinterpret_cast<const uint4*>(src);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += gridDim.x * blockDim.x) {
         const uint4 v = s8[i];
         m = max(m, max(max(max(v.x & 0xffffu, v.x >> 16), max(v.y & 0xffffu, v.y >> 16)), max(max(v.z & 0xffffu, v.z >> 16), max(v.w & 0xffffu, v.w >> 16))));
@@ -966,9 +966,8 @@ int launch_labels_resize_u8(hipStream_t s, const uint8_t* src, int* dst, int sw,
     hipLaunchKernelGGL(k_labels_resize<uint8_t>, dim3(divup(dw, 128), dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh), src_stride, dst_stride, use_prev); return SIND_OK; }
 int launch_labels_resize_i32(hipStream_t s, const int* src, int* dst, int sw, int sh, int dw, int dh, int B, size_t src_stride, size_t dst_stride) {
     hipLaunchKernelGGL(k_labels_resize<int>, dim3(divup(dw, 128), dh, B), dim3(128), 0, s, src, dst, sw, sh, dw, dh, 1. / ((double)dw / sw), 1. / ((double)dh / sh), src_stride, dst_stride, (const int*)nullptr); return SIND_OK; }
-int g_km_fused_min_batch = 32;      // ... and only for batches of at least this many frames
-int g_km_fused_max = 81920;          // levels of at most this many points run in the fused kernel (640 x 480: 4 800 / 19 200 / 76 800; 1280 x 720: 14 400 / 57 600); 0 = never
-int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const float* pz, int* labels, int n, int* segcnt, float* comp, KmState* st,
+KmFuse g_km_fuse_default;            // what a handle created from now on starts with (depth.hpp)
+int launch_kmeans_level(hipStream_t s, const KmFuse& fuse, const float* px, const float* py, const float* pz, int* labels, int n, int* segcnt, float* comp, KmState* st,
                         int maxCount, double eps2, int B, size_t pt_stride, size_t lab_stride, size_t seg_stride, size_t comp_stride, size_t st_stride) {
     // nseg wave-segments of seg_len (multiple of 64) contiguous points; at most KM_MAX_BLOCKS * KM_WAVES rows in the count table, then the totals row
     // and the 36 sequential sums of the pass
@@ -978,7 +977,7 @@ int launch_kmeans_level(hipStream_t s, const float* px, const float* py, const f
     // A coarse level of a BATCH of frames: every pass in one launch, one workgroup per frame (k_km_level_fused).  Measured (profiles/r04/kmeans_fused.txt): next to the flow
     // solver a round of 128 frames takes 17-18 ms instead of 23.4 (the ~40 small launches it replaces each wait for a CU slot); a single frame or a small batch on an idle GPU is
     // FASTER with the per-pass kernels, whose blocks spread over many CUs (in-order mode 245 frames/s against 190; a round of 13 replayed frames 2.4 ms against 3.4).
-    if (n <= g_km_fused_max && B >= g_km_fused_min_batch && KMF_WAVES <= KM_MAX_BLOCKS * 4) {
+    if (n <= fuse.max_points && B >= fuse.min_batch && KMF_WAVES <= KM_MAX_BLOCKS * 4) {
         const int fseg = divup(divup(n, KMF_WAVES), 64) * 64;
         hipLaunchKernelGGL(k_km_level_fused, dim3(1, B), dim3(64 * KMF_WAVES), 0, s, px, py, pz, labels, n, fseg, segcnt, comp, st, ks, maxCount, eps2, iters);
         return SIND_OK;
@@ -1011,8 +1010,10 @@ int launch_median5(hipStream_t s, const uint16_t* src, uint16_t* dst, int w, int
 int launch_max_u16(hipStream_t s, const uint16_t* src, int n, unsigned* out, int B, int out_stride) {
     if (B == 1 || out_stride == 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * sizeof(unsigned), s));
     else for (int b = 0; b < B; b++) HIP_TRY(hipMemsetAsync(out + (size_t)b * out_stride, 0, sizeof(unsigned), s));
-    if (((size_t)n * sizeof(uint16_t)) % 16 != 0 && B > 1) { sind_set_error("max_u16: %d samples per image (a batch needs a multiple of 8)", n); return SIND_E_ARG; }
-    hipLaunchKernelGGL(k_max_u16, dim3(std::max(1, std::min(divup(n, 8 * 256), 64)), B), dim3(256), 0, s, src, n, out, out_stride); return SIND_OK; }
+    // 16-byte loads need every image of the launch to start on a 16-byte boundary: the base pointer aligned (a per-frame pointer into a batch buffer is only when the frame
+    // size is a multiple of 8 samples) and, for a batch, a multiple of 8 samples per image; anything else takes the 2-byte loop
+    const int wide = ((uintptr_t)src % 16 == 0 && (B == 1 || n % 8 == 0)) ? 1 : 0;
+    hipLaunchKernelGGL(k_max_u16, dim3(std::max(1, std::min(divup(n, 8 * 256), 64)), B), dim3(256), 0, s, src, n, out, out_stride, wide); return SIND_OK; }
 int launch_grad_edge(hipStream_t s, const uint16_t* filt, const unsigned* dmax, uint8_t* edge, uint8_t* total_area, int w, int h, float depthScale, int B, int dmax_stride) {
     hipLaunchKernelGGL(k_grad_edge, dim3(divup(w, 128), divup(h, GE_ROWS), B), dim3(128), 0, s, filt, dmax, edge, total_area, w, h, depthScale, dmax_stride); return SIND_OK; }
 MorphElem make_ellipse(int n) {

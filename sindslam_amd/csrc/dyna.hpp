@@ -76,6 +76,7 @@ public:
     int run(const uint16_t* depth_base, size_t depth_stride, int B, const uint8_t* const* prev);
     const KmFrameResult& result(int b) const { return res[b]; }
     hipStream_t stream = nullptr;
+    KmFuse km_fuse = g_km_fuse_default;      // copied when the object is made; never changes afterwards
 private:
     DynaConfig cfg; int W = 0, H = 0, N = 0, maxB = 0;
     DevBuf<uint16_t> dpyr[4]; DevBuf<float> px, py, pz, comp; DevBuf<int> lab[4], seg, use_prev_d; DevBuf<uint8_t> labPrev8, lab8; DevBuf<KmState> kstate;
@@ -86,6 +87,7 @@ private:
 class DynaTail {
 public:
     DynaConfig cfg; hipStream_t stream = nullptr; DynaDebug dbg; bool keep_debug = false;
+    KmFuse km_fuse = g_km_fuse_default;      // copied when the object is made; never changes afterwards
     int piece_threads = 1;        // host threads for the per-cluster piece extraction of SegAndMerge (> 1 only when host cores idle: a single stream in the in-order mode)
     int init(const DynaConfig& c, hipStream_t s);
     ~DynaTail() { for (auto& g : kmGraph) if (g) (void)hipGraphExecDestroy(g); }

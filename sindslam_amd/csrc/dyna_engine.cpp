@@ -236,7 +236,7 @@ int DynaTail::kmeans_enqueue(const uint16_t* depth0, bool prevLabels) {
         SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale));
         if (level == 3) { if (!prevLabels) SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp)); else SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp)); }
         else SIND_TRY(launch_labels_resize_i32(stream, lab[level + 1].p, lab[level].p, wp / 2, hp / 2, wp, hp));
-        SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, kpart.p, kcomp.p, kstate.p + level, 4, 0.07 * 0.07));
+        SIND_TRY(launch_kmeans_level(stream, km_fuse, px.p, py.p, pz.p, lab[level].p, n, kpart.p, kcomp.p, kstate.p + level, 4, 0.07 * 0.07));
     }
     SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N));
     return SIND_OK;
@@ -301,7 +301,7 @@ int KMeansBatch::run(const uint16_t* depth_base, size_t depth_stride, int B, con
         SIND_TRY(launch_points(stream, dl[level], px.p, py.p, pz.p, wp, hp, scales[level], cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.depthScale, B, ds[level], N));
         if (level == 3) { SIND_TRY(launch_labels_grid(stream, lab[3].p, wp, hp, B, ls, use_prev_d.p)); SIND_TRY(launch_labels_resize_u8(stream, labPrev8.p, lab[3].p, W, H, wp, hp, B, N, ls, use_prev_d.p)); }
         else SIND_TRY(launch_labels_resize_i32(stream, lab[level + 1].p, lab[level].p, wp / 2, hp / 2, wp, hp, B, (size_t)N >> (2 * (level + 1)), ls));
-        SIND_TRY(launch_kmeans_level(stream, px.p, py.p, pz.p, lab[level].p, n, seg.p, comp.p, kstate.p + level, 4, 0.07 * 0.07, B, N, ls, KM_SEG_WORDS, (size_t)3 * N, 4));
+        SIND_TRY(launch_kmeans_level(stream, km_fuse, px.p, py.p, pz.p, lab[level].p, n, seg.p, comp.p, kstate.p + level, 4, 0.07 * 0.07, B, N, ls, KM_SEG_WORDS, (size_t)3 * N, 4));
     }
     SIND_TRY(launch_labels_to_u8(stream, lab[0].p, lab8.p, N, B, N, N));
     HIP_TRY(hipMemcpyAsync(h_state.p, kstate.p, (size_t)4 * B * sizeof(KmState), hipMemcpyDeviceToHost, stream));

@@ -116,6 +116,13 @@ int FlowEngine::varref_f32(const float* I0, const float* I1, int w, int h, int B
 
 }  // namespace sind
 
+// ---------------------------------------------------------------- process set-up
+// HIP streams are multiplexed onto GPU_MAX_HW_QUEUES hardware queues (runtime default 4).  A pipeline handle drives ~45 streams; with four queues its flow slices share queues
+// with the tail streams and a stand-alone sequence job runs 17 % slower, six keep them apart, ten and more are catastrophic (profiles/r04/hw_queues.txt).  The runtime reads
+// the variable when it initialises (the first HIP call of the process), so the library sets it when it is LOADED -- for the C++ integrator who links libsind_hip.so as much
+// as for the Python mirror.  An explicit setting in the environment wins; a process whose HIP runtime is already up keeps what it started with.
+__attribute__((constructor)) static void sind_process_setup() { setenv("GPU_MAX_HW_QUEUES", "6", 0); }
+
 // ---------------------------------------------------------------- error string (shared by the whole library)
 static thread_local char g_err[512] = "";
 std::atomic<long long> g_sind_wait_ns{0}, g_sind_wait_calls{0};

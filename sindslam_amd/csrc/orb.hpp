@@ -7,7 +7,10 @@ namespace sind {
 
 #define ORB_PAD 19            /* EDGE_THRESHOLD, reference ORBextractor.cc:74 */
 #define ORB_WIN_MAX 66        /* largest FAST cell window side: a cell is ceil(extent / int(extent / 30)) <= 59 px (ORBextractor.cc:789-807), + 6 px overlap; 640 x 480 needs 40 */
-#define ORB_CELL_CAP 256      /* NMS keeps at most one corner per 2x2 -> <= 21x21 for a 42x42 window interior */
+/* keypoints a FAST cell can emit: the 3x3 strict-maximum NMS keeps at most one corner per 2 x 2 block of the window's interior (the window minus its 3-px margin), i.e.
+   ceil((vw - 6) / 2) * ceil((vh - 6) / 2) -- 324 for the 42 x 42 windows of 640 x 480, 900 for the 66 x 66 limit.  OrbEngine sizes its per-cell records for the largest
+   cell of its levels (cell_cap), so that no image can overflow one. */
+static inline int orb_cell_bound(int vw, int vh) { return ((vw - 6 + 1) / 2) * ((vh - 6 + 1) / 2); }
 
 struct OrbLevel { int w, h; size_t off, blur_off; };                  // padded level inside the slab; interior inside the blur buffer
 struct OrbCell { size_t level_off; int pitch, x0, y0, vw, vh, shift_x, shift_y, level; };   // FAST window in padded coordinates
@@ -18,7 +21,7 @@ struct OrbKeyPoint { float x, y, size, angle, response; int octave, class_id; };
 int orb_upload_constants(const int umax[16]);
 int launch_pad(hipStream_t s, uint8_t* slab, size_t slab_stride, size_t off, int lw, int lh, int B);
 int launch_copy_into_slab(hipStream_t s, const uint8_t* gray, uint8_t* slab, size_t slab_stride, size_t off, int w, int h, int B);
-int launch_fast_cells(hipStream_t s, const uint8_t* slab, size_t slab_stride, const OrbCell* cells, int ncells, int iniTh, int minTh,
+int launch_fast_cells(hipStream_t s, const uint8_t* slab, size_t slab_stride, const OrbCell* cells, int ncells, int cell_cap, int iniTh, int minTh,
                       OrbRawKp* raw, int* counts, OrbRawKp* dense, int cap, int* frame_total, int* cell_offsets, int B);
 int launch_ic_angle(hipStream_t s, const uint8_t* slab, size_t slab_stride, const OrbLevel* levels, const OrbSelKp* sel, const int* nsel,
                     int cap, int max_n, float* angle, int B);
@@ -48,7 +51,7 @@ public:
     std::vector<OrbCell> cells;
     std::vector<int> level_cell_begin;   // first cell index of each level (+ sentinel)
     size_t slab_bytes = 0, blur_bytes = 0;
-    int dense_cap = 0, sel_cap = 0;
+    int dense_cap = 0, sel_cap = 0, cell_cap = 0;       // cell_cap: records per FAST cell = the NMS bound of the largest cell (orb_cell_bound)
     hipStream_t stream = nullptr;
     int init(int W, int H, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, int maxB, hipStream_t s);
     // gray: device u8 [B][H][W].  Runs pyramid + FAST + octree (host) + orientation + blur + BRIEF.  Synchronises the stream.

@@ -70,13 +70,15 @@ int OrbEngine::init(int W_, int H_, int nf, float sf, int nl, int ini, int mn, i
     }
     level_cell_begin.push_back((int)cells.size());
     const int nc = (int)cells.size();
-    dense_cap = nc * ORB_CELL_CAP;          // tight upper bound (every cell full): the dense list can never overflow
+    cell_cap = 64; for (const OrbCell& c : cells) cell_cap = std::max(cell_cap, orb_cell_bound(c.vw, c.vh));
+    cell_cap = (cell_cap + 3) / 4 * 4;      // what the NMS can leave in the largest cell: no image overflows a cell
+    dense_cap = nc * cell_cap;              // tight upper bound (every cell full): the dense list can never overflow
     sel_cap = nfeatures * 2 + 256;
     SIND_TRY(slab.alloc(slab_bytes * maxB)); SIND_TRY(blurred.alloc(blur_bytes * maxB)); SIND_TRY(blur_tmp.alloc(blur_bytes * maxB));
     SIND_TRY(cells_dev.alloc(nc)); SIND_TRY(levels_dev.alloc(nl));
     HIP_TRY(hipMemcpy(cells_dev.p, cells.data(), nc * sizeof(OrbCell), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(levels_dev.p, levels.data(), nl * sizeof(OrbLevel), hipMemcpyHostToDevice));
-    SIND_TRY(raw.alloc((size_t)maxB * nc * ORB_CELL_CAP)); SIND_TRY(dense.alloc((size_t)maxB * dense_cap));
+    SIND_TRY(raw.alloc((size_t)maxB * nc * cell_cap)); SIND_TRY(dense.alloc((size_t)maxB * dense_cap));
     SIND_TRY(counts.alloc((size_t)maxB * nc)); SIND_TRY(cell_offsets.alloc((size_t)maxB * nc)); SIND_TRY(frame_total.alloc(maxB)); SIND_TRY(nsel_dev.alloc(maxB));
     SIND_TRY(sel_dev.alloc((size_t)maxB * sel_cap)); SIND_TRY(angle_dev.alloc((size_t)maxB * sel_cap)); SIND_TRY(desc_dev.alloc((size_t)maxB * sel_cap * 32));
     return SIND_OK;
@@ -97,7 +99,7 @@ int OrbEngine::extract_all(const uint8_t* gray, int B, std::vector<OrbFrameResul
         SIND_TRY(launch_pad(stream, slab.p, slab_bytes, L.off, L.w, L.h, B));
     }
     // ---- cell-wise FAST + NMS, compaction
-    SIND_TRY(launch_fast_cells(stream, slab.p, slab_bytes, cells_dev.p, nc, iniTh, minTh, raw.p, counts.p, dense.p, dense_cap, frame_total.p, cell_offsets.p, B));
+    SIND_TRY(launch_fast_cells(stream, slab.p, slab_bytes, cells_dev.p, nc, cell_cap, iniTh, minTh, raw.p, counts.p, dense.p, dense_cap, frame_total.p, cell_offsets.p, B));
     // ---- blur of every level (needed by BRIEF; independent of the keypoints) overlaps with the host octree below
     for (int l = 0; l < nlevels; l++)
         SIND_TRY(launch_blur7(stream, slab.p, slab_bytes, levels[l].off, levels[l].w, levels[l].h, taps, blur_tmp.p, blur_bytes, levels[l].blur_off, blurred.p, blur_bytes, levels[l].blur_off, B));
@@ -111,7 +113,7 @@ int OrbEngine::extract_all(const uint8_t* gray, int B, std::vector<OrbFrameResul
         if (h_total[b] > dense_cap) { sind_set_error("OrbEngine: %d FAST keypoints exceed the dense capacity %d", h_total[b], dense_cap); return SIND_E_CAPACITY; }
         max_total = std::max(max_total, h_total[b]);
     }
-    for (size_t i = 0; i < h_cnt.size(); i++) if (h_cnt[i] & 0x40000000) { sind_set_error("OrbEngine: a FAST cell overflowed %d keypoints", ORB_CELL_CAP); return SIND_E_CAPACITY; }
+    for (size_t i = 0; i < h_cnt.size(); i++) if (h_cnt[i] & 0x40000000) { sind_set_error("OrbEngine: a FAST cell overflowed %d keypoints", cell_cap); return SIND_E_CAPACITY; }
     std::vector<OrbRawKp> h_dense((size_t)B * std::max(max_total, 1));
     if (max_total > 0)
         HIP_TRY(hipMemcpy2DAsync(h_dense.data(), (size_t)max_total * sizeof(OrbRawKp), dense.p, (size_t)dense_cap * sizeof(OrbRawKp),

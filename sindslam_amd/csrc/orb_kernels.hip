@@ -75,9 +75,9 @@ __device__ __forceinline__ int fast_score(const uint8_t* win, int stride, int id
 
 // One workgroup per (cell, frame).  Window (<= 40x40) -> LDS, scores for iniTh (retry with minTh if the cell has
 // no corner at all... note: OpenCV's retry condition is "no keypoint AFTER nms", reproduced), 3x3 strict-max NMS,
-// row-major compaction with wave ballots.  Output: per cell up to ORB_CELL_CAP (x, y, score) records.
+// row-major compaction with wave ballots.  Output: per cell up to cell_cap (x, y, score) records (cell_cap >= the NMS bound of the largest cell: orb.hpp).
 __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ slab, size_t slab_stride, const OrbCell* __restrict__ cells,
-                                                    int ncells, int iniTh, int minTh, OrbRawKp* __restrict__ out, int* __restrict__ counts) {
+                                                    int ncells, int cell_cap, int iniTh, int minTh, OrbRawKp* __restrict__ out, int* __restrict__ counts) {
     __shared__ uint8_t win[ORB_WIN_MAX * ORB_WIN_MAX];
     __shared__ uint8_t sc[ORB_WIN_MAX * ORB_WIN_MAX];
     __shared__ int wave_cnt[4];
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
     const int vw = cell.vw, vh = cell.vh, npx = vw * vh;
     for (int i = tid; i < npx; i += 256) { const int y = i / vw, x = i - y * vw; win[i] = L[(size_t)(cell.y0 + y) * cell.pitch + cell.x0 + x]; }
     __syncthreads();
-    OrbRawKp* dst = out + ((size_t)b * ncells + c) * ORB_CELL_CAP;
+    OrbRawKp* dst = out + ((size_t)b * ncells + c) * cell_cap;
     int emitted = 0;
     for (int pass = 0; pass < 2; pass++) {
         const int th = pass == 0 ? iniTh : minTh;
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
             __syncthreads();
             int off = base; for (int k = 0; k < wv; k++) off += wave_cnt[k];
             const int rank = off + __popcll(m & ((1ull << lane) - 1ull));
-            if (keep && rank < ORB_CELL_CAP) { OrbRawKp k; k.x = (short)(x + cell.shift_x); k.y = (short)(y + cell.shift_y); k.score = (short)s; k.level = (short)cell.level; dst[rank] = k; }
+            if (keep && rank < cell_cap) { OrbRawKp k; k.x = (short)(x + cell.shift_x); k.y = (short)(y + cell.shift_y); k.score = (short)s; k.level = (short)cell.level; dst[rank] = k; }
             base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
             __syncthreads();
         }
@@ -125,12 +125,12 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
         if (emitted > 0) break;
         __syncthreads();
     }
-    if (tid == 0) counts[(size_t)b * ncells + c] = min(emitted, ORB_CELL_CAP) | (emitted > ORB_CELL_CAP ? 0x40000000 : 0);
+    if (tid == 0) counts[(size_t)b * ncells + c] = min(emitted, cell_cap) | (emitted > cell_cap ? 0x40000000 : 0);
 }
 
 // exclusive scan of the per-cell counts of one frame (ncells <= 4096) and compaction into a dense per-frame list
 // ordered exactly like the reference's vToDistributeKeys (level, cell row, cell column, row-major inside the cell).
-__global__ void __launch_bounds__(256) k_compact_cells(const OrbRawKp* __restrict__ raw, const int* __restrict__ counts, int ncells,
+__global__ void __launch_bounds__(256) k_compact_cells(const OrbRawKp* __restrict__ raw, const int* __restrict__ counts, int ncells, int cell_cap,
                                                        OrbRawKp* __restrict__ dense, int cap, int* __restrict__ frame_total,
                                                        int* __restrict__ cell_offsets) {
     __shared__ int part[256];
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) k_compact_cells(const OrbRawKp* __restric
         const int excl = carry + part[tid] - n;
         if (c < ncells) {
             cell_offsets[(size_t)b * ncells + c] = excl;
-            const OrbRawKp* src = raw + ((size_t)b * ncells + c) * ORB_CELL_CAP;
+            const OrbRawKp* src = raw + ((size_t)b * ncells + c) * cell_cap;
             for (int k = 0; k < n; k++) if (excl + k < cap) dense[(size_t)b * cap + excl + k] = src[k];
         }
         __syncthreads();
@@ -279,10 +279,10 @@ int launch_copy_into_slab(hipStream_t s, const uint8_t* gray, uint8_t* slab, siz
     hipLaunchKernelGGL(k_copy_into_slab, dim3(divup(w, 128), h, B), dim3(128), 0, s, gray, slab, slab_stride, off, w, h, ORB_PAD);
     return SIND_OK;
 }
-int launch_fast_cells(hipStream_t s, const uint8_t* slab, size_t slab_stride, const OrbCell* cells, int ncells, int iniTh, int minTh,
+int launch_fast_cells(hipStream_t s, const uint8_t* slab, size_t slab_stride, const OrbCell* cells, int ncells, int cell_cap, int iniTh, int minTh,
                       OrbRawKp* raw, int* counts, OrbRawKp* dense, int cap, int* frame_total, int* cell_offsets, int B) {
-    hipLaunchKernelGGL(k_fast_cells, dim3(ncells, B), dim3(256), 0, s, slab, slab_stride, cells, ncells, iniTh, minTh, raw, counts);
-    hipLaunchKernelGGL(k_compact_cells, dim3(B), dim3(256), 0, s, raw, counts, ncells, dense, cap, frame_total, cell_offsets);
+    hipLaunchKernelGGL(k_fast_cells, dim3(ncells, B), dim3(256), 0, s, slab, slab_stride, cells, ncells, cell_cap, iniTh, minTh, raw, counts);
+    hipLaunchKernelGGL(k_compact_cells, dim3(B), dim3(256), 0, s, raw, counts, ncells, cell_cap, dense, cap, frame_total, cell_offsets);
     return SIND_OK;
 }
 int launch_ic_angle(hipStream_t s, const uint8_t* slab, size_t slab_stride, const OrbLevel* levels, const OrbSelKp* sel, const int* nsel,

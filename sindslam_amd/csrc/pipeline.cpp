@@ -98,7 +98,7 @@ struct sind_pipe {
         // and a gate per frame that opens when both its CalOccluded result and the stream's previous depth stage are there
         bool depth_ahead = false; std::vector<DepthStageOut> dout; std::unique_ptr<std::atomic<int>[]> gate; TaskGroup depth_group;
         std::vector<int> depth_rc; std::vector<std::string> depth_err;
-        TaskGroup occ_group, tail_group, km_tails[4]; int km_groups = 1, km_first[5] = {0, 0, 0, 0, 0};       /* (4 = sind_pipe::KM_GROUPS) the step's own partition of the streams */ std::vector<int> occ_rc, tail_rc; std::vector<std::string> occ_err, tail_err;
+        TaskGroup occ_group, tail_group, km_tails[4]; int km_groups = 1, km_first[5] = {0, 0, 0, 0, 0};       /* (4 = sind_pipe::KM_GROUPS) the step's own partition of the streams */ std::vector<int> occ_rc, tail_rc, dchain_rc; std::vector<std::string> occ_err, tail_err, dchain_err;      /* dchain_*: the depth chain of a stream in two-chain mode (its flow chain writes tail_*: two workers, two slots) */
         std::vector<int> active, first; std::vector<uint64_t> state_hash;      // tails of stream s run for first[s] <= t < active[s] (empty: 0 / all T); per-frame state fingerprints [S][T][2]
         bool few_chain = false;                                        // this step runs a handful of streams as per-stream chains (see phase_b_start)
         bool two_chain = false; std::unique_ptr<std::atomic<int>[]> fgate; int fgate_n = 0;      // ... each as a depth chain running ahead of a flow chain; per frame: depth stage done + previous flow stage done
@@ -193,12 +193,14 @@ static int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->orb_stream));
     // CPU share of this process: the cores it may run on (affinity), bounded by the container's quota (cgroup v2 cpu.max: 16 cores per GPU on the MI355X
     // boxes) and divided among the ranks of the node when a launcher started several in this container (LOCAL_WORLD_SIZE: they share cores and quota) --
-    // never below 4, so that a rank keeps a working pool on a lease whose quota was not scaled with the GPU count.  sind_pipe_host_info reports the decision.
+    // never below 4 where no quota is set (below 2 where one is), so that a rank keeps a working pool on a lease whose quota was not scaled with the GPU count.  sind_pipe_host_info reports the decision.
     int nproc = (int)std::thread::hardware_concurrency(); if (nproc <= 0) nproc = 16;
     { cpu_set_t set; CPU_ZERO(&set); if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) nproc = std::min(nproc, a); } }
     int cpu_share = nproc, quota = -1, lw = 1;
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { long long q = 0, per = 0; if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) { quota = (int)std::max<long long>(1, q / per); cpu_share = std::min(cpu_share, quota); } fclose(f); }
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { lw = std::max(1, atoi(e)); if (lw > 1) cpu_share = std::max(std::min(4, cpu_share), cpu_share / lw); }
+    // (the floor of 4 only where no quota bounds the container: with a quota the shares of all ranks must stay inside it -- 8 ranks on a 16-core quota get 2 cores each, not 4,
+    // or the container burns its quota early in every period and the kernel stalls all of its threads until the period ends)
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { lw = std::max(1, atoi(e)); if (lw > 1) cpu_share = quota > 0 ? std::max(std::min(2, cpu_share), cpu_share / lw) : std::max(std::min(4, cpu_share), cpu_share / lw); }
     cpu_share = std::min(cpu_share, 16);                                          // more host threads than this per GPU bring nothing (measured)
     p->host_info[0] = cpu_share; p->host_info[3] = nproc; p->host_info[4] = quota; p->host_info[5] = lw;
     p->cpu_share = cpu_share;
@@ -597,13 +599,13 @@ static void depth_chain(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, 
     for (int t = t0; t < t1; t++) {
         const int k = s * p->T + t;
         const int r = dt->depth_stage(sb->depth_h.data() + np * k, sb->depth_dev.p + np * k, &sb->occ[k], sb->dout[k], nullptr);
-        if (r != SIND_OK) { sb->tail_rc[s] = r; sb->tail_err[s] = sind_last_error(); return; }      // the flow chain of this stream stops at the frame before
+        if (r != SIND_OK) { sb->dchain_rc[s] = r; sb->dchain_err[s] = sind_last_error(); return; }      // the flow chain of this stream stops at the frame before
         if (sb->fgate[k].fetch_add(1) == 1) p->workers.push(sb->tail_group, [p, sb, o, s, t, t1](int w) { flow_chain(p, sb, o, s, t, t1, w); });
     }
 }
 static void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
     const int S = p->S;
-    sb.tail_rc.assign(S, SIND_OK); sb.tail_err.assign(S, std::string());
+    sb.tail_rc.assign(S, SIND_OK); sb.tail_err.assign(S, std::string()); sb.dchain_rc.assign(S, SIND_OK); sb.dchain_err.assign(S, std::string());
     sind_pipe::StepBuf* sbp = &sb;
     // A step in which only a few streams have frames (the repair runs of the chunked sequence mode: the slow runners of a round, sind_pipe_replay) runs them as
     // per-stream chains with their own k-means launches instead of rounds: a round costs the batched k-means' ~60 dependent launches for every frame whatever the
@@ -669,6 +671,7 @@ static int phase_b_finish(sind_pipe* p, sind_pipe::StepBuf& sb) {
         p->kept.push_back(std::move(r));
     }
     for (int s = 0; s < p->S; s++) if (sb.tail_rc[s] != SIND_OK) { sind_set_error("stream %d: %s", s, sb.tail_err[s].c_str()); return sb.tail_rc[s]; }
+    for (int s = 0; s < p->S && s < (int)sb.dchain_rc.size(); s++) if (sb.dchain_rc[s] != SIND_OK) { sind_set_error("stream %d (depth chain): %s", s, sb.dchain_err[s].c_str()); return sb.dchain_rc[s]; }
     return SIND_OK;
 }
 static int phase_b(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) { phase_b_start(p, sb, o); return phase_b_finish(p, sb); }
@@ -827,6 +830,9 @@ int sind_pipe_reserve_retained(sind_pipe* p, int steps) {
     if (!p || steps < 0 || steps > 64) { sind_set_error("sind_pipe_reserve_retained: 0..64 steps"); return SIND_E_ARG; }
     HIP_TRY(hipSetDevice(p->c.device));
     const size_t np = (size_t)p->c.width * p->c.height, B = (size_t)p->S * p->T, gsz = (size_t)2 * ((p->c.width - 1) / 10) * ((p->c.height - 1) / 10);
+    // the reserve is `steps` sets, not "at least": spare sets beyond it are freed (their HBM and page-locked host memory go back), so that a caller whose larger request
+    // failed half-way can retry with a smaller one and really get the difference back (kept sets hold results and are never freed here: release them first)
+    while (!p->spare.empty() && (int)(p->spare.size() + p->kept.size()) > steps) p->spare.pop_back();
     while ((int)(p->spare.size() + p->kept.size()) < steps) {
         std::unique_ptr<sind_pipe::Retained> r(new sind_pipe::Retained());
         SIND_TRY(r->U.alloc(np * B)); SIND_TRY(r->V.alloc(np * B)); SIND_TRY(r->grid_dev.alloc(gsz * B)); SIND_TRY(r->depth_dev.alloc(np * B)); SIND_TRY(r->depth_h.alloc(np * B));

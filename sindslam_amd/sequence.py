@@ -168,6 +168,8 @@ class VerifiedChunks:
                         raise
                     self.stats["retained_steps_dropped"] = self.stats.get("retained_steps_dropped", 0) + len(self.retained) - len(self.retained) // 2
                     self.retained = self.retained[:len(self.retained) // 2]
+                    # (the failed call kept the sets it had completed; the retry with the smaller count FREES the surplus -- reserve_retained(n) means exactly n -- so the
+                    # depth-half objects, the repair pipeline's buffers and the input batches that are allocated next find memory)
             if hasattr(self.pipe, "set_depth_ahead"):
                 # the last runners of a repair run as two chains per stream (depth half ahead of the flow half) on separate depth-half objects: switching depth-ahead on
                 # and off again creates them now, outside any timed region, instead of at the first replay

@@ -337,3 +337,23 @@ def test_pipeline_group_equals_one_pipeline(frames):
         assert np.array_equal(res["one"][1][s], res["grp"][1][s]), s
     h = res["grp"][0][1][6]; assert (h[2] == 0).all() and (h[1, 1] == 0).all() and (h[1, 0] != 0).any()
     one.close(); grp.close()
+
+
+def test_reserve_retained_is_exact_and_gives_memory_back():
+    """sind_pipe_reserve_retained(n) means exactly n sets: a smaller request after a larger one frees the surplus (what the out-of-memory fallback of
+    VerifiedChunks.prime relies on: the sets a failed larger request had completed must not stay allocated)"""
+    import torch
+    from sindslam_amd.pipeline import Pipeline
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    pipe = Pipeline(8, 2, 640, 480, *K, 1500, 1.2, 8, 15, 5)
+    try:
+        torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
+        pipe.reserve_retained(6); torch.cuda.synchronize(); free6 = torch.cuda.mem_get_info()[0]
+        per_set = (free0 - free6) / 6
+        assert per_set > 16 * 640 * 480 * 10                      # a set holds the flow, depth, plane-edge mask and normalised depth of the step's 16 frames
+        pipe.reserve_retained(2); torch.cuda.synchronize(); free2 = torch.cuda.mem_get_info()[0]
+        assert free2 - free6 > 3.5 * per_set                      # four of the six sets went back
+        pipe.reserve_retained(2); torch.cuda.synchronize(); assert abs(torch.cuda.mem_get_info()[0] - free2) < 0.5 * per_set        # idempotent
+        pipe.reserve_retained(0); torch.cuda.synchronize(); assert free0 - torch.cuda.mem_get_info()[0] < 0.5 * per_set
+    finally:
+        pipe.close()

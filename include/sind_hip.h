@@ -279,6 +279,8 @@ int sind_comm_destroy(sind_comm* c);
 int sind_comm_rank(const sind_comm* c);
 int sind_comm_world(const sind_comm* c);
 int sind_comm_allgather_u8(sind_comm* c, const uint8_t* local_host, size_t bytes, uint8_t* all_dev, uint8_t* all_host_or_null);
+/* one hand-over along the chain of ranks as one RCCL group: `bytes` bytes of host memory to rank `to` (-1: nothing to send) and as many from rank `from` (-1: nothing) */
+int sind_comm_sendrecv_u8(sind_comm* c, const uint8_t* send_host, int to, uint8_t* recv_host, int from, size_t bytes);
 int sind_pipe_gather_masks(sind_pipe* p, sind_comm* c, const uint8_t* dyna_host, uint8_t* all_dev, uint8_t* all_host_or_null);
 /* Where the PEAC region grow of CalOccluded (AHCPlaneFitter.hpp:546-601) runs: `quarters` of every four frames on the GPU (k_peac_grow, one compute unit for
  * a few ms per frame), the others on a host core; the results are bit-identical, the share only moves load between the GPU and the host.  -1 (default): the
@@ -362,6 +364,56 @@ int sind_cloud_generate(sind_cloud* c, int B, const uint8_t* bgr, const uint16_t
 
 /* helper of the rgbd_tum_noros-shaped harness (sindslam_amd/harness.py): PNG scanline reconstruction, raw = h x (1 + stride) bytes */
 int sind_png_unfilter(const uint8_t* raw, int h, int stride, int bytes_per_pixel, uint8_t* out);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * One long sequence, sharded by frame, with results EQUAL to the sequential loop (rgbd_tum_noros.cc:110-170 is the loop it equals).
+ * The sequence is cut into world x streams contiguous lock-step chunks, one per pipeline stream; chunk 0 starts like the reference loop, a later chunk starts `warmup`
+ * frames early from an empty state (speculation).  After the lock-step steps every chunk seam is VERIFIED by comparing 128-bit fingerprints of the inter-frame state
+ * (DynaDetect.h:165-178, rolled at DynaDetect.cc:1660-1664) and a chunk whose rebuilt state is not its predecessor's true end state is REPAIRED: the stateful tails of
+ * its first frames run again from the true state (on the retained phase-A outputs, then as whole frames on a small second pipeline) until the states agree.  Between
+ * ranks a round costs one all-gather of 32 bytes per chunk and, for a mismatching seam between two ranks, one send / receive of the state blob -- over RCCL
+ * (sind_seq_net_rccl on a sind_comm) or TCP (sind_seq_net_tcp: ranks without a communicator between them, several ranks rehearsed on one card).
+ * Everything below is C++ inside the library (csrc/host/seq.cpp): a C++ caller needs neither Python nor torch.distributed for the exact sharded mode.
+ *
+ * Positions: position q = frame q + 1 of the sequence (frame 0 only primes, like the reference's first frame).  Outputs are caller arrays indexed by FRAME. */
+typedef struct sind_seq sind_seq;
+typedef struct sind_seq_net sind_seq_net;
+typedef struct sind_seq_config {
+    sind_pipe_config pipe;          /* streams = chunks PER RANK; frames_per_step is set by the plan (ignored on input) */
+    long long frames;               /* positions of the job = sequence length - 1 */
+    int steps;                      /* > 0: exactly this many lock-step steps (bench.py); 0: as many as frames_per_step asks for */
+    int frames_per_step;            /* steps == 0: a step holds at most this many frames per chunk */
+    int warmup;                     /* frames a chunk after the first starts early to rebuild the inter-frame state */
+    int repair_streams, repair_frames_per_step;     /* the repair pipeline (0 = min(streams, 8) x 4) */
+    int retain_frames;              /* steps holding the first n owned frames of the later chunks keep their phase-A outputs for replays; -1 = every step, 0 = none */
+    int verify;                     /* 0: keep the speculative results (valid masks, not identical behind some seams) */
+} sind_seq_config;
+/* source callbacks: device pointers of the `count` frames at these positions, laid out [count][H][W][3] / [count][H][W] (valid until the next call), and the HOST bgr
+ * frame of one position (priming); return 0 */
+typedef int (*sind_seq_batch_fn)(void* user, const long long* positions, int count, const uint8_t** bgr_dev, const uint16_t** depth_dev);
+typedef int (*sind_seq_frame_fn)(void* user, long long position, const uint8_t** bgr_host);
+typedef int (*sind_seq_hook_fn)(void* user, int index);       /* step hook: the owned frames of step `index` are out; round hook: repair round `index` has ended (called on every rank) */
+int sind_seq_net_tcp(int rank, int world, const char* host_or_null /* 127.0.0.1 */, int base_port, sind_seq_net** out);      /* rank r listens on base_port + r */
+int sind_seq_net_rccl(sind_comm* c, sind_seq_net** out);
+int sind_seq_net_destroy(sind_seq_net* n);
+int sind_seq_create(const sind_seq_config* cfg, sind_seq_net* net_or_null /* one rank */, sind_seq** out);
+int sind_seq_destroy(sind_seq* q);
+int sind_seq_plan(sind_seq* q, int* frames_per_step, int* steps, int* n_chunks, long long* first_last_start /* n_chunks x 3, or NULL */);
+int sind_seq_set_host_source(sind_seq* q, const uint8_t* bgr, const uint16_t* depth, long long n_frames);      /* the whole sequence in host memory: [n][H][W][3] u8, [n][H][W] u16 */
+int sind_seq_set_source(sind_seq* q, sind_seq_batch_fn batch, sind_seq_frame_fn frame, void* user);
+/* sink: arrays of n_frames entries indexed by frame (dyna / label / mask [n][H][W]; kps [n][cap], nkp [n], desc [n][cap][32]); any may be NULL; a rank fills the frames it owns */
+int sind_seq_set_outputs(sind_seq* q, long long n_frames, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated, sind_keypoint* kps, int cap, int* nkp, uint8_t* desc);
+int sind_seq_set_hooks(sind_seq* q, sind_seq_hook_fn step_hook, sind_seq_hook_fn round_hook, void* user);
+int sind_seq_prime(sind_seq* q);
+int sind_seq_submit(sind_seq* q, int step);       /* steps 0 .. steps - 1 in order; software-pipelined: the results of step - 1 are delivered */
+int sind_seq_flush(sind_seq* q);                  /* delivers the last step */
+int sind_seq_verify(sind_seq* q);                 /* seam verification and repairs (collective over the ranks) */
+int sind_seq_run(sind_seq* q);                    /* prime + every step + flush + verify */
+/* seams, mismatched seams, rounds, runners, repaired chunks, repair frames, repair steps, overridden frames, runners to chunk end, max frames to converge, replay frames,
+ * replay calls, runners past replay, retained steps dropped, repair seconds, flush seconds */
+int sind_seq_stats(sind_seq* q, double out16[16]);
+sind_pipe* sind_seq_pipeline(sind_seq* q);        /* the main pipeline of this rank (sind_pipe_stats, sind_pipe_gather_masks, ...) */
+int sind_seq_step_outputs(sind_seq* q, const uint8_t** dyna, const uint8_t** label, const uint8_t** mask_dilated);   /* the page-locked [S][T][H][W] arrays of the last delivered step */
 
 #ifdef __cplusplus
 }

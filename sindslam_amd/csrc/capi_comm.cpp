@@ -17,6 +17,10 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool load() {
         static std::once_flag once;
@@ -29,14 +33,15 @@ struct Rccl {
             GetUniqueId = (decltype(GetUniqueId))dlsym(so, "ncclGetUniqueId"); CommInitRank = (decltype(CommInitRank))dlsym(so, "ncclCommInitRank");
             CommDestroy = (decltype(CommDestroy))dlsym(so, "ncclCommDestroy"); AllGather = (decltype(AllGather))dlsym(so, "ncclAllGather");
             GetErrorString = (decltype(GetErrorString))dlsym(so, "ncclGetErrorString");
-            if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) { err = "librccl lacks an expected symbol"; (void)dlclose(so); so = nullptr; }
+            Send = (decltype(Send))dlsym(so, "ncclSend"); Recv = (decltype(Recv))dlsym(so, "ncclRecv"); GroupStart = (decltype(GroupStart))dlsym(so, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(so, "ncclGroupEnd");
+            if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString || !Send || !Recv || !GroupStart || !GroupEnd) { err = "librccl lacks an expected symbol"; (void)dlclose(so); so = nullptr; }
         });
         return so != nullptr;
     }
 } g_rccl;
 }  // namespace
 
-struct sind_comm { ncclComm_t comm = nullptr; int rank = 0, world = 1, device = 0; hipStream_t stream = nullptr; DevBuf<uint8_t> send; };
+struct sind_comm { ncclComm_t comm = nullptr; int rank = 0, world = 1, device = 0; hipStream_t stream = nullptr; DevBuf<uint8_t> send, p2p_send, p2p_recv; };
 
 #define RCCL_TRY(expr)                                                                                          \
     do { const ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { sind_set_error("%s -> %s", #expr, g_rccl.GetErrorString(r_)); return SIND_E_HIP; } } while (0)
@@ -76,6 +81,22 @@ int sind_comm_allgather_u8(sind_comm* c, const uint8_t* local, size_t bytes, uin
     HIP_TRY(hipMemcpyAsync(c->send.p, local, bytes, hipMemcpyHostToDevice, c->stream));
     RCCL_TRY(g_rccl.AllGather(c->send.p, all_dev, bytes, ncclUint8, c->comm, c->stream));
     if (all_host) HIP_TRY(hipMemcpyAsync(all_host, all_dev, bytes * c->world, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(sind_stream_wait(c->stream));
+    return SIND_OK;
+}
+// One hand-over along the chain of ranks (the state blob of a mismatching chunk seam between two ranks, sequence driver): `bytes` bytes from host memory to rank `to`
+// (-1: nothing to send) and as many from rank `from` (-1: nothing to receive) into host memory, as ONE RCCL group (a rank in the middle does both).  Blocks until done.
+int sind_comm_sendrecv_u8(sind_comm* c, const uint8_t* send, int to, uint8_t* recv, int from, size_t bytes) {
+    if (!c || bytes == 0 || (to >= 0 && (!send || to >= c->world || to == c->rank)) || (from >= 0 && (!recv || from >= c->world || from == c->rank))) { sind_set_error("sind_comm_sendrecv_u8: bad arguments"); return SIND_E_ARG; }
+    if (to < 0 && from < 0) return SIND_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (to >= 0) { SIND_TRY(c->p2p_send.alloc(bytes)); HIP_TRY(hipMemcpyAsync(c->p2p_send.p, send, bytes, hipMemcpyHostToDevice, c->stream)); }
+    if (from >= 0) SIND_TRY(c->p2p_recv.alloc(bytes));
+    RCCL_TRY(g_rccl.GroupStart());
+    if (to >= 0) RCCL_TRY(g_rccl.Send(c->p2p_send.p, bytes, ncclUint8, to, c->comm, c->stream));
+    if (from >= 0) RCCL_TRY(g_rccl.Recv(c->p2p_recv.p, bytes, ncclUint8, from, c->comm, c->stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    if (from >= 0) HIP_TRY(hipMemcpyAsync(recv, c->p2p_recv.p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(sind_stream_wait(c->stream));
     return SIND_OK;
 }

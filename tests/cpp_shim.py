@@ -24,3 +24,12 @@ def build_boundary(out_path):
            os.path.join(ROOT, "tests", "cpp", "boundary_callsites.cpp"), "-L" + lib_dir, "-lsind_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", out_path]
     subprocess.check_call(cmd)
     return out_path
+
+
+def build_seq_fake(out_path):
+    """tests/cpp/seq_fake.cpp + the product's HIP-free sequence driver (csrc/host/seq.cpp, seq_net_tcp.cpp) as one shared library, plain g++: the driver's logic on the CPU"""
+    host = os.path.join(ROOT, "sindslam_amd", "csrc", "host")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-fPIC", "-shared", os.path.join(ROOT, "tests", "cpp", "seq_fake.cpp"), os.path.join(host, "seq.cpp"),
+           os.path.join(host, "seq_net_tcp.cpp"), "-lpthread", "-o", out_path]
+    subprocess.check_call(cmd)
+    return out_path

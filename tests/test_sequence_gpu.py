@@ -195,3 +195,60 @@ def test_verified_chunks_1280x720_three_level_pyramid_and_bonn():
     print("bonn:", {k: v for k, v in st.items() if k != "plan"})
     for f in range(1, n):
         assert np.array_equal(got["dyna"][f], ex["dyna"][f]) and np.array_equal(got["label"][f], ex["label"][f]) and np.array_equal(got["mask"][f], ex["mask"][f]), f
+
+
+# ---- the same through the C++ driver behind sind_seq_* (no Python in the loop, no torch.distributed between the ranks)
+@pytest.mark.timeout(2400)
+def test_cabi_verified_chunks_equal_the_oracle_on_125_frames():
+    """125 frames on 5 chunks (warm-up 6: short on purpose, so that seams mismatch and runners repair them) through sind_seq_run against the ORACLE's sequential loop:
+    imgDyna, imgLabel, the dilated mask, ORB keypoints and descriptors of every frame are equal"""
+    import oracle_lib as O
+    from sindslam_amd.seq import run_sequence
+    n = 126
+    bgr, depth = SyntheticStream(seed=2024).frames(0, n)
+    st = {}
+    got = run_sequence(bgr, depth, TUM3, streams=5, frames_per_step=4, warmup=6, repair_streams=4, repair_frames_per_step=4, stats=st, retain_frames=6)
+    print("C ABI, 5 chunks / warm-up 6:", st)
+    assert got["owned"] == list(range(1, n)) and st["seams"] == 4 and st["mismatched_seams"] >= 1
+    ref = O.sequence_run(bgr, depth, TUM3, threads=12)
+    for f in range(1, n):
+        assert np.array_equal(got["dyna"][f], ref["dyna"][f]) and np.array_equal(got["label"][f], ref["label"][f]) and np.array_equal(got["mask"][f], ref["mask"][f]), f
+        assert got["keypoints"][f].tobytes() == ref["keypoints"][f].tobytes() and np.array_equal(got["descriptors"][f], ref["descriptors"][f]), f
+
+
+@pytest.mark.timeout(900)
+def test_cabi_forced_mismatch_no_warmup_equals_the_python_driver():
+    """warm-up 0 through sind_seq_run: every seam mismatches and is repaired; results and statistics equal the Python driver's on the same input"""
+    from sindslam_amd.seq import run_sequence
+    n = 31
+    bgr, depth = SyntheticStream(seed=4242).frames(0, n)
+    st = {}; pst = {}
+    got = run_sequence(bgr, depth, TUM3, streams=3, frames_per_step=2, warmup=0, repair_streams=2, repair_frames_per_step=3, stats=st, want_keypoints=False, retain_frames=0)
+    py = process_sequence(bgr, depth, TUM3, streams=3, frames_per_step=2, warmup=0, repair_streams=2, repair_frames_per_step=3, stats=pst, want_keypoints=False, retain_frames=0)
+    assert st["mismatched_seams"] == 2 and st["rounds"] >= 1 and st["repair_frames"] > 0
+    for k in ("seams", "mismatched_seams", "rounds", "runners", "repaired_chunks", "repair_frames", "overridden_frames", "max_frames_to_converge"):
+        assert st[k] == pst[k], (k, st[k], pst[k])
+    for f in range(1, n):
+        assert np.array_equal(got["dyna"][f], py["dyna"][f]) and np.array_equal(got["label"][f], py["label"][f]) and np.array_equal(got["mask"][f], py["mask"][f]), f
+
+
+@pytest.mark.parametrize("world,warm", [(2, 1), (3, 0)])
+@pytest.mark.timeout(1200)
+def test_cabi_ranks_forced_mismatch_over_tcp(tmp_path, world, warm):
+    """two / three PROCESSES on this one card, 2 chunks each, the exchange over loopback TCP (sind_seq_net_tcp): the seams between the ranks mismatch, a rank receives its
+    predecessor's end-state blob (the middle rank of three also sends its own) and repairs; together the ranks reproduce the sequential loop bit for bit"""
+    import json, os, subprocess, sys
+    n = 33
+    bgr, depth = SyntheticStream(seed=99).frames(0, n)
+    ref = _sequential_gpu(bgr, depth)
+    port = 33000 + (os.getpid() * 3 + world) % 20000
+    procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "seq_cabi_worker.py"), str(n), str(tmp_path), str(warm), str(r), str(world), str(port)]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=1000) == 0
+    owned = []; mism = 0
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz"); st = json.loads(str(z["stats"])); print(f"rank {r}:", st); mism = max(mism, st["mismatched_seams"])
+        for f in z["owned"]:
+            assert np.array_equal(z["dyna"][f], ref[int(f)][0]) and np.array_equal(z["label"][f], ref[int(f)][1]) and np.array_equal(z["mask"][f], ref[int(f)][2]), (r, int(f))
+        owned += z["owned"].tolist()
+    assert sorted(owned) == list(range(1, n)) and mism >= world - 1

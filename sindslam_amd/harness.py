@@ -180,7 +180,7 @@ def run_sequence_chunked(settings_path: str, sequence_dir: str, association_path
     decoded up front and go through the batched pipeline as `chunks` verified chunks (sindslam_amd.sequence.process_sequence: speculate, verify the chunk seams by
     state fingerprints, repair).  Offline use -- the whole sequence has to be there; a live camera is run_sequence / the DynaDetect class."""
     from .orb import ORBextractor
-    from .sequence import process_sequence
+    from .seq import run_sequence as run_chunks          # the C++ driver behind sind_seq_* (csrc/host/seq.cpp)
     S = read_settings(settings_path)
     ts, rgbs, deps = load_associations(association_path)
     if len(rgbs) != len(deps):
@@ -202,8 +202,8 @@ def run_sequence_chunked(settings_path: str, sequence_dir: str, association_path
     rgb_order = int(S.get("Camera.RGB", 0)) == 1
     nf, sf, nl = int(S["ORBextractor.nFeatures"]), float(S["ORBextractor.scaleFactor"]), int(S["ORBextractor.nLevels"])
     st = {}; t0 = time.perf_counter()
-    got = process_sequence(bgr, depth, intr, streams=max(1, min(chunks, (n - 1) // 2)), frames_per_step=frames_per_step, warmup=warmup, nfeatures=nf, scale_factor=sf, nlevels=nl,
-                           orb_gray_rgb_order=1 if rgb_order else 0, device=device, stats=st)
+    got = run_chunks(bgr, depth, intr, streams=max(1, min(chunks, (n - 1) // 2)), frames_per_step=frames_per_step, warmup=warmup, nfeatures=nf, scale_factor=sf, nlevels=nl,
+                     orb_gray_rgb_order=1 if rgb_order else 0, device=device, stats=st)
     t_run = time.perf_counter() - t0
     # frame 0 passes through with an all-zero mask (rgbd_tum_noros.cc:100-116): its keypoints come from the extractor alone
     orb = ORBextractor(nf, sf, nl, intr["ini_th"], intr["min_th"], device=device)
@@ -220,7 +220,7 @@ def run_sequence_chunked(settings_path: str, sequence_dir: str, association_path
     if verbose:
         print("-------\n")
         print(f"Images in the sequence: {n}")
-        print(f"decoded in {t_load:.2f} s; DynaDetect + ORB on {st['plan'].n_chunks} verified chunks: {t_run:.2f} s = {(n - 1) / t_run:.1f} frames/s "
+        print(f"decoded in {t_load:.2f} s; DynaDetect + ORB on {len(st['chunks'])} verified chunks: {t_run:.2f} s = {(n - 1) / t_run:.1f} frames/s "
               f"({st['mismatched_seams']} of {st['seams']} chunk seams repaired, {st['replay_frames'] + st['repair_frames']} frames re-run)")
         print(f"mean dynamic detecting time: {t_run / max(n - 1, 1):.6f}")
     return results

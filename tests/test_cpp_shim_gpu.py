@@ -91,3 +91,63 @@ def test_opencv_overloads_and_public_pyramid(frames, tmp_path):
     patch = np.frombuffer(raw, np.uint8, 121, off).reshape(11, 11); off += 121
     assert np.array_equal(patch, lvl1[35:46, 55:66]) and off == len(raw)
     dd.close(); orb.close()
+
+
+def _read_chunked(path, n, w, h):
+    raw = open(path, "rb").read(); off = 0; npx = w * h; out = {}
+    for f in range(n):
+        owned = int(np.frombuffer(raw, np.int32, 1, off)[0]); off += 4
+        if not owned:
+            continue
+        dyna = np.frombuffer(raw, np.uint8, npx, off).reshape(h, w); off += npx
+        label = np.frombuffer(raw, np.uint8, npx, off).reshape(h, w); off += npx
+        mask = np.frombuffer(raw, np.uint8, npx, off).reshape(h, w); off += npx
+        nk = int(np.frombuffer(raw, np.int32, 1, off)[0]); off += 4
+        kps = np.frombuffer(raw, KP_DTYPE, nk, off); off += nk * KP_DTYPE.itemsize
+        desc = np.frombuffer(raw, np.uint8, nk * 32, off).reshape(nk, 32); off += nk * 32
+        out[f] = (dyna, label, mask, kps, desc)
+    assert off == len(raw)
+    return out
+
+
+@pytest.mark.timeout(1200)
+def test_cpp_chunked_mode_equals_the_cpp_frame_loop(tmp_path):
+    """rgbd_tum_noros_shim --chunks N (sind_seq_* from C++: verified chunks, no Python, no torch.distributed) returns for every frame what the same binary's frame loop
+    returns -- on one rank, and on two ranks (two processes on this card, the exchange over loopback TCP) that each write the frames they own"""
+    import os
+    from sindslam_amd.synth import SyntheticStream
+    n = 41
+    bgr, depth = SyntheticStream(seed=515).frames(0, n); h, w = bgr.shape[1:3]
+    exe = cpp_shim.build(str(tmp_path / "rgbd_tum_noros_shim"))
+    fin = str(tmp_path / "in.raw")
+    with open(fin, "wb") as f:
+        np.array([n, w, h], np.int32).tofile(f); np.ascontiguousarray(bgr).tofile(f); np.ascontiguousarray(depth).tofile(f)
+    args = [repr(float(a)) if isinstance(a, float) else str(a) for a in [TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"], 1500, 1.2, 8, TUM3["ini_th"], TUM3["min_th"], 1]]
+    r = subprocess.run([exe, fin, str(tmp_path / "loop.raw")] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    raw = open(tmp_path / "loop.raw", "rb").read(); off = 0; npx = w * h; loop = []
+    for ni in range(n):
+        rec = [np.frombuffer(raw, np.uint8, npx, off + k * npx).reshape(h, w) for k in range(3)]; off += 3 * npx
+        nk = int(np.frombuffer(raw, np.int32, 1, off)[0]); off += 4
+        rec.append(np.frombuffer(raw, KP_DTYPE, nk, off)); off += nk * KP_DTYPE.itemsize
+        rec.append(np.frombuffer(raw, np.uint8, nk * 32, off).reshape(nk, 32)); off += nk * 32
+        loop.append(rec)
+
+    def same(got, frames):
+        for f in frames:
+            for a, b in zip(got[f][:3], loop[f][:3]):
+                assert np.array_equal(a, b), f
+            assert got[f][3].tobytes() == loop[f][3].tobytes() and np.array_equal(got[f][4], loop[f][4]), f
+    # one rank, 4 chunks, a warm-up of 2 frames (short on purpose: seams mismatch and are repaired)
+    r = subprocess.run([exe, fin, str(tmp_path / "c1.raw")] + args + ["--chunks", "4", "--warmup", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    print(r.stdout.strip())
+    got = _read_chunked(tmp_path / "c1.raw", n, w, h); assert sorted(got) == list(range(n)); same(got, range(n))
+    # two ranks x 2 chunks over TCP
+    port = 36000 + os.getpid() % 20000
+    ps = [subprocess.Popen([exe, fin, str(tmp_path / f"c2_{k}.raw")] + args + ["--chunks", "2", "--warmup", "1", "--rank", str(k), "--world", "2", "--port", str(port)]) for k in range(2)]
+    for p in ps:
+        assert p.wait(timeout=900) == 0
+    g0 = _read_chunked(tmp_path / "c2_0.raw", n, w, h); g1 = _read_chunked(tmp_path / "c2_1.raw", n, w, h)
+    assert sorted(list(g0) + list(g1)) == list(range(n)) and len(g1) >= 10
+    same(g0, g0); same(g1, g1)

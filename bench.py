@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--chain-max", type=int, default=-1, help="sequence workload: replayed steps with at most this many live runners run as per-stream chains (-1 = library default 12, 0 = always rounds)")
     ap.add_argument("--repair-streams", type=int, default=0, help="sequence workload: runners of the repair pipeline (0 = half the chunks of a GPU, 2..16)")
     ap.add_argument("--repair-frames-per-step", type=int, default=4)
+    ap.add_argument("--seq-driver", choices=["cabi", "python"], default="cabi", help="sequence workload on ONE rank: cabi = the C++ driver behind sind_seq_* (csrc/host/seq.cpp; default), "
+                                                                                       "python = sindslam_amd/sequence.py VerifiedChunks (the same algorithm; what several ranks under torch.distributed run)")
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
     ap.add_argument("--exact-leg-frames", type=int, default=0, help="sequence workload: frames of the in-order re-run the chunked masks are compared with (0 = chunk 0, chunks 1-2 and what else fits into 320-480 frames)")
     ap.add_argument("--flow-slices", type=int, default=0, help="experiment: dense-flow slices of a step (sind_pipe_config.flow_slices; 0 = the library's rule by step size)")
@@ -533,22 +535,37 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
         raise SystemExit(f"sequence workload: {S} chunks x {T} frames per step is more than one step should hold; use more --steps, fewer --streams or a shorter --sequence-frames")
     src = BenchFrames(base_b, base_d); bb, bd = src.bb, src.bd; fidx = src.fidx
     parts = pipelines_for(S, T, args.pipelines)
-    pipe = make_pipeline(cfg, intr, S, T, local, args.host_threads, parts)
-    # the runners that repair mismatching chunks: a second, small pipeline (created and warmed before the clock starts, like the main one)
     R = args.repair_streams or max(2, min(16, (S + 1) // 2)); Tr = max(1, args.repair_frames_per_step)
-    rp = make_pipeline(cfg, intr, R, Tr, local, args.host_threads) if (n > 1 and not args.no_verify) else None
+    verify = n > 1 and not args.no_verify
+    # ONE rank: the C++ driver behind sind_seq_* owns both pipelines and runs plan, steps, verification and repairs (csrc/host/seq.cpp); this function only feeds it the
+    # device-resident batches and reads the step's masks in the step hook.  Several ranks (under torch.distributed, which also carries the mask gather): the Python twin.
+    use_cabi = args.seq_driver == "cabi" and world == 1 and parts == 1
+    job = vc = rp = None
+    if use_cabi:
+        from sindslam_amd.seq import SeqJob
+        job = SeqJob(args.sequence_frames, S, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],
+                     orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=args.host_threads, flow_max_levels=cfg["flow_max_levels"], steps=K, warmup=SW, repair_streams=R,
+                     repair_frames_per_step=Tr, retain_frames=args.retain_frames if verify else 0, verify=verify, flow_slices=cfg.get("flow_slices", 0), flow_opts_off=cfg.get("flow_opts_off", 0))
+        assert job.T == T and job.steps == K and job.chunks.tolist() == [[c.first, c.last, c.start] for c in plan.chunks], "the C++ plan is the Python plan"
+        pipe = job.pipeline_view()
+    else:
+        pipe = make_pipeline(cfg, intr, S, T, local, args.host_threads, parts)
+        # the runners that repair mismatching chunks: a second, small pipeline (created and warmed before the clock starts, like the main one)
+        rp = make_pipeline(cfg, intr, R, Tr, local, args.host_threads) if verify else None
     if args.chain_max >= 0 and hasattr(pipe, "set_chain_max_streams"):
         pipe.set_chain_max_streams(args.chain_max)
-    vc = VerifiedChunks(plan, S, pipe, rp, src, rank, world, retain_frames=args.retain_frames if rp is not None else 0)
-    mine = vc.mine
+    if not use_cabi:
+        vc = VerifiedChunks(plan, S, pipe, rp, src, rank, world, retain_frames=args.retain_frames if rp is not None else 0)
+    mine = plan.chunks[rank * S:(rank + 1) * S]
 
     def prime_all():
+        if use_cabi:
+            job.prime(); return
         vc.prime()
         if rp is not None:
             for j in range(R):
                 rp.prime(j, src.host_frame(-1), src.host_frame(-2))
             rp.set_state_hashing(True)
-    prime_all()
     dev_b, dev_d = [], []
     for i in range(K):
         idx = torch.tensor([[fidx(c.start + i * T + t) for t in range(T)] for c in mine], device="cuda")
@@ -556,6 +573,21 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     # dynamic masks of every processed frame of ALL chunks, on every rank: [chunk][step][t]
     seq_masks = torch.zeros((world, S, K, T, H, W), dtype=torch.uint8, device="cuda" if comm_dev == "cuda" else "cpu")
     gbuf = {}
+    if use_cabi:
+        start0 = mine[0].start; keep = {}
+        step_pos = [np.array([[c.start + i * T + t for t in range(T)] for c in mine], np.int64).ravel() for i in range(K)]
+
+        def batch_source(pos):              # the K lock-step batches were built before the clock; a runner's batch is gathered from the resident base frames
+            i = (int(pos[0]) - start0) // T
+            if len(pos) == S * T and 0 <= i < K and np.array_equal(pos, step_pos[i]):
+                return dev_b[i].data_ptr(), dev_d[i].data_ptr()
+            b_, d_, keep["last"] = src.device_batch(pos.reshape(-1, Tr) if len(pos) == R * Tr else pos.reshape(S, T))
+            return b_, d_
+        job.set_source(batch_source, lambda q: np.ascontiguousarray(src.host_frame(q)))
+        # sink: only REPAIRED frames are copied out (nkp marks them); the step hook below takes a lock-step step's masks from the step's own page-locked array
+        fix_dyna = np.zeros((args.sequence_frames + 1, H, W), np.uint8); fix_mark = np.full(args.sequence_frames + 1, -1, np.int32)
+        job.set_outputs(args.sequence_frames + 1, dyna=fix_dyna, nkp=fix_mark); job.set_emit_main(False)
+    prime_all()
 
     cabi = None
     if pg and args.collective == "cabi":     # the library's own collective (RCCL through the C ABI): torch.distributed only carries the 128-byte id to the ranks
@@ -566,7 +598,7 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
         cabi = Comm(box[0], rank, world, local)
 
     def gather(step):
-        m = pipe.dyna_pinned if pipe.dyna_pinned is not None else torch.from_numpy(pipe.dyna)
+        m = torch.from_numpy(job.step_masks()) if use_cabi else (pipe.dyna_pinned if pipe.dyna_pinned is not None else torch.from_numpy(pipe.dyna))
         if cabi is not None:
             if "out" not in gbuf:
                 gbuf["out"] = torch.empty((world,) + tuple(m.shape), dtype=m.dtype, device="cuda")
@@ -588,12 +620,17 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
             if cabi is not None and out.is_cuda:
                 torch.cuda.current_stream().synchronize()        # the comm's own stream rewrites gbuf["out"] at the next step: the copy out of it must be done by then
 
-    for i in range(Wm):                     # untimed: the first steps of the job, results and state dropped afterwards
-        pipe.process_dev(dev_b[i % K].data_ptr(), dev_d[i % K].data_ptr()); gather(None)
-    if rp is not None:                      # one untimed step of the repair pipeline as well (first-use allocations)
-        inp = src.device_batch(np.tile(np.arange(Tr), (R, 1))); rp.process_dev(inp[0], inp[1]); del inp
-    if Wm or rp is not None:
-        prime_all()                         # priming resets a stream's tail state: the timed region starts the job from scratch
+    if use_cabi:
+        job.warm(Wm)                        # untimed: the first steps of the job + one step of the repair pipeline (first-use allocations), results and state dropped
+        if Wm or verify:
+            prime_all()
+    else:
+        for i in range(Wm):                 # untimed: the first steps of the job, results and state dropped afterwards
+            pipe.process_dev(dev_b[i % K].data_ptr(), dev_d[i % K].data_ptr()); gather(None)
+        if rp is not None:                  # one untimed step of the repair pipeline as well (first-use allocations)
+            inp = src.device_batch(np.tile(np.arange(Tr), (R, 1))); rp.process_dev(inp[0], inp[1]); del inp
+        if Wm or rp is not None:
+            prime_all()                     # priming resets a stream's tail state: the timed region starts the job from scratch
     if pg:
         dist.barrier()
     torch.cuda.synchronize()
@@ -604,8 +641,14 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
 
     def after_submit(i, seconds):
         acc.submit_wall += seconds; acc.add(pipe.stats(), True); step_wall.append(round(seconds * 1e3, 1))
-    vc.run_main(on_step=lambda i, p_: gather(i), inputs=lambda i: (dev_b[i].data_ptr(), dev_d[i].data_ptr()), after_submit=after_submit)
-    flush_ms = vc.flush_seconds * 1e3
+    if use_cabi:
+        job.set_hooks(on_step=gather)
+        for i in range(K):
+            ts_ = time.perf_counter(); job.submit(i); after_submit(i, time.perf_counter() - ts_)
+        tf_ = time.perf_counter(); job.flush(); flush_ms = (time.perf_counter() - tf_) * 1e3
+    else:
+        vc.run_main(on_step=lambda i, p_: gather(i), inputs=lambda i: (dev_b[i].data_ptr(), dev_d[i].data_ptr()), after_submit=after_submit)
+        flush_ms = vc.flush_seconds * 1e3
     t_main = time.perf_counter() - t0
     # ---- verify the chunk seams, repair the mismatching chunks (inside the clock); corrected masks replace the speculative ones on every rank
     fixes = []                              # (global chunk, position, mask) of this round
@@ -635,7 +678,15 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
                     g, i = int(all_ids[r_][k_, 0]), int(all_ids[r_][k_, 1])
                     seq_masks[g // S, g % S, i // T, i % T].copy_(all_blk[r_][k_])
         fixes.clear()
-    vstats = vc.verify_and_repair(on_frame=on_frame, on_round=on_round) if rp is not None else dict(vc.stats)
+    if use_cabi:
+        job.verify(); vstats = job.stats()
+        rf_ = args.retain_frames if args.retain_frames > 0 else max(1, plan.processed - SW)
+        n_retained = len(range(SW // T, min(K, (SW + rf_ - 1) // T + 1))) if (verify and args.retain_frames != 0) else 0
+        for f in np.nonzero(fix_mark >= 0)[0]:            # the frames a runner re-ran: their masks replace the speculative ones
+            q = int(f) - 1; g = next(g_ for g_, c in enumerate(plan.chunks) if c.first <= q < c.last); i = q - plan.chunks[g].start
+            seq_masks[0, g, i // T, i % T].copy_(torch.from_numpy(fix_dyna[f]))
+    else:
+        vstats = vc.verify_and_repair(on_frame=on_frame, on_round=on_round) if rp is not None else dict(vc.stats); n_retained = len(vc.retained)
     torch.cuda.synchronize()
     if pg:
         dist.barrier()
@@ -649,14 +700,15 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
             "processed_frames_per_chunk": plan.processed, "state_warmup_frames": SW, "state_warmup_steps": -(-SW // T),
             "processed_frames": plan.processed_total, "warmup_overhead": plan.processed_total / owned - 1.0,
             "value": owned / dt, "value_excl_warmup": plan.processed_total / dt, "seconds": dt, "final_flush_ms": flush_ms, "region_grow_gpu_quarters": grow_q, "kmeans_groups": km_groups,
-            "exact": rp is not None or n == 1, "pipelines_per_gpu": parts, "host_cores_busy": loads[0][0], "submit_wall_ms_by_step": step_wall,
+            "exact": verify or n == 1, "pipelines_per_gpu": parts, "host_cores_busy": loads[0][0], "submit_wall_ms_by_step": step_wall,
             "cpu_quota": (None if loads[0][1] < 0 else {"periods": int(loads[0][1]), "throttled_periods": int(loads[0][2]), "throttled_ms": loads[0][3]}),
             "stage_ms_per_step": {"dense_flow": acc.stages[1] / K, "tails": acc.stages[3] / K, "total": acc.stages[4] / K, "tails_wait_after_phase_a": acc.tail_wait / K},
             "verify": {"seams": vstats["seams"], "mismatched_seams": vstats["mismatched_seams"], "rounds": vstats["rounds"], "repaired_chunks": vstats["repaired_chunks"],
                        "repair_frames": vstats["repair_frames"], "repair_steps": vstats["repair_steps"], "runners_to_chunk_end": vstats["runners_to_chunk_end"],
-                       "replay_frames": vstats["replay_frames"], "replay_calls": vstats["replay_calls"], "runners_past_replay": vstats["runners_past_replay"], "retained_steps": len(vc.retained),
+                       "replay_frames": vstats["replay_frames"], "replay_calls": vstats["replay_calls"], "runners_past_replay": vstats["runners_past_replay"], "retained_steps": n_retained,
+                       "driver": "C++ (sind_seq_*, csrc/host/seq.cpp)" if use_cabi else "Python (sindslam_amd/sequence.py VerifiedChunks)",
                        "max_frames_to_converge": vstats["max_frames_to_converge"], "repair_seconds": vstats["repair_seconds"], "lockstep_seconds": t_main,
-                       "repair_pipeline": f"{R} runners x {Tr} frames per step" if rp is not None else None,
+                       "repair_pipeline": f"{R} runners x {Tr} frames per step" if verify else None,
                        "note": "every chunk seam is verified by comparing 128-bit fingerprints of the inter-frame state (the chunk's rebuilt state vs the predecessor's true end state); "
                                "a mismatching chunk is re-run from the true state until its state equals the speculative one of the same frame -- all inside the timed region; "
                                "replay_frames were re-run as tails only on retained phase-A outputs, repair_frames as whole frames on the repair pipeline"},
@@ -667,9 +719,12 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
             "sequence_masks_bytes_per_rank": int(seq_masks.numel())}
     if cabi is not None:
         cabi.close()
-    pipe.close()
-    if rp is not None:
-        rp.close()
+    if use_cabi:
+        job.close()
+    else:
+        pipe.close()
+        if rp is not None:
+            rp.close()
     # ---- rank 0: the first frames again in the in-order ("exact") mode -> IoU of the chunked masks at and behind the chunk seams, and the exact mode's own rate
     if rank == 0 and exact_leg and n > 1:
         from sindslam_amd.pipeline import Pipeline

@@ -405,6 +405,8 @@ int sind_seq_set_source(sind_seq* q, sind_seq_batch_fn batch, sind_seq_frame_fn 
 int sind_seq_set_outputs(sind_seq* q, long long n_frames, uint8_t* dyna, uint8_t* label, uint8_t* mask_dilated, sind_keypoint* kps, int cap, int* nkp, uint8_t* desc);
 int sind_seq_set_hooks(sind_seq* q, sind_seq_hook_fn step_hook, sind_seq_hook_fn round_hook, void* user);
 int sind_seq_prime(sind_seq* q);
+int sind_seq_warm(sind_seq* q, int steps);        /* untimed rehearsal after sind_seq_prime: the first `steps` steps synchronously + one step of the repair pipeline; call sind_seq_prime again */
+int sind_seq_set_emit_main(sind_seq* q, int on);  /* 0: the frames of a lock-step step are not copied to the sink (the step hook reads sind_seq_step_outputs itself); repaired frames always are */
 int sind_seq_submit(sind_seq* q, int step);       /* steps 0 .. steps - 1 in order; software-pipelined: the results of step - 1 are delivered */
 int sind_seq_flush(sind_seq* q);                  /* delivers the last step */
 int sind_seq_verify(sind_seq* q);                 /* seam verification and repairs (collective over the ranks) */

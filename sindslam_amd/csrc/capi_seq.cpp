@@ -199,6 +199,8 @@ int sind_seq_set_outputs(sind_seq* q, long long n_frames, uint8_t* dyna, uint8_t
 int sind_seq_set_hooks(sind_seq* q, sind_seq_hook_fn step_hook, sind_seq_hook_fn round_hook, void* user) { if (!q) return SIND_E_ARG; q->step_hook = step_hook; q->round_hook = round_hook; q->hook_user = user; return SIND_OK; }
 static int drv_rc(sind_seq* q, int r, const char* what) { if (r) { sind_set_error("%s: %s", what, q->drv->err.c_str()); return r < 0 && r >= SIND_E_CAPACITY ? r : SIND_E_STATE; } return SIND_OK; }
 int sind_seq_prime(sind_seq* q) { if (!q) return SIND_E_ARG; HIP_TRY(hipSetDevice(q->cfg.pipe.device)); return drv_rc(q, q->drv->prime(), "sind_seq_prime"); }
+int sind_seq_warm(sind_seq* q, int steps) { if (!q || steps < 0) return SIND_E_ARG; HIP_TRY(hipSetDevice(q->cfg.pipe.device)); return drv_rc(q, q->drv->warm(steps), "sind_seq_warm"); }
+int sind_seq_set_emit_main(sind_seq* q, int on) { if (!q) return SIND_E_ARG; q->drv->emit_main = on != 0; return SIND_OK; }
 int sind_seq_submit(sind_seq* q, int step) { if (!q) return SIND_E_ARG; HIP_TRY(hipSetDevice(q->cfg.pipe.device)); return drv_rc(q, q->drv->submit(step), "sind_seq_submit"); }
 int sind_seq_flush(sind_seq* q) { if (!q) return SIND_E_ARG; HIP_TRY(hipSetDevice(q->cfg.pipe.device)); return drv_rc(q, q->drv->finish_main(), "sind_seq_flush"); }
 int sind_seq_verify(sind_seq* q) { if (!q) return SIND_E_ARG; HIP_TRY(hipSetDevice(q->cfg.pipe.device)); if (!q->has_repair) return SIND_OK; return drv_rc(q, q->drv->verify_and_repair(), "sind_seq_verify"); }

@@ -71,12 +71,26 @@ int SeqDriver::prime() {
     return 0;
 }
 
+int SeqDriver::warm(int steps) {
+    const int T = plan_.T;
+    std::vector<long long> pos((size_t)S_ * T);
+    for (int i = 0; i < std::min(steps, plan_.steps); i++) {
+        for (int s = 0; s < S_; s++) for (int t = 0; t < T; t++) pos[(size_t)s * T + t] = mine_[s].start + (long long)i * T + t;
+        if (pipe_->process(pos.data(), nullptr)) return fail("process (warm-up)", pipe_);
+    }
+    if (repair_) {                          // one untimed step of the repair pipeline as well (first-use allocations)
+        const int R = repair_->S(), Tr = repair_->T(); std::vector<long long> rp((size_t)R * Tr);
+        for (int j = 0; j < R; j++) for (int t = 0; t < Tr; t++) rp[(size_t)j * Tr + t] = t;
+        if (repair_->process(rp.data(), nullptr)) return fail("process (warm-up of the repair pipeline)", repair_);
+    }
+    return 0;
+}
 int SeqDriver::collect(int step) {
     const int T = plan_.T;
     std::vector<uint64_t> hh((size_t)S_ * T * 2);
     if (pipe_->state_hashes(hh.data())) return fail("state_hashes", pipe_);
     for (int s = 0; s < S_; s++) std::memcpy(H(s, (long long)step * T), &hh[(size_t)s * T * 2], (size_t)T * 2 * sizeof(uint64_t));
-    for (int s = 0; s < S_; s++) for (int t = 0; t < T; t++) {
+    if (emit_main) for (int s = 0; s < S_; s++) for (int t = 0; t < T; t++) {
         const long long q = mine_[s].start + (long long)step * T + t;
         if (mine_[s].first <= q && q < mine_[s].last) if (pipe_->emit(s, t, q)) return fail("emit", pipe_);
     }

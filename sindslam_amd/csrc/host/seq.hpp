@@ -87,6 +87,8 @@ public:
     // first owned frame on; 0: runners re-process whole frames on the repair pipeline only.
     SeqDriver(const SeqPlan& plan, int S, SeqPipe* pipe, SeqPipe* repair, SeqNet* net, int retain_frames);
     int prime();
+    int warm(int steps);                    // untimed rehearsal: the first `steps` steps of the job synchronously (and one step of the repair pipeline); prime() afterwards
+    bool emit_main = true;                  // false: the owned frames of a lock-step step are NOT handed to the sink (the step hook reads the step's own arrays); repairs always are
     int submit(int step);                   // lock-step step `step` (0 .. steps - 1, in order); the results of step - 1 are emitted
     int finish_main();                      // drains the last step
     int verify_and_repair();

@@ -46,7 +46,9 @@ class Pipeline:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().sind_pipe_destroy(self._h); self._h = None
+            if getattr(self, "_owned", True):        # (a view of a pipeline that a sind_seq owns -- seq.SeqJob.pipeline_view -- never destroys it)
+                lib().sind_pipe_destroy(self._h)
+            self._h = None
 
     __del__ = close
 

@@ -57,9 +57,9 @@ class SeqJob:
 
     def __init__(self, frames: int, streams: int, width=640, height=480, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_scale=5000.0, nfeatures=1500, scale_factor=1.2, nlevels=8,
                  ini_th=15, min_th=5, orb_gray_rgb_order=0, device=0, host_threads=0, flow_max_levels=0, steps=0, frames_per_step=4, warmup=16, repair_streams=0,
-                 repair_frames_per_step=4, retain_frames=-1, verify=True, net: SeqNet | None = None):
+                 repair_frames_per_step=4, retain_frames=-1, verify=True, net: SeqNet | None = None, flow_slices=0, flow_opts_off=0):
         pc = PipeConfig(width, height, fx, fy, cx, cy, depth_scale, nfeatures, scale_factor, nlevels, ini_th, min_th, orb_gray_rgb_order, streams, max(1, frames_per_step), device,
-                        host_threads, flow_max_levels, 0, 0)
+                        host_threads, flow_max_levels, flow_slices, flow_opts_off)
         self.cfg = SeqConfig(pc, frames, steps, frames_per_step, warmup, repair_streams, repair_frames_per_step, retain_frames, 1 if verify else 0)
         self.net = net; self.S = streams; self.w, self.h = width, height; self.cap = 2 * nfeatures + 256
         self.rank = net.rank if net else 0; self.world = net.world if net else 1
@@ -120,6 +120,8 @@ class SeqJob:
         check(lib().sind_seq_set_hooks(self._h, self._hooks[0], self._hooks[1], None), "sind_seq_set_hooks")
 
     def prime(self): check(lib().sind_seq_prime(self._h), "sind_seq_prime")
+    def warm(self, steps: int): check(lib().sind_seq_warm(self._h, int(steps)), "sind_seq_warm")
+    def set_emit_main(self, on: bool): check(lib().sind_seq_set_emit_main(self._h, 1 if on else 0), "sind_seq_set_emit_main")
     def submit(self, step: int): check(lib().sind_seq_submit(self._h, int(step)), "sind_seq_submit")
     def flush(self): check(lib().sind_seq_flush(self._h), "sind_seq_flush")
     def verify(self): check(lib().sind_seq_verify(self._h), "sind_seq_verify")
@@ -135,6 +137,13 @@ class SeqJob:
     def pipeline_handle(self):
         lib().sind_seq_pipeline.restype = C.c_void_p
         return C.c_void_p(lib().sind_seq_pipeline(self._h))
+
+    def pipeline_view(self):
+        """the main pipeline as a Pipeline object WITHOUT ownership (statistics, settings): stats(), grow_share(), kmeans_groups(), host_info(), set_chain_max_streams() ..."""
+        from .pipeline import Pipeline
+        v = Pipeline.__new__(Pipeline); v.S, v.T, v.w, v.h, v.cap = self.S, self.T, self.w, self.h, self.cap
+        v._h = self.pipeline_handle(); v._owned = False
+        return v
 
     def step_masks(self) -> np.ndarray:
         """the dyna array [S][T][H][W] of the last delivered step (page-locked memory of the library: a view, copy what must outlive the next step)"""

@@ -68,8 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--chain-max", type=int, default=-1, help="sequence workload: replayed steps with at most this many live runners run as per-stream chains (-1 = library default 12, 0 = always rounds)")
     ap.add_argument("--repair-streams", type=int, default=0, help="sequence workload: runners of the repair pipeline (0 = half the chunks of a GPU, 2..16)")
     ap.add_argument("--repair-frames-per-step", type=int, default=4)
-    ap.add_argument("--seq-driver", choices=["cabi", "python"], default="cabi", help="sequence workload on ONE rank: cabi = the C++ driver behind sind_seq_* (csrc/host/seq.cpp; default), "
-                                                                                       "python = sindslam_amd/sequence.py VerifiedChunks (the same algorithm; what several ranks under torch.distributed run)")
+    ap.add_argument("--seq-driver", choices=["cabi", "python"], default="cabi", help="sequence workload: cabi = the C++ driver behind sind_seq_* (csrc/host/seq.cpp; default), "
+                                                                                       "python = sindslam_amd/sequence.py VerifiedChunks (the same algorithm over torch.distributed)")
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
     ap.add_argument("--exact-leg-frames", type=int, default=0, help="sequence workload: frames of the in-order re-run the chunked masks are compared with (0 = chunk 0, chunks 1-2 and what else fits into 320-480 frames)")
     ap.add_argument("--flow-slices", type=int, default=0, help="experiment: dense-flow slices of a step (sind_pipe_config.flow_slices; 0 = the library's rule by step size)")
@@ -539,13 +539,17 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     verify = n > 1 and not args.no_verify
     # ONE rank: the C++ driver behind sind_seq_* owns both pipelines and runs plan, steps, verification and repairs (csrc/host/seq.cpp); this function only feeds it the
     # device-resident batches and reads the step's masks in the step hook.  Several ranks (under torch.distributed, which also carries the mask gather): the Python twin.
-    use_cabi = args.seq_driver == "cabi" and world == 1 and parts == 1
-    job = vc = rp = None
+    use_cabi = args.seq_driver == "cabi" and parts == 1
+    job = vc = rp = net = None
     if use_cabi:
-        from sindslam_amd.seq import SeqJob
+        from sindslam_amd.seq import SeqJob, SeqNet
+        if world > 1:
+            # the driver's own exchange (32 bytes of fingerprints per chunk and round, a state blob per mismatching seam between ranks) runs over TCP between the ranks' hosts
+            # -- torch.distributed is left with what the bench contract asks of it: the per-step mask gather, the barrier and the reductions of the timing
+            net = SeqNet.tcp(rank, world, 20000 + (int(os.environ.get("MASTER_PORT", "29500")) * 7) % 20000, os.environ.get("MASTER_ADDR", "127.0.0.1") if os.environ.get("MASTER_ADDR", "127.0.0.1")[0].isdigit() else None)
         job = SeqJob(args.sequence_frames, S, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], intr["depth_factor"], 1500, 1.2, 8, intr["ini_th"], intr["min_th"],
                      orb_gray_rgb_order=cfg["rgb"], device=local, host_threads=args.host_threads, flow_max_levels=cfg["flow_max_levels"], steps=K, warmup=SW, repair_streams=R,
-                     repair_frames_per_step=Tr, retain_frames=args.retain_frames if verify else 0, verify=verify, flow_slices=cfg.get("flow_slices", 0), flow_opts_off=cfg.get("flow_opts_off", 0))
+                     repair_frames_per_step=Tr, retain_frames=args.retain_frames if verify else 0, verify=verify, flow_slices=cfg.get("flow_slices", 0), flow_opts_off=cfg.get("flow_opts_off", 0), net=net)
         assert job.T == T and job.steps == K and job.chunks.tolist() == [[c.first, c.last, c.start] for c in plan.chunks], "the C++ plan is the Python plan"
         pipe = job.pipeline_view()
     else:
@@ -642,7 +646,7 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
     def after_submit(i, seconds):
         acc.submit_wall += seconds; acc.add(pipe.stats(), True); step_wall.append(round(seconds * 1e3, 1))
     if use_cabi:
-        job.set_hooks(on_step=gather)
+        job.set_hooks(on_step=gather, on_round=lambda r_: on_round_cabi())
         for i in range(K):
             ts_ = time.perf_counter(); job.submit(i); after_submit(i, time.perf_counter() - ts_)
         tf_ = time.perf_counter(); job.flush(); flush_ms = (time.perf_counter() - tf_) * 1e3
@@ -678,13 +682,20 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
                     g, i = int(all_ids[r_][k_, 0]), int(all_ids[r_][k_, 1])
                     seq_masks[g // S, g % S, i // T, i % T].copy_(all_blk[r_][k_])
         fixes.clear()
+    def on_round_cabi():
+        # the frames the runners of this round re-ran (the sink's marks): their masks replace the speculative ones -- on this rank directly, on the others through on_round's exchange
+        for f in np.nonzero(fix_mark >= 0)[0]:
+            q = int(f) - 1; g = next(g_ for g_, c in enumerate(plan.chunks) if c.first <= q < c.last); i = q - plan.chunks[g].start
+            if world == 1:
+                seq_masks[0, g, i // T, i % T].copy_(torch.from_numpy(fix_dyna[f]))
+            else:
+                fixes.append((g, i, fix_dyna[f].copy()))
+            fix_mark[f] = -1
+        on_round()
     if use_cabi:
         job.verify(); vstats = job.stats()
         rf_ = args.retain_frames if args.retain_frames > 0 else max(1, plan.processed - SW)
         n_retained = len(range(SW // T, min(K, (SW + rf_ - 1) // T + 1))) if (verify and args.retain_frames != 0) else 0
-        for f in np.nonzero(fix_mark >= 0)[0]:            # the frames a runner re-ran: their masks replace the speculative ones
-            q = int(f) - 1; g = next(g_ for g_, c in enumerate(plan.chunks) if c.first <= q < c.last); i = q - plan.chunks[g].start
-            seq_masks[0, g, i // T, i % T].copy_(torch.from_numpy(fix_dyna[f]))
     else:
         vstats = vc.verify_and_repair(on_frame=on_frame, on_round=on_round) if rp is not None else dict(vc.stats); n_retained = len(vc.retained)
     torch.cuda.synchronize()
@@ -706,7 +717,7 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
             "verify": {"seams": vstats["seams"], "mismatched_seams": vstats["mismatched_seams"], "rounds": vstats["rounds"], "repaired_chunks": vstats["repaired_chunks"],
                        "repair_frames": vstats["repair_frames"], "repair_steps": vstats["repair_steps"], "runners_to_chunk_end": vstats["runners_to_chunk_end"],
                        "replay_frames": vstats["replay_frames"], "replay_calls": vstats["replay_calls"], "runners_past_replay": vstats["runners_past_replay"], "retained_steps": n_retained,
-                       "driver": "C++ (sind_seq_*, csrc/host/seq.cpp)" if use_cabi else "Python (sindslam_amd/sequence.py VerifiedChunks)",
+                       "driver": ("C++ (sind_seq_*, csrc/host/seq.cpp)" + ("; fingerprints and seam states between the ranks over TCP (sind_seq_net_tcp)" if world > 1 else "")) if use_cabi else "Python (sindslam_amd/sequence.py VerifiedChunks)",
                        "max_frames_to_converge": vstats["max_frames_to_converge"], "repair_seconds": vstats["repair_seconds"], "lockstep_seconds": t_main,
                        "repair_pipeline": f"{R} runners x {Tr} frames per step" if verify else None,
                        "note": "every chunk seam is verified by comparing 128-bit fingerprints of the inter-frame state (the chunk's rebuilt state vs the predecessor's true end state); "
@@ -721,6 +732,8 @@ def sequence_job(args, cfg, intr, base_b, base_d, rank, world, local, pg, comm_d
         cabi.close()
     if use_cabi:
         job.close()
+        if net is not None:
+            net.close()
     else:
         pipe.close()
         if rp is not None:

@@ -100,7 +100,7 @@ int sind_comm_sendrecv_u8(sind_comm* c, const uint8_t* send, int to, uint8_t* re
     HIP_TRY(sind_stream_wait(c->stream));
     return SIND_OK;
 }
-int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes);       // pipeline.cpp: S * T * H * W
+int sind_pipe_mask_bytes(sind_pipe* p, size_t* bytes);       // pipeline_capi.cpp: S * T * H * W
 // The step's dynamic masks ([S][T][H][W] u8, as sind_pipe_process / submit / flush wrote them to `dyna`) of every rank, in rank order
 int sind_pipe_gather_masks(sind_pipe* p, sind_comm* c, const uint8_t* dyna, uint8_t* all_dev, uint8_t* all_host) {
     size_t n = 0; SIND_TRY(sind_pipe_mask_bytes(p, &n));

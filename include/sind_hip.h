@@ -56,6 +56,9 @@ int sind_flow_set_coarse_chain(sind_flow* f, int on);
 /* per handle: on != 0 (default) solves a tiled level whose tiles all find a compute unit of their own (few images per launch: the launch is latency-bound) with 1024-thread
  * tiles and up to 13 iterations per launch on deeper halos (k_sor_tile); 0 = the 512-thread tiles / streaming kernel at every batch size.  Same bits either way. */
 int sind_flow_set_latency_tiles(sind_flow* f, int on);
+/* per handle: on != 0 (default) makes the transition between two pyramid levels -- W += dW, the bilinear up-sampling / 0.95 and the next level's warp, average and temporal
+ * difference -- one launch (k_level_up) instead of three; 0 = the three kernels (cross-check).  Same bits either way. */
+int sind_flow_set_level_up(sind_flow* f, int on);
 /* solver variant of THIS handle (every variant returns the same bits; nothing here is process-wide).  Fused register-resident SOR with 1x8 pixel strips: mode 4 = divisions
  * through a reciprocal formed on the fly (hardware estimate + one Newton step, then Markstein's correction; default: 5 iterations per launch on 64 x 64 tiles), 5 = the
  * streaming kernel on every level it fits, 0 = one launch per colour (cross-check); lab builds also: 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and
@@ -183,7 +186,7 @@ typedef struct sind_pipe_config {
     int host_threads;            /* 0 = library default (2 x the CPU share of the process) */
     int flow_max_levels;         /* 0 = the reference's full DeepFlow pyramid; n > 0: finest n levels only (see sind_flow_set_max_levels) */
     int flow_slices;             /* dense-flow slices of a step that run concurrently on their own streams: 0 = by step size (default), 1..4 fixed; same results */
-    int flow_opts_off;           /* A/B switches, same results: bit 0 = no k_coarse_chain (see sind_flow_set_coarse_chain), bit 1 = no k_sor_tile (see sind_flow_set_latency_tiles); 0 = defaults */
+    int flow_opts_off;           /* A/B switches, same results: bit 0 = no k_coarse_chain (see sind_flow_set_coarse_chain), bit 1 = no k_sor_tile (see sind_flow_set_latency_tiles), bit 2 = no k_level_up (see sind_flow_set_level_up); 0 = defaults */
 } sind_pipe_config;
 int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out);
 int sind_pipe_destroy(sind_pipe* p);

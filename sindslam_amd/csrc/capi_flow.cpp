@@ -16,6 +16,7 @@ extern "C" {
 
 int sind_flow_set_max_levels(sind_flow* f, int n) { if (!f || n < 0) return SIND_E_ARG; f->eng.max_levels = n; return SIND_OK; }
 int sind_flow_set_coarse_chain(sind_flow* f, int on) { if (!f) return SIND_E_ARG; f->eng.coarse_chain = on != 0; return SIND_OK; }
+int sind_flow_set_level_up(sind_flow* f, int on) { if (!f) return SIND_E_ARG; f->eng.level_up = on != 0; return SIND_OK; }
 int sind_flow_set_latency_tiles(sind_flow* f, int on) { if (!f) return SIND_E_ARG; f->eng.latency_tiles = on != 0; return SIND_OK; }
 int sind_device_count(int* count) { if (!count) return SIND_E_ARG; HIP_TRY(hipGetDeviceCount(count)); return SIND_OK; }
 

@@ -51,7 +51,8 @@ int debug_coef_math_scan(hipStream_t s, int exp_lo, int exp_hi, const float nume
 struct SolverCfg;
 int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total, float omega, long long* nlaunch, const SolverCfg& C, int* streamed = nullptr);
 #define FLOW_OPT_COARSE_CHAIN 1      /* levels of <= 4096 pixels: the whole level (all of them, in a pyramid) in one launch (flow_coarse.hip) */
-#define FLOW_OPT_LATENCY_TILES 2     /* tiled levels with a compute unit per tile (few images): 1024-thread tiles, up to 13 iterations per launch (k_sor_tile) */
+#define FLOW_OPT_LATENCY_TILES 2
+#define FLOW_OPT_LEVEL_UP 4          /* W += dW, the up-sampling and the next level's warp in one launch (k_level_up) instead of three */     /* tiled levels with a compute unit per tile (few images): 1024-thread tiles, up to 13 iterations per launch (k_sor_tile) */
 // Solver settings of ONE flow handle (every variant returns the same bits; sind_flow_set_sor_tiled / _solver_workgroups / _coef_kernel / _coarse_chain / _latency_tiles).
 struct SolverCfg {
     int mode = 4;              // fused register-resident SOR with 1x8 strips: 4 = divisions through a reciprocal formed on the fly (hardware estimate + Newton step, then Markstein's
@@ -66,9 +67,11 @@ struct SolverCfg {
     int stream_wg_cap = 0;     // k_sor_stream: at most this many (persistent) workgroups per launch (0 = one per item)
     int coef_kernel = 1;       // 1: k_coef_lanes (neighbours from lanes; short forms of sqrt and c / sqrt), 2: k_coef_lanes with the IEEE forms, 0: k_coef (neighbours from memory)
     double plan_cost = 14;     // prologue of a tile in iterations (sor_fuse_plan)
-    int opts = FLOW_OPT_COARSE_CHAIN | FLOW_OPT_LATENCY_TILES;
+    int opts = FLOW_OPT_COARSE_CHAIN | FLOW_OPT_LATENCY_TILES | FLOW_OPT_LEVEL_UP;
 };
-int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer, const SolverCfg& C);
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer, const SolverCfg& C,
+                 bool have_buffers = false, bool leave_increment = false);
+int launch_level_up(hipStream_t s, FlowPlanes& P, int sw, int sh, const float* I0_next, const float* I1_next, int dw, int dh, int B, float post);
 // flow_coarse.hip: the one-workgroup levels of a pyramid (or one such level) in one launch
 int coarse_level_P(int w, int h);
 int launch_sor_tile(hipStream_t s, FlowPlanes& P, int w, int h, int B, int iters, float omega);
@@ -106,7 +109,8 @@ public:
     int launch_ahead = 3;                        // pyramid levels the launching thread may be ahead of the GPU (0 = unbounded)
     SolverCfg solver;                            // this handle's solver settings
     bool latency_tiles = true;                   // tiled levels of few images: 1024-thread tiles and deep halos (k_sor_tile) where every tile has a compute unit to itself
-    const SolverCfg& opts() { solver.opts = (coarse_chain ? FLOW_OPT_COARSE_CHAIN : 0) | (latency_tiles ? FLOW_OPT_LATENCY_TILES : 0); return solver; }
+    bool level_up = true;                        // W += dW, up-sampling and the next level's warp in one launch (k_level_up); false: the three kernels (cross-check)
+    const SolverCfg& opts() { solver.opts = (coarse_chain ? FLOW_OPT_COARSE_CHAIN : 0) | (latency_tiles ? FLOW_OPT_LATENCY_TILES : 0) | (level_up ? FLOW_OPT_LEVEL_UP : 0); return solver; }
     bool coarse_chain = true;                    // the one-workgroup levels (<= ~8 k pixels) run in ONE launch (k_coarse_chain); false: per-stage kernels everywhere (cross-check, A/B timing)
     ~FlowEngine() { for (hipEvent_t e : level_done) (void)hipEventDestroy(e); }
 private:

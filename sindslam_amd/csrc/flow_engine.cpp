@@ -78,15 +78,21 @@ int FlowEngine::deepflow(const uint8_t* g0, const uint8_t* g1, int B, float* u, 
     // One level is ~36 launches.  A thread that enqueues the whole pyramid runs far ahead of the GPU, fills the queue and then SPINS inside
     // the launch call for the rest of the solve (measured: a slice thread burnt a full core, 215 ms per step); so the thread stays at
     // most `launch_ahead` levels ahead and sleeps on the level events instead.
+    bool have_buffers = false;
     for (int l = lc - 1; l >= 0; --l) {
         const int w = levels[l].first, h = levels[l].second;
         if (launch_ahead > 0 && l + launch_ahead < L) HIP_TRY(sind_event_wait(level_done[l + launch_ahead]));
-        SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V, &sor_timer, opts()));
+        const bool fuse_up = level_up && l > 0 && solver.mode != 0;
+        SIND_TRY(varref_level(stream, P, level_ptr(pyr0, l, B), level_ptr(pyr1, l, B), w, h, B, V, &sor_timer, opts(), have_buffers, fuse_up));
         HIP_TRY(hipEventRecord(level_done[l], stream));
+        have_buffers = false;
         if (l > 0) {
             const int nw = levels[l - 1].first, nh = levels[l - 1].second;
-            SIND_TRY(launch_resize_f32_pair(stream, P.Wu, P.tWu, P.Wv, P.tWv, w, h, nw, nh, B, inv_scale, true));
-            std::swap(P.Wu, P.tWu); std::swap(P.Wv, P.tWv);
+            if (fuse_up) { SIND_TRY(launch_level_up(stream, P, w, h, level_ptr(pyr0, l - 1, B), level_ptr(pyr1, l - 1, B), nw, nh, B, inv_scale)); have_buffers = true; }
+            else {
+                SIND_TRY(launch_resize_f32_pair(stream, P.Wu, P.tWu, P.Wv, P.tWv, w, h, nw, nh, B, inv_scale, true));
+                std::swap(P.Wu, P.tWu); std::swap(P.Wv, P.tWv);
+            }
         }
     }
     const size_t n = (size_t)fw * fh * B;

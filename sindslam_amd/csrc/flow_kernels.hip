@@ -995,6 +995,58 @@ int debug_ss_profile(unsigned long long* out, int reset) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------
+// Level transition of the DeepFlow loop in ONE launch instead of three (k_add_flow, k_resize_f32_pair, k_warp_avg_iz of the next level; deepflow.cpp: W += dW; resize(W) / 0.95;
+// prepareBuffers of the next level).  A thread makes LU_ROWS pixels of one column of the NEXT level: the up-sampled flow from the four taps of fl(W + dW) -- the very values
+// k_add_flow would have stored --, times `post`; then the warp of I1 by that flow, the averaged image and the temporal difference; and the next level's zero increment, which goes
+// to the ping-pong partner of dW (other threads still read this level's dW as taps).  Same float operations on the same values as the three kernels: same bits.
+#define LU_ROWS 4
+__global__ void k_level_up(const float* __restrict__ Wu, const float* __restrict__ Wv, const float* __restrict__ dWu, const float* __restrict__ dWv, int sw, int sh,
+                           const float* __restrict__ I0, const float* __restrict__ I1, float* __restrict__ nWu, float* __restrict__ nWv, float* __restrict__ ndWu, float* __restrict__ ndWv,
+                           float* __restrict__ avg, float* __restrict__ Iz, int dw, int dh, double scale_x, double scale_y, float post) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy0 = blockIdx.y * LU_ROWS, b = blockIdx.z;
+    if (dx >= dw) return;
+    const size_t sbase = (size_t)b * sw * sh, dbase = (size_t)b * dw * dh;
+    const float* SU = Wu + sbase; const float* SV = Wv + sbase; const float* DU = dWu + sbase; const float* DV = dWv + sbase;
+    const float* S1 = I1 + dbase;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = d_cvFloorf(fx); fx -= sx;
+    const bool two = sx + 1 < sw;            // dx < xmax in OpenCV's HResizeLinear
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    const float a1 = fx, a0 = 1.f - a1;
+    #pragma unroll
+    for (int r = 0; r < LU_ROWS; r++) {
+        const int dy = dy0 + r;
+        if (dy >= dh) break;
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = d_cvFloorf(fy); fy -= sy;
+        const int y0 = d_clip(sy, 0, sh), y1 = d_clip(sy + 1, 0, sh);
+        const float b1 = fy, b0 = 1.f - b1;
+        const int i00 = y0 * sw + sx, i10 = y1 * sw + sx;
+        float ru0, ru1, rv0, rv1;
+        if (two) {
+            ru0 = (SU[i00] + DU[i00]) * a0 + (SU[i00 + 1] + DU[i00 + 1]) * a1; ru1 = (SU[i10] + DU[i10]) * a0 + (SU[i10 + 1] + DU[i10 + 1]) * a1;
+            rv0 = (SV[i00] + DV[i00]) * a0 + (SV[i00 + 1] + DV[i00 + 1]) * a1; rv1 = (SV[i10] + DV[i10]) * a0 + (SV[i10 + 1] + DV[i10 + 1]) * a1;
+        } else {
+            ru0 = (SU[i00] + DU[i00]) * 1.f; ru1 = (SU[i10] + DU[i10]) * 1.f; rv0 = (SV[i00] + DV[i00]) * 1.f; rv1 = (SV[i10] + DV[i10]) * 1.f;
+        }
+        float vu = ru0 * b0 + ru1 * b1, vv = rv0 * b0 + rv1 * b1;
+        vu = vu * post; vv = vv * post;
+        const size_t o = dbase + (size_t)dy * dw + dx;
+        nWu[o] = vu; nWv[o] = vv; ndWu[o] = 0.f; ndWv[o] = 0.f;
+        warp_px(S1, I0[o], vu, vv, dx, dy, dw, dh, avg[o], Iz[o]);
+    }
+}
+// after the call the planes of P describe the next level: W = the up-sampled flow, dW = 0, avg / Iz = its warped buffers
+int launch_level_up(hipStream_t s, FlowPlanes& P, int sw, int sh, const float* I0, const float* I1, int dw, int dh, int B, float post) {
+    hipLaunchKernelGGL(k_level_up, dim3(divup(dw, 128), divup(dh, LU_ROWS), B), dim3(128), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, sw, sh, I0, I1, P.tWu, P.tWv, P.dWu2, P.dWv2, P.avg, P.Iz, dw, dh,
+                       1. / ((double)dw / sw), 1. / ((double)dh / sh), post);
+    HIP_TRY(hipGetLastError());
+    std::swap(P.Wu, P.tWu); std::swap(P.Wv, P.tWv); std::swap(P.dWu, P.dWu2); std::swap(P.dWv, P.dWv2);
+    return SIND_OK;
+}
+
 // four elements per thread (16-byte accesses; `n4` whole quads, the n % 4 elements behind them by the last threads)
 __global__ void k_add_flow(const float* Wu, const float* Wv, const float* __restrict__ dWu,
                            const float* __restrict__ dWv, float* tWu, float* tWv, size_t n) {
@@ -1604,7 +1656,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
 }
 
 // VariationalRefinement::calcUV on one pyramid level for B pairs.  Wu/Wv: initial flow in, refined flow out.
-int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer, const SolverCfg& C) {
+int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1, int w, int h, int B, const VarParams& V, SorTimer* timer, const SolverCfg& C, bool have_buffers, bool leave_increment) {
     const bool coarse_chain = (C.opts & FLOW_OPT_COARSE_CHAIN) != 0;
     if (coarse_chain && V.epsilon >= 1e-12f && C.mode != 0 && coarse_level_P(w, h)) {       // one workgroup's work: the whole level in one launch (flow_coarse.hip)
         const std::vector<std::pair<int, int>> lv{{w, h}}; const std::vector<size_t> off{0};
@@ -1612,7 +1664,8 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     }
     const size_t n = (size_t)w * h * B;
     const dim3 blk(128);
-    hipLaunchKernelGGL(k_warp_avg_iz, grid2d(w, divup(h, WARP_ROWS), B), blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, P.dWu, P.dWv, w, h);
+    // have_buffers: the level transition (k_level_up) has left avg / Iz and a zero increment already; leave_increment: W += dW is the next transition's business
+    if (!have_buffers) hipLaunchKernelGGL(k_warp_avg_iz, grid2d(w, divup(h, WARP_ROWS), B), blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, P.dWu, P.dWv, w, h);
     for (int it = 0; it < V.fixedPointIterations; it++) {
         if (C.coef_kernel)
             hipLaunchKernelGGL(k_coef_lanes, dim3(divup(w, KL_COLS), divup(h, 4 * KL_ROWS), B), dim3(256), 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
@@ -1626,6 +1679,7 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
         // algorithmic bytes: 44 B per pixel per red+black iteration (9 reads + 2 writes of f32), SURVEY.md §8d
         if (timer) timer->end(s, nlaunch, 44.0 * (double)w * h * B * V.sorIterations, streamed ? 0 : 1);
     }
+    if (leave_increment) { HIP_TRY(hipGetLastError()); return SIND_OK; }
     if ((((uintptr_t)P.Wu | (uintptr_t)P.Wv | (uintptr_t)P.dWu | (uintptr_t)P.dWv) & 15) == 0)
         hipLaunchKernelGGL(k_add_flow, dim3((unsigned)(((n >> 2) + (n & 3) + 255) / 256)), dim3(256), 0, s, P.Wu, P.Wv, P.dWu, P.dWv, P.Wu, P.Wv, n);      // W = W + dW, in place
     else

@@ -38,6 +38,10 @@ class FlowStage:
         """the one-workgroup pyramid levels in one launch (default) or through the per-stage kernels (cross-check); same bits"""
         check(lib().sind_flow_set_coarse_chain(self._h, 1 if on else 0), "sind_flow_set_coarse_chain")
 
+    def set_level_up(self, on: bool):
+        """level transition (W += dW, up-sampling, next level's warp) in one launch (default) or three (cross-check); same bits"""
+        check(lib().sind_flow_set_level_up(self._h, 1 if on else 0), "sind_flow_set_level_up")
+
     def set_latency_tiles(self, on: bool):
         """tiled levels of few images through the 1024-thread tiles with deep halos (default) or the throughput kernels (cross-check); same bits"""
         check(lib().sind_flow_set_latency_tiles(self._h, 1 if on else 0), "sind_flow_set_latency_tiles")

@@ -98,10 +98,10 @@ def test_deepflow_384x288_chain_equals_per_stage_and_oracle(fs, frames):
     fs.set_coarse_chain(True); fs.set_latency_tiles(True)
     u, v = fs.deepflow(i0, i1)
     try:
-        fs.set_coarse_chain(False); fs.set_latency_tiles(False)
+        fs.set_coarse_chain(False); fs.set_latency_tiles(False); fs.set_level_up(False)
         su, sv = fs.deepflow(i0, i1)
     finally:
-        fs.set_coarse_chain(True); fs.set_latency_tiles(True)
+        fs.set_coarse_chain(True); fs.set_latency_tiles(True); fs.set_level_up(True)
     assert np.array_equal(u.view(np.uint32), su.view(np.uint32)) and np.array_equal(v.view(np.uint32), sv.view(np.uint32))
     o = O.deepflow(g0, g1)
     assert np.array_equal(u[0].view(np.uint32), o[..., 0].view(np.uint32)) and np.array_equal(v[0].view(np.uint32), o[..., 1].view(np.uint32))
@@ -116,7 +116,7 @@ def test_deepflow_768x432_chain_equals_per_stage():
         a = _textured_pair(768, 432, 21); b = _textured_pair(768, 432, 22)
         i0 = np.stack([a[0], b[0]]).astype(np.uint8); i1 = np.stack([a[1], b[1]]).astype(np.uint8)
         u, v = f.deepflow(i0, i1)
-        f.set_coarse_chain(False); f.set_latency_tiles(False)
+        f.set_coarse_chain(False); f.set_latency_tiles(False); f.set_level_up(False)
         su, sv = f.deepflow(i0, i1)
         assert np.array_equal(u.view(np.uint32), su.view(np.uint32)) and np.array_equal(v.view(np.uint32), sv.view(np.uint32))
     finally:

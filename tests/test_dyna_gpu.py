@@ -81,3 +81,24 @@ def test_bit_plane_dilation_equals_oracle_morphology(w, n):
     for p in range(planes):
         assert np.array_equal(got[p] * 255, O.morph(imgs[p], n, "dilate")), (p, w, n)
     assert not np.unpackbits(out.view(np.uint8).reshape(planes, h, wpr * 8), axis=-1, bitorder="little")[:, :, w:].any()      # tail bits stay clear
+
+
+def test_overlapped_lean_path_equals_the_serial_debug_path(frames):
+    """the drop-in's default path (depth half of a frame beside its dense flow on a second stream and host thread, no debug copies, the large-motion candidate riding along as a
+    batch of two) returns what the serial path with every debug copy returns -- over frames that do and do not take the large-motion pass -- and reports its stage times"""
+    from sindslam_amd.dyna import DynaDetect
+    from sindslam_amd.synth import SyntheticStream
+    K = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["depth_factor"])
+    flagged = calm = 0
+    for bgr, depth in (SyntheticStream(seed=31, motion_scale=4.0).frames(0, 6), frames):          # fast motion: every frame takes the second pass; the fixture's stream: none does
+        a = DynaDetect(bgr[1], bgr[0], *K, debug=False, overlap=True); b = DynaDetect(bgr[1], bgr[0], *K, debug=True, overlap=False)
+        for t in range(2, 6):
+            da, la = a.DetectDynaArea(bgr[t], depth[t], t); db, lb = b.DetectDynaArea(bgr[t], depth[t], t)
+            assert np.array_equal(da, db) and np.array_equal(la, lb), t
+            flagged += int(b.debug()["info"][0]); calm += int(not b.debug()["info"][0])
+        st = a.timing(); b.close()
+        if (bgr is not frames[0]): a.close()
+    assert flagged >= 1 and calm >= 1
+    assert st["calls"] == 4 and st["total"] > 0 and st["dense_flow"] > 0 and st["depth_half"] > 0 and abs(st["total"] - (st["upload"] + st["dense_flow"] + st["wait_depth_half"] + st["flow_masks_and_fusion"])) < 0.05 * st["total"] + 0.05
+    print("large-motion frames:", flagged, "others:", calm, st)
+    a.close()

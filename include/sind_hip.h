@@ -117,7 +117,8 @@ typedef struct sind_dyna sind_dyna;
 int sind_dyna_create(int width, int height, float fx, float fy, float cx, float cy, float depth_scale, int device, sind_dyna** out);
 int sind_dyna_destroy(sind_dyna* d);
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n);      /* see sind_flow_set_max_levels */
-int sind_dyna_timing(sind_dyna* d, double ms6[6], int reset);   /* mean ms per detect call: upload, dense flow, wait for the depth half, flow masks + fusion, depth half, whole call; returns calls */
+int sind_dyna_timing(sind_dyna* d, double ms12[12], int reset); /* mean ms per detect call: upload, dense flow, wait for the depth half, flow masks + fusion, depth half, whole call;
+                                                                    then the tail's stages: flow masks, k-means, label preparation, CalOccluded, SegAndMerge, fusion; returns calls */
 int sind_dyna_set_debug(sind_dyna* d, int on);               /* on: keep the intermediate images sind_dyna_debug reports (costs four flow-sized copies per frame); default off */
 int sind_dyna_set_overlap(sind_dyna* d, int on);             /* default on: the depth half of a frame (k-means, CalOccluded, SegAndMerge) runs beside its dense flow, as the reference's
                                                                  flow thread runs beside the segmentation (DynaDetect.cc:1396-1398); 0 = one after the other; same results */

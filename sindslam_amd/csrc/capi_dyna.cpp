@@ -62,13 +62,15 @@ int sind_debug_set_kmeans_fused_min_batch(int b) { if (b < 1) return SIND_E_ARG;
 int sind_dyna_set_debug(sind_dyna* d, int on) { if (!d) return SIND_E_ARG; d->debug = on != 0; d->tail.keep_debug = d->debug; return SIND_OK; }
 // overlap != 0 (default): the depth half of a frame runs beside its dense flow (own stream, own host thread); 0 = one after the other.  Same results.
 int sind_dyna_set_overlap(sind_dyna* d, int on) { if (!d) return SIND_E_ARG; d->overlap = on != 0; return SIND_OK; }
-// mean milliseconds per sind_dyna_detect call since the last reset: upload, dense flow (calling thread), wait for the depth half after the flow, flow masks + fusion,
-// depth half (its own thread when overlapped), whole call; returns the number of calls averaged
-int sind_dyna_timing(sind_dyna* d, double ms6[6], int reset) {
-    if (!d || !ms6) return SIND_E_ARG;
-    for (int i = 0; i < 6; i++) ms6[i] = d->n_timed ? d->t_ms[i] / d->n_timed : 0.0;
+// mean milliseconds per sind_dyna_detect call since the last reset: [0..5] upload, dense flow (calling thread), wait for the depth half after the flow, flow masks + fusion,
+// depth half (its own thread when overlapped), whole call; [6..11] the tail's stages: flow masks, k-means, label preparation, CalOccluded, SegAndMerge, fusion.
+// Returns the number of calls averaged
+int sind_dyna_timing(sind_dyna* d, double ms12[12], int reset) {
+    if (!d || !ms12) return SIND_E_ARG;
+    for (int i = 0; i < 6; i++) ms12[i] = d->n_timed ? d->t_ms[i] / d->n_timed : 0.0;
+    for (int i = 0; i < 6; i++) ms12[6 + i] = d->n_timed ? d->tail.t_stage[i] / d->n_timed : 0.0;
     const int n = (int)d->n_timed;
-    if (reset) { for (double& v : d->t_ms) v = 0; d->n_timed = 0; }
+    if (reset) { for (double& v : d->t_ms) v = 0; for (double& v : d->tail.t_stage) v = 0; d->n_timed = 0; }
     return n;
 }
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n) { if (!d || n < 0) return SIND_E_ARG; d->front.flow.max_levels = n; return SIND_OK; }

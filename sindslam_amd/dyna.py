@@ -29,8 +29,9 @@ class DynaDetect:
 
     def timing(self, reset: bool = True):
         """mean milliseconds per DetectDynaArea call since the last reset, by stage"""
-        ms = (C.c_double * 6)(); n = check(lib().sind_dyna_timing(self._h, ms, 1 if reset else 0), "sind_dyna_timing")
-        return dict(calls=n, upload=ms[0], dense_flow=ms[1], wait_depth_half=ms[2], flow_masks_and_fusion=ms[3], depth_half=ms[4], total=ms[5])
+        ms = (C.c_double * 12)(); n = check(lib().sind_dyna_timing(self._h, ms, 1 if reset else 0), "sind_dyna_timing")
+        return dict(calls=n, upload=ms[0], dense_flow=ms[1], wait_depth_half=ms[2], flow_masks_and_fusion=ms[3], depth_half=ms[4], total=ms[5],
+                    tail_stages=dict(flow_masks=ms[6], kmeans=ms[7], labels=ms[8], cal_occluded=ms[9], seg_and_merge=ms[10], fusion=ms[11]))
 
     def close(self):
         if getattr(self, "_h", None):

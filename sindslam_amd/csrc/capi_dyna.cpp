@@ -5,7 +5,8 @@
 #include "peac_grow.hpp"
 
 struct sind_dyna {
-    sind::DynaConfig cfg; hipStream_t stream = nullptr, tail_stream = nullptr; hipEvent_t flow_done = nullptr; sind::DynaFront front; sind::DynaTail tail;
+    sind::DynaConfig cfg; hipStream_t stream = nullptr, tail_stream = nullptr, km_stream = nullptr; hipEvent_t flow_done = nullptr, depth_up = nullptr; sind::DynaFront front; sind::DynaTail tail;
+    sind::KMeansBatch kmb;       // the frame's k-means on its own stream beside CalOccluded (both need the depth frame only)
     DevBuf<uint8_t> bgr, gray, pool, dil_a, dil_b; DevBuf<uint16_t> depth; DevBuf<float> U, V;
     PinnedBuf<uint16_t> depth_h; PinnedBuf<uint8_t> bgr_h, dil_h;       // page-locked staging of the caller's frames (a copy from pageable memory is staged by the runtime and blocks the call)
     int t = 0; bool primed = false; int largeMotion = 0; bool debug = false, overlap = true;
@@ -31,6 +32,8 @@ int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float
     int r = d->front.init(d->cfg, 2, d->stream);       // (2: the candidate of the large-motion pass rides along with every frame, see DynaFront::speculate)
     d->front.speculate = true;
     if (r == SIND_OK) r = d->tail.init(d->cfg, d->tail_stream);
+    if (r == SIND_OK && (hipStreamCreateWithFlags(&d->km_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->depth_up, hipEventDisableTiming) != hipSuccess)) { sind_set_error("sind_dyna_create: hipStreamCreate failed"); r = SIND_E_HIP; }
+    if (r == SIND_OK) r = d->kmb.init(d->cfg, 1, d->km_stream);
     if (r == SIND_OK) r = d->depth_h.alloc((size_t)w * h);
     if (r == SIND_OK) r = d->bgr_h.alloc((size_t)w * h * 3);
     if (r == SIND_OK) r = d->dil_h.alloc((size_t)w * h);
@@ -43,7 +46,7 @@ int sind_dyna_create(int w, int h, float fx, float fy, float cx, float cy, float
     if (r == SIND_OK) r = d->V.alloc(np);
     if (r == SIND_OK) r = d->dil_a.alloc(np);
     if (r == SIND_OK) r = d->dil_b.alloc(np);
-    if (r != SIND_OK) { hipStream_t st = d->stream, ts = d->tail_stream; hipEvent_t ev = d->flow_done; delete d; (void)hipStreamDestroy(st); (void)hipStreamDestroy(ts); (void)hipEventDestroy(ev); return r; }
+    if (r != SIND_OK) { hipStream_t st = d->stream, ts = d->tail_stream, ks = d->km_stream; hipEvent_t ev = d->flow_done, e2 = d->depth_up; delete d; (void)hipStreamDestroy(st); (void)hipStreamDestroy(ts); if (ks) (void)hipStreamDestroy(ks); (void)hipEventDestroy(ev); if (e2) (void)hipEventDestroy(e2); return r; }
     d->tail.keep_debug = false; d->tail.piece_threads = 4;      // (one camera per handle: the host cores are idle while a frame is in flight)
     *out = d; return SIND_OK;
 }
@@ -77,10 +80,11 @@ int sind_dyna_set_flow_max_levels(sind_dyna* d, int n) { if (!d || n < 0) return
 int sind_dyna_destroy(sind_dyna* d) {
     if (!d) return SIND_OK;
     (void)hipSetDevice(d->cfg.device);
-    hipStream_t s = d->stream, ts = d->tail_stream; hipEvent_t ev = d->flow_done;
+    hipStream_t s = d->stream, ts = d->tail_stream, ks = d->km_stream; hipEvent_t ev = d->flow_done, e2 = d->depth_up;
     if (s) (void)hipStreamSynchronize(s);
     if (ts) (void)hipStreamSynchronize(ts);
-    delete d; if (s) (void)hipStreamDestroy(s); if (ts) (void)hipStreamDestroy(ts); if (ev) (void)hipEventDestroy(ev);
+    if (ks) (void)hipStreamSynchronize(ks);
+    delete d; if (s) (void)hipStreamDestroy(s); if (ts) (void)hipStreamDestroy(ts); if (ks) (void)hipStreamDestroy(ks); if (ev) (void)hipEventDestroy(ev); if (e2) (void)hipEventDestroy(e2);
     return SIND_OK;
 }
 static int upload_bgr(sind_dyna* d, const uint8_t* bgr, int stride, int slot) {
@@ -115,13 +119,25 @@ int sind_dyna_detect(sind_dyna* d, const uint8_t* bgr, int bstride, const uint16
     uint16_t* dh = d->depth_h.p;
     for (int y = 0; y < h; y++) std::memcpy(dh + (size_t)y * w, (const uint8_t*)depth + (size_t)y * dstride, (size_t)w * 2);
     HIP_TRY(hipMemcpyAsync(d->depth.p, dh, (size_t)w * h * 2, hipMemcpyHostToDevice, d->tail_stream));      // the depth frame is the tail's input only
+    HIP_TRY(hipEventRecord(d->depth_up, d->tail_stream)); HIP_TRY(hipStreamWaitEvent(d->km_stream, d->depth_up, 0));
     const size_t nf = (size_t)d->front.fw * d->front.fh;
     float *du = nullptr, *dv = nullptr, *ru = nullptr, *rv = nullptr;
     if (d->debug) { d->deep.resize(nf * 2); d->refined.resize(nf * 2); du = d->deep.data(); dv = du + nf; ru = d->refined.data(); rv = ru + nf; }
     sind::DepthStageOut dso; int rc_depth = SIND_OK; std::string err_depth;
     std::thread side;
     const double t1 = now_ms();
-    if (d->overlap) side = std::thread([&] { SpinScope sp; const double a = now_ms(); rc_depth = d->tail.depth_stage(dh, d->depth.p, nullptr, dso, nullptr); t_depth = now_ms() - a; if (rc_depth != SIND_OK) err_depth = sind_last_error(); });
+    // the depth half: CalOccluded (GPU edges + PEAC: ~7 ms of a frame's ~10) on this thread and the tail's stream, the k-means (~1.7 ms) beside it on a third thread and stream
+    // -- neither needs the other (DynaDetect.cc:1410 / :1497) --, then the label preparation and SegAndMerge, which need both
+    if (d->overlap) side = std::thread([&] {
+        SpinScope sp; const double a = now_ms(); (void)hipSetDevice(d->cfg.device);
+        int rc_km = SIND_OK; std::string err_km;
+        std::thread kmt([&] { SpinScope s2; (void)hipSetDevice(d->cfg.device); const uint8_t* prev = d->tail.prev_km_labels(); rc_km = d->kmb.run(d->depth.p, (size_t)w * h, 1, &prev); if (rc_km != SIND_OK) err_km = sind_last_error(); });
+        sind::OccResult occ; rc_depth = d->tail.compute_occluded(dh, d->depth.p, occ, nullptr);
+        if (rc_depth != SIND_OK) err_depth = sind_last_error();
+        kmt.join();
+        if (rc_depth == SIND_OK && rc_km != SIND_OK) { rc_depth = rc_km; err_depth = err_km; }
+        if (rc_depth == SIND_OK) { rc_depth = d->tail.depth_stage(dh, d->depth.p, &occ, dso, &d->kmb.result(0)); if (rc_depth != SIND_OK) err_depth = sind_last_error(); }
+        t_depth = now_ms() - a; });
     const int rc_flow = d->front.dense_flow(d->pool.p, &cur, &p1, &p2, 1, d->U.p, d->V.p, &d->largeMotion, du, dv, ru, rv);
     const double t2 = now_ms();
     if (side.joinable()) side.join();

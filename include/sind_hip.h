@@ -61,7 +61,7 @@ int sind_flow_set_latency_tiles(sind_flow* f, int on);
 int sind_flow_set_level_up(sind_flow* f, int on);
 /* solver variant of THIS handle (every variant returns the same bits; nothing here is process-wide).  Fused register-resident SOR with 1x8 pixel strips: mode 4 = divisions
  * through a reciprocal formed on the fly (hardware estimate + one Newton step, then Markstein's correction; default: 5 iterations per launch on 64 x 64 tiles), 5 = the
- * streaming kernel on every level it fits, 0 = one launch per colour (cross-check); lab builds also: 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and
+ * streaming kernel on every level it fits, 6 = the one-wave pipeline on every level beyond one workgroup, 0 = one launch per colour (cross-check); lab builds also: 1 = IEEE division, 3 = reciprocals of A11 / A22 read from planes and
  * held in registers (three waves per SIMD; tiles of 256, 384 and 768 threads), 2 = 1x4 strips + reciprocal division.  fuse = iterations per launch on tiled levels
  * (default 5), 0 = a plan per level (lab builds); tile_w x tile_h = extended tile (tile_w * tile_h / 8 threads).  sind_flow_set_sor keeps the round-1 argument list
  * (tile height 48 for mode 3, 64 otherwise). */
@@ -70,6 +70,10 @@ int sind_flow_set_sor_tiled(sind_flow* f, int mode, int fuse, int tile_w, int ti
 /* streaming solver: at most `cap` workgroups per launch, each taking several (column strip, image) items in turn (persistent workgroups); 0 = one workgroup per item.
  * Same results.  See DESIGN.md 3.1-12 for when it pays. */
 int sind_flow_set_solver_workgroups(sind_flow* f, int cap);
+/* one-wave row pipelines (k_sor_wave, flow_wave.hip) for the levels and batch sizes that would otherwise go to the streaming kernel: on != 0 (default) / 0 = k_sor_stream;
+ * target_items = waves a launch should have (row bands are cut until it does; 0 keeps the default), bands > 0 = exactly that many row bands (tests).  Mode 6 of
+ * sind_flow_set_sor_tiled runs the kernel on every level beyond one workgroup at any batch size.  Same bits either way. */
+int sind_flow_set_wave_solver(sind_flow* f, int on, int target_items, int bands);
 /* coefficient kernel: 1 = k_coef_lanes (neighbours from lanes, short correctly rounded sqrt / quotient forms; default), 2 = k_coef_lanes with the compiler's IEEE forms,
  * 0 = k_coef (neighbours from memory).  Same results. */
 int sind_flow_set_coef_kernel(sind_flow* f, int variant);
@@ -187,7 +191,7 @@ typedef struct sind_pipe_config {
     int host_threads;            /* 0 = library default (2 x the CPU share of the process) */
     int flow_max_levels;         /* 0 = the reference's full DeepFlow pyramid; n > 0: finest n levels only (see sind_flow_set_max_levels) */
     int flow_slices;             /* dense-flow slices of a step that run concurrently on their own streams: 0 = by step size (default), 1..4 fixed; same results */
-    int flow_opts_off;           /* A/B switches, same results: bit 0 = no k_coarse_chain (see sind_flow_set_coarse_chain), bit 1 = no k_sor_tile (see sind_flow_set_latency_tiles), bit 2 = no k_level_up (see sind_flow_set_level_up); 0 = defaults */
+    int flow_opts_off;           /* A/B switches, same results: bit 0 = no k_coarse_chain (see sind_flow_set_coarse_chain), bit 1 = no k_sor_tile (see sind_flow_set_latency_tiles), bit 2 = no k_level_up (see sind_flow_set_level_up), bit 3 = k_sor_stream instead of k_sor_wave (see sind_flow_set_wave_solver), bits 8.. = that call's target_items; 0 = defaults */
 } sind_pipe_config;
 int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out);
 int sind_pipe_destroy(sind_pipe* p);

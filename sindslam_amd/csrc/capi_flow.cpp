@@ -144,18 +144,23 @@ int sind_debug_flow_thresholds(const int* hist, int n, int width, int height, in
 int sind_flow_set_sor_tiled(sind_flow* f, int mode, int fuse, int tile_w, int tile_h) {
     if (!f) { sind_set_error("sind_flow_set_sor_tiled: null handle"); return SIND_E_ARG; }
     const int nt = tile_w * tile_h / 8;
-    if (mode < 0 || mode > 5 || fuse < 0 || fuse > 12 || tile_w < 16 || tile_w % 8 || tile_h < 8 || tile_h % 2 || nt % 128 || nt > 1024 || 4 * fuse >= tile_w || 4 * fuse >= tile_h ||
+    if (mode < 0 || mode > 6 || fuse < 0 || fuse > 12 || tile_w < 16 || tile_w % 8 || tile_h < 8 || tile_h % 2 || nt % 128 || nt > 1024 || 4 * fuse >= tile_w || 4 * fuse >= tile_h ||
         (mode == 3 && nt != 256 && nt != 384 && nt != 768)) {
         sind_set_error("sind_flow_set_sor_tiled: bad arguments (mode %d, fuse %d, tile %d x %d)", mode, fuse, tile_w, tile_h); return SIND_E_ARG;
     }
 #ifndef SIND_LAB
     // the shipped library carries the per-colour reference (0), the tiled kernel with the reciprocal formed on the fly (4, fixed fuse depth) and the streaming
     // kernel (5); IEEE-division, reciprocal-plane and 1 x 4-strip variants and the per-level fuse plans are lab builds (make -C sindslam_amd/csrc lab)
-    if ((mode != 0 && mode != 4 && mode != 5) || fuse == 0) { sind_set_error("sind_flow_set_sor_tiled: solver variant (mode %d, fuse %d) exists in lab builds only", mode, fuse); return SIND_E_ARG; }
+    if ((mode != 0 && mode != 4 && mode != 5 && mode != 6) || fuse == 0) { sind_set_error("sind_flow_set_sor_tiled: solver variant (mode %d, fuse %d) exists in lab builds only", mode, fuse); return SIND_E_ARG; }
 #endif
     sind::SolverCfg& C = f->eng.solver; C.mode = mode; C.fuse = fuse; C.tile_w = tile_w; C.tile_h = tile_h; return SIND_OK;
 }
 int sind_flow_set_solver_workgroups(sind_flow* f, int cap) { if (!f || cap < 0) return SIND_E_ARG; f->eng.solver.stream_wg_cap = cap; return SIND_OK; }
+int sind_flow_set_wave_solver(sind_flow* f, int on, int target_items, int bands) {
+    if (!f || target_items < 0 || bands < 0) return SIND_E_ARG;
+    if (on > 1) f->eng.solver.wave_prefetch = std::min(on - 1, 3);       // (experiment: on = 2 / 3 / 4 selects 1 / 2 / 3 rows in flight)
+    f->eng.solver.wave = on ? 1 : 0; f->eng.solver.wave_items = target_items > 0 ? target_items : sind::SolverCfg().wave_items; f->eng.solver.wave_bands = bands; return SIND_OK;
+}
 int sind_flow_set_coef_kernel(sind_flow* f, int variant) { if (!f || variant < 0 || variant > 2) return SIND_E_ARG; f->eng.solver.coef_kernel = variant; return SIND_OK; }
 int sind_flow_set_sor(sind_flow* f, int mode, int fuse, int tile_w) {
     if (tile_w != 64 && tile_w != 128) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }

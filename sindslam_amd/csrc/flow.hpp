@@ -56,7 +56,7 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
 // Solver settings of ONE flow handle (every variant returns the same bits; sind_flow_set_sor_tiled / _solver_workgroups / _coef_kernel / _coarse_chain / _latency_tiles).
 struct SolverCfg {
     int mode = 4;              // fused register-resident SOR with 1x8 strips: 4 = divisions through a reciprocal formed on the fly (hardware estimate + Newton step, then Markstein's
-                               // correction; default), 5 = the streaming kernel on every level it fits, 0 = one launch per colour (cross-check); lab builds: 1 = IEEE division, 3 = reciprocal
+                               // correction; default), 5 = the streaming kernel on every level it fits, 6 = the one-wave pipeline (k_sor_wave) on every level beyond one workgroup, 0 = one launch per colour (cross-check); lab builds: 1 = IEEE division, 3 = reciprocal
                                // planes held in registers (three waves per SIMD), 2 = 1x4 strips + reciprocal division
     int fuse = 5;              // iterations per launch on the tiled levels; 0 = per-level plan (sor_fuse_plan: measured 1-2 % faster, 10 % more launches; lab builds)
     int tile_w = 64, tile_h = 64;      // extended tile (multiple of 8 wide, even height, tile_w * tile_h / 8 threads)
@@ -65,6 +65,11 @@ struct SolverCfg {
                                // (profiles/r05/stream_min_batch.txt: 48 images per launch 907 pairs/s streamed vs 1093-1110 tiled; 112 images 1356 vs 1237; 170 images 1514 vs 1296)
     int stream_min_px = 0;     // ... and only for levels of at least this many pixels
     int stream_wg_cap = 0;     // k_sor_stream: at most this many (persistent) workgroups per launch (0 = one per item)
+    int wave = 1;              // mode 4: levels that would go to the streaming kernel go to the one-wave pipeline instead (k_sor_wave, flow_wave.hip); 0 = k_sor_stream (cross-check, A/B timing)
+    int wave_items = 1024;     // k_sor_wave: row bands are cut while a launch has fewer waves than this (2048 fill the chip; every cut recomputes 20 rows, and the slices of a step run side by side:
+                               // headline step 1571-1607 pairs/s at 1024, 1522-1578 at 680, 1534-1542 at 2048, profiles/r05/ab_wave_bench.txt)
+    int wave_bands = 0;        // > 0: exactly this many row bands (tests)
+    int wave_prefetch = 2;     // k_sor_wave: steps between a row's request and its take-over (1 .. 3; 16 registers per row in flight)
     int coef_kernel = 1;       // 1: k_coef_lanes (neighbours from lanes; short forms of sqrt and c / sqrt), 2: k_coef_lanes with the IEEE forms, 0: k_coef (neighbours from memory)
     double plan_cost = 14;     // prologue of a tile in iterations (sor_fuse_plan)
     int opts = FLOW_OPT_COARSE_CHAIN | FLOW_OPT_LATENCY_TILES | FLOW_OPT_LEVEL_UP;
@@ -75,6 +80,9 @@ int launch_level_up(hipStream_t s, FlowPlanes& P, int sw, int sh, const float* I
 // flow_coarse.hip: the one-workgroup levels of a pyramid (or one such level) in one launch
 int coarse_level_P(int w, int h);
 int launch_sor_tile(hipStream_t s, FlowPlanes& P, int w, int h, int B, int iters, float omega);
+// flow_wave.hip: 5 iterations of a level as one-wave row pipelines (column strips x row bands x images); the result is in P.dWu / P.dWv (swapped with their partners)
+int launch_sor_wave(hipStream_t s, FlowPlanes& P, int w, int h, int B, float omega, int target_items, int force_bands, int prefetch);
+void sor_wave_layout(int w, int h, int B, int target_items, int force_bands, int* strips, int* IW, int* bands, int* BH);
 int sor_tile_count(int w, int h, int iters);
 int launch_coarse_chain(hipStream_t s, FlowPlanes& Pl, const float* pyr0, const float* pyr1, const std::vector<std::pair<int, int>>& levels, const std::vector<size_t>& level_off,
                         int first, int last, int B, const VarParams& V, bool init_zero, bool upsample_last, float post, float* out_u, float* out_v);

@@ -1590,7 +1590,13 @@ int sor_iterations(hipStream_t s, FlowPlanes& P, int w, int h, int B, int total,
                            P.r11, P.r22, P.dWu, P.dWv, P.dWu, P.dWv);
         *nlaunch += 1; return SIND_OK;
     }
-    // large levels, enough images to fill the GPU with one workgroup each: the streaming kernel (no halo, loads and stores overlapped with the iterations)
+    // large levels, many images: one-wave row pipelines (flow_wave.hip) -- no workgroup barrier anywhere
+    if (total % 5 == 0 && (C.mode == 6 || (C.mode == 4 && C.wave && B >= C.stream_min_b && w * h >= C.stream_min_px))) {
+        for (int done = 0; done < total; done += 5) { SIND_TRY(launch_sor_wave(s, P, w, h, B, omega, C.wave_items, C.wave_bands, C.wave_prefetch)); *nlaunch += 1; }
+        if (streamed) *streamed = 1;
+        return SIND_OK;
+    }
+    // ... or the streaming kernel (one workgroup per image and column strip; no halo, loads and stores overlapped with the iterations)
     {
         // column strips: n = fewest strips whose working width (kept columns + 12 on each cut side, a multiple of 4) fits 4 SS_MAXSW = 152 columns
         int n = 1, IW = divup(w, 4) * 4, SW = IW / 4;

@@ -21,8 +21,9 @@ int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
         p->extra_fronts.emplace_back(new DynaFront()); SIND_TRY(p->extra_fronts.back()->init(p->dc, Bs, st));
     }
     p->front.flow.max_levels = std::max(0, cfg->flow_max_levels); for (auto& f : p->extra_fronts) f->flow.max_levels = p->front.flow.max_levels;
-    p->front.flow.coarse_chain = !(cfg->flow_opts_off & 1); p->front.flow.latency_tiles = !(cfg->flow_opts_off & 2); p->front.flow.level_up = !(cfg->flow_opts_off & 4);
-    for (auto& f : p->extra_fronts) { f->flow.coarse_chain = p->front.flow.coarse_chain; f->flow.latency_tiles = p->front.flow.latency_tiles; f->flow.level_up = p->front.flow.level_up; }
+    p->front.flow.coarse_chain = !(cfg->flow_opts_off & 1); p->front.flow.latency_tiles = !(cfg->flow_opts_off & 2); p->front.flow.level_up = !(cfg->flow_opts_off & 4); p->front.flow.solver.wave = !(cfg->flow_opts_off & 8);
+    if (cfg->flow_opts_off >> 8) p->front.flow.solver.wave_items = cfg->flow_opts_off >> 8;      // (experiment: bits 8.. = waves per launch the row bands of k_sor_wave are cut for)
+    for (auto& f : p->extra_fronts) { f->flow.coarse_chain = p->front.flow.coarse_chain; f->flow.latency_tiles = p->front.flow.latency_tiles; f->flow.level_up = p->front.flow.level_up; f->flow.solver.wave = p->front.flow.solver.wave; f->flow.solver.wave_items = p->front.flow.solver.wave_items; }
     p->fw = p->front.fw; p->fh = p->front.fh;
     SIND_TRY(p->orb.init(cfg->width, cfg->height, cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, B, p->orb_stream));
     // CPU share of this process: the cores it may run on (affinity), bounded by the container's quota (cgroup v2 cpu.max: 16 cores per GPU on the MI355X

@@ -21,7 +21,7 @@ class FlowStage:
 
     def set_sor_variant(self, mode: int = 4, fuse: int = 5, tile_w: int = 64, tile_h: int | None = None):
         """solver variant of this handle (all return the same bits).  Fused register-resident SOR with 1x8 strips: mode 4 = divisions through a reciprocal formed on the fly
-        (default), 5 = the streaming kernel wherever it fits, 0 = one launch per colour (cross-check); lab builds: 1 = IEEE division, 3 = reciprocal planes held in registers
+        (default), 5 = the streaming kernel wherever it fits, 6 = the one-wave pipeline on every level beyond one workgroup, 0 = one launch per colour (cross-check); lab builds: 1 = IEEE division, 3 = reciprocal planes held in registers
         (three waves per SIMD; 256/384/768-thread tiles), 2 = 1x4 strips and reciprocal division.  fuse = iterations per launch on the tiled levels, 0 = a per-level plan
         (lab builds).  tile_h defaults to 48 (mode 3) / 64."""
         if tile_h is None:
@@ -30,6 +30,11 @@ class FlowStage:
 
     def set_solver_workgroups(self, cap: int):
         check(lib().sind_flow_set_solver_workgroups(self._h, int(cap)), "sind_flow_set_solver_workgroups")
+
+    def set_wave_solver(self, on: bool = True, target_items: int = 0, bands: int = 0):
+        """one-wave row pipelines (k_sor_wave) where the streaming kernel would run (default on); target_items: waves per launch the row bands are cut for (0 = default),
+        bands > 0: exactly that many row bands (tests); same bits"""
+        check(lib().sind_flow_set_wave_solver(self._h, 1 if on else 0, int(target_items), int(bands)), "sind_flow_set_wave_solver")
 
     def set_coef_kernel(self, variant: int):
         check(lib().sind_flow_set_coef_kernel(self._h, int(variant)), "sind_flow_set_coef_kernel")

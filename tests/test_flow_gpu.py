@@ -132,6 +132,42 @@ def test_streaming_solver_equals_the_oracle_on_strip_cuts(fs_big, w, h):
         assert np.array_equal(gv[b].view(np.uint32), ov.view(np.uint32)), (w, h, b, float(np.abs(gv[b] - ov).max()))
 
 
+# k_sor_wave: one, two, three and more column strips (128 columns per wave; kept widths of 118 / 108 next to a cut), odd widths (a last lane with one pixel inside the image),
+# a level lower than the 10-row halo, and 1 / 2 / 3 / 5 row bands (a band cut costs 10 rows of halo on either side; bands lower than the halo)
+WAVE_SHAPES = [(129, 67, 1), (128, 70, 2), (127, 66, 3), (236, 40, 1), (237, 36, 2), (230, 173, 2), (230, 173, 5), (302, 73, 3), (303, 65, 1), (385, 288, 3), (768, 431, 2), (1000, 9, 1), (1001, 9, 2), (612, 99, 5)]
+
+
+@pytest.mark.parametrize("w,h,bands", WAVE_SHAPES)
+def test_wave_solver_equals_the_oracle_on_strip_and_band_cuts(fs_big, w, h, bands):
+    """the one-wave row pipeline (k_sor_wave, solver mode 6 = on every level beyond one workgroup) against the ORACLE's VariationalRefinement: 5 fixed-point iterations x 25 SOR
+    iterations with DeepFlow's level parameters, every column-strip and row-band cut"""
+    i0, i1 = _textured_pair(w, h, 7 * w + h)
+    rng = np.random.default_rng(w + 1000 * h)
+    u0 = rng.normal(0, 1.0, (h, w)).astype(np.float32); v0 = rng.normal(0, 1.0, (h, w)).astype(np.float32)
+    a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
+    ou, ov = O.varref(i0, i1, u0, v0, 5, 25, a, d, g, 1.6)
+    try:
+        fs_big.set_sor_variant(6, 5, 64, 64); fs_big.set_wave_solver(True, 0, bands)
+        gu, gv = fs_big.varref_f32(np.stack([i0, i0]), np.stack([i1, i1]), np.stack([u0, u0]), np.stack([v0, v0]), 5, 25, a, d, g, 1.6)
+    finally:
+        fs_big.set_sor_variant(); fs_big.set_wave_solver()
+    for b in range(2):
+        assert np.array_equal(gu[b].view(np.uint32), ou.view(np.uint32)), (w, h, b, float(np.abs(gu[b] - ou).max()), int((gu[b] != ou).sum()))
+        assert np.array_equal(gv[b].view(np.uint32), ov.view(np.uint32)), (w, h, b, float(np.abs(gv[b] - ov).max()))
+
+
+def test_wave_solver_on_the_768x432_pyramid(fs_big):
+    """DeepFlow on the 768 x 432 grid (57 levels): one-wave pipelines with automatic bands (mode 6) == one launch per colour (mode 0) on every pixel of both pairs"""
+    a0, a1 = _textured_pair(768, 432, 5); b0, b1 = _textured_pair(768, 432, 6)
+    i0 = np.stack([a0, b1]).astype(np.uint8); i1 = np.stack([a1, b0]).astype(np.uint8)
+    try:
+        fs_big.set_sor_variant(0, 5, 64, 64); ru, rv = fs_big.deepflow(i0, i1)
+        fs_big.set_sor_variant(6, 5, 64, 64); u, v = fs_big.deepflow(i0, i1)
+    finally:
+        fs_big.set_sor_variant()
+    assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32))
+
+
 def test_streaming_solver_on_the_768x432_pyramid(fs_big):
     """DeepFlow on the 1280 x 720 configuration's flow grid (768 x 432, 57 levels, six column strips of 128 on the top level): streaming (mode 5) ==
     one launch per colour (mode 0) on every pixel of both pairs"""

@@ -73,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="sequence workload: keep the speculative chunk results (round-3 behaviour; masks not identical behind some seams)")
     ap.add_argument("--exact-leg-frames", type=int, default=0, help="sequence workload: frames of the in-order re-run the chunked masks are compared with (0 = chunk 0, chunks 1-2 and what else fits into 320-480 frames)")
     ap.add_argument("--flow-slices", type=int, default=0, help="experiment: dense-flow slices of a step (sind_pipe_config.flow_slices; 0 = the library's rule by step size)")
-    ap.add_argument("--flow-opts-off", type=int, default=0, help="experiment: bit 0 = no k_coarse_chain, bit 1 = no k_sor_tile (sind_pipe_config.flow_opts_off; same results)")
+    ap.add_argument("--flow-opts-off", type=int, default=0, help="experiment: bit 0 = no k_coarse_chain, bit 1 = no k_sor_tile, bit 2 = no k_level_up, bit 3 = k_sor_stream instead of k_sor_wave, bits 8.. = waves per launch k_sor_wave cuts its row bands for (sind_pipe_config.flow_opts_off; same results)")
     ap.add_argument("--pipelines", type=int, default=0, help="independent pipelines a step is cut into on one GPU (experiment; 0 = one; results do not depend on it)")
     ap.add_argument("--no-n1-leg", action="store_true", help="sequence workload on N > 1 ranks: skip the one-rank run of the same job on rank 0 after the timed region (sequence.n1_value)")
     ap.add_argument("--no-tum-leg", action="store_true", help="streams workload on one GPU: skip the TUM-length single sequence (line field `sequence_tum_length`)")
@@ -284,7 +284,7 @@ class StepAcc:
     """sums of the per-step pipeline statistics (solver HIP-event brackets, stage times) over the timed steps"""
     def __init__(self):
         import numpy as np
-        self.sor_ms = self.sor_bytes = self.sor_union = 0.0; self.sor_launches = 0; self.sor_slices = 1           # streaming solver (k_sor_stream)
+        self.sor_ms = self.sor_bytes = self.sor_union = 0.0; self.sor_launches = 0; self.sor_slices = 1           # the solver of the large levels (k_sor_wave / k_sor_stream)
         self.other_ms = self.other_bytes = 0.0; self.other_launches = 0                                           # solver launches of the other kernels (tiles, one-workgroup levels)
         self.stages = np.zeros(6); self.tail_wait = 0.0; self.submit_wall = 0.0
 
@@ -316,22 +316,24 @@ VALU_PEAK = 78.6e12      # float operations per second of the vector units: 1024
 
 
 def roofline_of(acc, K, dt, pairs_per_launch, config_name, cfg=None):
-    """`roofline` object of the dominant kernel, k_sor_stream (the SOR solver of every pyramid level above 8192 pixels in slices of 80 pairs and more).
+    """`roofline` object of the dominant kernel: the SOR solver of every pyramid level above 8192 pixels in slices of 80 pairs and more -- k_sor_wave (one-wave row
+    pipelines, flow_wave.hip), or k_sor_stream when --flow-opts-off has bit 3.
 
     bound = "hbm" (SURVEY 8d).  achieved = REAL HBM bytes per launch (committed rocprofv3 PMC passes of this command: FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction)
-    x the streaming launches of the timed steps / the time with at least one of them in flight (HIP events on the launching streams, union over the concurrent slices);
-    frac = achieved / 8 TB/s, <= 1 by construction.  The kernel is NOT near that roof and the line says why: it keeps a row pair's system in registers for five iterations
-    (temporal blocking), so it moves 40 B per pixel and launch where the 8d yardstick prices 5 x 44 B -- achieved_algorithmic / frac_algorithmic keep that yardstick and can
-    exceed 1 -- and spends its time in VALU issue and the step barriers of its row pipeline: valu_frac_from_counts (instructions counted by SQ_INSTS_VALU per kept pixel update x
-    updates / time / VALU_PEAK) and valu_busy (an occupancy counter: SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES) are reported beside it, never as `frac`."""
+    x the solver launches of the timed steps / the time with at least one of them in flight (HIP events on the launching streams, union over the concurrent slices);
+    frac = achieved / 8 TB/s, <= 1 by construction.  The kernel runs five iterations per launch out of registers and LDS (temporal blocking), so it moves 40 B per pixel and
+    launch where the 8d yardstick prices 5 x 44 B -- achieved_algorithmic / frac_algorithmic keep that yardstick and can exceed 1.  Where it stands against BOTH roofs is
+    measured by two experiments on the pyramid alone (bound_experiments: the same loads and stores with a tenth of the arithmetic; the same arithmetic with every load hitting
+    the cache); valu_frac_from_counts (SQ_INSTS_VALU per kept pixel update x updates / time / VALU_PEAK) and valu_busy (an occupancy counter) are reported beside it, never as `frac`."""
     busy_s = acc.sor_union * 1e-3
     alg = acc.sor_bytes / busy_s / 1e9 if busy_s > 0 else 0.0                                   # algorithmic GB/s, device level
     pmc = pmc_profile() if config_name == "tum3" else None
-    bk = (pmc or {}).get("by_kernel", {}).get("k_sor_stream")
+    kname = "k_sor_stream" if (cfg or {}).get("flow_opts_off", 0) & 8 else "k_sor_wave"
+    bk = (pmc or {}).get("by_kernel", {}).get(kname)
     traffic = None
     if bk:
         traffic = (2.0 * bk["FETCH_SIZE_kb_per_launch"] + bk["WRITE_SIZE_kb_per_launch"]) * 1024.0 * pairs_per_launch / pmc["pairs_per_launch"]
-    roof = {"kernel": "k_sor_stream (SOR solver of the pyramid levels above 8192 pixels, slices of 80 pairs and more; 5 iterations per launch)", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+    roof = {"kernel": kname + " (SOR solver of the pyramid levels above 8192 pixels, slices of 80 pairs and more; 5 iterations per launch)", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
             "launches": acc.sor_launches, "avg_launch_us": (acc.sor_ms * 1e3 / acc.sor_launches) if acc.sor_launches else None,
             "concurrent_slices": acc.sor_slices, "solver_busy_ms_per_step": acc.sor_union / K,
             "traffic": traffic,
@@ -350,8 +352,14 @@ def roofline_of(acc, K, dt, pairs_per_launch, config_name, cfg=None):
             px = [n for n in flow_level_pixels(cfg["width"], cfg["height"], cfg["flow_max_levels"]) if n > 8192]
             comp = 40.0 * (sum(px) / len(px)) * pairs_per_launch                                # per streaming launch: every streamed level has the same number of launches
             roof["compulsory_bytes_per_launch"] = comp; roof["traffic_over_compulsory"] = traffic / comp
-        roof["bound_note"] = ("frac = achieved / peak of HBM, the roof SURVEY 8d names.  The solver is a temporally blocked stencil (five iterations per launch out of registers and LDS): it moves "
-                              "traffic_over_compulsory x its compulsory 40 B per pixel and launch and is limited by VALU issue and the step barriers of its row pipeline, not by HBM (DESIGN.md 3.1)")
+        roof["bound_note"] = ("frac = achieved / peak of HBM, the roof SURVEY 8d names, while the solver shares the GPU with the step's other kernels (k_coef_lanes alone moves 0.4 x the solver's bytes).  "
+                              "The solver is a temporally blocked stencil (five iterations per launch out of registers and LDS) that moves traffic_over_compulsory x its compulsory 40 B per pixel and launch; "
+                              "alone on the GPU it needs bound_experiments.avg_launch_us per launch of 512 pairs against a memory floor and a compute floor measured with the same kernel (DESIGN.md 3.1)")
+        if kname == "k_sor_wave" and pmc.get("bound_experiments"):
+            be = dict(pmc["bound_experiments"]); per_pair = pmc["hbm_bytes_per_launch_per_pair"]
+            be["frac_alone"] = per_pair * 512 / (be["avg_launch_us"] * 1e-6) / 8e12           # real bytes of a launch of 512 pairs / its measured duration / peak
+            be["frac_alone_note"] = "committed measurement of the pyramid alone (one slice of 512 pairs), not re-measured in this run"
+            roof["bound_experiments"] = be
     else:
         roof["bound_note"] = "no committed PMC passes for this config or no streaming launches in the timed steps (slices below 80 pairs run the tiled kernels): see achieved_algorithmic"
     # VALU side, from COUNTS: pixel updates (algorithmic bytes / 44 B) x VALU instructions per kept update (SQ_INSTS_VALU x 64 lanes / updates; a packed instruction counted as two) / time / VALU_PEAK
@@ -360,7 +368,8 @@ def roofline_of(acc, K, dt, pairs_per_launch, config_name, cfg=None):
     if busy_s > 0 and ipu2:
         roof["valu_frac_from_counts"] = (acc.sor_bytes / 44.0) * ipu2 / VALU_PEAK / busy_s
         roof["valu_note"] = ("instr_per_update VALU instructions per kept pixel update (counter-measured; 32 float operations are the arithmetic of an update, no FMA by contract), priced at "
-                             "%.1f issue slots per update (packed instructions count twice: profiles/r05/valu_rate.txt) against VALU_PEAK" % ipu2)
+                             "%.1f issue slots per kept update (idle lanes of the 128-column strips and the halo columns / rows of every cut included; a packed instruction would count twice: "
+                             "profiles/r05/valu_rate.txt) against VALU_PEAK" % ipu2)
     if pmc and pmc.get("valu_busy_measured") is not None:
         roof["valu_busy"] = pmc["valu_busy_measured"]; roof["valu_busy_source"] = pmc.get("sq_counters")
         roof["valu_busy_note"] = "occupancy counter (SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES), not achieved / peak"

@@ -18,14 +18,14 @@ fi
 if [ "$part" = all ] || [ "$part" = 1b ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sequence-leg --no-dropin-leg --no-small-step-leg > $O/pmc_$c.json 2> $O/pmc_$c.err || exit 1
-    for k in k_sor_stream k_sor_fused k_sor_tile k_coarse_chain k_coef; do python3 $R/profiles/pmc_sum.py $k $O/pmc_$c; done > $O/pmc_$c.txt
+    for k in k_sor_wave k_sor_stream k_sor_fused k_sor_tile k_coarse_chain k_coef; do python3 $R/profiles/pmc_sum.py $k $O/pmc_$c; done > $O/pmc_$c.txt
     rm -rf $O/pmc_$c
   done
   rm -f $O/sq_counters_solver.txt; i=0
-  for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CU_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
     i=$((i+1))
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- python3 $R/profiles/tools/sor_only.py 170 1 384 288 > $O/pmc$i.log 2>&1 || { echo "set $i failed: $set"; tail -3 $O/pmc$i.log; }
-    python3 $R/profiles/tools/pmc_table.py k_sor_stream $O/pmc$i >> $O/sq_counters_solver.txt 2>&1; rm -rf $O/pmc$i
+    python3 $R/profiles/tools/pmc_table.py k_sor_wave $O/pmc$i >> $O/sq_counters_solver.txt 2>&1; rm -rf $O/pmc$i
   done
 fi
 cd $R

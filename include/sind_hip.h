@@ -75,7 +75,7 @@ int sind_flow_set_solver_workgroups(sind_flow* f, int cap);
  * sind_flow_set_sor_tiled runs the kernel on every level beyond one workgroup at any batch size.  Same bits either way. */
 int sind_flow_set_wave_solver(sind_flow* f, int on, int target_items, int bands);
 /* coefficient kernel: 1 = k_coef_lanes (neighbours from lanes, short correctly rounded sqrt / quotient forms; default), 2 = k_coef_lanes with the compiler's IEEE forms,
- * 0 = k_coef (neighbours from memory).  Same results. */
+ * 0 = k_coef (neighbours from memory), 3 = variant 1 with its tiles in plain grid order over the XCDs (A/B timing: by default the tiles of a pair share an XCD's L2).  Same results. */
 int sind_flow_set_coef_kernel(sind_flow* f, int variant);
 int sind_lab_build(void);        /* 1: built with -DSIND_LAB (dormant solver variants and the SIND_* experiment switches of the measurement rounds), 0: the shipped drop-in */
 /* HIP-event timing of everything enqueued on the handle's stream between begin and end (bench.py roofline leg) */

@@ -22,6 +22,10 @@ stages = [FlowStage(w, h, B) for _ in range(S)]
 if CAP:
     for st_ in stages:
         st_.set_solver_workgroups(CAP)
+COEF = os.environ.get("COEF")
+if COEF is not None:
+    for st_ in stages:
+        st_.set_coef_kernel(int(COEF))
 if WAVE is not None:
     for st_ in stages:
         check_rc = lib().sind_flow_set_wave_solver(st_._h, int(WAVE), WAVE_ITEMS, WAVE_BANDS); assert check_rc == 0

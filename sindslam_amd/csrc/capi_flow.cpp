@@ -161,7 +161,7 @@ int sind_flow_set_wave_solver(sind_flow* f, int on, int target_items, int bands)
     if (on > 1) f->eng.solver.wave_prefetch = std::min(on - 1, 3);       // (experiment: on = 2 / 3 / 4 selects 1 / 2 / 3 rows in flight)
     f->eng.solver.wave = on ? 1 : 0; f->eng.solver.wave_items = target_items > 0 ? target_items : sind::SolverCfg().wave_items; f->eng.solver.wave_bands = bands; return SIND_OK;
 }
-int sind_flow_set_coef_kernel(sind_flow* f, int variant) { if (!f || variant < 0 || variant > 2) return SIND_E_ARG; f->eng.solver.coef_kernel = variant; return SIND_OK; }
+int sind_flow_set_coef_kernel(sind_flow* f, int variant) { if (!f || variant < 0 || variant > 3) return SIND_E_ARG; f->eng.solver.coef_kernel = variant == 3 ? 1 : variant; f->eng.solver.coef_xcd = variant == 3 ? 0 : 1; return SIND_OK; }
 int sind_flow_set_sor(sind_flow* f, int mode, int fuse, int tile_w) {
     if (tile_w != 64 && tile_w != 128) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }
     return sind_flow_set_sor_tiled(f, mode, fuse, tile_w, mode == 3 ? (tile_w == 64 ? 48 : 48) : 64);

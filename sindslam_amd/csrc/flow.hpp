@@ -71,6 +71,7 @@ struct SolverCfg {
     int wave_bands = 0;        // > 0: exactly this many row bands (tests)
     int wave_prefetch = 2;     // k_sor_wave: steps between a row's request and its take-over (1 .. 3; 16 registers per row in flight)
     int coef_kernel = 1;       // 1: k_coef_lanes (neighbours from lanes; short forms of sqrt and c / sqrt), 2: k_coef_lanes with the IEEE forms, 0: k_coef (neighbours from memory)
+    int coef_xcd = 1;          // k_coef_lanes: the tiles of a pair go to one XCD (1) or round-robin over the eight in grid order (0: A/B timing)
     double plan_cost = 14;     // prologue of a tile in iterations (sor_fuse_plan)
     int opts = FLOW_OPT_COARSE_CHAIN | FLOW_OPT_LATENCY_TILES | FLOW_OPT_LEVEL_UP;
 };

@@ -246,11 +246,17 @@ __global__ void k_coef(VarParams P, int w, int h, const float* __restrict__ gAvg
 // grid (tiles of KL_COLS columns, groups of 4 x KL_ROWS rows, pairs), 256 threads: wave k of a workgroup takes the rows (4 * blockIdx.y + k) * KL_ROWS ...
 __global__ __launch_bounds__(256) void k_coef_lanes(VarParams P, int w, int h, const float* __restrict__ gAvg, const float* __restrict__ gIz, const float* __restrict__ gWu,
                        const float* __restrict__ gWv, const float* __restrict__ gdWu, const float* __restrict__ gdWv, float* __restrict__ A11, float* __restrict__ A12,
-                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11, float* __restrict__ R22, int fast_math) {
+                       float* __restrict__ A22, float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ Wgt, float* __restrict__ R11, float* __restrict__ R22, int fast_math,
+                       int tiles_x, int tiles_y, int n_tiles, int xcd) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c0 = blockIdx.x * KL_COLS - 2, y0 = (blockIdx.y * 4 + wave) * KL_ROWS;
+    // 1-D grid (a multiple of 8): tile = x + tiles_x * (y + tiles_y * pair).  xcd: consecutive tiles -- the tiles of one pair, which share their halo rows and columns -- go to the
+    // SAME XCD (workgroups are handed to the eight XCDs round-robin), so the second reader of a halo line finds it in that XCD's L2
+    const int tile = xcd ? ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    if (tile >= n_tiles) return;
+    const int bx = tile % tiles_x, byz = tile / tiles_x, by = byz % tiles_y, bz = byz / tiles_y;
+    const int c0 = bx * KL_COLS - 2, y0 = (by * 4 + wave) * KL_ROWS;
     if (y0 >= h) return;                                    // whole wave
-    const size_t base = (size_t)blockIdx.z * w * h;
+    const size_t base = (size_t)bz * w * h;
     const int col = c0 + lane;
     const bool store_lane = lane >= 2 && lane < 2 + KL_COLS && col < w;
     // the short forms of sqrt and c / sqrt need arguments >= 2^-96: every argument carries epsilon^2 (1e-6 with the reference's parameters); any other epsilon takes the IEEE forms
@@ -1673,9 +1679,11 @@ int varref_level(hipStream_t s, FlowPlanes& P, const float* I0, const float* I1,
     // have_buffers: the level transition (k_level_up) has left avg / Iz and a zero increment already; leave_increment: W += dW is the next transition's business
     if (!have_buffers) hipLaunchKernelGGL(k_warp_avg_iz, grid2d(w, divup(h, WARP_ROWS), B), blk, 0, s, I0, I1, P.Wu, P.Wv, P.avg, P.Iz, P.dWu, P.dWv, w, h);
     for (int it = 0; it < V.fixedPointIterations; it++) {
-        if (C.coef_kernel)
-            hipLaunchKernelGGL(k_coef_lanes, dim3(divup(w, KL_COLS), divup(h, 4 * KL_ROWS), B), dim3(256), 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
-                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, C.mode == 3 ? P.r11 : nullptr, C.mode == 3 ? P.r22 : nullptr, C.coef_kernel == 2 ? 0 : 1);
+        if (C.coef_kernel) {
+            const int tx = divup(w, KL_COLS), ty = divup(h, 4 * KL_ROWS), nt = tx * ty * B;
+            hipLaunchKernelGGL(k_coef_lanes, dim3(divup(nt, 8) * 8), dim3(256), 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
+                               P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, C.mode == 3 ? P.r11 : nullptr, C.mode == 3 ? P.r22 : nullptr, C.coef_kernel == 2 ? 0 : 1, tx, ty, nt, C.coef_xcd);
+        }
         else
             hipLaunchKernelGGL(k_coef, dim3(divup(w, 128), divup(h, KC_ROWS), B), blk, 0, s, V, w, h, P.avg, P.Iz, P.Wu, P.Wv,
                                P.dWu, P.dWv, P.A11, P.A12, P.A22, P.b1, P.b2, P.wgt, C.mode == 3 ? P.r11 : nullptr, C.mode == 3 ? P.r22 : nullptr);

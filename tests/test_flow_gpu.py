@@ -205,7 +205,7 @@ def test_coefficients_from_lanes_equal_coefficients_from_memory(fs_big, w, h):
         fs_big.set_coef_kernel(1); lu, lv = fs_big.varref_f32(*args)          # lanes, short forms (the default)
     finally:
         fs_big.set_coef_kernel(1)
-    assert lib().sind_flow_set_coef_kernel(fs_big._h, 3) == -1
+    assert lib().sind_flow_set_coef_kernel(fs_big._h, 4) == -1
     assert np.array_equal(iu.view(np.uint32), mu.view(np.uint32)) and np.array_equal(iv.view(np.uint32), mv.view(np.uint32)), (w, h, float(np.abs(iu - mu).max()))
     assert np.array_equal(lu.view(np.uint32), mu.view(np.uint32)) and np.array_equal(lv.view(np.uint32), mv.view(np.uint32)), (w, h, float(np.abs(lu - mu).max()))
     assert np.isfinite(lu).all() and np.abs(lu - np.stack([u0, v0])).max() > 1e-3          # the refinement moved the field

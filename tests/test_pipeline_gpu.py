@@ -238,7 +238,8 @@ def test_kmeans_stream_groups_do_not_change_the_results(frames):
 @pytest.mark.timeout(1200)
 def test_pipeline_in_the_shape_the_bench_runs_streaming_solver_and_ragged_step(frames):
     """48 streams x 3 frames = 144 pairs per step, the dense flow in ONE slice (flow_slices = 1; the rule by step size would cut 144 pairs into three slices of 48, below the
-    80 images per launch from which the streaming solver takes over): the STREAMING solver (k_sor_stream, the kernel of the bench's 170-pair slices) inside the pipeline.  Four sampled streams against the ORACLE: imgDyna / imgLabel / mask / keypoints / descriptors of every
+    80 images per launch from which the large-level solver takes over): the ONE-WAVE solver (k_sor_wave, the kernel of the bench's 170-pair slices) inside the pipeline; the
+    workgroup pipeline it replaced (k_sor_stream, flow_opts_off bit 3) gives the same step.  Four sampled streams against the ORACLE: imgDyna / imgLabel / mask / keypoints / descriptors of every
     frame are equal.  Then a ragged step (sind_pipe_set_active_frames): the sampled streams stop after 0, 1, 2 and 3 frames -- their state fingerprints and state
     blobs are exactly those of the oracle-checked prefix."""
     from sindslam_amd.pipeline import Pipeline
@@ -274,6 +275,14 @@ def test_pipeline_in_the_shape_the_bench_runs_streaming_solver_and_ragged_step(f
             k, d = pipe.keypoints(s, t)
             assert k.tobytes() == rk.tobytes() and np.array_equal(d, rdesc), (s, t)
     blobs_full = {s: pipe.get_state(s) for s in sample}
+    # the same step through k_sor_stream
+    alt = Pipeline(S, T, 640, 480, *K, 1500, 1.2, 8, 15, 5, orb_gray_rgb_order=1, flow_slices=1, flow_opts_off=8)
+    alt.set_state_hashing(True)
+    for s in range(S):
+        alt.prime(s, sb[s, 1], sb[s, 0])
+    alt.process(sb[:, 2:5], sd[:, 2:5])
+    assert alt.stats()["sor_launches"] > 0 and np.array_equal(alt.dyna, pipe.dyna) and np.array_equal(alt.label, pipe.label) and np.array_equal(alt.state_hashes(), h_full)
+    alt.close()
     # ragged step on the same inputs: stream sample[i] runs i frames
     for s in range(S):
         pipe.prime(s, sb[s, 1], sb[s, 0])

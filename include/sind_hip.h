@@ -74,6 +74,9 @@ int sind_flow_set_solver_workgroups(sind_flow* f, int cap);
  * target_items = waves a launch should have (row bands are cut until it does; 0 keeps the default), bands > 0 = exactly that many row bands (tests).  Mode 6 of
  * sind_flow_set_sor_tiled runs the kernel on every level beyond one workgroup at any batch size.  Same bits either way. */
 int sind_flow_set_wave_solver(sind_flow* f, int on, int target_items, int bands);
+/* how k_sor_wave cuts a w x h level of B pairs (host arithmetic only, no GPU needed): out = {column strips, kept columns per strip, row bands, kept rows per band}.  A strip works on
+ * 128 columns -- its kept ones plus 10 on every side that is not an image border --, a band on its kept rows plus 10 on every cut side. */
+int sind_flow_wave_layout(int w, int h, int B, int target_items, int bands, int out[4]);
 /* coefficient kernel: 1 = k_coef_lanes (neighbours from lanes, short correctly rounded sqrt / quotient forms; default), 2 = k_coef_lanes with the compiler's IEEE forms,
  * 0 = k_coef (neighbours from memory), 3 = variant 1 with its tiles in plain grid order over the XCDs (A/B timing: by default the tiles of a pair share an XCD's L2).  Same results. */
 int sind_flow_set_coef_kernel(sind_flow* f, int variant);

@@ -161,6 +161,10 @@ int sind_flow_set_wave_solver(sind_flow* f, int on, int target_items, int bands)
     if (on > 1) f->eng.solver.wave_prefetch = std::min(on - 1, 3);       // (experiment: on = 2 / 3 / 4 selects 1 / 2 / 3 rows in flight)
     f->eng.solver.wave = on ? 1 : 0; f->eng.solver.wave_items = target_items > 0 ? target_items : sind::SolverCfg().wave_items; f->eng.solver.wave_bands = bands; return SIND_OK;
 }
+int sind_flow_wave_layout(int w, int h, int B, int target_items, int bands, int out[4]) {
+    if (w < 1 || h < 1 || B < 1 || target_items < 0 || bands < 0 || !out) return SIND_E_ARG;
+    sind::sor_wave_layout(w, h, B, target_items > 0 ? target_items : sind::SolverCfg().wave_items, bands, &out[0], &out[1], &out[2], &out[3]); return SIND_OK;
+}
 int sind_flow_set_coef_kernel(sind_flow* f, int variant) { if (!f || variant < 0 || variant > 3) return SIND_E_ARG; f->eng.solver.coef_kernel = variant == 3 ? 1 : variant; f->eng.solver.coef_xcd = variant == 3 ? 0 : 1; return SIND_OK; }
 int sind_flow_set_sor(sind_flow* f, int mode, int fuse, int tile_w) {
     if (tile_w != 64 && tile_w != 128) { sind_set_error("sind_flow_set_sor: bad arguments"); return SIND_E_ARG; }

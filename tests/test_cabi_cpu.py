@@ -94,3 +94,28 @@ def test_region_grow_size_gate_and_chunk_calls_without_a_gpu():
     assert L.sind_pipe_set_state_hashing(None, 1) == -1 and L.sind_pipe_set_active_frames(None, None) == -1 and L.sind_pipe_reserve_retained(None, 1) == -1
     assert L.sind_pipe_retain_next(None, 0) == -1 and L.sind_pipe_host_info(None, None) == -1 and L.sind_pipe_get_state_hashes(None, None, 0) == -1
     assert L.sind_pipe_replay(None, 0, None, None, None, None, None, None, 0, None, None) == -1
+
+
+def test_wave_solver_layout_covers_every_level_size():
+    """k_sor_wave's strips and bands (sind_flow_wave_layout, host arithmetic): for every width up to 2000 the strips cover the level, a strip's kept columns plus its halos fit the
+    128 columns a wave works on, the kept width is even (a lane's two pixels never straddle a cut); for heights and batch sizes the bands cover the rows and are never empty"""
+    import ctypes as C
+    import numpy as np
+    from sindslam_amd._lib import lib
+    out = (C.c_int * 4)()
+    for w in list(range(1, 700)) + list(range(700, 2001, 7)):
+        assert lib().sind_flow_wave_layout(w, 173, 170, 0, 0, out) == 0
+        n, iw = out[0], out[1]
+        assert n >= 1 and iw % 2 == 0 and n * iw >= w and (n - 1) * iw < w, (w, n, iw)
+        for s in range(n):
+            ix0 = s * iw; ix1 = min(ix0 + iw, w); ex0 = max(ix0 - 10, 0)
+            right_cut = ix1 < w
+            assert ix1 + (10 if right_cut else 0) <= ex0 + 128, (w, s, n, iw)            # kept columns + the halo of a cut side lie inside the wave's 128 columns
+    for h in range(1, 500):
+        for B, items, forced in ((1, 0, 0), (170, 0, 0), (512, 0, 0), (3, 4096, 0), (2, 0, 5)):
+            assert lib().sind_flow_wave_layout(230, h, B, items, forced, out) == 0
+            nb, bh = out[2], out[3]
+            assert nb >= 1 and bh >= 1 and nb * bh >= h and (nb - 1) * bh < h, (h, B, nb, bh)
+            if forced:
+                assert nb <= forced
+    assert lib().sind_flow_wave_layout(0, 10, 1, 0, 0, out) == -1 and lib().sind_flow_wave_layout(10, 10, 1, 0, 0, None) == -1

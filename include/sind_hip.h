@@ -126,6 +126,10 @@ int sind_dyna_destroy(sind_dyna* d);
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n);      /* see sind_flow_set_max_levels */
 int sind_dyna_timing(sind_dyna* d, double ms12[12], int reset); /* mean ms per detect call: upload, dense flow, wait for the depth half, flow masks + fusion, depth half, whole call;
                                                                     then the tail's stages: flow masks, k-means, label preparation, CalOccluded, SegAndMerge, fusion; returns calls */
+/* summed milliseconds of the tail's sub-stages since the last reset (dyna.hpp t_fine: CalOccluded 0 gpu + d2h, 1 pack, 2 end points, 3 PEAC host parts, 4 contour filter, 5 close;
+ * SegAndMerge 6 pieces, 7 alloc, 8 rag (h2d, kernels, d2h, wait), 9 merge, 10 sort + paint + pack, 11 h2d enqueue, 12 - 16 inside pieces: open, contours, masks, lianjie, centre; 20 - 23 flow masks on
+ * the host: weights, sort + wait, homography, pack; 24 - 27 fusion) */
+int sind_dyna_timing_fine(sind_dyna* d, double ms40[40], int reset);
 int sind_dyna_set_debug(sind_dyna* d, int on);               /* on: keep the intermediate images sind_dyna_debug reports (costs four flow-sized copies per frame); default off */
 int sind_dyna_set_overlap(sind_dyna* d, int on);             /* default on: the depth half of a frame (k-means, CalOccluded, SegAndMerge) runs beside its dense flow, as the reference's
                                                                  flow thread runs beside the segmentation (DynaDetect.cc:1396-1398); 0 = one after the other; same results */

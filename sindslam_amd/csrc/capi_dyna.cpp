@@ -76,6 +76,12 @@ int sind_dyna_timing(sind_dyna* d, double ms12[12], int reset) {
     if (reset) { for (double& v : d->t_ms) v = 0; for (double& v : d->tail.t_stage) v = 0; d->n_timed = 0; }
     return n;
 }
+int sind_dyna_timing_fine(sind_dyna* d, double ms40[40], int reset) {
+    if (!d || !ms40) return SIND_E_ARG;
+    for (int i = 0; i < 40; i++) ms40[i] = d->tail.t_fine[i];
+    if (reset) for (double& v : d->tail.t_fine) v = 0;
+    return SIND_OK;
+}
 int sind_dyna_set_flow_max_levels(sind_dyna* d, int n) { if (!d || n < 0) return SIND_E_ARG; d->front.flow.max_levels = n; return SIND_OK; }
 int sind_dyna_destroy(sind_dyna* d) {
     if (!d) return SIND_OK;

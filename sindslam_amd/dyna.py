@@ -33,6 +33,11 @@ class DynaDetect:
         return dict(calls=n, upload=ms[0], dense_flow=ms[1], wait_depth_half=ms[2], flow_masks_and_fusion=ms[3], depth_half=ms[4], total=ms[5],
                     tail_stages=dict(flow_masks=ms[6], kmeans=ms[7], labels=ms[8], cal_occluded=ms[9], seg_and_merge=ms[10], fusion=ms[11]))
 
+    def timing_fine(self, reset: bool = True):
+        """summed milliseconds of the tail's sub-stages since the last reset (sind_dyna_timing_fine; indices in include/sind_hip.h)"""
+        ms = (C.c_double * 40)(); check(lib().sind_dyna_timing_fine(self._h, ms, 1 if reset else 0), "sind_dyna_timing_fine")
+        return [float(v) for v in ms]
+
     def close(self):
         if getattr(self, "_h", None):
             lib().sind_dyna_destroy(self._h); self._h = None

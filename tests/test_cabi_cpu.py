@@ -50,7 +50,7 @@ def test_bad_arguments():
     assert lib().sind_cloud_create(C.c_double(0.0), C.c_double(1.0), C.c_double(0.0), C.c_double(0.0), C.c_double(5000.0), 640, 480, 1, 0, C.byref(h)) == -1
     # solver settings are per flow handle (round 5): a null handle is an argument error, nothing is process-wide
     assert lib().sind_flow_set_sor(None, 4, 5, 64) == -1 and lib().sind_flow_set_sor_tiled(None, 4, 5, 64, 64) == -1
-    assert lib().sind_flow_set_wave_solver(None, 1, 0, 0) == -1
+    assert lib().sind_flow_set_wave_solver(None, 1, 0, 0) == -1 and lib().sind_dyna_timing_fine(None, None, 0) == -1
     assert lib().sind_flow_set_solver_workgroups(None, 0) == -1 and lib().sind_flow_set_coef_kernel(None, 1) == -1
     assert lib().sind_flow_set_coarse_chain(None, 1) == -1 and lib().sind_flow_set_latency_tiles(None, 1) == -1
 

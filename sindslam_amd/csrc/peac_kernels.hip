@@ -90,7 +90,11 @@ __device__ __forceinline__ unsigned pg_block_excl_scan(unsigned cnt, unsigned* s
     return base + inc - cnt;
 }
 
-__global__ void __launch_bounds__(PG_THREADS) k_peac_grow(PeacGrowArgs A) {
+// NT: threads of the workgroup.  512 for launches of many frames (a workgroup per frame, several per compute unit); 1024 when a launch holds one or two frames (the one-frame
+// call of the drop-in path): a level of a 1280 x 720 frame is ~2 000 seeds = 8 000 visits, ~3 500 of them active -- 17.0 -> 14.5 ms per frame there, 640 x 480 unchanged at 3 - 5 ms
+// (phase 2b, two dependent rounds of global loads per batch of active visits, is 2/3 of a level's ~30 us: latency, not bandwidth; a larger LDS level capacity changed nothing)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_peac_grow(PeacGrowArgs A) {
     const int f = blockIdx.x, tid = threadIdx.x, W = A.W, H = A.H, N = W * H, Nw = W / 16, NB = Nw * (H / 16);
     const uint8_t* in = A.in + (size_t)f * A.in_stride;
     const PeacGrowHdr hdr = *reinterpret_cast<const PeacGrowHdr*>(in);
@@ -301,7 +305,8 @@ __global__ void __launch_bounds__(PG_THREADS) k_peac_grow(PeacGrowArgs A) {
 int launch_peac_grow(hipStream_t s, const PeacGrowArgs& A, int frames) {
     static_assert(PG_U == 4, "phase 3 reads four keys per thread as one 16-byte word");
     if (frames < 1 || A.W % 16 || A.H % 16 || (A.W / 16) * (A.H / 16) > PG_MAX_BLOCKS || (size_t)A.W * A.H > (1u << 20)) { sind_set_error("peac_grow: unsupported size %d x %d", A.W, A.H); return SIND_E_ARG; }
-    hipLaunchKernelGGL(k_peac_grow, dim3(frames), dim3(PG_THREADS), 0, s, A);
+    if (frames <= 2) hipLaunchKernelGGL(k_peac_grow<1024>, dim3(frames), dim3(1024), 0, s, A);
+    else hipLaunchKernelGGL(k_peac_grow<PG_THREADS>, dim3(frames), dim3(PG_THREADS), 0, s, A);
     return SIND_OK;
 }
 

@@ -38,6 +38,17 @@ def test_grow_equals_the_fifo_on_stream_frames(stream):
     assert (mg >= 0).mean() > 0.3
 
 
+def test_one_and_two_frame_launches_take_the_1024_thread_instance(stream):
+    """launches of one or two frames (the drop-in path's call) run the kernel with 1024 threads per workgroup: same membership, same pairs"""
+    _, depth = stream.frames(0, 4)
+    for k in range(4):
+        _same(*_grow(depth[k:k + 1], TUM3))
+    _same(*_grow(depth[1:3], TUM3))
+    sc = 2.0; intr = dict(D455, fx=D455["fx"] * sc, fy=D455["fy"] * sc, cx=D455["cx"] * sc, cy=D455["cy"] * sc)
+    _, d720 = SyntheticStream(1280, 720, 4242, D455).frames(0, 2)
+    _same(*_grow(d720[:1], intr)); _same(*_grow(d720[:2], intr))
+
+
 def test_grow_on_a_second_scene_and_a_mirrored_one():
     s = SyntheticStream(seed=777)
     _, depth = s.frames(3, 6)

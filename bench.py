@@ -425,22 +425,25 @@ def make_pipeline(cfg, intr, S, T, local, host_threads=0, parts=1):
 
 
 def sequence_streams(world, frames, cfg_streams, steps, warm=None):
-    """chunks per GPU of the fixed-length sequence when --streams is not given.  Every chunk after the first re-processes 24 state warm-up frames, so the
-    chunk count trades batch size and tail parallelism (one tail chain per chunk) against warm-up work: start from the power of two that keeps the warm-up at
-    about a quarter of the sequence (>= 4 chunks per GPU), then take the count near it whose lock-step plan processes the fewest frames in `steps` steps."""
+    """chunks per GPU of the fixed-length sequence when --streams is not given.  Every chunk after the first re-processes `warm` state warm-up frames, so more chunks mean
+    more frames per step; fewer chunks mean more frames PER CHUNK per step, and the stateful tails of a chunk's frames are a serial chain (k-means from the previous frame's
+    merged labels).  Measured on one MI355X at ~30 pairs per step (profiles/r05/rank_step_shapes.txt: what a rank of an 8-GPU job sees with the driver's 20 steps): 4 chunks x 8
+    frames 509 pairs/s, 5 x 6 543, 6 x 5 658, 8 x 4 765, 10 x 3 783, 16 x 2 874 -- the step is max(dense flow of S * T pairs, T tails in a row).  So: among the chunk counts
+    around the one that keeps the warm-up at about a quarter of the sequence, the one whose lock-step plan has the shortest estimated step (flow ~ 20 + 0.55 ms per pair, a tail
+    ~ 8.5 ms per frame of a chunk; fitted to that table and to the 512-pair headline), ties to the plan that processes fewer frames."""
     from sindslam_amd.sequence import plan_lockstep
     warm = SEQ_WARMUP_FRAMES if warm is None else warm
     s0 = 4
     while s0 * 2 <= cfg_streams and s0 * 2 * world * 4 * max(warm, 8) <= frames:
         s0 *= 2
     best = None
-    for s in range(max(4, (3 * s0) // 4), 2 * s0):
-        tot = plan_lockstep(frames, world * s, steps, warm).processed_total
-        if best is None or tot <= best[0]:
-            best = (tot, s)
+    for s in range(max(4, (3 * s0) // 4), min(max(2 * s0, 13), cfg_streams + 1)):
+        plan = plan_lockstep(frames, world * s, steps, warm)
+        est = max(20.0 + 0.55 * s * plan.T, 8.5 * plan.T + 5.0)
+        key = (est, plan.processed_total)
+        if best is None or key < best[0]:
+            best = (key, s)
     return best[1]
-
-
 
 
 def dropin_leg(cfg, intr, frames_b, frames_d, device, n_frames=120):

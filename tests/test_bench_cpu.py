@@ -77,3 +77,5 @@ def test_sequence_chunk_count_heuristic():
     for n, s in got.items():
         p = plan_lockstep(4000, n * s, 20, bench.SEQ_WARMUP_FRAMES)
         assert p.processed_total <= 1.3 * 4000 and sum(c.last - c.first for c in p.chunks) == 4000
+        if n == 8:
+            assert p.T <= 4 and s * p.T <= 40          # a rank's ~30 pairs per step as at least eight short chains (the tails of a chunk's frames run one after the other)

@@ -198,7 +198,7 @@ typedef struct sind_pipe_config {
     int host_threads;            /* 0 = library default (2 x the CPU share of the process) */
     int flow_max_levels;         /* 0 = the reference's full DeepFlow pyramid; n > 0: finest n levels only (see sind_flow_set_max_levels) */
     int flow_slices;             /* dense-flow slices of a step that run concurrently on their own streams: 0 = by step size (default), 1..4 fixed; same results */
-    int flow_opts_off;           /* A/B switches, same results: bit 0 = no k_coarse_chain (see sind_flow_set_coarse_chain), bit 1 = no k_sor_tile (see sind_flow_set_latency_tiles), bit 2 = no k_level_up (see sind_flow_set_level_up), bit 3 = k_sor_stream instead of k_sor_wave (see sind_flow_set_wave_solver), bits 8.. = that call's target_items; 0 = defaults */
+    int flow_opts_off;           /* A/B switches, same results: bit 0 = no k_coarse_chain (see sind_flow_set_coarse_chain), bit 1 = no k_sor_tile (see sind_flow_set_latency_tiles), bit 2 = no k_level_up (see sind_flow_set_level_up), bit 3 = k_sor_stream instead of k_sor_wave (see sind_flow_set_wave_solver), bit 4 = a round's k-means waits for the whole tails of the frame before (not only for their depth halves), bits 8.. = target_items of sind_flow_set_wave_solver; 0 = defaults */
 } sind_pipe_config;
 int sind_pipe_create(const sind_pipe_config* cfg, sind_pipe** out);
 int sind_pipe_destroy(sind_pipe* p);

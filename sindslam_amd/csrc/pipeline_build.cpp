@@ -22,6 +22,7 @@ int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     }
     p->front.flow.max_levels = std::max(0, cfg->flow_max_levels); for (auto& f : p->extra_fronts) f->flow.max_levels = p->front.flow.max_levels;
     p->front.flow.coarse_chain = !(cfg->flow_opts_off & 1); p->front.flow.latency_tiles = !(cfg->flow_opts_off & 2); p->front.flow.level_up = !(cfg->flow_opts_off & 4); p->front.flow.solver.wave = !(cfg->flow_opts_off & 8);
+    p->split_rounds = !(cfg->flow_opts_off & 16);
     if (cfg->flow_opts_off >> 8) p->front.flow.solver.wave_items = cfg->flow_opts_off >> 8;      // (experiment: bits 8.. = waves per launch the row bands of k_sor_wave are cut for)
     for (auto& f : p->extra_fronts) { f->flow.coarse_chain = p->front.flow.coarse_chain; f->flow.latency_tiles = p->front.flow.latency_tiles; f->flow.level_up = p->front.flow.level_up; f->flow.solver.wave = p->front.flow.solver.wave; f->flow.solver.wave_items = p->front.flow.solver.wave_items; }
     p->fw = p->front.fw; p->fh = p->front.fh;

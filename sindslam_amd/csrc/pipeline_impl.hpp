@@ -122,7 +122,7 @@ struct sind_pipe {
     std::vector<char> primed;
     // Chunked sequences (sindslam_amd/sequence.py): hashing = every tail leaves the fingerprint of its rolled state per frame (last_hash: the step whose results
     // were returned last, [S][T][2]); active_next = per-stream number of frames whose TAILS run in the next step (one step only; empty = all T)
-    bool hashing = false; std::vector<uint64_t> last_hash; std::vector<int> active_next; int chain_max_streams = 12;
+    bool hashing = false; std::vector<uint64_t> last_hash; std::vector<int> active_next; int chain_max_streams = 12; bool split_rounds = true;      /* rounds: the next k-means waits for the depth halves of the tails only (pipeline_tails.cpp) */
     double stage_ms[6] = {0}; double tail_wait_ms = 0; double sor_ms = 0, sor_union_ms = 0, sor_bytes = 0; long long sor_launches = 0; int sor_slices = 1;      // streaming solver (k_sor_stream) launch groups of the last step
     double sor_other_ms = 0, sor_other_bytes = 0; long long sor_other_launches = 0;                             // every other solver kernel outside k_coarse_chain (tiles, one-workgroup levels)
     SindHostGate gate;           // CPU tokens of this handle's pool tasks (common.hpp)

@@ -57,8 +57,8 @@ static void tail_task(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, in
 // Two chains per stream for a handful of live streams (the slow runners of a repair): the depth chain -- k-means from the previous frame's merged labels, SegAndMerge; it
 // needs nothing from the flow half -- runs ahead on the stream's depth-half object, the flow chain (flow masks, fusion, dilation, keypoint filter) follows frame by frame
 // as soon as its frame's depth stage and the previous frame's flow stage are done.  A frame then costs max(depth, flow) instead of their sum (the in-order mode's schedule).
-static void flow_chain(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int t1, int worker) {
-    struct Spin { int keep; Spin() : keep(t_sind_spin_us) { t_sind_spin_us = 400; } ~Spin() { t_sind_spin_us = keep; } } spin;
+static void flow_chain(sind_pipe* p, sind_pipe::StepBuf* sb, PipeOut o, int s, int t, int t1, int worker, bool poll = true) {
+    struct Spin { int keep; explicit Spin(bool on) : keep(t_sind_spin_us) { if (on) t_sind_spin_us = 400; } ~Spin() { t_sind_spin_us = keep; } } spin(poll);      // (a few chains on an idle host poll before they sleep; the rounds of a full pipeline do not)
     for (;;) {
         if (!tail_one(p, sb, o, s, t, worker, nullptr) || t + 1 >= t1) return;
         if (sb->fgate[s * p->T + t + 1].fetch_add(1) != 1) return;          // the next frame's depth stage is still out: its completion starts the flow stage
@@ -99,9 +99,21 @@ void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
         return;
     }
     if (p->batch_km && !sb.depth_ahead && !few) {
-        // rounds: frame t of every stream -- the batched k-means chain on its own stream, then the S tails of that frame on the pool
+        // rounds: frame t of every stream -- the batched k-means chain on its own stream, then the S tails of that frame on the pool.
+        // split (default): what the NEXT round's k-means waits for is only the depth half of a tail (cluster order, SegAndMerge: its merged labels start that k-means); the flow
+        // half (flow masks, fusion, dilation, keypoint filter) of frame t follows on the stream's tail object as soon as its depth half and the flow half of frame t - 1 are
+        // done, beside the next round.  A chunk's frames are a serial chain: this takes ~a third of a frame's tail off it.
+        // Measured (profiles/r05/ab_split_rounds.txt): 5 streams x 6 frames 562 - 582 -> 665 - 676 pairs/s, 8 x 4 745 - 758 -> 816 - 826, 16 x 2 and 32 x 2 unchanged, 128 x 4 within
+        // noise on the losing side -- so only while there are no more streams than pool workers (with more, other streams' tails fill the pool during a round anyway).
+        const bool split = p->split_rounds && S <= (int)p->worker_streams.size() && ensure_dtails(p) == SIND_OK;
+        if (split) {
+            const int B = S * p->T;
+            if (sb.fgate_n < B) { sb.fgate.reset(new std::atomic<int>[B]); sb.fgate_n = B; }
+            sb.dout.assign(B, DepthStageOut()); sb.two_chain = true;
+            for (int s = 0; s < S; s++) { const int t0 = sb.first.empty() ? 0 : sb.first[s]; for (int t = 0; t < p->T; t++) sb.fgate[s * p->T + t].store(t == t0 ? 1 : 0); }
+        }
         sbp->km_groups = p->km_groups; for (int g = 0; g <= sbp->km_groups; g++) sbp->km_first[g] = (int)((long long)S * g / sbp->km_groups);
-        for (int g = 0; g < sbp->km_groups; g++) p->round_threads.emplace_back([p, sbp, o, g] {
+        for (int g = 0; g < sbp->km_groups; g++) p->round_threads.emplace_back([p, sbp, o, g, split] {
             (void)pthread_setname_np(pthread_self(), "sind-rounds"); (void)hipSetDevice(p->c.device);
             const size_t np = (size_t)p->c.width * p->c.height;
             const int s0 = sbp->km_first[g], ns = sbp->km_first[g + 1] - s0; std::vector<const uint8_t*> prev(ns);
@@ -109,7 +121,7 @@ void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
                 bool any = false;                                        // ragged / replayed steps: rounds in which no stream of the group has a frame are passed over
                 for (int s = s0; s < s0 + ns && !any; s++) any = (sbp->first.empty() || t >= sbp->first[s]) && (sbp->active.empty() || t < sbp->active[s]);
                 if (!any) continue;
-                if (t > 0) WorkerPool::wait(sbp->km_tails[g]);           // this group's tails of frame t - 1 (their merged labels start this round's k-means)
+                if (t > 0) WorkerPool::wait(sbp->km_tails[g]);           // this group's tails (split: their depth halves) of frame t - 1: their merged labels start this round's k-means
                 for (int s = 0; s < ns; s++) prev[s] = depth_half(p, s0 + s)->prev_km_labels();
                 const double tk = now_ms();
                 int rc;
@@ -117,7 +129,17 @@ void phase_b_start(sind_pipe* p, sind_pipe::StepBuf& sb, const PipeOut& o) {
                   rc = p->kmb[g].run(sbp->depth_dev.p + np * ((size_t)s0 * p->T + t), np * p->T, ns, prev.data()); }
                 { std::lock_guard<std::mutex> lk(p->km_stat_mu); p->km_round_ms += now_ms() - tk; p->km_rounds++; }
                 if (rc != SIND_OK) { const std::string e = sind_last_error(); for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK) { sbp->tail_rc[s] = rc; sbp->tail_err[s] = "batched k-means: " + e; } return; }
-                for (int s = s0; s < s0 + ns; s++) if (sbp->tail_rc[s] == SIND_OK && (sbp->first.empty() || t >= sbp->first[s]) && (sbp->active.empty() || t < sbp->active[s])) p->workers.push(sbp->km_tails[g], [p, sbp, o, s, t, g, s0](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb[g].result(s - s0), false); });
+                for (int s = s0; s < s0 + ns; s++) {
+                    if (!(sbp->tail_rc[s] == SIND_OK && (sbp->first.empty() || t >= sbp->first[s]) && (sbp->active.empty() || t < sbp->active[s]))) continue;
+                    if (!split) { p->workers.push(sbp->km_tails[g], [p, sbp, o, s, t, g, s0](int w) { tail_task(p, sbp, o, s, t, w, &p->kmb[g].result(s - s0), false); }); continue; }
+                    p->workers.push(sbp->km_tails[g], [p, sbp, o, s, t, g, s0, np](int w) {
+                        const int k = s * p->T + t, t1 = sbp->active.empty() ? p->T : std::min(p->T, sbp->active[s]);
+                        DynaTail* dt = p->dtails[s].get(); dt->stream = p->worker_streams[w];      // (on the chain that the next round waits for: the pool's high-priority stream)
+                        const int r = dt->depth_stage(sbp->depth_h.data() + np * k, sbp->depth_dev.p + np * k, &sbp->occ[k], sbp->dout[k], &p->kmb[g].result(s - s0));
+                        if (r != SIND_OK) { sbp->dchain_rc[s] = r; sbp->dchain_err[s] = sind_last_error(); return; }      // the flow halves of this stream stop at the frame before
+                        if (sbp->fgate[k].fetch_add(1) == 1) p->workers.push(sbp->tail_group, [p, sbp, o, s, t, t1](int w2) { flow_chain(p, sbp, o, s, t, t1, w2, false); });
+                    });
+                }
             } });
         return;
     }
@@ -133,7 +155,8 @@ void swap_phase_a_outputs(sind_pipe::StepBuf& sb, sind_pipe::Retained& r) {
 int phase_b_finish(sind_pipe* p, sind_pipe::StepBuf& sb) {
     for (std::thread& t : p->round_threads) if (t.joinable()) t.join();
     p->round_threads.clear();
-    WorkerPool::wait(sb.tail_group); for (TaskGroup& g : sb.km_tails) WorkerPool::wait(g);
+    for (TaskGroup& g : sb.km_tails) WorkerPool::wait(g);      // (first: with split rounds a depth half queues its frame's flow half into tail_group when it is done)
+    WorkerPool::wait(sb.tail_group);
     sb.pending = false;
     p->last_hash = sb.state_hash;
     if (sb.retain_tag >= 0) {                       // keep this step's phase-A outputs: they change places with a reserve set of the same sizes

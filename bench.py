@@ -428,9 +428,10 @@ def sequence_streams(world, frames, cfg_streams, steps, warm=None):
     """chunks per GPU of the fixed-length sequence when --streams is not given.  Every chunk after the first re-processes `warm` state warm-up frames, so more chunks mean
     more frames per step; fewer chunks mean more frames PER CHUNK per step, and the stateful tails of a chunk's frames are a serial chain (k-means from the previous frame's
     merged labels).  Measured on one MI355X at ~30 pairs per step (profiles/r05/rank_step_shapes.txt: what a rank of an 8-GPU job sees with the driver's 20 steps): 4 chunks x 8
-    frames 509 pairs/s, 5 x 6 543, 6 x 5 658, 8 x 4 765, 10 x 3 783, 16 x 2 874 -- the step is max(dense flow of S * T pairs, T tails in a row).  So: among the chunk counts
-    around the one that keeps the warm-up at about a quarter of the sequence, the one whose lock-step plan has the shortest estimated step (flow ~ 20 + 0.55 ms per pair, a tail
-    ~ 8.5 ms per frame of a chunk; fitted to that table and to the 512-pair headline), ties to the plan that processes fewer frames."""
+    frames 509 pairs/s, 5 x 6 543, 6 x 5 658, 8 x 4 765, 10 x 3 783, 16 x 2 874 -- the step is max(dense flow of S * T pairs, T tails in a row); with the rounds split
+    into depth and flow halves (profiles/r05/ab_split_rounds.txt) 5 x 6 670, 8 x 4 820, 16 x 2 unchanged.  So: among the chunk counts
+    around the one that keeps the warm-up at about a quarter of the sequence, the one whose lock-step plan has the shortest estimated step (flow ~ 20 + 0.55 ms per pair, a round
+    ~ 7 ms per frame of a chunk; fitted to those tables and to the 512-pair headline), ties to the plan that processes fewer frames."""
     from sindslam_amd.sequence import plan_lockstep
     warm = SEQ_WARMUP_FRAMES if warm is None else warm
     s0 = 4
@@ -439,7 +440,7 @@ def sequence_streams(world, frames, cfg_streams, steps, warm=None):
     best = None
     for s in range(max(4, (3 * s0) // 4), min(max(2 * s0, 13), cfg_streams + 1)):
         plan = plan_lockstep(frames, world * s, steps, warm)
-        est = max(20.0 + 0.55 * s * plan.T, 8.5 * plan.T + 5.0)
+        est = max(20.0 + 0.55 * s * plan.T, 7.0 * plan.T + 5.0)
         key = (est, plan.processed_total)
         if best is None or key < best[0]:
             best = (key, s)

@@ -15,9 +15,12 @@
 //   * horizontal neighbours across lanes come through whole-wave DPP shifts of the PRODUCT weight x value formed in the neighbour's lane (same two operands, same bits);
 //     a lane outside the wave reads 0, which is the image border's value -- or a cut edge's: what a cut falsifies creeps inwards one pixel per half-sweep, so a strip / band
 //     computes 10 columns / rows beyond what it keeps on every cut side;
-//   * loads of row t + 2 are issued at the start of step t into a separate set of registers and taken over a step later (a step is ~1 us; no wave ever waits for memory
-//     unless the memory system is the bound); reciprocals RN(1 / a) are formed at the take-over (sor_rcp), 0 for pixels outside the image: their update returns exactly 0.
+//   * a row is requested PF = 2 steps before it enters the window, into a separate set of registers (16 per row in flight; a step is 1 - 2 us); reciprocals RN(1 / a) are
+//     formed at the take-over (sor_rcp), 0 for pixels outside the image: their update returns exactly 0;
+//   * consecutive workgroups go to the same XCD, so the strips of an image share their halo columns and seam cache lines in that XCD's L2.
 // Same float operations on the same operands in the same order as SS_UPDATE / sor_pixel: bit-identical results (tests/test_flow_gpu.py, against the oracle).
+// Where it stands: 227 us per launch of 512 pairs against 192 us with a tenth of the arithmetic (memory alone) and 171 us with every load from the cache
+// (instructions alone); -DSWV_SKIP=n / -DSWV_ROWFIX build those two experiments (profiles/tools/wave_skip.sh).
 #include "flow_dev.hpp"
 
 namespace sind {

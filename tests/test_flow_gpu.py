@@ -156,6 +156,29 @@ def test_wave_solver_equals_the_oracle_on_strip_and_band_cuts(fs_big, w, h, band
         assert np.array_equal(gv[b].view(np.uint32), ov.view(np.uint32)), (w, h, b, float(np.abs(gv[b] - ov).max()))
 
 
+def test_wave_solver_on_random_level_sizes_equals_the_per_colour_kernel(fs_big):
+    """40 random level sizes (129 - 1500 columns: one to fourteen strips; 9 - 432 rows) and band counts (automatic, 1 - 6): the one-wave pipelines (mode 6) against one launch
+    per colour and iteration (mode 0, the kernel the oracle tests pin on the fixed shapes above) -- every float of both pairs bit-identical"""
+    rng = np.random.default_rng(20260505)
+    a, d, g = 4 * np.float32(1.0), np.float32(0.5) / np.float32(3), np.float32(5.0) / np.float32(3)
+    done = 0
+    while done < 40:
+        w = int(rng.integers(129, 1501)); h = int(rng.integers(9, 433))
+        if w * h <= 8192 or w * h > 768 * 432:
+            continue
+        bands = int(rng.integers(0, 7))
+        i0, i1 = _textured_pair(w, h, 3 * w + h)
+        u0 = rng.normal(0, 1.0, (h, w)).astype(np.float32); v0 = rng.normal(0, 1.0, (h, w)).astype(np.float32)
+        args = (np.stack([i0, i1]), np.stack([i1, i0]), np.stack([u0, v0]), np.stack([v0, u0]), 2, 10, a, d, g, 1.6)
+        try:
+            fs_big.set_sor_variant(0, 5, 64, 64); ru, rv = fs_big.varref_f32(*args)
+            fs_big.set_sor_variant(6, 5, 64, 64); fs_big.set_wave_solver(True, 0, bands); gu, gv = fs_big.varref_f32(*args)
+        finally:
+            fs_big.set_sor_variant(); fs_big.set_wave_solver()
+        assert np.array_equal(gu.view(np.uint32), ru.view(np.uint32)) and np.array_equal(gv.view(np.uint32), rv.view(np.uint32)), (w, h, bands, int((gu != ru).sum()))
+        done += 1
+
+
 def test_wave_solver_on_the_768x432_pyramid(fs_big):
     """DeepFlow on the 768 x 432 grid (57 levels): one-wave pipelines with automatic bands (mode 6) == one launch per colour (mode 0) on every pixel of both pairs"""
     a0, a1 = _textured_pair(768, 432, 5); b0, b1 = _textured_pair(768, 432, 6)

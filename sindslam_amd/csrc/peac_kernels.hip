@@ -21,7 +21,9 @@ namespace sind {
 
 static constexpr unsigned PG_EMPTY = 0xFFFFFFFFu;
 #define PG_U 4                      /* visits (phase 2) and keys (phase 3) a thread works on per pass: their loads are in flight together */
+#ifndef PG_LDS_N
 #define PG_LDS_N 2048               /* levels of at most this many seeds keep their frontier and their visit keys in LDS (most levels are a few hundred seeds) */
+#endif
 
 // slot of a pixel: the seeds that sit on it in one level.  One 64-bit word carries the level tag, the count and the first seed, so the common case (one
 // seed) costs one load; further seeds of the same pixel and level (a pixel taken over twice within a level) go to a side array.

@@ -71,7 +71,8 @@ int sind_flow_set_sor_tiled(sind_flow* f, int mode, int fuse, int tile_w, int ti
  * Same results.  See DESIGN.md 3.1-12 for when it pays. */
 int sind_flow_set_solver_workgroups(sind_flow* f, int cap);
 /* one-wave row pipelines (k_sor_wave, flow_wave.hip) for the levels and batch sizes that would otherwise go to the streaming kernel: on != 0 (default) / 0 = k_sor_stream;
- * target_items = waves a launch should have (row bands are cut until it does; 0 keeps the default), bands > 0 = exactly that many row bands (tests).  Mode 6 of
+ * target_items = waves a launch should have (row bands are cut until it does; 0 keeps the default), bands > 0 = exactly that many row bands (tests); on = 2 / 3 / 4 additionally selects 1 / 2 / 3 rows
+ * in flight per wave (A/B timing; default 2).  Mode 6 of
  * sind_flow_set_sor_tiled runs the kernel on every level beyond one workgroup at any batch size.  Same bits either way. */
 int sind_flow_set_wave_solver(sind_flow* f, int on, int target_items, int bands);
 /* how k_sor_wave cuts a w x h level of B pairs (host arithmetic only, no GPU needed): out = {column strips, kept columns per strip, row bands, kept rows per band}.  A strip works on

@@ -157,7 +157,7 @@ int sind_flow_set_sor_tiled(sind_flow* f, int mode, int fuse, int tile_w, int ti
 }
 int sind_flow_set_solver_workgroups(sind_flow* f, int cap) { if (!f || cap < 0) return SIND_E_ARG; f->eng.solver.stream_wg_cap = cap; return SIND_OK; }
 int sind_flow_set_wave_solver(sind_flow* f, int on, int target_items, int bands) {
-    if (!f || target_items < 0 || bands < 0) return SIND_E_ARG;
+    if (!f || target_items < 0 || bands < 0 || on < 0 || on > 4) return SIND_E_ARG;
     if (on > 1) f->eng.solver.wave_prefetch = std::min(on - 1, 3);       // (experiment: on = 2 / 3 / 4 selects 1 / 2 / 3 rows in flight)
     f->eng.solver.wave = on ? 1 : 0; f->eng.solver.wave_items = target_items > 0 ? target_items : sind::SolverCfg().wave_items; f->eng.solver.wave_bands = bands; return SIND_OK;
 }

@@ -121,10 +121,10 @@ int DynaTail::init(const DynaConfig& c, hipStream_t s) {
     for (int l = 0; l < 4; l++) SIND_TRY(lab[l].alloc((size_t)N >> (2 * l)));
     SIND_TRY(filt.alloc(N)); SIND_TRY(px.alloc(N)); SIND_TRY(py.alloc(N)); SIND_TRY(pz.alloc(N)); SIND_TRY(lab8.alloc(N)); SIND_TRY(labPrev8.alloc(N));
     SIND_TRY(edge.alloc(N)); SIND_TRY(edgeTmp.alloc(N)); SIND_TRY(total.alloc(N)); SIND_TRY(depthN.alloc(N)); SIND_TRY(occ2_d.alloc(N));
-    SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc((size_t)2 * N)); SIND_TRY(mag.alloc(N));       // low_d: low mask, then high mask (one D2H)
+    SIND_TRY(magu8.alloc(N)); SIND_TRY(low_d.alloc(((size_t)2 * N + 15) / 16 * 16 + 1088)); SIND_TRY(mag.alloc(N));       // low_d: low mask, high mask, then (16-byte aligned) the thresholds' 261-word result block: ONE D2H for the stage
     SIND_TRY(kpart.alloc((size_t)(KM_MAX_BLOCKS * 4 + 1) * KM_K + 64));       // count table, totals row, the 36 sums
     SIND_TRY(kcomp.alloc((size_t)3 * N + 8)); /* + 8: k_km_seqsum's window loads may touch up to 7 floats behind the last run */ SIND_TRY(umax_d.alloc(2));
-    SIND_TRY(h_grid.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(h_hist.alloc(261)); SIND_TRY(h_ab.alloc((size_t)2 * N)); SIND_TRY(h_lab8.alloc(N));
+    SIND_TRY(h_grid.alloc((size_t)2 * ((W - 1) / 10) * ((H - 1) / 10) + 2)); SIND_TRY(h_hist.alloc(261)); SIND_TRY(h_ab.alloc(((size_t)2 * N + 15) / 16 * 16 + 1088)); SIND_TRY(h_lab8.alloc(N));
     SIND_TRY(h_kstate.alloc(4)); SIND_TRY(h_blocks.alloc((size_t)(W / 16) * (H / 16)));
     { // RAG workspaces for up to 64 pieces up front: a later (re)allocation synchronises the whole device, i.e. waits for the
       // flow solver of the next step when tails and dense flow overlap
@@ -202,16 +202,18 @@ int DynaTail::flow_masks(const float* U, const float* V, BitImg& low, BitImg& hi
     SIND_TRY(launch_residual(stream, U, V, Hm, mag.p, (unsigned*)(hist_d.p + 256), hist_d.p, magu8.p, W, H, hist_clean));
     hist_clean = false;
     // thresholds (Otsu / triangle + the clamping of DD:1309-1367) and the two masks on the device: one host round trip for the stage
-    int* res = hist_d.p + 264;                              // result block: histogram, maximum, four thresholds
+    // result block (histogram, maximum, four thresholds) right behind the two masks: it travels with them (a copy of 1 KB of its own was a blit kernel and a launch per frame)
+    const size_t res_off = ((size_t)2 * N + 15) / 16 * 16;
+    int* res = reinterpret_cast<int*>(low_d.p + res_off);
     SIND_TRY(launch_flow_thresholds_and_masks(stream, hist_d.p, W, H, res, magu8.p, low_d.p, (low_d.p + N)));
-    HIP_TRY(hipMemcpyAsync(h_hist.p, res, 261 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(h_ab.p, low_d.p, (size_t)2 * N, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_ab.p, low_d.p, res_off + 261 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(sind_stream_wait(stream));
     hist_clean = true;
     {
-        float f[5]; std::memcpy(&f[0], h_hist.p + 256, 4); std::memcpy(&f[1], h_hist.p + 257, 16);
+        const int* hh = reinterpret_cast<const int*>(h_ab.p + res_off);
+        float f[5]; std::memcpy(&f[0], hh + 256, 4); std::memcpy(&f[1], hh + 257, 16);
         dbg.maxError = f[0]; dbg.thr_low = f[1]; dbg.thr_high = f[2]; dbg.otsu = f[3]; dbg.triangle = f[4];
-        dbg.nPairs = (int)in.size(); std::copy(Hm, Hm + 9, dbg.H); std::copy(h_hist.p, h_hist.p + 256, dbg.hist);
+        dbg.nPairs = (int)in.size(); std::copy(Hm, Hm + 9, dbg.H); std::copy(hh, hh + 256, dbg.hist);
     }
     tq = tick_ms();
     low = BitImg::from_u8(h_ab.p, W, H, W); high = BitImg::from_u8((h_ab.p + N), W, H, W);

@@ -1115,21 +1115,29 @@ __global__ void k_mag_hist(const float* __restrict__ mag, const unsigned* __rest
 
 // ---------------------------------------------------------------------------------------------------------
 // Residual stage, reference DynaDetect.cc:1252-1271: flow - (p - H p), homography part in FP64 then cast to FP32.
+// A thread takes RM_ROWS pixels of one column (2 400 workgroups of one row segment each were mostly workgroup turnover: 11 us of the whole GPU per 640 x 480 frame, 512 times a step)
+#define RM_ROWS 4
 __global__ void k_residual_mag(const float* __restrict__ u, const float* __restrict__ v, HMat Hm, float* __restrict__ mag,
                                unsigned* __restrict__ maxbits, int w, int h) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, row0 = blockIdx.y * RM_ROWS;
     float m = 0.f;
     if (col < w) {
         const double* H = Hm.h;
-        const double den = H[6] * col + H[7] * row + H[8];
-        const double fx2 = (col - (H[0] * col + H[1] * row + H[2]) / den);
-        const double fy2 = (row - (H[3] * col + H[4] * row + H[5]) / den);
-        const float dx = u[row * w + col] - (float)fx2, dy = v[row * w + col] - (float)fy2;
-        m = sqrtf(dx * dx + dy * dy);
-        mag[row * w + col] = m;
+        #pragma unroll
+        for (int r = 0; r < RM_ROWS; r++) {
+            const int row = row0 + r;
+            if (row >= h) break;
+            const double den = H[6] * col + H[7] * row + H[8];
+            const double fx2 = (col - (H[0] * col + H[1] * row + H[2]) / den);
+            const double fy2 = (row - (H[3] * col + H[4] * row + H[5]) / den);
+            const float dx = u[row * w + col] - (float)fx2, dy = v[row * w + col] - (float)fy2;
+            const float mm = sqrtf(dx * dx + dy * dy);
+            mag[row * w + col] = mm;
+            m = fmaxf(m, mm);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    // 4 800 waves hitting one address serialise in L2 (48 of the kernel's 57 us): a wave only issues the atomic when it can still raise the maximum
+    // thousands of waves hitting one address serialise in L2: a wave only issues the atomic when it can still raise the maximum
     if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *(volatile unsigned*)maxbits) atomicMax(maxbits, __float_as_uint(m));
 }
 // masks from the u8 residual: low -> 128, high -> 255 (stImgMasks), thresholds decided on the host from the histogram
@@ -1355,12 +1363,32 @@ __global__ void __launch_bounds__(64) k_flow_thresholds(int* __restrict__ hist, 
     if (lane == 0) { float* out = reinterpret_cast<float*>(res + 257); out[0] = lo; out[1] = hi; out[2] = otsu_f; out[3] = tri_f; }
     if (!keep_hist) { *reinterpret_cast<int4*>(hist + 4 * lane) = make_int4(0, 0, 0, 0); if (lane == 0) hist[256] = 0; }
 }
-__global__ void k_threshold_masks_dev(const uint8_t* __restrict__ magu8, const float* __restrict__ thr, uint8_t* __restrict__ low, uint8_t* __restrict__ high, int n) {
+// (16 pixels per thread where the planes allow 16-byte accesses: one pixel per thread was 1 200 workgroups of turnover per 640 x 480 frame)
+__global__ void k_threshold_masks_dev(const uint8_t* __restrict__ magu8, const float* __restrict__ thr, uint8_t* __restrict__ low, uint8_t* __restrict__ high, int n, int wide) {
+    const double tl = (double)thr[0], th = (double)thr[1];
+    if (wide) {
+        const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
+        if (i >= n) return;
+        if (i + 16 <= n) {
+            const uint4 q4 = *reinterpret_cast<const uint4*>(magu8 + i);
+            const unsigned qs[4] = {q4.x, q4.y, q4.z, q4.w}; unsigned lo[4], hi[4];
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                lo[k] = hi[k] = 0u;
+                #pragma unroll
+                for (int b = 0; b < 4; b++) { const double q = (double)((qs[k] >> (8 * b)) & 255u); lo[k] |= (q > tl ? 128u : 0u) << (8 * b); hi[k] |= (q > th ? 255u : 0u) << (8 * b); }
+            }
+            *reinterpret_cast<uint4*>(low + i) = make_uint4(lo[0], lo[1], lo[2], lo[3]); *reinterpret_cast<uint4*>(high + i) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            return;
+        }
+        for (int k = i; k < n; k++) { const double q = (double)magu8[k]; low[k] = q > tl ? 128 : 0; high[k] = q > th ? 255 : 0; }
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double q = (double)magu8[i];
-    low[i] = q > (double)thr[0] ? 128 : 0;
-    high[i] = q > (double)thr[1] ? 255 : 0;
+    low[i] = q > tl ? 128 : 0;
+    high[i] = q > th ? 255 : 0;
 }
 // gather flow at the 63x47 sample grid (DD:1182-1204) so the host can build the PROSAC-ordered pairs
 __global__ void k_gather_grid(const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ out, int w, int h, int step) {
@@ -1715,7 +1743,7 @@ int launch_residual(hipStream_t s, const float* u, const float* v, const double 
     if (already_zero) {}                                  // the consumer of the previous frame (k_flow_thresholds) left the block zeroed
     else if ((const void*)maxbits == (const void*)(hist + 256)) HIP_TRY(hipMemsetAsync(hist, 0, 257 * sizeof(int), s));       // histogram and maximum in one block: one fill
     else { HIP_TRY(hipMemsetAsync(maxbits, 0, sizeof(unsigned), s)); HIP_TRY(hipMemsetAsync(hist, 0, 256 * sizeof(int), s)); }
-    hipLaunchKernelGGL(k_residual_mag, dim3(divup(w, 128), h), dim3(128), 0, s, u, v, Hm, mag, maxbits, w, h);
+    hipLaunchKernelGGL(k_residual_mag, dim3(divup(w, 128), divup(h, RM_ROWS)), dim3(128), 0, s, u, v, Hm, mag, maxbits, w, h);
     const int n = w * h, gx = std::min(divup(n, 256), 64);
     hipLaunchKernelGGL(k_mag_hist, dim3(gx, 1), dim3(256), 0, s, mag, maxbits, hist, magu8, n);
     return SIND_OK;
@@ -1726,7 +1754,8 @@ int launch_threshold_masks(hipStream_t s, const uint8_t* magu8, float lo, float 
 }
 int launch_flow_thresholds_and_masks(hipStream_t s, int* hist, int W, int H, int* res, const uint8_t* magu8, uint8_t* low, uint8_t* high) {
     hipLaunchKernelGGL(k_flow_thresholds, dim3(1), dim3(64), 0, s, hist, W, H, res, (double*)nullptr, 0);
-    hipLaunchKernelGGL(k_threshold_masks_dev, dim3(divup(W * H, 256)), dim3(256), 0, s, magu8, reinterpret_cast<const float*>(res + 257), low, high, W * H);
+    const int wide = ((((uintptr_t)magu8 | (uintptr_t)low | (uintptr_t)high) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_threshold_masks_dev, dim3(divup(wide ? divup(W * H, 16) : W * H, 256)), dim3(256), 0, s, magu8, reinterpret_cast<const float*>(res + 257), low, high, W * H, wide);
     return SIND_OK;
 }
 // test entry: n histograms (257 words each, device) through the one-wave kernel (variant 1; mu1 chain optionally dumped) or the serial reference (variant 0)

@@ -41,7 +41,8 @@ int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     p->host_info[0] = cpu_share; p->host_info[3] = nproc; p->host_info[4] = quota; p->host_info[5] = lw;
     p->cpu_share = cpu_share;
     if (const char* e = getenv("SIND_GROW_GPU")) { p->grow_q_fixed = std::max(0, std::min(4, atoi(e))); p->grow_q = p->grow_q_fixed; }
-    const int nworkers = sind_lab_env("SIND_WORKERS") ? std::max(2, atoi(sind_lab_env("SIND_WORKERS"))) : cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 2);         // default: 2x the CPU share (workers sleep while they wait for the GPU)
+    const int nworkers = sind_lab_env("SIND_WORKERS") ? std::max(2, atoi(sind_lab_env("SIND_WORKERS"))) : cfg->host_threads > 0 ? cfg->host_threads : std::max(2, cpu_share * 3);         // default: 3x the CPU share (workers sleep while they wait for the GPU: a tail waits ~6 ms of its ~11; 48 against 32 workers:
+                                                                                                                                                                                        // 1280 x 720 790 - 818 -> 813 - 866 pairs/s, headline 1530 - 1577 -> 1548 - 1593, small steps unchanged, profiles/r05/pool_workers.txt)
     // A task leaves its stream idle (every GPU section ends in a wait), so the HIP streams belong to the workers, not to the camera
     // streams: their number does not grow with S.
     p->worker_streams.resize(nworkers); p->occ_tails.resize(nworkers); p->tails.resize(p->S);

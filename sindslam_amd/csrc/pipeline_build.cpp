@@ -63,7 +63,8 @@ int pipe_build(sind_pipe* p, const sind_pipe_config* cfg) {
     // CPU tokens of the pool tasks: the flow's three launch threads, the ORB thread and the round drivers run beside them and are not gated, so share - 1 tokens
     // overshoot the quota in bursts (10-17 of 77 periods throttled) and share - 3 do not (0 periods, -1 % at 640x480 where the GPU is the bottleneck); a
     // host-bound configuration wants every core it can get.  The controller below moves between the two on the same signal as the region grow's share.
-    p->cpu_tokens_max = std::max(2, cpu_share - 1); p->cpu_tokens_min = std::max(2, cpu_share - 3); p->cpu_tokens = p->cpu_tokens_min;
+    p->cpu_tokens_max = std::max(2, cpu_share + 2);      // (the controller only goes there while steps wait for the host: 1280 x 720, host-bound, 798 - 809 pairs/s with 15 tokens, 822 - 855 with 17, 836 - 857 with 20 -- a token is held
+                                                              // through short waits too, so a few more tokens than cores keep the 16 cores of the quota busy: 13.6 -> 14.5 - 14.8; profiles/r05/cpu_tokens_720p.txt) p->cpu_tokens_min = std::max(2, cpu_share - 3); p->cpu_tokens = p->cpu_tokens_min;
     if (sind_lab_env("SIND_CPU_TOKENS")) { p->cpu_tokens = std::max(1, atoi(sind_lab_env("SIND_CPU_TOKENS"))); p->cpu_tokens_fixed = true; }
     p->host_info[1] = nworkers; p->host_info[2] = p->cpu_tokens_max;
     p->occ_workers = std::max(1, std::min(nworkers, cpu_share - 2));             // CalOccluded runners: leave two cores of the share to the flow's launch threads

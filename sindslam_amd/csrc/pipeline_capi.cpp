@@ -221,7 +221,7 @@ int sind_pipe_set_cpu_share(sind_pipe* p, int cores) {
     if (!p || cores < 1) { sind_set_error("sind_pipe_set_cpu_share: at least one core"); return SIND_E_ARG; }
     if (p->sb[0].pending || p->sb[1].pending) { sind_set_error("sind_pipe_set_cpu_share: a submitted step is still pending"); return SIND_E_STATE; }
     cores = std::min(cores, 16); p->cpu_share = cores; p->host_info[0] = cores;
-    p->cpu_tokens_max = std::max(2, cores - 1); p->cpu_tokens_min = std::max(2, cores - 3); if (!p->cpu_tokens_fixed) p->cpu_tokens = p->cpu_tokens_min;
+    p->cpu_tokens_max = std::max(2, cores + 2); p->cpu_tokens_min = std::max(2, cores - 3); if (!p->cpu_tokens_fixed) p->cpu_tokens = p->cpu_tokens_min;
     p->host_info[2] = p->cpu_tokens_max;
     p->occ_workers = std::max(1, std::min(p->workers.size(), std::max(1, cores - 2)));
     return SIND_OK;

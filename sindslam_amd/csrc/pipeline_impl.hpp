@@ -139,7 +139,8 @@ static inline void grow_adapt(sind_pipe* p, double host_wait_ms, double step_ms)
     if (host_wait_ms > 0.03 * step_ms) {
         if ((p->grow_q >= 4 || host_wait_ms > 0.15 * step_ms) && p->batch_km && p->km_groups_fixed < 0) p->km_groups = std::min(p->km_groups_max, p->km_groups + 1);      // every grow is on the GPU already (or the wait is long): one more k-means chain
         p->grow_q = std::min(4, p->grow_q + 1); p->grow_idle_steps = 0;
-        if (!p->cpu_tokens_fixed) p->cpu_tokens = host_wait_ms > 0.10 * step_ms ? p->cpu_tokens_max : std::min(p->cpu_tokens_max, p->cpu_tokens + 1);      // clearly host-bound: every core of the share at once; else one more
+        // clearly host-bound (the step waits for the tails for > 10 % of its time): a few more tokens than cores (a token is held through short waits too: 1280 x 720 + 3 - 6 %); else one more, up to share - 1
+        if (!p->cpu_tokens_fixed) p->cpu_tokens = host_wait_ms > 0.10 * step_ms ? p->cpu_tokens_max : std::max(p->cpu_tokens, std::min(p->cpu_tokens_max - 3, p->cpu_tokens + 1));
     } else if (host_wait_ms < 0.005 * step_ms) {
         if (!p->cpu_tokens_fixed) p->cpu_tokens = std::max(p->cpu_tokens_min, p->cpu_tokens - 1);
         if (++p->grow_idle_steps >= 3) {
